@@ -1,0 +1,199 @@
+/*
+ * mtseg.h — C ABI of libmtseg_hip.so, the MI355X (gfx950) hot path of the 3D patch segmentation engine.
+ *
+ * The reference (MIC-DKFZ/MultiTalent, nnU-Net v1) has no FFI: its plugin surface is Python
+ * (SURVEY.md §8b).  This ABI sits UNDER that surface: the Python modules that mirror
+ * `Generic_UNet` / `FabiansUNet` / the trainers call these entry points through ctypes with raw
+ * device pointers owned by the caller (torch), a hipStream_t and plain sizes.  No torch types,
+ * no allocation, no synchronisation inside; every function returns 0 on success or a negative
+ * MT_E* code (text via mt_last_error()).
+ *
+ * Layout: activations are NDHWC fp32 ("channels last"), possibly a channel slice of a wider
+ * buffer (channel stride `cs`, first channel folded into the pointer).  A "lazy activation" is a
+ * raw conv output y plus per-(n,c) scale/shift and a LeakyReLU slope:
+ *     a = lrelu_slope(y*scale + shift)         (InstanceNorm + LeakyReLU applied on load)
+ * which is how `ConvDropoutNormNonlin.forward` (generic_UNet.py:66-70) is fused away.
+ *
+ * Each entry point cites the reference code it replaces (paths relative to the reference root).
+ */
+#ifndef MTSEG_H
+#define MTSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MT_OK 0
+#define MT_EINVAL (-1)  /* bad argument / unsupported shape */
+#define MT_EWORKSPACE (-2) /* workspace too small */
+#define MT_EHIP (-3)    /* HIP runtime error on launch */
+
+#define MT_ABI_VERSION 1
+#define MT_MAX_CHUNKS 48
+
+typedef void* mt_stream_t; /* hipStream_t */
+
+/* One input source of a convolution: channel slice [0,C) of an NDHWC buffer with channel stride cs.
+ * scale/shift: [N][C] per-sample affine applied on load (NULL = none); slope: LeakyReLU slope
+ * applied after the affine (1.0f = identity). */
+typedef struct {
+  const float* ptr;
+  int32_t cs;
+  int32_t C;
+  const float* scale;
+  const float* shift;
+  float slope;
+  int32_t _pad;
+} mt_src_t;
+
+/* Convolution problem.  Forward conv (nn.Conv3d, generic_UNet.py:57,67; conv_blocks.py:49-85,116-213):
+ *   out[n,o,co] = bias[co] + sum_{t,ci} in[n, o*S + t - P, ci] * W[t][ci][co]
+ * with the input being the channel concatenation of src[0..nsrc) (torch.cat((x, skip), 1),
+ * generic_UNet.py:392).  `dil` inserts zeros between stored input samples (virtual input coordinate
+ * u maps to stored u/dil when divisible) — this is how the backward-data of a strided conv and
+ * nothing else is expressed.  Weights are pre-packed by mt_pack_conv_weights. */
+typedef struct {
+  mt_src_t src[2];
+  int32_t nsrc;
+  int32_t N, Di, Hi, Wi;      /* stored input dims */
+  int32_t dilD, dilH, dilW;   /* zero-insertion factor of the virtual input (1 or 2) */
+  int32_t Do, Ho, Wo;         /* output dims */
+  int32_t KD, KH, KW, SD, SH, SW, PD, PH, PW;
+  int32_t Cin, Cout;
+  const float* wpack;         /* packed weights (mt_pack_conv_weights, ck = MT_CONV_CK) */
+  const float* bias;          /* [Cout] or NULL */
+  float* out0; int32_t ocs0;  /* channels [0,csplit) -> out0[... * ocs0 + co] */
+  float* out1; int32_t ocs1;  /* channels [csplit,Cout) -> out1[... * ocs1 + (co - csplit)] (may be NULL if csplit>=Cout) */
+  int32_t csplit;
+  int32_t accumulate;         /* 1: out += result (gradient accumulation on skip connections) */
+  float* stats_part;          /* NULL or [N][nsb][Cout][2] per-block (sum, sumsq) partials, nsb = mt_conv3d_stats_blocks() */
+} mt_conv3d_t;
+
+const char* mt_last_error(void);
+int mt_abi_version(void);
+
+/* ---- weight packing ------------------------------------------------------------------------
+ * Packs W_eff[tap][ci][co] = w[ci*s_ci + co*s_co + kd'*s_kd + kh'*s_kh + kw'*s_kw] (k' = K-1-k when
+ * flip) into the MFMA B-fragment order [ntile][chunk][tap][ck/2][64] used by the conv kernels, where
+ * the input channels are split into chunks of at most `ck` channels that never straddle the two
+ * sources (C0 | C1).  Returns number of floats via *packed_floats (query with dst == NULL). */
+int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats,
+                         int C0, int C1, int Cout, int KD, int KH, int KW,
+                         long s_ci, long s_co, long s_kd, long s_kh, long s_kw, int flip, int ck,
+                         mt_stream_t stream);
+
+/* ---- convolution (N1/N2/N5 forward, and backward-data through flipped weights) --------------- */
+int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream);
+int mt_conv3d_stats_blocks(const mt_conv3d_t* p); /* spatial blocks per sample (size of stats_part dim 1) */
+int mt_conv3d_ck(const mt_conv3d_t* p);           /* channel chunk the kernel will use (pack weights with it) */
+
+/* ---- backward-weight -------------------------------------------------------------------------
+ * dW[tap][ci][co] = sum_{n,o} X[n, o*S + t - P, ci] * Y[n, o, co]   (autograd of nn.Conv3d /
+ * nn.ConvTranspose3d weights).  X is described by p->src (lazy activations allowed), Y by ysrc
+ * (N,Do,Ho,Wo from p).  Result is written (or accumulated) into dw with the given element strides,
+ * i.e. directly in the torch parameter layout.  Workspace: query mt_conv3d_bwd_weight_workspace. */
+size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p);
+int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, float* dw,
+                         long s_ci, long s_co, long s_kd, long s_kh, long s_kw, int accumulate,
+                         void* workspace, size_t workspace_bytes, mt_stream_t stream);
+
+/* ---- pointwise / transposed convolution -----------------------------------------------------
+ * Base grid [N][Db][Hb][Wb].  in voxel = base*si (gather), out voxel = base*so + tap (scatter, taps
+ * = prod(so)).  si=so=1: 1x1x1 conv (seg heads generic_UNet.py:349-351; backward-data with packed
+ * transposed weights).  si=2: strided 1x1x1 skip projection (conv_blocks.py:192-197).
+ * so=pool kernel: nn.ConvTranspose3d with kernel==stride, bias=False (generic_UNet.py:335-336),
+ * written straight into the concat buffer through ocs. */
+typedef struct {
+  mt_src_t src;
+  int32_t N, Db, Hb, Wb;
+  int32_t Di, Hi, Wi;          /* stored input dims (base*si must be inside) */
+  int32_t siD, siH, siW;
+  int32_t soD, soH, soW;
+  int32_t Cin, Cout;
+  const float* wpack;  /* mt_pack_conv_weights(C0=Cin, C1=0, taps = so, ck = Cin rounded up to even) */
+  const float* bias;   /* [Cout] or NULL */
+  float* out; int32_t ocs;
+  int32_t accumulate;
+  float* stats_part;   /* NULL or [N][nsb][Cout][2] */
+} mt_pointwise_t;
+int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream);
+int mt_pointwise_stats_blocks(const mt_pointwise_t* p);
+
+/* ---- InstanceNorm3d(eps, affine) + LeakyReLU (generic_UNet.py:63-64,69-70) ------------------- */
+/* partials [N][nsb][C][2] -> mean,rstd,scale,shift each [N][C]; scale = gamma*rstd, shift = beta - mean*scale */
+int mt_inorm_finalize(const float* part, int N, int nsb, int C, double count, const float* gamma,
+                      const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                      mt_stream_t stream);
+/* materialise a = lrelu(y*scale+shift) (+ optional residual add BEFORE the lrelu: conv_blocks.py:201-213) */
+int mt_inorm_lrelu_apply(const float* y, int ycs, const float* scale, const float* shift, float slope,
+                         const float* res, int rcs, const float* rscale, const float* rshift, float rslope,
+                         float* out, int ocs, int N, long V, int C, mt_stream_t stream);
+/* Backward of out = lrelu(IN(y)): given g = dL/dout (in place), produce dy in place, plus
+ * dgamma[C] += , dbeta[C] +=, dbias[C] (= sum dy, may be NULL).  ws: mt_inorm_bwd_workspace bytes. */
+size_t mt_inorm_bwd_workspace(int N, long V, int C);
+int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, float slope, int N, long V, int C,
+                       float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                       mt_stream_t stream);
+/* g *= lrelu'(y*scale+shift) in place, optionally also writes a copy (residual branch gradient) */
+int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale, const float* shift,
+                 float slope, const float* y2, int y2cs, const float* scale2, const float* shift2,
+                 float slope2, float* gcopy, int gcopycs, int N, long V, int C, mt_stream_t stream);
+/* per-channel sum over all voxels: out[C] (+)= sum_{n,v} x[n,v,c]  (bias gradients of heads) */
+int mt_channel_sum(const float* x, int xcs, int N, long V, int C, float* out, int accumulate,
+                   void* ws, size_t ws_bytes, mt_stream_t stream);
+
+/* ---- losses --------------------------------------------------------------------------------- */
+/* MultiTalent loss for one deep-supervision level (MultiTalent_Trainer_DDP.py:544-623):
+ * logits [B][V][C=47 (cs)], target [B][V] float label map, valid[B] = 64-bit mask of valid output
+ * channels, lut[C] = 64-bit mask over label values belonging to each channel's region
+ * (Task100_MultiTalent.py:118-166).  Forward: stats[B][C][4] = (bce_sum, tp, fp, fn).
+ * Backward: dlogits = w * ( valid*(sigmoid-y)/V  +  d(-dice)/dlogit ) with coefficients
+ * gtp,gfp,gfn [B][C] (dLoss/dtp etc., already including -w). */
+int mt_multitalent_loss_fwd(const float* logits, int cs, const float* target, int B, long V, int C,
+                            const uint64_t* valid, const uint64_t* lut, float* stats, void* ws,
+                            size_t ws_bytes, mt_stream_t stream);
+size_t mt_loss_workspace(int B, long V, int C);
+int mt_multitalent_loss_bwd(const float* logits, int cs, const float* target, int B, long V, int C,
+                            const uint64_t* valid, const uint64_t* lut, float bce_coef,
+                            const float* gtp, const float* gfp, const float* gfn,
+                            float* dlogits, int dcs, mt_stream_t stream);
+/* Softmax Dice+CE for one level (dice_loss.py:100-195,488-545; crossentropy.py:4-11):
+ * stats[B][C][4] = (ce_sum (only c=0 slot used), tp, fp, fn). */
+int mt_softmax_dice_ce_fwd(const float* logits, int cs, const float* target, int B, long V, int C,
+                           float* stats, void* ws, size_t ws_bytes, mt_stream_t stream);
+int mt_softmax_dice_ce_bwd(const float* logits, int cs, const float* target, int B, long V, int C,
+                           float ce_coef, const float* gtp, const float* gfp, const float* gfn,
+                           float* dlogits, int dcs, mt_stream_t stream);
+
+/* ---- optimizer (nnUNetTrainerV2.py:166-170; clip MultiTalent_Trainer_DDP.py:352,362) --------- */
+int mt_sumsq(const float* x, long n, float* out /* [1], overwritten */, void* ws, size_t ws_bytes,
+             mt_stream_t stream);
+size_t mt_sumsq_workspace(long n);
+/* torch.optim.SGD(nesterov=True, dampening=0): g = clip*g + wd*p; buf = mom*buf + g (buf=g on first
+ * step); p -= lr*(g + mom*buf).  clip_coef_dev: device scalar total_norm^2 -> coef = min(1, max_norm/(sqrt+1e-6)) */
+int mt_sgd_nesterov(float* p, const float* g, float* buf, long n, float lr, float wd, float mom,
+                    int first_step, const float* sumsq_dev, float max_norm, mt_stream_t stream);
+
+/* ---- sliding-window inference (neural_network.py:287-428,502-591) ---------------------------- */
+/* acc[c][x] (+)= w * nonlin(logits[flip(x)][c])  NCDHW accumulator over one tile: mirror-TTA mean */
+int mt_flip_accumulate(const float* logits, int cs, int D, int H, int W, int C, int flipD, int flipH,
+                       int flipW, int nonlin /*0 none,1 sigmoid,2 softmax*/, float weight, float* acc,
+                       int first, mt_stream_t stream);
+/* agg[c, tile] += acc * gauss ; nb[tile] += gauss   (neural_network.py:388-394) */
+int mt_tile_accumulate(const float* acc, const float* gauss, int C, int D, int H, int W, float* agg,
+                       float* nb, long aX, long aY, long aZ, int x0, int y0, int z0, mt_stream_t stream);
+/* probs = agg/nb; seg = argmax_c or per-channel >0.5 in regions_class_order (neural_network.py:405-417) */
+int mt_normalize_threshold(float* agg, const float* nb, int C, long V, const int32_t* class_order,
+                           int use_regions, int32_t* seg, mt_stream_t stream);
+/* NCDHW <-> NDHWC transposes used at the module boundary */
+int mt_ncdhw_to_ndhwc(const float* in, float* out, int N, int C, long V, int ocs, mt_stream_t stream);
+int mt_ndhwc_to_ncdhw(const float* in, int ics, float* out, int N, int C, long V, mt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTSEG_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of libmtseg_hip.so (C ABI declared in include/mtseg.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError is
+raised (the engine must never silently run on a PyTorch/CPU path).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmtseg_hip.so')
+
+MT_MAX_CHUNKS = 48
+c_float_p = C.POINTER(C.c_float)
+
+
+class mt_src_t(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('cs', C.c_int32), ('C', C.c_int32), ('scale', C.c_void_p),
+                ('shift', C.c_void_p), ('slope', C.c_float), ('_pad', C.c_int32)]
+
+
+class mt_conv3d_t(C.Structure):
+    _fields_ = [('src', mt_src_t * 2), ('nsrc', C.c_int32),
+                ('N', C.c_int32), ('Di', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32),
+                ('dilD', C.c_int32), ('dilH', C.c_int32), ('dilW', C.c_int32),
+                ('Do', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
+                ('KD', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32),
+                ('SD', C.c_int32), ('SH', C.c_int32), ('SW', C.c_int32),
+                ('PD', C.c_int32), ('PH', C.c_int32), ('PW', C.c_int32),
+                ('Cin', C.c_int32), ('Cout', C.c_int32),
+                ('wpack', C.c_void_p), ('bias', C.c_void_p),
+                ('out0', C.c_void_p), ('ocs0', C.c_int32),
+                ('out1', C.c_void_p), ('ocs1', C.c_int32),
+                ('csplit', C.c_int32), ('accumulate', C.c_int32),
+                ('stats_part', C.c_void_p)]
+
+
+class mt_pointwise_t(C.Structure):
+    _fields_ = [('src', mt_src_t),
+                ('N', C.c_int32), ('Db', C.c_int32), ('Hb', C.c_int32), ('Wb', C.c_int32),
+                ('Di', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32),
+                ('siD', C.c_int32), ('siH', C.c_int32), ('siW', C.c_int32),
+                ('soD', C.c_int32), ('soH', C.c_int32), ('soW', C.c_int32),
+                ('Cin', C.c_int32), ('Cout', C.c_int32),
+                ('wpack', C.c_void_p), ('bias', C.c_void_p),
+                ('out', C.c_void_p), ('ocs', C.c_int32), ('accumulate', C.c_int32),
+                ('stats_part', C.c_void_p)]
+
+
+_vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
+_P = C.POINTER
+
+# name -> (restype, argtypes); must list EVERY symbol of include/mtseg.h (checked by tests/test_abi.py)
+SIGNATURES = {
+    'mt_last_error': (C.c_char_p, []),
+    'mt_abi_version': (_i, []),
+    'mt_pack_conv_weights': (_i, [_vp, _vp, _P(_sz), _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _vp]),
+    'mt_conv3d_fwd': (_i, [_P(mt_conv3d_t), _vp]),
+    'mt_conv3d_stats_blocks': (_i, [_P(mt_conv3d_t)]),
+    'mt_conv3d_ck': (_i, [_P(mt_conv3d_t)]),
+    'mt_conv3d_bwd_weight_workspace': (_sz, [_P(mt_conv3d_t)]),
+    'mt_conv3d_bwd_weight': (_i, [_P(mt_conv3d_t), _P(mt_src_t), _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp]),
+    'mt_pointwise_fwd': (_i, [_P(mt_pointwise_t), _vp]),
+    'mt_pointwise_stats_blocks': (_i, [_P(mt_pointwise_t)]),
+    'mt_inorm_finalize': (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    'mt_inorm_lrelu_apply': (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _vp]),
+    'mt_inorm_bwd_workspace': (_sz, [_i, _l, _i]),
+    'mt_inorm_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _i, _l, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'mt_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _vp]),
+    'mt_channel_sum': (_i, [_vp, _i, _i, _l, _i, _vp, _i, _vp, _sz, _vp]),
+    'mt_multitalent_loss_fwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'mt_loss_workspace': (_sz, [_i, _l, _i]),
+    'mt_multitalent_loss_bwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp]),
+    'mt_softmax_dice_ce_fwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _sz, _vp]),
+    'mt_softmax_dice_ce_bwd': (_i, [_vp, _i, _vp, _i, _l, _i, _f, _vp, _vp, _vp, _vp, _i, _vp]),
+    'mt_sumsq': (_i, [_vp, _l, _vp, _vp, _sz, _vp]),
+    'mt_sumsq_workspace': (_sz, [_l]),
+    'mt_sgd_nesterov': (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp, _f, _vp]),
+    'mt_flip_accumulate': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),
+    'mt_tile_accumulate': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _l, _l, _l, _i, _i, _i, _vp]),
+    'mt_normalize_threshold': (_i, [_vp, _vp, _i, _l, _vp, _i, _vp, _vp]),
+    'mt_ncdhw_to_ndhwc': (_i, [_vp, _vp, _i, _i, _l, _i, _vp]),
+    'mt_ndhwc_to_ncdhw': (_i, [_vp, _i, _vp, _i, _i, _l, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises RuntimeError when it is missing — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            "libmtseg_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C multitalent_amd/csrc`). The engine has no CPU/PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mt_abi_version() != 1:
+        raise RuntimeError("libmtseg_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().mt_last_error()
+        raise RuntimeError("libmtseg_hip %s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ''))

@@ -1,0 +1,343 @@
+// norm.hip — InstanceNorm3d(eps, affine) + LeakyReLU forward finalisation / materialisation and the
+// fused backward, channel reductions, layout transposes.  All HBM-bound: one pass per tensor,
+// "channel-lane" mapping (32 consecutive lanes = 32 consecutive channels of one voxel, 128 B
+// coalesced), fp32 per-thread partial sums combined in fp64.
+//
+// Reference: nn.InstanceNorm3d(eps=1e-5, affine=True) + nn.LeakyReLU(1e-2, inplace) inside
+// ConvDropoutNormNonlin (generic_UNet.py:63-64,69-70; nnUNetTrainerV2.py:152-155), biased variance.
+#include "mt_common.h"
+
+// ---- finalize: partial (sum,sumsq) -> mean, rstd, scale, shift ---------------------------------
+__global__ __launch_bounds__(64) void inorm_finalize_kernel(const float* __restrict__ part, int nsb, int C, double count,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, float* mean, float* rstd, float* scale, float* shift) {
+  const int n = blockIdx.x / C, c = blockIdx.x % C;
+  const float* p = part + ((size_t)n * nsb * C + c) * 2;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = threadIdx.x; s < nsb; s += 64) {
+    s1 += (double)p[(size_t)s * C * 2];
+    s2 += (double)p[(size_t)s * C * 2 + 1];
+  }
+  s1 = mt_wave_sum_d(s1);
+  s2 = mt_wave_sum_d(s2);
+  if (threadIdx.x == 0) {
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double rs = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+    const size_t o = (size_t)n * C + c;
+    mean[o] = (float)m;
+    rstd[o] = (float)rs;
+    scale[o] = (float)(g * rs);
+    shift[o] = (float)(b - m * g * rs);
+  }
+}
+
+extern "C" int mt_inorm_finalize(const float* part, int N, int nsb, int C, double count, const float* gamma,
+                                 const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                                 mt_stream_t stream) {
+  MT_REQUIRE(part && mean && rstd && scale && shift && N > 0 && C > 0 && nsb > 0 && count > 0, "inorm_finalize: bad args");
+  hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N * C), dim3(64), 0, (hipStream_t)stream, part, nsb, C, count, gamma, beta,
+                     eps, mean, rstd, scale, shift);
+  MT_CHECK_LAUNCH("inorm_finalize");
+  return MT_OK;
+}
+
+// ---- generic voxel-block geometry for channel-lane kernels -------------------------------------
+// grid = (nvb, N); block 256 = 8 voxel rows x 32 channel lanes; block covers VB voxels.
+#define NB_VB 2048
+static inline int nb_blocks(long V) { return mt_cdiv(V, NB_VB); }
+
+// ---- materialise a = lrelu(y*sc+sh [+ residual]) ----------------------------------------------
+struct ApplyParams {
+  const float* y; int ycs; const float* scale; const float* shift; float slope;
+  const float* res; int rcs; const float* rscale; const float* rshift; float rslope;
+  float* out; int ocs; long V; int C;
+};
+__global__ __launch_bounds__(256) void inorm_apply_kernel(const ApplyParams P) {
+  const int n = blockIdx.y;
+  const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
+  const long v0 = (long)blockIdx.x * NB_VB;
+  const long v1 = (v0 + NB_VB < P.V) ? v0 + NB_VB : P.V;
+  for (int cb = 0; cb < P.C; cb += 32) {
+    const int c = cb + cl;
+    if (c >= P.C) continue;
+    const float sc = P.scale ? P.scale[(size_t)n * P.C + c] : 1.f, sh = P.scale ? P.shift[(size_t)n * P.C + c] : 0.f;
+    const float rsc = (P.res && P.rscale) ? P.rscale[(size_t)n * P.C + c] : 1.f;
+    const float rsh = (P.res && P.rscale) ? P.rshift[(size_t)n * P.C + c] : 0.f;
+    for (long v = v0 + vr; v < v1; v += 8) {
+      const size_t e = (size_t)n * P.V + v;
+      float t = fmaf(P.y[e * P.ycs + c], sc, sh);
+      if (P.res) t += mt_lrelu(fmaf(P.res[e * P.rcs + c], rsc, rsh), P.rslope);
+      P.out[e * P.ocs + c] = mt_lrelu(t, P.slope);
+    }
+  }
+}
+extern "C" int mt_inorm_lrelu_apply(const float* y, int ycs, const float* scale, const float* shift, float slope,
+                                    const float* res, int rcs, const float* rscale, const float* rshift, float rslope,
+                                    float* out, int ocs, int N, long V, int C, mt_stream_t stream) {
+  MT_REQUIRE(y && out && N > 0 && V > 0 && C > 0, "inorm_lrelu_apply: bad args");
+  ApplyParams P{y, ycs, scale, shift, slope, res, rcs, rscale, rshift, rslope, out, ocs, V, C};
+  hipLaunchKernelGGL(inorm_apply_kernel, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P);
+  MT_CHECK_LAUNCH("inorm_lrelu_apply");
+  return MT_OK;
+}
+
+// ---- backward of out = lrelu(IN(y)) -------------------------------------------------------------
+// pass 1: per (n,c) A = sum dz, B = sum dz*zhat   (dz = g * lrelu'(z)); pass 2: dy in place.
+struct InBwdParams {
+  float* g; int gcs; const float* y; int ycs;
+  const float* mean; const float* rstd; const float* gamma; const float* beta; float slope;
+  long V; int C; int nvb;
+  float* part1;  // [N][nvb][C][2]
+  float* m;      // [N][C][2]  (A/V, B/V)
+  float* part2;  // [N][nvb][C]
+};
+__global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const InBwdParams P) {
+  __shared__ float red[8][32][2];
+  const int n = blockIdx.y;
+  const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
+  const long v0 = (long)blockIdx.x * NB_VB;
+  const long v1 = (v0 + NB_VB < P.V) ? v0 + NB_VB : P.V;
+  for (int cb = 0; cb < P.C; cb += 32) {
+    const int c = cb + cl;
+    float a = 0.f, b = 0.f;
+    if (c < P.C) {
+      const float mu = P.mean[(size_t)n * P.C + c], rs = P.rstd[(size_t)n * P.C + c];
+      const float ga = P.gamma ? P.gamma[c] : 1.f, be = P.beta ? P.beta[c] : 0.f;
+      for (long v = v0 + vr; v < v1; v += 8) {
+        const size_t e = (size_t)n * P.V + v;
+        const float zh = (P.y[e * P.ycs + c] - mu) * rs;
+        const float z = fmaf(zh, ga, be);
+        float dz = P.g[e * P.gcs + c];
+        dz = z > 0.f ? dz : dz * P.slope;
+        a += dz;
+        b += dz * zh;
+      }
+    }
+    red[vr][cl][0] = a; red[vr][cl][1] = b;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int k = threadIdx.x & 1, cc = threadIdx.x >> 1;
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += red[r][cc][k];
+      if (cb + cc < P.C) P.part1[(((size_t)n * P.nvb + blockIdx.x) * P.C + cb + cc) * 2 + k] = s;
+    }
+    __syncthreads();
+  }
+}
+// finalize pass 1: m[n][c] = (A/V, B/V); dgamma[c] += sum_n B; dbeta[c] += sum_n A
+__global__ __launch_bounds__(64) void inorm_bwd_finalize_kernel(const InBwdParams P, int N, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x;
+  double ta = 0.0, tb = 0.0;
+  for (int n = 0; n < N; ++n) {
+    double a = 0.0, b = 0.0;
+    for (int s = threadIdx.x; s < P.nvb; s += 64) {
+      a += (double)P.part1[(((size_t)n * P.nvb + s) * P.C + c) * 2];
+      b += (double)P.part1[(((size_t)n * P.nvb + s) * P.C + c) * 2 + 1];
+    }
+    a = mt_wave_sum_d(a); b = mt_wave_sum_d(b);
+    if (threadIdx.x == 0) {
+      P.m[((size_t)n * P.C + c) * 2] = (float)(a / (double)P.V);
+      P.m[((size_t)n * P.C + c) * 2 + 1] = (float)(b / (double)P.V);
+    }
+    ta += a; tb += b;
+  }
+  if (threadIdx.x == 0) {
+    if (dgamma) dgamma[c] += (float)tb;
+    if (dbeta) dbeta[c] += (float)ta;
+  }
+}
+__global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const InBwdParams P) {
+  __shared__ float red[8][32];
+  const int n = blockIdx.y;
+  const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
+  const long v0 = (long)blockIdx.x * NB_VB;
+  const long v1 = (v0 + NB_VB < P.V) ? v0 + NB_VB : P.V;
+  for (int cb = 0; cb < P.C; cb += 32) {
+    const int c = cb + cl;
+    float sdy = 0.f;
+    if (c < P.C) {
+      const float mu = P.mean[(size_t)n * P.C + c], rs = P.rstd[(size_t)n * P.C + c];
+      const float ga = P.gamma ? P.gamma[c] : 1.f, be = P.beta ? P.beta[c] : 0.f;
+      const float m1 = P.m[((size_t)n * P.C + c) * 2], m2 = P.m[((size_t)n * P.C + c) * 2 + 1];
+      const float k = ga * rs;
+      for (long v = v0 + vr; v < v1; v += 8) {
+        const size_t e = (size_t)n * P.V + v;
+        const float zh = (P.y[e * P.ycs + c] - mu) * rs;
+        const float z = fmaf(zh, ga, be);
+        float dz = P.g[e * P.gcs + c];
+        dz = z > 0.f ? dz : dz * P.slope;
+        const float dy = k * (dz - m1 - zh * m2);
+        P.g[e * P.gcs + c] = dy;
+        sdy += dy;
+      }
+    }
+    if (P.part2) {
+      red[vr][cl] = sdy;
+      __syncthreads();
+      if (threadIdx.x < 32) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+        if (cb + threadIdx.x < P.C) P.part2[((size_t)n * P.nvb + blockIdx.x) * P.C + cb + threadIdx.x] = s;
+      }
+      __syncthreads();
+    }
+  }
+}
+// out[c] (+)= sum over rows of part[rows][C]
+__global__ __launch_bounds__(64) void colsum_kernel(const float* part, long rows, int C, float* out, int accumulate) {
+  const int c = blockIdx.x;
+  double a = 0.0;
+  for (long s = threadIdx.x; s < rows; s += 64) a += (double)part[(size_t)s * C + c];
+  a = mt_wave_sum_d(a);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)a : (float)a;
+}
+
+extern "C" size_t mt_inorm_bwd_workspace(int N, long V, int C) {
+  const size_t nvb = (size_t)nb_blocks(V);
+  return ((size_t)N * nvb * C * 3 + (size_t)N * C * 2) * sizeof(float);
+}
+extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, float slope, int N, long V, int C,
+                                  float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                                  mt_stream_t stream) {
+  MT_REQUIRE(g && y && mean && rstd && N > 0 && V > 0 && C > 0, "inorm_lrelu_bwd: bad args");
+  if (ws == nullptr || ws_bytes < mt_inorm_bwd_workspace(N, V, C)) { mt_set_error("inorm_lrelu_bwd: workspace too small"); return MT_EWORKSPACE; }
+  InBwdParams P;
+  P.g = g; P.gcs = gcs; P.y = y; P.ycs = ycs; P.mean = mean; P.rstd = rstd; P.gamma = gamma; P.beta = beta; P.slope = slope;
+  P.V = V; P.C = C; P.nvb = nb_blocks(V);
+  float* w = (float*)ws;
+  P.part1 = w; w += (size_t)N * P.nvb * C * 2;
+  P.m = w; w += (size_t)N * C * 2;
+  P.part2 = dbias ? w : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, P, N, dgamma, dbeta);
+  hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
+  if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(64), 0, st, (const float*)P.part2, (long)N * P.nvb, C, dbias, 0);
+  MT_CHECK_LAUNCH("inorm_lrelu_bwd");
+  return MT_OK;
+}
+
+// ---- g *= lrelu'(t), t = y*sc+sh (+ second term) ; optional copy --------------------------------
+struct LBwdParams {
+  float* g; int gcs; const float* y; int ycs; const float* scale; const float* shift; float slope;
+  const float* y2; int y2cs; const float* scale2; const float* shift2; float slope2;
+  float* gcopy; int gcopycs; long V; int C;
+};
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const LBwdParams P) {
+  const int n = blockIdx.y;
+  const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
+  const long v0 = (long)blockIdx.x * NB_VB;
+  const long v1 = (v0 + NB_VB < P.V) ? v0 + NB_VB : P.V;
+  for (int cb = 0; cb < P.C; cb += 32) {
+    const int c = cb + cl;
+    if (c >= P.C) continue;
+    const float sc = P.scale ? P.scale[(size_t)n * P.C + c] : 1.f, sh = P.scale ? P.shift[(size_t)n * P.C + c] : 0.f;
+    const float sc2 = (P.y2 && P.scale2) ? P.scale2[(size_t)n * P.C + c] : 1.f;
+    const float sh2 = (P.y2 && P.scale2) ? P.shift2[(size_t)n * P.C + c] : 0.f;
+    for (long v = v0 + vr; v < v1; v += 8) {
+      const size_t e = (size_t)n * P.V + v;
+      float t = fmaf(P.y[e * P.ycs + c], sc, sh);
+      if (P.y2) t += mt_lrelu(fmaf(P.y2[e * P.y2cs + c], sc2, sh2), P.slope2);
+      float gv = P.g[e * P.gcs + c];
+      gv = t > 0.f ? gv : gv * P.slope;
+      P.g[e * P.gcs + c] = gv;
+      if (P.gcopy) P.gcopy[e * P.gcopycs + c] = gv;
+    }
+  }
+}
+extern "C" int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale, const float* shift, float slope,
+                            const float* y2, int y2cs, const float* scale2, const float* shift2, float slope2,
+                            float* gcopy, int gcopycs, int N, long V, int C, mt_stream_t stream) {
+  MT_REQUIRE(g && y && N > 0 && V > 0 && C > 0, "lrelu_bwd: bad args");
+  LBwdParams P{g, gcs, y, ycs, scale, shift, slope, y2, y2cs, scale2, shift2, slope2, gcopy, gcopycs, V, C};
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P);
+  MT_CHECK_LAUNCH("lrelu_bwd");
+  return MT_OK;
+}
+
+// ---- per-channel sum -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* x, int xcs, long V, int C, int nvb, float* part) {
+  __shared__ float red[8][32];
+  const int n = blockIdx.y;
+  const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
+  const long v0 = (long)blockIdx.x * NB_VB;
+  const long v1 = (v0 + NB_VB < V) ? v0 + NB_VB : V;
+  for (int cb = 0; cb < C; cb += 32) {
+    const int c = cb + cl;
+    float a = 0.f;
+    if (c < C)
+      for (long v = v0 + vr; v < v1; v += 8) a += x[((size_t)n * V + v) * xcs + c];
+    red[vr][cl] = a;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+      if (cb + threadIdx.x < C) part[((size_t)n * nvb + blockIdx.x) * C + cb + threadIdx.x] = s;
+    }
+    __syncthreads();
+  }
+}
+extern "C" int mt_channel_sum(const float* x, int xcs, int N, long V, int C, float* out, int accumulate, void* ws,
+                              size_t ws_bytes, mt_stream_t stream) {
+  MT_REQUIRE(x && out && N > 0 && V > 0 && C > 0, "channel_sum: bad args");
+  const int nvb = nb_blocks(V);
+  if (ws == nullptr || ws_bytes < (size_t)N * nvb * C * sizeof(float)) { mt_set_error("channel_sum: workspace too small"); return MT_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(nvb, N), dim3(256), 0, st, x, xcs, V, C, nvb, (float*)ws);
+  hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(64), 0, st, (const float*)ws, (long)N * nvb, C, out, accumulate);
+  MT_CHECK_LAUNCH("channel_sum");
+  return MT_OK;
+}
+
+// ---- layout transposes at the module boundary (NCDHW <-> NDHWC) ------------------------------------
+__global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const float* in, float* out, int C, long V, int ocs) {
+  __shared__ float t[32][33];
+  const int n = blockIdx.z;
+  const long v0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r; const long v = v0 + tx;
+    t[r][tx] = (c < C && v < V) ? in[((size_t)n * C + c) * V + v] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const long v = v0 + r; const int c = c0 + tx;
+    if (c < C && v < V) out[((size_t)n * V + v) * ocs + c] = t[tx][r];
+  }
+}
+__global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* in, int ics, float* out, int C, long V) {
+  __shared__ float t[32][33];
+  const int n = blockIdx.z;
+  const long v0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const long v = v0 + r; const int c = c0 + tx;
+    t[r][tx] = (c < C && v < V) ? in[((size_t)n * V + v) * ics + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r; const long v = v0 + tx;
+    if (c < C && v < V) out[((size_t)n * C + c) * V + v] = t[tx][r];
+  }
+}
+extern "C" int mt_ncdhw_to_ndhwc(const float* in, float* out, int N, int C, long V, int ocs, mt_stream_t stream) {
+  MT_REQUIRE(in && out && N > 0 && C > 0 && V > 0, "ncdhw_to_ndhwc: bad args");
+  hipLaunchKernelGGL(ncdhw_to_ndhwc_kernel, dim3(mt_cdiv(V, 32), mt_cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, in, out, C, V, ocs);
+  MT_CHECK_LAUNCH("ncdhw_to_ndhwc");
+  return MT_OK;
+}
+extern "C" int mt_ndhwc_to_ncdhw(const float* in, int ics, float* out, int N, int C, long V, mt_stream_t stream) {
+  MT_REQUIRE(in && out && N > 0 && C > 0 && V > 0, "ndhwc_to_ncdhw: bad args");
+  hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel, dim3(mt_cdiv(V, 32), mt_cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, in, ics, out, C, V);
+  MT_CHECK_LAUNCH("ndhwc_to_ncdhw");
+  return MT_OK;
+}

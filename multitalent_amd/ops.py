@@ -1,0 +1,317 @@
+"""Thin torch-tensor wrappers over the C ABI (include/mtseg.h).
+
+Everything here is plumbing: torch owns device memory and streams, the arithmetic happens in
+libmtseg_hip.so.  Activations are NDHWC float32 tensors [N, D, H, W, C] (possibly channel slices of a
+wider buffer).  There is NO CPU fallback: tensors must live on a HIP device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import mt_conv3d_t, mt_pointwise_t, mt_src_t
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _check_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("multitalent_amd ops require HIP device tensors (no CPU fallback)")
+
+
+class Act:
+    """A (lazy) activation: channel slice [c0, c0+C) of an NDHWC buffer `buf` [N,D,H,W,cs], read as
+    lrelu_slope(buf*scale + shift) when scale is not None (InstanceNorm+LeakyReLU applied on load)."""
+
+    __slots__ = ('buf', 'c0', 'C', 'scale', 'shift', 'slope', 'mean', 'rstd')
+
+    def __init__(self, buf, c0=0, C=None, scale=None, shift=None, slope=1.0, mean=None, rstd=None):
+        assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype == torch.float32
+        self.buf, self.c0 = buf, c0
+        self.C = buf.shape[4] - c0 if C is None else C
+        self.scale, self.shift, self.slope = scale, shift, float(slope)
+        self.mean, self.rstd = mean, rstd
+
+    @property
+    def N(self): return self.buf.shape[0]
+
+    @property
+    def spatial(self): return tuple(self.buf.shape[1:4])
+
+    @property
+    def cs(self): return self.buf.shape[4]
+
+    @property
+    def V(self): return self.buf.shape[1] * self.buf.shape[2] * self.buf.shape[3]
+
+    def data_ptr(self):
+        return self.buf.data_ptr() + 4 * self.c0
+
+    def src(self):
+        s = mt_src_t()
+        s.ptr = self.data_ptr()
+        s.cs = self.cs
+        s.C = self.C
+        s.scale = self.scale.data_ptr() if self.scale is not None else None
+        s.shift = self.shift.data_ptr() if self.shift is not None else None
+        s.slope = self.slope
+        return s
+
+    def dense(self):
+        """Materialise to a plain [N,D,H,W,C] tensor with torch ops (test/debug helper only)."""
+        x = self.buf[..., self.c0:self.c0 + self.C]
+        if self.scale is not None:
+            x = x * self.scale[:, None, None, None, :] + self.shift[:, None, None, None, :]
+            x = torch.where(x > 0, x, x * self.slope)
+        return x.contiguous()
+
+
+def _triple(v):
+    return tuple(int(i) for i in v) if isinstance(v, (list, tuple)) or hasattr(v, '__len__') else (int(v),) * 3
+
+
+class ConvGeom:
+    """Geometry of one convolution problem as the kernels see it."""
+
+    def __init__(self, in_spatial, kernel, stride=(1, 1, 1), pad=None, dil=(1, 1, 1), out_spatial=None):
+        self.inp = _triple(in_spatial)
+        self.k = _triple(kernel)
+        self.s = _triple(stride)
+        self.p = tuple((k - 1) // 2 for k in self.k) if pad is None else _triple(pad)
+        self.dil = _triple(dil)
+        if out_spatial is None:
+            out_spatial = tuple(((i - 1) * d + 1 + 2 * p - k) // s + 1
+                                for i, d, p, k, s in zip(self.inp, self.dil, self.p, self.k, self.s))
+        self.out = _triple(out_spatial)
+
+
+def fill_conv(srcs, geom, Cout, wpack=None, bias=None, out0=None, out1=None, csplit=None, accumulate=False,
+              stats_part=None):
+    """Build an mt_conv3d_t.  srcs: list of 1-2 Act; out0/out1: Act-like destination slices."""
+    p = mt_conv3d_t()
+    p.nsrc = len(srcs)
+    for i, a in enumerate(srcs):
+        p.src[i] = a.src()
+    p.N = srcs[0].N
+    p.Di, p.Hi, p.Wi = geom.inp
+    p.dilD, p.dilH, p.dilW = geom.dil
+    p.Do, p.Ho, p.Wo = geom.out
+    p.KD, p.KH, p.KW = geom.k
+    p.SD, p.SH, p.SW = geom.s
+    p.PD, p.PH, p.PW = geom.p
+    p.Cin = sum(a.C for a in srcs)
+    p.Cout = Cout
+    p.wpack = wpack.data_ptr() if wpack is not None else None
+    p.bias = bias.data_ptr() if bias is not None else None
+    if out0 is not None:
+        p.out0 = out0.data_ptr()
+        p.ocs0 = out0.cs
+    if out1 is not None:
+        p.out1 = out1.data_ptr()
+        p.ocs1 = out1.cs
+    p.csplit = Cout if csplit is None else csplit
+    p.accumulate = 1 if accumulate else 0
+    p.stats_part = stats_part.data_ptr() if stats_part is not None else None
+    return p
+
+
+def conv_ck(p):
+    ck = _lib.load().mt_conv3d_ck(C.byref(p))
+    if ck <= 0:
+        raise RuntimeError("conv3d: no kernel configuration for this shape")
+    return ck
+
+
+def conv_stats_blocks(p):
+    return _lib.load().mt_conv3d_stats_blocks(C.byref(p))
+
+
+def pack_conv_weights(w, C0, C1, Cout, kernel, strides, flip, ck, out=None):
+    """strides = (s_ci, s_co, s_kd, s_kh, s_kw) element strides of `w` for W_eff[tap][ci][co]."""
+    lib = _lib.load()
+    _check_dev(w)
+    n = C.c_size_t(0)
+    kd, kh, kw = kernel
+    _lib.check(lib.mt_pack_conv_weights(None, None, C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, None), 'pack(query)')
+    if out is None:
+        out = torch.empty(n.value, dtype=torch.float32, device=w.device)
+    assert out.numel() >= n.value
+    _lib.check(lib.mt_pack_conv_weights(_ptr(w), _ptr(out), C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, _stream()), 'pack')
+    return out
+
+
+def conv_weight_strides(w, transposed_layout=False, as_bwd_data=False):
+    """Element strides (s_ci, s_co, s_kd, s_kh, s_kw) for a contiguous nn.Conv3d weight [Cout,Cin,kd,kh,kw]
+    (or nn.ConvTranspose3d weight [Cin,Cout,kd,kh,kw] when transposed_layout).  as_bwd_data swaps the
+    roles of ci/co (the backward-data conv maps Cout channels back to Cin channels)."""
+    k = w.shape[2] * w.shape[3] * w.shape[4]
+    s_first, s_second = w.shape[1] * k, k  # strides of dim0 / dim1
+    if not transposed_layout:
+        s_co, s_ci = s_first, s_second
+    else:
+        s_ci, s_co = s_first, s_second
+    if as_bwd_data:
+        s_ci, s_co = s_co, s_ci
+    return (s_ci, s_co, w.shape[3] * w.shape[4], w.shape[4], 1)
+
+
+def conv3d_fwd(p):
+    _lib.check(_lib.load().mt_conv3d_fwd(C.byref(p), _stream()), 'conv3d_fwd')
+
+
+def conv3d_bwd_weight_workspace(p):
+    return _lib.load().mt_conv3d_bwd_weight_workspace(C.byref(p))
+
+
+def conv3d_bwd_weight(p, y, dw, strides, accumulate, ws):
+    ys = y.src()
+    _lib.check(_lib.load().mt_conv3d_bwd_weight(C.byref(p), C.byref(ys), _ptr(dw), *strides, int(accumulate), _ptr(ws),
+                                                ws.numel() * ws.element_size(), _stream()), 'conv3d_bwd_weight')
+
+
+def fill_pointwise(src, base, in_spatial, si, so, Cout, wpack, bias, out, accumulate=False, stats_part=None):
+    p = mt_pointwise_t()
+    p.src = src.src()
+    p.N = src.N
+    p.Db, p.Hb, p.Wb = base
+    p.Di, p.Hi, p.Wi = in_spatial
+    p.siD, p.siH, p.siW = si
+    p.soD, p.soH, p.soW = so
+    p.Cin = src.C
+    p.Cout = Cout
+    p.wpack = wpack.data_ptr()
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.out = out.data_ptr()
+    p.ocs = out.cs
+    p.accumulate = 1 if accumulate else 0
+    p.stats_part = stats_part.data_ptr() if stats_part is not None else None
+    return p
+
+
+def pointwise_fwd(p):
+    _lib.check(_lib.load().mt_pointwise_fwd(C.byref(p), _stream()), 'pointwise_fwd')
+
+
+def pointwise_stats_blocks(p):
+    return _lib.load().mt_pointwise_stats_blocks(C.byref(p))
+
+
+def inorm_finalize(part, N, nsb, Cn, count, gamma, beta, eps, mean, rstd, scale, shift):
+    _lib.check(_lib.load().mt_inorm_finalize(_ptr(part), N, nsb, Cn, float(count), _ptr(gamma), _ptr(beta), float(eps),
+                                             _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift), _stream()), 'inorm_finalize')
+
+
+def inorm_lrelu_apply(y, out, res=None):
+    """out = lrelu_slope(y*scale+shift [+ res as lazy act]) materialised; y/res/out are Act."""
+    _lib.check(_lib.load().mt_inorm_lrelu_apply(
+        C.c_void_p(y.data_ptr()), y.cs, _ptr(y.scale), _ptr(y.shift), y.slope,
+        C.c_void_p(res.data_ptr()) if res is not None else None, res.cs if res is not None else 0,
+        _ptr(res.scale) if res is not None else None, _ptr(res.shift) if res is not None else None,
+        res.slope if res is not None else 1.0,
+        C.c_void_p(out.data_ptr()), out.cs, y.N, y.V, y.C, _stream()), 'inorm_lrelu_apply')
+
+
+def inorm_bwd_workspace(N, V, Cn):
+    return _lib.load().mt_inorm_bwd_workspace(N, V, Cn)
+
+
+def inorm_lrelu_bwd(g, y, gamma, beta, dgamma, dbeta, dbias, ws):
+    """g (Act over the gradient buffer, in place -> dy); y: Act with mean/rstd/slope of the forward."""
+    _lib.check(_lib.load().mt_inorm_lrelu_bwd(
+        C.c_void_p(g.data_ptr()), g.cs, C.c_void_p(y.data_ptr()), y.cs, _ptr(y.mean), _ptr(y.rstd), _ptr(gamma), _ptr(beta),
+        y.slope, y.N, y.V, y.C, _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ws), ws.numel() * ws.element_size(), _stream()),
+        'inorm_lrelu_bwd')
+
+
+def channel_sum(x, out, accumulate, ws):
+    _lib.check(_lib.load().mt_channel_sum(C.c_void_p(x.data_ptr()), x.cs, x.N, x.V, x.C, _ptr(out), int(accumulate), _ptr(ws),
+                                          ws.numel() * ws.element_size(), _stream()), 'channel_sum')
+
+
+def loss_workspace(B, V, Cn):
+    return _lib.load().mt_loss_workspace(B, V, Cn)
+
+
+def multitalent_loss_fwd(logits, target, valid, lut, stats, ws):
+    _lib.check(_lib.load().mt_multitalent_loss_fwd(C.c_void_p(logits.data_ptr()), logits.cs, _ptr(target), logits.N, logits.V,
+                                                   logits.C, _ptr(valid), _ptr(lut), _ptr(stats), _ptr(ws),
+                                                   ws.numel() * ws.element_size(), _stream()), 'multitalent_loss_fwd')
+
+
+def multitalent_loss_bwd(logits, target, valid, lut, bce_coef, gtp, gfp, gfn, dlogits):
+    _lib.check(_lib.load().mt_multitalent_loss_bwd(C.c_void_p(logits.data_ptr()), logits.cs, _ptr(target), logits.N, logits.V,
+                                                   logits.C, _ptr(valid), _ptr(lut), float(bce_coef), _ptr(gtp), _ptr(gfp),
+                                                   _ptr(gfn), C.c_void_p(dlogits.data_ptr()), dlogits.cs, _stream()),
+               'multitalent_loss_bwd')
+
+
+def softmax_dice_ce_fwd(logits, target, stats, ws):
+    _lib.check(_lib.load().mt_softmax_dice_ce_fwd(C.c_void_p(logits.data_ptr()), logits.cs, _ptr(target), logits.N, logits.V,
+                                                  logits.C, _ptr(stats), _ptr(ws), ws.numel() * ws.element_size(), _stream()),
+               'softmax_dice_ce_fwd')
+
+
+def softmax_dice_ce_bwd(logits, target, ce_coef, gtp, gfp, gfn, dlogits):
+    _lib.check(_lib.load().mt_softmax_dice_ce_bwd(C.c_void_p(logits.data_ptr()), logits.cs, _ptr(target), logits.N, logits.V,
+                                                  logits.C, float(ce_coef), _ptr(gtp), _ptr(gfp), _ptr(gfn),
+                                                  C.c_void_p(dlogits.data_ptr()), dlogits.cs, _stream()), 'softmax_dice_ce_bwd')
+
+
+def sumsq(x, out, ws):
+    _lib.check(_lib.load().mt_sumsq(_ptr(x), x.numel(), _ptr(out), _ptr(ws), ws.numel() * ws.element_size(), _stream()), 'sumsq')
+
+
+def sumsq_workspace(n):
+    return _lib.load().mt_sumsq_workspace(n)
+
+
+def sgd_nesterov(p, g, buf, lr, wd, mom, first_step, sumsq_dev, max_norm):
+    _lib.check(_lib.load().mt_sgd_nesterov(_ptr(p), _ptr(g), _ptr(buf), p.numel(), float(lr), float(wd), float(mom),
+                                           int(first_step), _ptr(sumsq_dev), float(max_norm), _stream()), 'sgd_nesterov')
+
+
+def flip_accumulate(logits, flips, nonlin, weight, acc, first):
+    D, H, W = logits.spatial
+    _lib.check(_lib.load().mt_flip_accumulate(C.c_void_p(logits.data_ptr()), logits.cs, D, H, W, logits.C, int(flips[0]),
+                                              int(flips[1]), int(flips[2]), int(nonlin), float(weight), _ptr(acc), int(first),
+                                              _stream()), 'flip_accumulate')
+
+
+def tile_accumulate(acc, gauss, Cn, patch, agg, nb, agg_shape, origin):
+    _lib.check(_lib.load().mt_tile_accumulate(_ptr(acc), _ptr(gauss), Cn, patch[0], patch[1], patch[2], _ptr(agg), _ptr(nb),
+                                              agg_shape[0], agg_shape[1], agg_shape[2], origin[0], origin[1], origin[2],
+                                              _stream()), 'tile_accumulate')
+
+
+def normalize_threshold(agg, nb, Cn, V, class_order, use_regions, seg):
+    _lib.check(_lib.load().mt_normalize_threshold(_ptr(agg), _ptr(nb), Cn, V, _ptr(class_order), int(use_regions), _ptr(seg),
+                                                  _stream()), 'normalize_threshold')
+
+
+def ncdhw_to_ndhwc(x, out=None, out_act=None):
+    """x [N,C,D,H,W] contiguous -> NDHWC.  Writes into out_act (Act slice) if given."""
+    N, Cn = x.shape[0], x.shape[1]
+    V = x.shape[2] * x.shape[3] * x.shape[4]
+    if out_act is None:
+        if out is None:
+            out = torch.empty((N,) + tuple(x.shape[2:]) + (Cn,), dtype=torch.float32, device=x.device)
+        out_act = Act(out)
+    _lib.check(_lib.load().mt_ncdhw_to_ndhwc(_ptr(x), C.c_void_p(out_act.data_ptr()), N, Cn, V, out_act.cs, _stream()),
+               'ncdhw_to_ndhwc')
+    return out_act.buf
+
+
+def ndhwc_to_ncdhw(a, out=None):
+    N, Cn = a.N, a.C
+    D, H, W = a.spatial
+    if out is None:
+        out = torch.empty((N, Cn, D, H, W), dtype=torch.float32, device=a.buf.device)
+    _lib.check(_lib.load().mt_ndhwc_to_ncdhw(C.c_void_p(a.data_ptr()), a.cs, _ptr(out), N, Cn, a.V, _stream()), 'ndhwc_to_ncdhw')
+    return out

@@ -1,0 +1,275 @@
+"""Parity of every HIP kernel (called through the C ABI) against the oracle's torch-fp32 CPU ops.
+Tolerances: 1e-4 relative-to-scale for single kernels (fp32 MFMA = exact fp32 FMA chains; only the
+summation order differs), stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from multitalent_amd import ops
+    return ops
+
+
+def to_ndhwc(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def to_ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def run_conv(dev, srcs_cpu, w, b, stride, pad, lazy=None, stats=False):
+    """srcs_cpu: list of NCDHW cpu tensors (raw); lazy: list of (scale[N,C], shift[N,C], slope) or None per src."""
+    ops = _ops()
+    N = srcs_cpu[0].shape[0]
+    acts = []
+    for i, s in enumerate(srcs_cpu):
+        buf = to_ndhwc(s).to(dev)
+        if lazy is not None and lazy[i] is not None:
+            sc, sh, sl = lazy[i]
+            acts.append(ops.Act(buf, scale=sc.to(dev).contiguous(), shift=sh.to(dev).contiguous(), slope=sl))
+        else:
+            acts.append(ops.Act(buf))
+    Cout = w.shape[0]
+    geom = ops.ConvGeom(srcs_cpu[0].shape[2:], w.shape[2:], stride, pad)
+    out = torch.full((N,) + geom.out + (Cout,), float('nan'), device=dev)
+    bd = b.to(dev) if b is not None else None   # keep alive: the struct only holds raw pointers
+    p = ops.fill_conv(acts, geom, Cout, out0=ops.Act(out), bias=bd)
+    ck = ops.conv_ck(p)
+    wd = w.to(dev).contiguous()
+    C0 = acts[0].C
+    C1 = acts[1].C if len(acts) > 1 else 0
+    wp = ops.pack_conv_weights(wd, C0, C1, Cout, w.shape[2:], ops.conv_weight_strides(wd), False, ck)
+    p.wpack = wp.data_ptr()
+    part = None
+    if stats:
+        nsb = ops.conv_stats_blocks(p)
+        part = torch.zeros((N, nsb, Cout, 2), device=dev)
+        p.stats_part = part.data_ptr()
+    ops.conv3d_fwd(p)
+    torch.cuda.synchronize()
+    return out, part
+
+
+def ref_inputs(srcs_cpu, lazy):
+    xs = []
+    for i, s in enumerate(srcs_cpu):
+        if lazy is not None and lazy[i] is not None:
+            sc, sh, sl = lazy[i]
+            t = s * sc[:, :, None, None, None] + sh[:, :, None, None, None]
+            t = torch.where(t > 0, t, t * sl)
+            xs.append(t)
+        else:
+            xs.append(s)
+    return torch.cat(xs, 1)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,shape,k,stride", [
+    (1, 30, 30, (4, 8, 32), (3, 3, 3), (1, 1, 1)),
+    (2, 30, 30, (5, 9, 37), (3, 3, 3), (1, 1, 1)),      # ragged tiles
+    (1, 1, 30, (4, 8, 32), (3, 3, 3), (1, 1, 1)),        # stem
+    (1, 30, 60, (6, 12, 34), (3, 3, 3), (2, 2, 2)),      # strided
+    (1, 60, 47, (3, 6, 12), (1, 3, 3), (1, 1, 1)),       # anisotropic kernel, Cout not multiple of 32
+    (1, 320, 320, (3, 6, 6), (3, 3, 3), (1, 2, 2)),      # bottleneck
+    (1, 30, 2, (4, 8, 16), (1, 1, 1), (1, 1, 1)),        # 1x1x1 via the conv kernel
+    (1, 17, 33, (3, 5, 7), (3, 3, 3), (1, 1, 1)),        # odd everything
+])
+def test_conv_fwd(dev, N, Cin, Cout, shape, k, stride):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((N, Cin) + shape, generator=g)
+    w = torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))
+    b = torch.randn(Cout, generator=g)
+    pad = tuple((kk - 1) // 2 for kk in k)
+    out, part = run_conv(dev, [x], w, b, stride, pad, stats=True)
+    ref = F.conv3d(x, w, b, stride=stride, padding=pad)
+    got = to_ncdhw(out.cpu())
+    assert got.shape == ref.shape
+    assert relerr(got, ref) < 1e-5
+    # per-block statistics partials sum to per-(n,c) sums
+    s = part.cpu().double().sum(1)
+    V = ref[0, 0].numel()
+    assert np.allclose(s[..., 0].numpy(), ref.double().sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3 * np.sqrt(V))
+    assert np.allclose(s[..., 1].numpy(), (ref.double() ** 2).sum((2, 3, 4)).numpy(), rtol=1e-4)
+
+
+def test_conv_fwd_two_lazy_sources(dev):
+    """concat(tconv output [identity], skip [InstanceNorm+LeakyReLU on load]) -> conv, generic_UNet.py:392."""
+    g = torch.Generator().manual_seed(2)
+    N, shape = 2, (4, 8, 32)
+    x0 = torch.randn((N, 30) + shape, generator=g)
+    x1 = torch.randn((N, 30) + shape, generator=g)
+    sc = torch.rand((N, 30), generator=g) + 0.5
+    sh = torch.randn((N, 30), generator=g)
+    w = torch.randn((30, 60, 3, 3, 3), generator=g) / 40
+    b = torch.randn(30, generator=g)
+    lazy = [None, (sc, sh, 0.01)]
+    out, _ = run_conv(dev, [x0, x1], w, b, (1, 1, 1), (1, 1, 1), lazy=lazy)
+    ref = F.conv3d(ref_inputs([x0, x1], lazy), w, b, padding=1)
+    assert relerr(to_ncdhw(out.cpu()), ref) < 1e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,shape,k,stride", [
+    (30, 30, (4, 8, 32), (3, 3, 3), (1, 1, 1)),
+    (30, 60, (6, 12, 34), (3, 3, 3), (2, 2, 2)),
+    (30, 60, (6, 12, 32), (3, 3, 3), (1, 2, 2)),
+    (24, 40, (5, 7, 9), (1, 3, 3), (1, 1, 1)),
+])
+def test_conv_bwd_data(dev, Cin, Cout, shape, k, stride):
+    """dX of nn.Conv3d = stride-1 conv of the zero-inserted dY with flipped, transposed weights."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    N = 2
+    x = torch.randn((N, Cin) + shape, generator=g, requires_grad=True)
+    w = torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))
+    pad = tuple((kk - 1) // 2 for kk in k)
+    y = F.conv3d(x, w, None, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dyb = ops.Act(to_ndhwc(dy).to(dev))
+    geom = ops.ConvGeom(dy.shape[2:], k, (1, 1, 1), tuple(kk - 1 - pp for kk, pp in zip(k, pad)), dil=stride, out_spatial=shape)
+    dx = torch.full((N,) + shape + (Cin,), float('nan'), device=dev)
+    p = ops.fill_conv([dyb], geom, Cin, out0=ops.Act(dx))
+    ck = ops.conv_ck(p)
+    wd = w.to(dev).contiguous()
+    wp = ops.pack_conv_weights(wd, Cout, 0, Cin, k, ops.conv_weight_strides(wd, as_bwd_data=True), True, ck)
+    p.wpack = wp.data_ptr()
+    ops.conv3d_fwd(p)
+    torch.cuda.synchronize()
+    assert relerr(to_ncdhw(dx.cpu()), x.grad) < 1e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,shape,k,stride", [
+    (30, 30, (4, 8, 32), (3, 3, 3), (1, 1, 1)),
+    (30, 60, (6, 12, 34), (3, 3, 3), (2, 2, 2)),
+    (60, 47, (3, 6, 12), (1, 1, 1), (1, 1, 1)),
+    (17, 33, (3, 5, 7), (3, 3, 3), (1, 1, 1)),
+    (40, 24, (5, 7, 9), (1, 3, 3), (1, 2, 2)),
+])
+def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    N = 2
+    x = torch.randn((N, Cin) + shape, generator=g)
+    w = (torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))).requires_grad_(True)
+    pad = tuple((kk - 1) // 2 for kk in k)
+    y = F.conv3d(x, w, None, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xa = ops.Act(to_ndhwc(x).to(dev))
+    ya = ops.Act(to_ndhwc(dy).to(dev))
+    geom = ops.ConvGeom(shape, k, stride, pad)
+    p = ops.fill_conv([xa], geom, Cout)
+    ws = torch.empty(max(ops.conv3d_bwd_weight_workspace(p) // 4, 1), device=dev)
+    dw = torch.full(w.shape, float('nan'), device=dev)
+    ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu(), w.grad) < 2e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,base,so", [
+    (60, 30, (4, 6, 10), (2, 2, 2)),
+    (320, 320, (3, 6, 6), (1, 2, 2)),
+    (30, 47, (4, 8, 16), (1, 1, 1)),
+])
+def test_pointwise_tconv_and_heads(dev, Cin, Cout, base, so):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    N = 2
+    x = torch.randn((N, Cin) + base, generator=g)
+    xa = ops.Act(to_ndhwc(x).to(dev))
+    if so == (1, 1, 1):
+        w = torch.randn((Cout, Cin, 1, 1, 1), generator=g) / np.sqrt(Cin)
+        ref = F.conv3d(x, w)
+        wd = w.to(dev).contiguous()
+        strides = ops.conv_weight_strides(wd)
+    else:
+        w = torch.randn((Cin, Cout) + so, generator=g) / np.sqrt(Cin)
+        ref = F.conv_transpose3d(x, w, stride=so)
+        wd = w.to(dev).contiguous()
+        strides = ops.conv_weight_strides(wd, transposed_layout=True)
+    ck = Cin + (Cin & 1)
+    wp = ops.pack_conv_weights(wd, Cin, 0, Cout, so, strides, False, ck)
+    outshape = tuple(b * s for b, s in zip(base, so))
+    out = torch.full((N,) + outshape + (Cout + 3,), float('nan'), device=dev)   # write into a wider buffer (concat slot)
+    oa = ops.Act(out, c0=0, C=Cout)
+    p = ops.fill_pointwise(xa, base, base, (1, 1, 1), so, Cout, wp, None, oa)
+    ops.pointwise_fwd(p)
+    torch.cuda.synchronize()
+    got = to_ncdhw(out[..., :Cout].cpu())
+    assert relerr(got, ref) < 1e-5
+    assert torch.isnan(out[..., Cout:]).all()
+
+
+def test_instance_norm_fwd_bwd(dev):
+    """conv epilogue partials -> finalize -> lazy apply, and the fused IN+LeakyReLU backward vs autograd."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    N, Cn, shape = 2, 30, (5, 9, 37)
+    V = int(np.prod(shape))
+    y = (torch.randn((N, Cn) + shape, generator=g) * 2 + 0.7).requires_grad_(True)
+    gamma = (torch.rand(Cn, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(Cn, generator=g).requires_grad_(True)
+    a = F.leaky_relu(F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5), 0.01)
+    ga = torch.randn(a.shape, generator=g)
+    a.backward(ga)
+    yb = to_ndhwc(y.detach()).to(dev)
+    # statistics partials the way the conv epilogue would write them: one block per sample here
+    part = torch.stack([yb.sum((1, 2, 3)), (yb * yb).sum((1, 2, 3))], -1)[:, None].contiguous()  # [N,1,C,2]
+    mean = torch.empty((N, Cn), device=dev); rstd = torch.empty_like(mean); scale = torch.empty_like(mean); shift = torch.empty_like(mean)
+    gd, bd = gamma.detach().to(dev), beta.detach().to(dev)
+    ops.inorm_finalize(part, N, 1, Cn, V, gd, bd, 1e-5, mean, rstd, scale, shift)
+    act = ops.Act(yb, scale=scale, shift=shift, slope=0.01, mean=mean, rstd=rstd)
+    out = torch.empty_like(yb)
+    ops.inorm_lrelu_apply(act, ops.Act(out))
+    torch.cuda.synchronize()
+    assert relerr(to_ncdhw(out.cpu()), a.detach()) < 2e-5
+    gbuf = to_ndhwc(ga).to(dev)
+    dgamma = torch.zeros(Cn, device=dev); dbeta = torch.zeros(Cn, device=dev); dbias = torch.empty(Cn, device=dev)
+    ws = torch.empty(ops.inorm_bwd_workspace(N, V, Cn) // 4, device=dev)
+    ops.inorm_lrelu_bwd(ops.Act(gbuf), act, gd, bd, dgamma, dbeta, dbias, ws)
+    torch.cuda.synchronize()
+    assert relerr(to_ncdhw(gbuf.cpu()), y.grad) < 5e-5
+    assert relerr(dgamma.cpu(), gamma.grad) < 5e-5
+    assert relerr(dbeta.cpu(), beta.grad) < 5e-5
+    assert float(dbias.abs().max()) < 1e-3 * float(ga.abs().sum() / Cn) + 1e-3   # sum dy == 0 analytically
+
+
+def test_sgd_nesterov_and_clip(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    n = 100003
+    p0 = torch.randn(n, generator=g); g1 = torch.randn(n, generator=g) * 0.2; g2 = torch.randn(n, generator=g) * 0.001
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([pr], 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    nflat = (n + 3) // 4 * 4
+    pd = torch.zeros(nflat, device=dev); pd[:n] = p0.to(dev)
+    gd = torch.zeros(nflat, device=dev); buf = torch.zeros(nflat, device=dev)
+    ss = torch.zeros(1, device=dev); ws = torch.empty(ops.sumsq_workspace(nflat) // 4, device=dev)
+    for step, gg in enumerate([g1, g2]):
+        pr.grad = gg.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 12)
+        opt.step()
+        gd[:n] = gg.to(dev)
+        ops.sumsq(gd, ss, ws)
+        ops.sgd_nesterov(pd, gd, buf, 1e-2, 3e-5, 0.99, step == 0, ss, 12.0)
+        torch.cuda.synchronize()
+        assert abs(float(ss.cpu()) - float((gg.double() ** 2).sum())) < 1e-4 * float((gg.double() ** 2).sum())
+        assert relerr(pd[:n].cpu(), pr.detach()) < 1e-6
+
+
+def test_layout_transposes(dev):
+    ops = _ops()
+    x = torch.randn(2, 5, 3, 7, 9)
+    nd = ops.ncdhw_to_ndhwc(x.to(dev))
+    assert torch.equal(nd.cpu(), to_ndhwc(x))
+    back = ops.ndhwc_to_ncdhw(ops.Act(nd))
+    assert torch.equal(back.cpu(), x)
