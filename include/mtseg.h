@@ -151,22 +151,22 @@ int mt_channel_sum(const float* x, int xcs, int N, long V, int C, float* out, in
  * logits [B][V][C=47 (cs)], target [B][V] float label map, valid[B] = 64-bit mask of valid output
  * channels, lut[C] = 64-bit mask over label values belonging to each channel's region
  * (Task100_MultiTalent.py:118-166).  Forward: stats[B][C][4] = (bce_sum, tp, fp, fn).
- * Backward: dlogits = w * ( valid*(sigmoid-y)/V  +  d(-dice)/dlogit ) with coefficients
- * gtp,gfp,gfn [B][C] (dLoss/dtp etc., already including -w). */
+ * Backward = exact vector-Jacobian product of the forward: given gstats[B][C][4] = dLoss/dstats,
+ * dlogits[b,v,c] = valid * ( g0*(sigmoid-y) + sigmoid*(1-sigmoid)*( y*(g1-g3) + (1-y)*g2 ) ), 0 for invalid
+ * channels — written once (the reference's autograd zero-fills a full tensor per region). */
 int mt_multitalent_loss_fwd(const float* logits, int cs, const float* target, int B, long V, int C,
                             const uint64_t* valid, const uint64_t* lut, float* stats, void* ws,
                             size_t ws_bytes, mt_stream_t stream);
 size_t mt_loss_workspace(int B, long V, int C);
 int mt_multitalent_loss_bwd(const float* logits, int cs, const float* target, int B, long V, int C,
-                            const uint64_t* valid, const uint64_t* lut, float bce_coef,
-                            const float* gtp, const float* gfp, const float* gfn,
+                            const uint64_t* valid, const uint64_t* lut, const float* gstats,
                             float* dlogits, int dcs, mt_stream_t stream);
 /* Softmax Dice+CE for one level (dice_loss.py:100-195,488-545; crossentropy.py:4-11):
  * stats[B][C][4] = (ce_sum (only c=0 slot used), tp, fp, fn). */
 int mt_softmax_dice_ce_fwd(const float* logits, int cs, const float* target, int B, long V, int C,
                            float* stats, void* ws, size_t ws_bytes, mt_stream_t stream);
 int mt_softmax_dice_ce_bwd(const float* logits, int cs, const float* target, int B, long V, int C,
-                           float ce_coef, const float* gtp, const float* gfp, const float* gfn,
+                           const float* gstats /* [B][C][4], slot (b,0,0) = dLoss/dce_sum[b] */,
                            float* dlogits, int dcs, mt_stream_t stream);
 
 /* ---- optimizer (nnUNetTrainerV2.py:166-170; clip MultiTalent_Trainer_DDP.py:352,362) --------- */

@@ -69,9 +69,9 @@ SIGNATURES = {
     'mt_channel_sum': (_i, [_vp, _i, _i, _l, _i, _vp, _i, _vp, _sz, _vp]),
     'mt_multitalent_loss_fwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'mt_loss_workspace': (_sz, [_i, _l, _i]),
-    'mt_multitalent_loss_bwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp]),
+    'mt_multitalent_loss_bwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     'mt_softmax_dice_ce_fwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _sz, _vp]),
-    'mt_softmax_dice_ce_bwd': (_i, [_vp, _i, _vp, _i, _l, _i, _f, _vp, _vp, _vp, _vp, _i, _vp]),
+    'mt_softmax_dice_ce_bwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),
     'mt_sumsq': (_i, [_vp, _l, _vp, _vp, _sz, _vp]),
     'mt_sumsq_workspace': (_sz, [_l]),
     'mt_sgd_nesterov': (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp, _f, _vp]),

@@ -85,8 +85,7 @@ extern "C" int mt_multitalent_loss_fwd(const float* logits, int cs, const float*
 __global__ __launch_bounds__(256) void mt_loss_bwd_kernel(const float* __restrict__ logits, int cs,
                                                           const float* __restrict__ target, long V, int C,
                                                           const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
-                                                          float bce_coef, const float* __restrict__ gtp,
-                                                          const float* __restrict__ gfp, const float* __restrict__ gfn,
+                                                          const float* __restrict__ gstats,
                                                           float* __restrict__ dlogits, int dcs) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -98,7 +97,8 @@ __global__ __launch_bounds__(256) void mt_loss_bwd_kernel(const float* __restric
     if (c >= C) continue;
     const bool act = (vmask >> c) & 1ull;
     const uint64_t l = act ? lut[c] : 0ull;
-    const float a_tp = act ? gtp[(size_t)b * C + c] : 0.f, a_fp = act ? gfp[(size_t)b * C + c] : 0.f, a_fn = act ? gfn[(size_t)b * C + c] : 0.f;
+    const float* gs = gstats + ((size_t)b * C + c) * 4;
+    const float bce_coef = act ? gs[0] : 0.f, a_tp = act ? gs[1] : 0.f, a_fp = act ? gs[2] : 0.f, a_fn = act ? gs[3] : 0.f;
     for (long v = v0 + wave; v < v1; v += 4) {
       const size_t e = (size_t)b * V + v;
       float d = 0.f;
@@ -118,11 +118,11 @@ __global__ __launch_bounds__(256) void mt_loss_bwd_kernel(const float* __restric
 }
 
 extern "C" int mt_multitalent_loss_bwd(const float* logits, int cs, const float* target, int B, long V, int C,
-                                       const uint64_t* valid, const uint64_t* lut, float bce_coef, const float* gtp,
-                                       const float* gfp, const float* gfn, float* dlogits, int dcs, mt_stream_t stream) {
-  MT_REQUIRE(logits && target && valid && lut && gtp && gfp && gfn && dlogits && B > 0 && V > 0 && C > 0 && C <= 64, "multitalent_loss_bwd: bad args");
+                                       const uint64_t* valid, const uint64_t* lut, const float* gstats,
+                                       float* dlogits, int dcs, mt_stream_t stream) {
+  MT_REQUIRE(logits && target && valid && lut && gstats && dlogits && B > 0 && V > 0 && C > 0 && C <= 64, "multitalent_loss_bwd: bad args");
   hipLaunchKernelGGL(mt_loss_bwd_kernel, dim3(mt_cdiv(V, LS_VB), B), dim3(256), 0, (hipStream_t)stream, logits, cs, target, V, C,
-                     valid, lut, bce_coef, gtp, gfp, gfn, dlogits, dcs);
+                     valid, lut, gstats, dlogits, dcs);
   MT_CHECK_LAUNCH("multitalent_loss_bwd");
   return MT_OK;
 }
@@ -194,16 +194,16 @@ extern "C" int mt_softmax_dice_ce_fwd(const float* logits, int cs, const float* 
 
 template <int MAXC>
 __global__ __launch_bounds__(256) void softmax_loss_bwd_kernel(const float* __restrict__ logits, int cs,
-                                                               const float* __restrict__ target, long V, int C, float ce_coef,
-                                                               const float* __restrict__ gtp, const float* __restrict__ gfp,
-                                                               const float* __restrict__ gfn, float* __restrict__ dlogits, int dcs) {
+                                                               const float* __restrict__ target, long V, int C,
+                                                               const float* __restrict__ gstats, float* __restrict__ dlogits, int dcs) {
   const int b = blockIdx.y;
   float a_tp[MAXC], a_fp[MAXC], a_fn[MAXC];
+  const float ce_coef = gstats[(size_t)b * C * 4];
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
-    a_tp[c] = (c < C) ? gtp[(size_t)b * C + c] : 0.f;
-    a_fp[c] = (c < C) ? gfp[(size_t)b * C + c] : 0.f;
-    a_fn[c] = (c < C) ? gfn[(size_t)b * C + c] : 0.f;
+    a_tp[c] = (c < C) ? gstats[((size_t)b * C + c) * 4 + 1] : 0.f;
+    a_fp[c] = (c < C) ? gstats[((size_t)b * C + c) * 4 + 2] : 0.f;
+    a_fn[c] = (c < C) ? gstats[((size_t)b * C + c) * 4 + 3] : 0.f;
   }
   const long v0 = (long)blockIdx.x * LS_VB;
   const long v1 = (v0 + LS_VB < V) ? v0 + LS_VB : V;
@@ -237,14 +237,13 @@ __global__ __launch_bounds__(256) void softmax_loss_bwd_kernel(const float* __re
 }
 
 extern "C" int mt_softmax_dice_ce_bwd(const float* logits, int cs, const float* target, int B, long V, int C,
-                                      float ce_coef, const float* gtp, const float* gfp, const float* gfn,
-                                      float* dlogits, int dcs, mt_stream_t stream) {
-  MT_REQUIRE(logits && target && gtp && gfp && gfn && dlogits && B > 0 && V > 0 && C > 1 && C <= 16, "softmax_dice_ce_bwd: bad args");
+                                      const float* gstats, float* dlogits, int dcs, mt_stream_t stream) {
+  MT_REQUIRE(logits && target && gstats && dlogits && B > 0 && V > 0 && C > 1 && C <= 16, "softmax_dice_ce_bwd: bad args");
   const int nblk = mt_cdiv(V, LS_VB);
   hipStream_t st = (hipStream_t)stream;
-  if (C <= 4) hipLaunchKernelGGL(softmax_loss_bwd_kernel<4>, dim3(nblk, B), dim3(256), 0, st, logits, cs, target, V, C, ce_coef, gtp, gfp, gfn, dlogits, dcs);
-  else if (C <= 8) hipLaunchKernelGGL(softmax_loss_bwd_kernel<8>, dim3(nblk, B), dim3(256), 0, st, logits, cs, target, V, C, ce_coef, gtp, gfp, gfn, dlogits, dcs);
-  else hipLaunchKernelGGL(softmax_loss_bwd_kernel<16>, dim3(nblk, B), dim3(256), 0, st, logits, cs, target, V, C, ce_coef, gtp, gfp, gfn, dlogits, dcs);
+  if (C <= 4) hipLaunchKernelGGL(softmax_loss_bwd_kernel<4>, dim3(nblk, B), dim3(256), 0, st, logits, cs, target, V, C, gstats, dlogits, dcs);
+  else if (C <= 8) hipLaunchKernelGGL(softmax_loss_bwd_kernel<8>, dim3(nblk, B), dim3(256), 0, st, logits, cs, target, V, C, gstats, dlogits, dcs);
+  else hipLaunchKernelGGL(softmax_loss_bwd_kernel<16>, dim3(nblk, B), dim3(256), 0, st, logits, cs, target, V, C, gstats, dlogits, dcs);
   MT_CHECK_LAUNCH("softmax_dice_ce_bwd");
   return MT_OK;
 }

@@ -1,0 +1,605 @@
+"""Execution engine: turns a Generic_UNet / FabiansUNet parameter-holder module into a static program
+of fused HIP ops and runs forward / backward through the C ABI (include/mtseg.h).
+
+Python here only sequences launches and owns buffers (torch tensors); all arithmetic is in
+libmtseg_hip.so.  Design points (MI355X-first):
+  * activations live NDHWC in HBM as RAW conv outputs + per-(n,c) scale/shift ("lazy activations"):
+    InstanceNorm+LeakyReLU is applied by the CONSUMER on load, so a conv block is one read of its input
+    and one write of its output; torch.cat is never materialised (the conv reads two sources);
+  * every buffer is allocated once and reused across iterations (288 GB HBM: no allocator traffic);
+  * all parameters are views into ONE flat buffer laid out in backward-completion order, gradients
+    likewise, so clip/SGD are single kernels and the DDP all-reduce streams contiguous slices as
+    soon as they are final (overlap with the rest of backward on a side stream).
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .ops import Act, ConvGeom
+
+LRELU_DEFAULT = 1e-2
+
+
+class Val:
+    """A node output: (lazy) activation + its gradient buffer."""
+
+    def __init__(self, name, C):
+        self.name, self.C = name, C
+        self.act = None
+        self.grad = None
+        self.grad_init = False
+        self.spatial = None
+
+
+class _Op:
+    params = ()
+
+    def plan(self, eng, N):  # allocate buffers for batch N, given input spatial dims are set
+        raise NotImplementedError
+
+    def param_list(self):
+        return []
+
+
+def _strides(w, **kw):
+    return ops.conv_weight_strides(w, **kw)
+
+
+class ConvNormOp(_Op):
+    """conv (+bias) -> InstanceNorm (stats in the conv epilogue) -> LeakyReLU (lazy).  With norm=None it is a
+    bare conv.  `lrelu=False` gives conv->norm only (residual branch / skip projection)."""
+
+    def __init__(self, name, srcs, out, conv, norm, lrelu=True, pointwise=False):
+        self.name, self.srcs, self.out, self.conv, self.norm, self.lrelu = name, srcs, out, conv, norm, lrelu
+        self.kernel = tuple(conv.kernel_size)
+        self.stride = tuple(conv.stride)
+        self.pad = tuple(conv.padding)
+        self.slope = LRELU_DEFAULT
+        self.pointwise = pointwise   # 1x1x1 (possibly strided) conv on the pointwise kernel
+
+    def param_list(self):
+        ps = [self.conv.weight]
+        if self.conv.bias is not None:
+            ps.append(self.conv.bias)
+        if self.norm is not None:
+            ps += [self.norm.weight, self.norm.bias]
+        return ps
+
+    def plan(self, eng, N):
+        dev = eng.device
+        sp = self.srcs[0].spatial
+        self.geom = ConvGeom(sp, self.kernel, self.stride, self.pad)
+        self.out.spatial = self.geom.out
+        Cout = self.conv.out_channels
+        buf = eng.buffer(self.name + '.y', (N,) + self.geom.out + (Cout,))
+        if self.norm is not None:
+            st = eng.buffer(self.name + '.stats', (4, N, Cout))
+            self.out.act = Act(buf, scale=st[2], shift=st[3], slope=self.slope if self.lrelu else 1.0, mean=st[0], rstd=st[1])
+        else:
+            self.out.act = Act(buf)
+        self.part = None
+        self.wf = self.wb = None
+
+    def _fwd_params(self, eng):
+        Cout = self.conv.out_channels
+        acts = [s.act for s in self.srcs]
+        if self.pointwise:
+            a = acts[0]
+            p = ops.fill_pointwise(a, self.geom.out, a.spatial, self.stride, (1, 1, 1), Cout, eng.dummy, self.conv.bias, self.out.act)
+            if self.norm is not None and self.part is None:
+                self.part = eng.buffer(self.name + '.part', (a.N, ops.pointwise_stats_blocks(p), Cout, 2))
+        else:
+            p = ops.fill_conv(acts, self.geom, Cout, bias=self.conv.bias, out0=self.out.act)
+            if self.norm is not None and self.part is None:
+                self.part = eng.buffer(self.name + '.part', (acts[0].N, ops.conv_stats_blocks(p), Cout, 2))
+        if self.part is not None:
+            p.stats_part = self.part.data_ptr()
+        return p
+
+    def pack(self, eng, need_bwd):
+        w = self.conv.weight
+        Cout = self.conv.out_channels
+        C0 = self.srcs[0].C
+        C1 = self.srcs[1].C if len(self.srcs) > 1 else 0
+        if self.pointwise:
+            ck = C0 + (C0 & 1)
+            self.wf = ops.pack_conv_weights(w, C0, 0, Cout, (1, 1, 1), _strides(w), False, ck, out=self.wf)
+            if need_bwd and self.srcs[0].grad is not None and self.stride == (1, 1, 1):
+                ckb = Cout + (Cout & 1)
+                self.wb = ops.pack_conv_weights(w, Cout, 0, C0, (1, 1, 1), _strides(w, as_bwd_data=True), False, ckb, out=self.wb)
+            return
+        p = self._fwd_params(eng)
+        self.ck_f = ops.conv_ck(p)
+        self.wf = ops.pack_conv_weights(w, C0, C1, Cout, self.kernel, _strides(w), False, self.ck_f, out=self.wf)
+        if need_bwd and any(s.grad is not None for s in self.srcs):
+            pb = self._bwd_data_params(eng, None)
+            self.ck_b = ops.conv_ck(pb)
+            self.wb = ops.pack_conv_weights(w, Cout, 0, C0 + C1, self.kernel, _strides(w, as_bwd_data=True), True, self.ck_b, out=self.wb)
+
+    def forward(self, eng):
+        p = self._fwd_params(eng)
+        p.wpack = self.wf.data_ptr()
+        if self.pointwise:
+            ops.pointwise_fwd(p)
+        else:
+            ops.conv3d_fwd(p)
+        if self.norm is not None:
+            a = self.out.act
+            nsb = self.part.shape[1]
+            ops.inorm_finalize(self.part, a.N, nsb, a.C, a.V, self.norm.weight, self.norm.bias, self.norm.eps,
+                               a.mean, a.rstd, a.scale, a.shift)
+
+    def _bwd_data_params(self, eng, g):
+        Cin = sum(s.C for s in self.srcs)
+        geomT = ConvGeom(self.geom.out, self.kernel, (1, 1, 1), tuple(k - 1 - p for k, p in zip(self.kernel, self.pad)),
+                         dil=self.stride, out_spatial=self.geom.inp)
+        gact = Act(g) if g is not None else Act(self.out.act.buf)  # geometry-only when g is None
+        p = ops.fill_conv([gact], geomT, Cin)
+        return p
+
+    def backward(self, eng):
+        g = self.out.grad
+        assert g is not None and self.out.grad_init, "gradient of %s was never produced" % self.name
+        gact = Act(g)
+        dbias = eng.grad_of(self.conv.bias) if self.conv.bias is not None else None
+        if self.norm is not None:
+            a = self.out.act
+            ws = eng.workspace(ops.inorm_bwd_workspace(a.N, a.V, a.C))
+            ops.inorm_lrelu_bwd(gact, a, self.norm.weight, self.norm.bias, eng.grad_of(self.norm.weight),
+                                eng.grad_of(self.norm.bias), dbias, ws)
+        elif dbias is not None:
+            ws = eng.workspace(4 * gact.N * ((gact.V + 2047) // 2048) * gact.C)
+            ops.channel_sum(gact, dbias, False, ws)
+        # backward-weight straight into the flat gradient buffer (torch parameter layout)
+        acts = [s.act for s in self.srcs]
+        pw = ops.fill_conv(acts, self.geom, self.conv.out_channels)
+        ws = eng.workspace(ops.conv3d_bwd_weight_workspace(pw))
+        dw = eng.grad_of(self.conv.weight)
+        ops.conv3d_bwd_weight(pw, gact, dw, _strides(self.conv.weight), False, ws)
+        # backward-data into the sources' gradient buffers
+        dsts = [s for s in self.srcs if s.grad is not None]
+        if not dsts:
+            return
+        assert len(dsts) == len(self.srcs)
+        inits = {s.grad_init for s in self.srcs}
+        assert len(inits) == 1, "mixed accumulate state on the sources of %s" % self.name
+        acc = inits.pop()
+        if self.pointwise:
+            if self.stride != (1, 1, 1):
+                raise NotImplementedError("backward-data of a strided pointwise conv is handled by ResBlockOp")
+            s0 = self.srcs[0]
+            p = ops.fill_pointwise(gact, self.geom.out, self.geom.out, (1, 1, 1), (1, 1, 1), s0.C, self.wb, None,
+                                   Act(s0.grad), accumulate=acc)
+            ops.pointwise_fwd(p)
+        else:
+            p = self._bwd_data_params(eng, g)
+            p.wpack = self.wb.data_ptr()
+            p.out0 = self.srcs[0].grad.data_ptr()
+            p.ocs0 = self.srcs[0].C
+            if len(self.srcs) > 1:
+                p.out1 = self.srcs[1].grad.data_ptr()
+                p.ocs1 = self.srcs[1].C
+                p.csplit = self.srcs[0].C
+            p.accumulate = 1 if acc else 0
+            ops.conv3d_fwd(p)
+        for s in self.srcs:
+            s.grad_init = True
+
+
+class TConvOp(_Op):
+    """nn.ConvTranspose3d(kernel == stride, bias=False) (generic_UNet.py:335-336)."""
+
+    def __init__(self, name, src, out, tu):
+        self.name, self.src, self.out, self.tu = name, src, out, tu
+        self.k = tuple(tu.kernel_size)
+        assert tuple(tu.stride) == self.k and tu.bias is None
+
+    def param_list(self):
+        return [self.tu.weight]
+
+    def plan(self, eng, N):
+        sp = self.src.spatial
+        self.out.spatial = tuple(a * b for a, b in zip(sp, self.k))
+        Cout = self.tu.out_channels
+        self.out.act = Act(eng.buffer(self.name + '.y', (N,) + self.out.spatial + (Cout,)))
+        self.wf = self.wb = None
+
+    def pack(self, eng, need_bwd):
+        w = self.tu.weight
+        Cin, Cout = self.tu.in_channels, self.tu.out_channels
+        self.wf = ops.pack_conv_weights(w, Cin, 0, Cout, self.k, _strides(w, transposed_layout=True), False, Cin + (Cin & 1), out=self.wf)
+        if need_bwd and self.src.grad is not None:
+            p = self._bwd_params()
+            self.ck_b = ops.conv_ck(p)
+            self.wb = ops.pack_conv_weights(w, Cout, 0, Cin, self.k, _strides(w, transposed_layout=True, as_bwd_data=True),
+                                            False, self.ck_b, out=self.wb)
+
+    def forward(self, eng):
+        a = self.src.act
+        p = ops.fill_pointwise(a, a.spatial, a.spatial, (1, 1, 1), self.k, self.tu.out_channels, self.wf, None, self.out.act)
+        ops.pointwise_fwd(p)
+
+    def _bwd_params(self):
+        # dX = conv(k = stride = pool kernel, pad 0) of dOut
+        geom = ConvGeom(self.out.spatial, self.k, self.k, (0, 0, 0))
+        g = self.out.grad if self.out.grad is not None else self.out.act.buf
+        return ops.fill_conv([Act(g)], geom, self.tu.in_channels)
+
+    def backward(self, eng):
+        g = self.out.grad
+        assert g is not None and self.out.grad_init
+        w = self.tu.weight
+        p = self._bwd_params()
+        # backward-weight: X = dOut (channels = Cout_t), Y = tconv input (lazy act, channels = Cin_t)
+        ws = eng.workspace(ops.conv3d_bwd_weight_workspace(p))
+        ops.conv3d_bwd_weight(p, self.src.act, eng.grad_of(w), _strides(w, transposed_layout=True, as_bwd_data=True), False, ws)
+        if self.src.grad is not None:
+            p.wpack = self.wb.data_ptr()
+            p.out0 = self.src.grad.data_ptr()
+            p.ocs0 = self.src.C
+            p.csplit = self.tu.in_channels
+            p.accumulate = 1 if self.src.grad_init else 0
+            ops.conv3d_fwd(p)
+            self.src.grad_init = True
+
+
+class ResAddOp(_Op):
+    """out = lrelu(main + residual) materialised (conv_blocks.py:210-213).  main = conv2->norm2 (lazy, slope 1);
+    residual = block input (dense activation) or the skip projection conv->norm (lazy, slope 1)."""
+
+    def __init__(self, name, main, res, out):
+        self.name, self.main, self.res, self.out = name, main, res, out
+        self.slope = LRELU_DEFAULT
+
+    def plan(self, eng, N):
+        self.out.spatial = self.main.spatial
+        self.out.act = Act(eng.buffer(self.name + '.a', (N,) + self.main.spatial + (self.main.C,)))
+
+    def pack(self, eng, need_bwd):
+        pass
+
+    def forward(self, eng):
+        m = self.main.act
+        y = Act(m.buf, scale=m.scale, shift=m.shift, slope=self.slope)   # outer lrelu slope; inner affine from norm2
+        ops.inorm_lrelu_apply(y, self.out.act, res=self.res.act)
+
+    def backward(self, eng):
+        g = self.out.grad
+        assert g is not None and self.out.grad_init
+        m, r = self.main.act, self.res.act
+        # g <- g * lrelu'(t), t = main + residual; the same tensor is the gradient of both branches
+        from . import _lib
+        import ctypes as C
+        gm = self.main.grad
+        # main branch gets its own buffer (it is transformed in place by the norm backward)
+        _lib.check(_lib.load().mt_lrelu_bwd(
+            C.c_void_p(g.data_ptr()), g.shape[4], C.c_void_p(m.data_ptr()), m.cs, ops._ptr(m.scale), ops._ptr(m.shift), self.slope,
+            C.c_void_p(r.data_ptr()), r.cs, ops._ptr(r.scale), ops._ptr(r.shift), r.slope,
+            C.c_void_p(gm.data_ptr()), gm.shape[4], m.N, m.V, m.C, ops._stream()), 'lrelu_bwd')
+        self.main.grad_init = True
+        # residual branch: g itself (already masked) is added to / becomes the residual's gradient
+        if self.res.grad is not None:
+            if self.res.grad_init:
+                self.res.grad.add_(g)
+            else:
+                self.res.grad.copy_(g)
+                self.res.grad_init = True
+
+
+class HeadOp(ConvNormOp):
+    """1x1x1 segmentation head (generic_UNet.py:349-351; generic_modular_UNet.py:244,251)."""
+
+    def __init__(self, name, src, out, conv):
+        super().__init__(name, [src], out, conv, None, lrelu=False, pointwise=True)
+
+
+class Engine:
+    def __init__(self, module, ops_list, x_val, head_vals, final_head_index):
+        self.module = module
+        self.ops = ops_list
+        self.x = x_val
+        self.heads = head_vals              # ordered like the module's forward output (highest resolution first)
+        self.final_head = final_head_index
+        self.device = None
+        self._buffers = {}
+        self._ws = None
+        self._planned = None
+        self._packed_version = None
+        self.flat = None
+        self.flat_grad = None
+        self._views = {}
+        self.params_version = 0
+        self.grad_ready_hook = None         # callable(lo, hi) on flat_grad element ranges, in completion order
+        self.dummy = None
+
+    # ---- memory -----------------------------------------------------------------------------------
+    def buffer(self, name, shape):
+        t = self._buffers.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            self._buffers[name] = t
+        return t
+
+    def workspace(self, nbytes):
+        n = (int(nbytes) + 3) // 4 + 16
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=self.device)
+        return self._ws
+
+    def ordered_params(self):
+        """Parameters in backward-completion order (reverse op order) — the flat-buffer layout."""
+        seen, out = set(), []
+        for op in reversed(self.ops):
+            for p in op.param_list():
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    out.append(p)
+        rest = [p for p in self.module.parameters() if id(p) not in seen]
+        return out + rest
+
+    def attach(self, device):
+        """Re-home all parameters into one flat fp32 buffer on `device` (views keep nn.Parameter identity)."""
+        params = self.ordered_params()
+        ok = self.flat is not None and self.flat.device == device
+        if ok:
+            lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
+            ok = all(lo <= p.data_ptr() < hi for p in params)
+        if ok:
+            return
+        self.device = device
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4        # 16-byte aligned slots
+        flat = torch.zeros(n, dtype=torch.float32, device=device)
+        for p, o in zip(params, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self.flat = flat
+        self.flat_grad = torch.zeros_like(flat)
+        self._views = {id(p): (o, self.flat_grad[o:o + p.numel()].view(p.shape)) for p, o in zip(params, offs)}
+        self._op_ranges = []
+        for op in reversed(self.ops):
+            ps = op.param_list()
+            if ps:
+                lo = min(self._views[id(p)][0] for p in ps)
+                hi = max(self._views[id(p)][0] + (p.numel() + 3) // 4 * 4 for p in ps)
+                self._op_ranges.append((op, lo, hi))
+        self.dummy = torch.zeros(64, dtype=torch.float32, device=device)
+        self._buffers.clear()
+        self._planned = None
+        self._packed_version = None
+        self.params_version += 1
+
+    def grad_of(self, p):
+        return self._views[id(p)][1]
+
+    def mark_params_dirty(self):
+        self.params_version += 1
+
+    # ---- planning ---------------------------------------------------------------------------------
+    def _plan(self, N, spatial, need_grad):
+        key = (N, tuple(spatial), need_grad)
+        if self._planned == key:
+            return
+        self.x.spatial = tuple(spatial)
+        for op in self.ops:
+            op.plan(self, N)
+        if need_grad:
+            for op in self.ops:
+                v = op.out
+                if isinstance(op, HeadOp):
+                    v.grad = None            # provided by the loss (dlogits)
+                else:
+                    v.grad = self.buffer(v.name + '.grad', tuple(v.act.buf.shape[:4]) + (v.C,))
+        else:
+            for op in self.ops:
+                op.out.grad = None
+        self.x.grad = None
+        self._planned = key
+        self._packed_version = None
+
+    def _pack(self, need_grad):
+        ver = (self.params_version, self.flat._version, need_grad)
+        if self._packed_version == ver:
+            return
+        for op in self.ops:
+            op.pack(self, need_grad)
+        self._packed_version = ver
+
+    # ---- execution --------------------------------------------------------------------------------
+    def forward(self, x, need_grad=True, all_heads=True):
+        """x: [N,C,D,H,W] float32 HIP tensor.  Returns list of NDHWC logits buffers (module output order)."""
+        if not x.is_cuda:
+            raise RuntimeError("multitalent_amd: the network runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
+        self.attach(x.device)
+        N, Cin = x.shape[0], x.shape[1]
+        spatial = tuple(x.shape[2:])
+        self._plan(N, spatial, need_grad)
+        x = x.contiguous().float()
+        if Cin == 1:
+            xb = x.reshape((N,) + spatial + (1,))       # NCDHW with C == 1 is already NDHWC
+        else:
+            xb = ops.ncdhw_to_ndhwc(x, out=self.buffer('x.ndhwc', (N,) + spatial + (Cin,)))
+        self.x.act = Act(xb)
+        self._pack(need_grad)
+        skip_heads = set()
+        if not all_heads:
+            skip_heads = {id(self.heads[i]) for i in range(len(self.heads)) if i != self.final_head}
+        for op in self.ops:
+            if isinstance(op, HeadOp) and id(op.out) in skip_heads:
+                continue
+            op.forward(self)
+        if all_heads:
+            return [h.act.buf for h in self.heads]
+        return [self.heads[self.final_head].act.buf]
+
+    def backward(self, dlogits):
+        """dlogits: list (module output order) of NDHWC gradient tensors or None.  Fills flat_grad."""
+        self.flat_grad.zero_()
+        for op in self.ops:
+            op.out.grad_init = False
+        for h, g in zip(self.heads, dlogits):
+            if g is not None:
+                assert tuple(g.shape) == tuple(h.act.buf.shape) and g.is_contiguous()
+                h.grad = g
+                h.grad_init = True
+            else:
+                h.grad_init = False
+        done_hi = 0
+        for op in reversed(self.ops):
+            if isinstance(op, HeadOp) and not op.out.grad_init:
+                continue
+            op.backward(self)
+            if self.grad_ready_hook is not None and op.param_list():
+                lo = min(self._views[id(p)][0] for p in op.param_list())
+                hi = max(self._views[id(p)][0] + (p.numel() + 3) // 4 * 4 for p in op.param_list())
+                done_hi = max(done_hi, hi)
+                self.grad_ready_hook(lo, done_hi)
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(self.flat_grad.numel(), self.flat_grad.numel())
+
+    # ---- autograd seam ----------------------------------------------------------------------------
+    def apply(self, x, all_heads=True):
+        need_grad = torch.is_grad_enabled() and self.module.training
+        if not x.is_cuda:
+            raise RuntimeError("multitalent_amd: the network runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
+        self.attach(x.device)   # parameters must already live in the flat device buffer when autograd records them
+        if not need_grad:
+            outs = self.forward(x, need_grad=False, all_heads=all_heads)
+            return [o.permute(0, 4, 1, 2, 3) for o in outs]
+        params = self.ordered_params()
+        return list(_UNetFunction.apply(self, all_heads, x, *params))
+
+
+class _UNetFunction(torch.autograd.Function):
+    """Whole-network autograd node: forward/backward run on the engine; gradients of the parameters are
+    returned as views of the engine's flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, eng, all_heads, x, *params):
+        ctx.eng, ctx.all_heads = eng, all_heads
+        outs = eng.forward(x, need_grad=True, all_heads=all_heads)
+        ctx.nparams = len(params)
+        return tuple(o.permute(0, 4, 1, 2, 3) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        eng = ctx.eng
+        gl = []
+        for g in gouts:
+            gl.append(None if g is None else g.permute(0, 2, 3, 4, 1).contiguous())
+        if ctx.all_heads:
+            dl = gl
+        else:
+            dl = [None] * len(eng.heads)
+            dl[eng.final_head] = gl[0]
+        eng.backward(dl)
+        grads = tuple(eng.grad_of(p) for p in eng.ordered_params())
+        return (None, None, None) + grads
+
+
+# ------------------------------------------------------------------------------------------------------
+def build_plain_unet_engine(net):
+    """Program for Generic_UNet.forward (reference generic_UNet.py:379-401)."""
+    ops_list = []
+    x = Val('x', net.conv_blocks_context[0].blocks[0].conv.in_channels)
+    cur = x
+    skips = []
+    num_pool = len(net.tu)
+
+    def block(name, srcs, blk):
+        out = Val(name, blk.conv.out_channels)
+        ops_list.append(ConvNormOp(name, srcs, out, blk.conv, blk.instnorm, lrelu=True))
+        return out
+
+    for d in range(num_pool):
+        st = net.conv_blocks_context[d]
+        for j, blk in enumerate(st.blocks):
+            cur = block('ctx%d.%d' % (d, j), [cur], blk)
+        skips.append(cur)
+    bott = net.conv_blocks_context[num_pool]
+    for i, st in enumerate(bott):
+        for j, blk in enumerate(st.blocks):
+            cur = block('ctx%d.%d.%d' % (num_pool, i, j), [cur], blk)
+    head_vals = []
+    for u in range(num_pool):
+        up = Val('tu%d' % u, net.tu[u].out_channels)
+        ops_list.append(TConvOp('tu%d' % u, cur, up, net.tu[u]))
+        srcs = [up, skips[-(u + 1)]]
+        for i, st in enumerate(net.conv_blocks_localization[u]):
+            for j, blk in enumerate(st.blocks):
+                cur = block('loc%d.%d.%d' % (u, i, j), srcs, blk)
+                srcs = [cur]
+        hv = Val('seg%d' % u, net.seg_outputs[u].out_channels)
+        ops_list.append(HeadOp('seg%d' % u, cur, hv, net.seg_outputs[u]))
+        head_vals.append(hv)
+    ordered = [head_vals[-1]] + head_vals[:-1][::-1]      # generic_UNet.py:396-399
+    return Engine(net, ops_list, x, ordered, 0)
+
+
+def build_resenc_unet_engine(net):
+    """Program for FabiansUNet.forward (generic_modular_residual_UNet.py:355-358)."""
+    enc, dec = net.encoder, net.decoder
+    ops_list = []
+    x = Val('x', enc.initial_conv.in_channels)
+    stem = Val('stem', enc.initial_conv.out_channels)
+    ops_list.append(ConvNormOp('stem', [x], stem, enc.initial_conv, enc.initial_norm, lrelu=True))
+    # the stem output is consumed by conv1 AND the residual add of the first block: materialise it
+    cur = Val('stem.a', stem.C)
+    ops_list.append(_MaterialiseOp('stem.a', stem, cur))
+    skips = []
+    for s, layer in enumerate(enc.stages):
+        for b, blk in enumerate(layer.convs):
+            name = 'enc%d.%d' % (s, b)
+            h1 = Val(name + '.c1', blk.conv1.out_channels)
+            ops_list.append(ConvNormOp(name + '.c1', [cur], h1, blk.conv1, blk.norm1, lrelu=True))
+            h2 = Val(name + '.c2', blk.conv2.out_channels)
+            ops_list.append(ConvNormOp(name + '.c2', [h1], h2, blk.conv2, blk.norm2, lrelu=False))
+            if blk.downsample_skip is not None:
+                res = Val(name + '.sk', blk.out_planes)
+                ops_list.append(ConvNormOp(name + '.sk', [cur], res, blk.downsample_skip[0], blk.downsample_skip[1],
+                                           lrelu=False))
+            else:
+                res = cur
+            out = Val(name, blk.out_planes)
+            ops_list.append(ResAddOp(name, h2, res, out))
+            cur = out
+        skips.append(cur)
+    skips = skips[::-1]
+    cur = skips[0]
+    head_vals = []
+    for i in range(len(dec.tus)):
+        up = Val('dtu%d' % i, dec.tus[i].out_channels)
+        ops_list.append(TConvOp('dtu%d' % i, cur, up, dec.tus[i]))
+        blk = dec.stages[i].convs[0]
+        cur = Val('dec%d' % i, blk.conv.out_channels)
+        ops_list.append(ConvNormOp('dec%d' % i, [up, skips[i + 1]], cur, blk.conv, blk.norm, lrelu=True))
+        hv = Val('dseg%d' % i, dec.deep_supervision_outputs[i].out_channels)
+        ops_list.append(HeadOp('dseg%d' % i, cur, hv, dec.deep_supervision_outputs[i]))
+        head_vals.append(hv)
+    ordered = head_vals[::-1]                               # generic_modular_UNet.py:288
+    return Engine(net, ops_list, x, ordered, 0)
+
+
+class _MaterialiseOp(_Op):
+    """dense copy a = lrelu(IN(y)) of a lazy activation that has more than one kind of consumer."""
+
+    def __init__(self, name, src, out):
+        self.name, self.src, self.out = name, src, out
+
+    def plan(self, eng, N):
+        self.out.spatial = self.src.spatial
+        self.out.act = Act(eng.buffer(self.name, (N,) + self.src.spatial + (self.src.C,)))
+
+    def pack(self, eng, need_bwd):
+        pass
+
+    def forward(self, eng):
+        ops.inorm_lrelu_apply(self.src.act, self.out.act)
+
+    def backward(self, eng):
+        # the gradient w.r.t. the materialised activation IS the gradient w.r.t. the lazy one: alias the buffer
+        assert self.out.grad_init
+        self.src.grad = self.out.grad
+        self.src.grad_init = True

@@ -245,10 +245,10 @@ def multitalent_loss_fwd(logits, target, valid, lut, stats, ws):
                                                    ws.numel() * ws.element_size(), _stream()), 'multitalent_loss_fwd')
 
 
-def multitalent_loss_bwd(logits, target, valid, lut, bce_coef, gtp, gfp, gfn, dlogits):
+def multitalent_loss_bwd(logits, target, valid, lut, gstats, dlogits):
     _lib.check(_lib.load().mt_multitalent_loss_bwd(C.c_void_p(logits.data_ptr()), logits.cs, _ptr(target), logits.N, logits.V,
-                                                   logits.C, _ptr(valid), _ptr(lut), float(bce_coef), _ptr(gtp), _ptr(gfp),
-                                                   _ptr(gfn), C.c_void_p(dlogits.data_ptr()), dlogits.cs, _stream()),
+                                                   logits.C, _ptr(valid), _ptr(lut), _ptr(gstats),
+                                                   C.c_void_p(dlogits.data_ptr()), dlogits.cs, _stream()),
                'multitalent_loss_bwd')
 
 
@@ -258,9 +258,9 @@ def softmax_dice_ce_fwd(logits, target, stats, ws):
                'softmax_dice_ce_fwd')
 
 
-def softmax_dice_ce_bwd(logits, target, ce_coef, gtp, gfp, gfn, dlogits):
+def softmax_dice_ce_bwd(logits, target, gstats, dlogits):
     _lib.check(_lib.load().mt_softmax_dice_ce_bwd(C.c_void_p(logits.data_ptr()), logits.cs, _ptr(target), logits.N, logits.V,
-                                                  logits.C, float(ce_coef), _ptr(gtp), _ptr(gfp), _ptr(gfn),
+                                                  logits.C, _ptr(gstats),
                                                   C.c_void_p(dlogits.data_ptr()), dlogits.cs, _stream()), 'softmax_dice_ce_bwd')
 
 

@@ -1,0 +1,186 @@
+"""Fused segmentation losses on the HIP path.
+
+Each deep-supervision level is ONE kernel pass producing a tiny statistics tensor stats[B, C, 4] =
+(bce/ce sum, tp, fp, fn); the scalar loss is then combined from these statistics with ordinary torch
+ops on [B, C]-sized tensors (host-side glue, a few hundred floats), and the backward kernel is the exact
+vector-Jacobian product of the statistics w.r.t. the logits — dlogits is written once, NDHWC, and
+handed to the network engine without a copy.
+
+Reference semantics:
+  * MultiTalent: MultiTalent_Trainer_DDP.py:544-623 (== MultiTalent_meets_resenc.py:713-798) — BCE is the
+    MEAN over voxels, SUMMED over valid regions and samples; Dice has NO smooth term, clamp 1e-7, summed;
+    with batch_dice the statistics are all_gathered and summed over RANKS only (distributed.py:63).
+  * softmax Dice+CE: dice_loss.py:100-195,488-545, crossentropy.py:4-11, deep_supervision.py:19-43,
+    DDP variant nnUNetTrainerV2_DDP.py:249-282.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import distributed_utils
+from ... import ops
+from ...dataset_conversion.Task100_MultiTalent import (MultiTalent_region_output_idx_mapping, MultiTalent_regions,
+                                                       region_label_lut, valid_mask)
+from ...ops import Act
+
+_ws_cache = {}
+
+
+def _workspace(dev, nbytes):
+    n = (int(nbytes) + 3) // 4 + 16
+    t = _ws_cache.get(dev)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1 << 18), dtype=torch.float32, device=dev)
+        _ws_cache[dev] = t
+    return t
+
+
+def _as_ndhwc(logits):
+    """logits: logical [B,C,D,H,W].  Returns a dense NDHWC tensor sharing memory when the strides are channels-last
+    (which is what the engine returns)."""
+    if not logits.is_cuda:
+        raise RuntimeError("fused losses run on the HIP device only (no CPU fallback)")
+    return logits.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _target_flat(target):
+    """[B,1,D,H,W] (or [B,D,H,W]) float label map -> contiguous float32 [B, V]."""
+    t = target
+    if t.dim() == 5:
+        t = t[:, 0]
+    return t.reshape(t.shape[0], -1).contiguous().float()
+
+
+class _MultiTalentStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, valid, lut):
+        x = _as_ndhwc(logits)
+        a = Act(x)
+        stats = torch.empty((a.N, a.C, 4), dtype=torch.float32, device=x.device)
+        ws = _workspace(x.device, ops.loss_workspace(a.N, a.V, a.C))
+        ops.multitalent_loss_fwd(a, target, valid, lut, stats, ws)
+        ctx.save_for_backward(x, target, valid, lut)
+        return stats
+
+    @staticmethod
+    def backward(ctx, gstats):
+        x, target, valid, lut = ctx.saved_tensors
+        d = torch.empty_like(x)
+        ops.multitalent_loss_bwd(Act(x), target, valid, lut, gstats.contiguous().float(), Act(d))
+        return d.permute(0, 4, 1, 2, 3), None, None, None
+
+
+class _SoftmaxStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        x = _as_ndhwc(logits)
+        a = Act(x)
+        stats = torch.empty((a.N, a.C, 4), dtype=torch.float32, device=x.device)
+        ws = _workspace(x.device, ops.loss_workspace(a.N, a.V, a.C))
+        ops.softmax_dice_ce_fwd(a, target, stats, ws)
+        ctx.save_for_backward(x, target)
+        return stats
+
+    @staticmethod
+    def backward(ctx, gstats):
+        x, target = ctx.saved_tensors
+        d = torch.empty_like(x)
+        ops.softmax_dice_ce_bwd(Act(x), target, gstats.contiguous().float(), Act(d))
+        return d.permute(0, 4, 1, 2, 3), None
+
+
+class MultiTalentLoss(nn.Module):
+    """Callable with the signature of MultiTalent_trainer_ddp.compute_loss(output, target, valid_regions)
+    -> (total_loss, total_ce, total_dc)."""
+
+    def __init__(self, ds_loss_weights, batch_dice=True, regions=None, region_idx=None):
+        super().__init__()
+        self.ds_loss_weights = [float(w) for w in ds_loss_weights]
+        self.batch_dice = batch_dice
+        self.regions = MultiTalent_regions if regions is None else regions
+        self.region_idx = MultiTalent_region_output_idx_mapping if region_idx is None else region_idx
+        lut = [0] * len(self.regions)
+        for name, labels in self.regions.items():
+            m = 0
+            for l in labels:
+                m |= (1 << int(l))
+            lut[self.region_idx[name]] = m
+        self._lut_host = np.array(lut, dtype=np.uint64).view(np.int64)
+        self._lut = {}
+
+    def _masks(self, valid_regions, dev):
+        if dev not in self._lut:
+            self._lut[dev] = torch.from_numpy(self._lut_host.copy()).to(dev)
+        v = []
+        for names in valid_regions:
+            m = 0
+            for r in names:
+                m |= (1 << self.region_idx[r])
+            v.append(m)
+        valid = torch.from_numpy(np.array(v, dtype=np.uint64).view(np.int64)).to(dev)
+        return valid, self._lut[dev]
+
+    def forward(self, output, target, valid_regions):
+        dev = output[0].device
+        valid, lut = self._masks(valid_regions, dev)
+        total_loss = total_ce = total_dc = None
+        stats_all, nvox = [], []
+        for i in range(len(output)):
+            t = _target_flat(target[i])
+            stats_all.append(_MultiTalentStats.apply(output[i], t, valid, lut))   # [B, C, 4]
+            nvox.append(t.shape[1])
+        stats_all = torch.stack(stats_all, 0)                                  # [L, B, C, 4]
+        dice_stats = stats_all[..., 1:]
+        if self.batch_dice:
+            # sum over RANKS only (same local sample index), one collective for all levels (distributed.py:60-73)
+            dice_stats = distributed_utils.sum_over_ranks(dice_stats)
+        for i in range(len(output)):
+            w = self.ds_loss_weights[i]
+            ce_loss = stats_all[i, :, :, 0].sum() / nvox[i]                    # mean over voxels, summed over (b, region)
+            tp, fp, fn = dice_stats[i, :, :, 0], dice_stats[i, :, :, 1], dice_stats[i, :, :, 2]
+            dc = (2 * tp / torch.clamp(2 * tp + fp + fn, min=1e-7)).sum()
+            l = w * (ce_loss - dc)
+            total_loss = l if total_loss is None else total_loss + l
+            total_ce = w * ce_loss if total_ce is None else total_ce + w * ce_loss
+            total_dc = w * dc if total_dc is None else total_dc + w * dc
+        return total_loss, total_ce, total_dc
+
+
+class DC_and_CE_DS_loss(nn.Module):
+    """MultipleOutputLoss2(DC_and_CE_loss({'batch_dice', 'smooth': 1e-5, 'do_bg': False}, {}), weights)
+    (nnUNetTrainer.py:108, nnUNetTrainerV2.py:78-90) fused per level.  `ddp=True` reproduces
+    nnUNetTrainerV2_DDP.compute_loss (no +1e-8 in the denominator, batch-dice statistics gathered over ranks)."""
+
+    def __init__(self, ds_loss_weights, batch_dice=False, smooth=1e-5, do_bg=False, ddp=False):
+        super().__init__()
+        self.ds_loss_weights = [float(w) for w in ds_loss_weights]
+        self.batch_dice, self.smooth, self.do_bg, self.ddp = batch_dice, smooth, do_bg, ddp
+
+    def level_loss(self, logits, target):
+        t = _target_flat(target)
+        stats = _SoftmaxStats.apply(logits, t)                                 # [B, C, 4]
+        B, V = t.shape
+        ce = stats[:, 0, 0].sum() / (B * V)                                    # CrossEntropyLoss mean over all voxels
+        tp, fp, fn = stats[:, :, 1], stats[:, :, 2], stats[:, :, 3]
+        if not self.do_bg:
+            tp, fp, fn = tp[:, 1:], fp[:, 1:], fn[:, 1:]
+        if self.ddp:
+            # nnUNetTrainerV2_DDP.py:262-279
+            nominator = 2 * tp
+            denominator = 2 * tp + fp + fn
+            if self.batch_dice:   # gathered [W,B,C-1] summed over the rank axis only -> still [B, C-1]
+                nd = distributed_utils.sum_over_ranks(torch.stack((nominator, denominator), 0))
+                nominator, denominator = nd[0], nd[1]
+            dice_loss = (-(nominator + self.smooth) / (denominator + self.smooth)).mean()
+            return ce + dice_loss
+        if self.batch_dice:
+            tp, fp, fn = tp.sum(0), fp.sum(0), fn.sum(0)
+        dc = (2 * tp + self.smooth) / (2 * tp + fp + fn + self.smooth + 1e-8)  # dice_loss.py:180-183
+        return ce - dc.mean()
+
+    def forward(self, output, target):
+        l = self.ds_loss_weights[0] * self.level_loss(output[0], target[0])
+        for i in range(1, len(output)):
+            if self.ds_loss_weights[i] != 0:
+                l = l + self.ds_loss_weights[i] * self.level_loss(output[i], target[i])
+        return l
