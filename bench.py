@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: CT patches/s (48x192x192) for one training iteration
+(forward + loss + backward + clip_grad_norm_(12) + SGD-Nesterov step) on synthetic device-resident batches,
+dummyLoad style (reference: nnUNet_variants/benchmarking/nnUNetTrainerV2_dummyLoad.py:26-64).
+
+  python bench.py --gpus N --steps K --warmup W
+N == 1: BASELINE.json configs[1] = Task009_Spleen Generic_UNet, bs=2, patch 48x192x192, fp32 (softmax Dice+CE).
+N  > 1: launched by torch.distributed.run, one rank per GPU (RCCL); same per-GPU workload (weak scaling), gradients
+        all-reduced (mean) overlapped with backward on a side stream.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+PATCH = (48, 192, 192)
+POOLS = [[2, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2]]
+KERNELS = [[3, 3, 3]] * 6
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+
+
+def build_network(workload):
+    from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
+    from multitalent_amd.network_architecture.initialization import InitWeights_He
+    nc = 2 if workload == 'task009' else 47
+    return Generic_UNet(1, 30, nc, len(POOLS), 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
+                        nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True},
+                        True, False, lambda x: x, InitWeights_He(1e-2), POOLS, KERNELS, False, True, True)
+
+
+def make_batch(workload, B, dev, rank):
+    from multitalent_amd.synthetic import ds_scales, synthetic_ct, synthetic_targets
+    from multitalent_amd.dataset_conversion.Task100_MultiTalent import MultiTalent_regions, MultiTalent_valid_regions
+    scales = ds_scales(POOLS)
+    x = synthetic_ct(B, PATCH, 1234 + rank, dev)
+    if workload == 'task009':
+        t = synthetic_targets(B, PATCH, scales, [[1]] * B, 1234 + rank, dev)
+        return x, (t,)
+    names = list(MultiTalent_valid_regions.keys())
+    valid = [MultiTalent_valid_regions[names[(rank * B + b) % len(names)]] for b in range(B)]
+    label_sets = [sorted({l for r in v for l in MultiTalent_regions[r]}) for v in valid]
+    t = synthetic_targets(B, PATCH, scales, label_sets, 1234 + rank, dev)
+    return x, (t, valid)
+
+
+def make_loss(workload, ddp):
+    from multitalent_amd.training.ds_weights import ds_loss_weights
+    from multitalent_amd.training.loss_functions.fused_losses import DC_and_CE_DS_loss, MultiTalentLoss
+    w = ds_loss_weights(len(POOLS))
+    if workload == 'task009':
+        return DC_and_CE_DS_loss(w, batch_dice=False, ddp=ddp)
+    return MultiTalentLoss(w, batch_dice=True)
+
+
+def conv_flops(engine):
+    """Algorithmic FLOPs of one fwd+bwd of the whole batch: fwd = sum_conv 2*|out|*Cin*k^3, fwd+bwd = 3x."""
+    from multitalent_amd.engine import ConvNormOp, TConvOp
+    f = 0.0
+    for op in engine.ops:
+        if isinstance(op, TConvOp):
+            a = op.src.act
+            f += 2.0 * a.N * a.V * op.tu.in_channels * op.tu.out_channels * int(np.prod(op.k))
+        elif isinstance(op, ConvNormOp):
+            a = op.out.act
+            cin = sum(s.C for s in op.srcs)
+            f += 2.0 * a.N * a.V * cin * a.C * int(np.prod(op.kernel))
+    return f
+
+
+def measure_roofline(step, x, largs, nrep=2):
+    """Per-launch HIP-event timing of the dominant kernel (conv_fwd_kernel: forward and backward-data convolutions)."""
+    from multitalent_amd import ops
+    rec = []
+    orig = ops.conv3d_fwd
+
+    def timed(p):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(p)
+        e1.record()
+        flops = 2.0 * p.N * p.Do * p.Ho * p.Wo * p.Cin * p.Cout * p.KD * p.KH * p.KW
+        # zero-insertion (strided backward-data) multiplies structural zeros: algorithmic work is 1/prod(dil)
+        flops /= (p.dilD * p.dilH * p.dilW)
+        rec.append((e0, e1, flops))
+
+    ops.conv3d_fwd = timed
+    try:
+        for _ in range(nrep):
+            step(x, *largs)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv3d_fwd = orig
+    tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+    tot_fl = sum(f for _, _, f in rec)
+    n = len(rec)
+    ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    return {"bound": "mfma", "kernel": "conv_fwd_kernel (fwd + bwd-data convs)", "achieved": round(ach, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": None, "launches_per_step": n // nrep, "avg_launch_ms": round(tot_ms / max(n, 1), 4),
+            "kernel_ms_per_step": round(tot_ms / nrep, 3)}
+
+
+def cpu_baseline(workload):
+    """Oracle (CPU restatement of the reference path) timed on the host cores: one full training iteration at B=1."""
+    from oracle import reference_ops as R
+    from multitalent_amd.synthetic import ds_scales, synthetic_ct, synthetic_targets
+    torch.manual_seed(0)
+    net = build_network(workload)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    B = 1
+    x = synthetic_ct(B, PATCH, 99, 'cpu')
+    t = synthetic_targets(B, PATCH, ds_scales(POOLS), [[1]] * B, 99, 'cpu')
+    w = R.ds_loss_weights(len(POOLS))
+    params = list(sd.values())
+    opt = torch.optim.SGD(params, 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    t0 = time.time()
+    out = R.generic_unet_forward(sd, x, POOLS, KERNELS)
+    if workload == 'task009':
+        loss = R.multiple_output_loss(out, t, w)
+    else:
+        from multitalent_amd.dataset_conversion.Task100_MultiTalent import (MultiTalent_regions, MultiTalent_region_output_idx_mapping,
+                                                                            MultiTalent_valid_regions)
+        loss = R.multitalent_loss(list(out), t, [MultiTalent_valid_regions['Task009_Spleen']], MultiTalent_regions,
+                                  MultiTalent_region_output_idx_mapping, w)[0]
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(params, 12)
+    opt.step()
+    dt = time.time() - t0
+    return {"value": round(B / dt, 4), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": "1 training iteration (fwd+loss+bwd+clip+SGD), batch 1, patch 48x192x192, fp32, torch CPU oracle, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default=None, choices=[None, 'task009', 'task100'])
+    ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    ddp = world > 1
+    if ddp:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', init_method='env://')
+    workload = args.workload or ('task009' if args.gpus == 1 else 'task100')
+    B = args.batch or (2 if workload == 'task009' else 4)
+
+    from multitalent_amd.training.hot_loop import FusedTrainStep
+    torch.manual_seed(1234)           # identical initial weights on all ranks (DDP broadcast semantics)
+    net = build_network(workload)
+    net.train()
+    step = FusedTrainStep(net, make_loss(workload, ddp), lr=1e-2, ddp=ddp)
+    x, largs = make_batch(workload, B, dev, rank)
+
+    for _ in range(args.warmup):
+        step(x, *largs)
+    torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step(x, *largs)
+    torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if ddp:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = res[0] if isinstance(res, tuple) else res
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    line = None
+    if rank == 0:
+        fl = conv_flops(step.eng) * 3.0
+        line = {
+            "metric": "CT patches/s (48x192x192) train fwd+bwd", "value": round(value, 3), "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("Task009_Spleen Generic_UNet nc=2 softmax Dice+CE" if workload == 'task009'
+                                    else "Task100_MultiTalent Generic_UNet nc=47 MultiTalent BCE+Dice loss"),
+                       "patch": list(PATCH), "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "dp%d" % world, "step": "fwd+loss+bwd+clip12+SGD-nesterov",
+                       "final_loss": round(float(loss), 5)},
+            "algorithmic_tflop_per_step": round(fl / 1e12, 3),
+            "step_frac_of_mfma_roofline": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+        }
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            line["roofline"] = measure_roofline(step, x, largs)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(workload)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if ddp:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

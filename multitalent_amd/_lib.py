@@ -53,7 +53,7 @@ _P = C.POINTER
 SIGNATURES = {
     'mt_last_error': (C.c_char_p, []),
     'mt_abi_version': (_i, []),
-    'mt_pack_conv_weights': (_i, [_vp, _vp, _P(_sz), _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _vp]),
+    'mt_pack_conv_weights': (_i, [_vp, _vp, _P(_sz), _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _i, _vp]),
     'mt_conv3d_fwd': (_i, [_P(mt_conv3d_t), _vp]),
     'mt_conv3d_stats_blocks': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_ck': (_i, [_P(mt_conv3d_t)]),
@@ -90,6 +90,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64: import it FIRST so this library binds to the same HIP runtime instance
+    # (two runtimes in one process cannot share streams / device pointers).
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(
             "libmtseg_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "

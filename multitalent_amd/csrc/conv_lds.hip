@@ -16,6 +16,7 @@
 //  * epilogue adds bias, writes NDHWC (optionally into two destinations = split of a concat
 //    gradient, optionally accumulating) and emits per-block (sum, sumsq) partials for InstanceNorm.
 #include "mt_common.h"
+#include <stdlib.h>
 
 struct ConvChunk { short src, c0, ck, cglob; };
 
@@ -23,6 +24,8 @@ struct ConvKParams {
   mt_conv3d_t c;
   int tilesD, tilesH, tilesW, nsb;
   int nchunks, ntaps;
+  int dbg;       // timing ablations (MT_CONV_DBG): 1 skip staging, 2 skip weight loads, 4 skip epilogue, 8 skip MFMA
+  int stagger;   // one-time start delay (units of ~6.4k cycles) per residency slot of the first block wave
   ConvChunk chunk[MT_MAX_CHUNKS];
 };
 
@@ -47,13 +50,22 @@ static int mt_build_chunks(int C0, int C1, int ck, ConvChunk* out) {
 // ------------------------------------------------------------------------------------------------
 // Input-tile staging shared by forward and backward-weight kernels.
 // Tile origin (ud0,uh0,uw0) in VIRTUAL input coordinates, extent LD x LH x LW, channel slots CK.
+// Each wave owns rows wave, wave+4, ... of the (LD*LH)-row tile; a row is walked in steps of VPS = 64/CK
+// voxels x CK channels (64 lanes = CK contiguous channels of VPS consecutive voxels).  Lean addressing:
+// global address = wave-uniform row base + per-lane constant + step * (VPS*cs); LDS address likewise, so a
+// staged element costs ~1 load, a bounds select, the fused InstanceNorm+LeakyReLU and 1 ds_write.
+// Two rows x STAGE_NI steps are issued back-to-back before the LDS stores (deep memory-level parallelism).
+// LDS image: voxel lv (linear index in the LD x LH x LW tile) x CK channel slots, channel c stored at slot
+// c ^ ((lv >> 1) & (CK-1)): with an even CK-dword voxel stride this XOR swizzle makes the A-fragment reads
+// (32 consecutive voxels, one channel) bank-conflict free WITHOUT padding the voxel stride, which is what lets
+// three 52 KiB workgroups share a CU's 160 KiB LDS.
+#define STAGE_NI 9
+__device__ __forceinline__ int mt_swz(int lv, int c, int ckmask) { return c ^ ((lv >> 1) & ckmask); }
 template <int CK>
 __device__ __forceinline__ void mt_stage_input(float* __restrict__ lds, const mt_conv3d_t& c,
                                                const ConvChunk ch, int nb, int ud0, int uh0, int uw0,
                                                int LD, int LH, int LW, int lane, int wave) {
-  constexpr int CKP = CK + 1;
   constexpr int VPS = 64 / CK;  // voxels per 64-lane step
-  constexpr int U = 4;
   const mt_src_t& S = c.src[ch.src];
   const int cl = lane % CK, vl = lane / CK;
   const bool cvalid = cl < ch.ck;
@@ -65,44 +77,221 @@ __device__ __forceinline__ void mt_stage_input(float* __restrict__ lds, const mt
   }
   const float slope = S.slope;
   const int nrows = LD * LH;
-  for (int row = wave; row < nrows; row += 4) {
-    const int ld = row / LH, lhh = row - ld * LH;
-    const int ud = ud0 + ld, uh = uh0 + lhh;
-    int sd = ud, shh = uh;
-    bool rvalid = (ud >= 0) && (uh >= 0);
-    if (c.dilD == 2) { rvalid = rvalid && !(ud & 1); sd = ud >> 1; }
-    if (c.dilH == 2) { rvalid = rvalid && !(uh & 1); shh = uh >> 1; }
-    rvalid = rvalid && (sd < c.Di) && (shh < c.Hi);
-    const float* rowp = S.ptr + ((size_t)((size_t)nb * c.Di + sd) * c.Hi + shh) * c.Wi * S.cs + ch.c0 + cl;
-    float* ldsrow = lds + (size_t)row * LW * CKP + cl;
-    for (int lw0 = 0; lw0 < LW; lw0 += VPS * U) {
-      float v[U];
+  const int NI = (LW + VPS - 1) / VPS;
+  const int dilW = c.dilW;
+  // per-lane constants: first virtual w of this lane, its stored-w offset (elements) and LDS offset
+  const int uwl = uw0 + vl;
+  const float* lanep = S.ptr + ch.c0 + cl;
+  const int cs = S.cs;
+  for (int row0 = wave; row0 < nrows; row0 += 8) {
+    for (int i0 = 0; i0 < NI; i0 += STAGE_NI) {
+      float v[2][STAGE_NI];
+      bool okv[2][STAGE_NI];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int lw = lw0 + u * VPS + vl;
-        const int uw = uw0 + lw;
-        int sw = uw;
-        bool ok = rvalid && cvalid && (lw < LW) && (uw >= 0);
-        if (c.dilW == 2) { ok = ok && !(uw & 1); sw = uw >> 1; }
-        ok = ok && (sw < c.Wi);
-        float x = 0.f;
-        if (ok) {
-          x = rowp[(size_t)sw * S.cs];
-          if (has_aff) x = mt_lrelu(fmaf(x, sc, sh), slope);
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = row0 + 4 * rr;
+        const int ld = row / LH, lhh = row - ld * LH;
+        const int ud = ud0 + ld, uh = uh0 + lhh;
+        int sd = ud, shh = uh;
+        bool rvalid = (row < nrows) && (ud >= 0) && (uh >= 0);
+        if (c.dilD == 2) { rvalid = rvalid && !(ud & 1); sd = ud >> 1; }
+        if (c.dilH == 2) { rvalid = rvalid && !(uh & 1); shh = uh >> 1; }
+        rvalid = rvalid && (sd < c.Di) && (shh < c.Hi) && cvalid;
+        const float* rowp = lanep + ((size_t)((size_t)nb * c.Di + sd) * c.Hi + shh) * c.Wi * cs;  // wave-uniform part + lane const
+#pragma unroll
+        for (int u = 0; u < STAGE_NI; ++u) {
+          const int i = i0 + u;
+          const int lw = i * VPS + vl;
+          const int uw = uwl + i * VPS;
+          int sw = uw;
+          bool ok = rvalid && (i < NI) && (lw < LW) && (uw >= 0);
+          if (dilW == 2) { ok = ok && !(uw & 1); sw = uw >> 1; }
+          ok = ok && (sw < c.Wi);
+          float x = 0.f;
+          if (ok) x = rowp[(long)sw * cs];
+          v[rr][u] = x;
+          okv[rr][u] = ok;
         }
-        v[u] = x;
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int lw = lw0 + u * VPS + vl;
-        if (lw < LW) ldsrow[lw * CKP] = v[u];
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = row0 + 4 * rr;
+        if (row < nrows) {
+          const int lv0 = row * LW + vl;
+#pragma unroll
+          for (int u = 0; u < STAGE_NI; ++u) {
+            const int i = i0 + u;
+            const int lw = i * VPS + vl;
+            if (i < NI && lw < LW) {
+              float x = v[rr][u];
+              if (has_aff && okv[rr][u]) x = mt_lrelu(fmaf(x, sc, sh), slope);
+              const int lv = lv0 + i * VPS;
+              lds[lv * CK + mt_swz(lv, cl, CK - 1)] = x;
+            }
+          }
+        }
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int MW, int RH, int TD, int CK>
+// FAST staging: compile-time tile geometry (3x3x3 / stride 1 / no zero insertion).  Buffer loads with hardware
+// bounds checking return 0 for out-of-range lanes (zero padding costs no branch): a lane whose w or channel is
+// out of range carries byte offset 0x80000000, which stays >= num_records after adding the row offset.  All
+// RPW x NI loads of a wave are in flight before the first LDS store.
+template <int CK, int LD, int LH, int LW>
+__device__ __forceinline__ void mt_stage_fast(float* __restrict__ lds, const mt_conv3d_t& c, const ConvChunk ch,
+                                              int nb, int ud0, int uh0, int uw0, int lane, int wave) {
+  constexpr int VPS = 64 / CK, NI = (LW + VPS - 1) / VPS, R = LD * LH, RPW = (R + 3) / 4;
+  const mt_src_t& S = c.src[ch.src];
+  const int cl = lane % CK, vl = lane / CK;
+  const bool cvalid = cl < ch.ck;
+  const bool has_aff = S.scale != nullptr;
+  float sc = 1.f, sh = 0.f;
+  if (has_aff && cvalid) {
+    sc = S.scale[(size_t)nb * S.C + ch.c0 + cl];
+    sh = S.shift[(size_t)nb * S.C + ch.c0 + cl];
+  }
+  const float slope = S.slope;
+  const int cs = S.cs;
+  const size_t sample_elems = (size_t)c.Di * c.Hi * c.Wi * cs;
+  __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * sample_elems), 0, (int)(sample_elems * 4), 0x00020000);
+  int voff[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int lw = vl + i * VPS;
+    const int uw = uw0 + lw;
+    const bool ok = cvalid && (lw < LW) && ((unsigned)uw < (unsigned)c.Wi);
+    voff[i] = ok ? (uw * cs + ch.c0 + cl) * 4 : (int)0x80000000;
+  }
+  constexpr int RG = (RPW > 3) ? 3 : RPW;       // rows per batch: RG*NI loads in flight, bounded register use
+#pragma unroll
+  for (int r0 = 0; r0 < RPW; r0 += RG) {
+    float v[RG][NI];
+    bool rv[RG];
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      const int row = wave + 4 * (r0 + q);
+      const int ld = row / LH, lhh = row % LH;
+      const int ud = ud0 + ld, uh = uh0 + lhh;
+      rv[q] = (r0 + q < RPW) && (row < R) && ((unsigned)ud < (unsigned)c.Di) && ((unsigned)uh < (unsigned)c.Hi);
+      if (rv[q]) {
+        const int srow = (ud * c.Hi + uh) * c.Wi * cs * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[q][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[i] + srow, 0, 0));
+      } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[q][i] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      const int row = wave + 4 * (r0 + q);
+      if (r0 + q < RPW && row < R) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int lw = vl + i * VPS;
+          if ((i + 1) * VPS <= LW || lw < LW) {
+            float x = v[q][i];
+            if (has_aff) x = (rv[q] && voff[i] >= 0) ? mt_lrelu(fmaf(x, sc, sh), slope) : 0.f;
+            const int lv = row * LW + lw;
+            lds[lv * CK + (cl ^ ((lv >> 1) & (CK - 1)))] = x;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA phase of one staged channel chunk: for every tap, NK channel pairs x MT voxel tiles of
+// v_mfma_f32_32x32x2_f32.  Straight-line per tap (NK is a compile-time constant, no branches), and the
+// A fragments (LDS) and B fragments (packed weights, L2) of tap t+1 are fetched into a second register
+// set while the MFMAs of tap t issue, so neither LDS nor L2 latency sits in front of the matrix pipe.
+struct TapWalk { int KH, KW, step_w, step_h, step_d; };
+
+template <int MT, int NK>
+struct ConvFrag { float a[MT][NK]; float b[NK]; };
+
+// swizzled LDS dword index of channel lhalf*NK of voxel lv; channel lhalf*NK + kp is this value ^ kp
+template <int CK>
+__device__ __forceinline__ int conv_a0(int lv, int lhalf) { return lv * CK + ((lhalf * (CK / 2)) ^ ((lv >> 1) & (CK - 1))); }
+// weights: layout 1 of mt_pack_conv_weights, wq points at this lane's float4 of (tap, q = 0)
+template <int NK>
+__device__ __forceinline__ void conv_load_b(float (&b)[NK], const float* __restrict__ wq) {
+#pragma unroll
+  for (int q = 0; q < NK / 4; ++q) {
+    const f32x4 v = *(const f32x4*)(wq + q * 256);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[q * 4 + e] = v[e];
+  }
+}
+
+// One tap = NK steps; step kp issues the loads of channel pair kp of the NEXT tap (1 weight load, MT LDS reads with
+// their XOR) and then the MT MFMAs of channel pair kp of the CURRENT tap.  sched_barrier(0) between steps pins this
+// even interleave: non-matrix instructions sit one-per-gap behind 64-cycle MFMAs instead of in a ~70-instruction bunch
+// that idles the matrix pipe (tools/ubench/mfma_peak.hip: interleaved fillers are free, bunched ones are not).
+template <int MT, int NK>
+__device__ __forceinline__ void conv_tap_step(ConvFrag<MT, NK>& nxt, const ConvFrag<MT, NK>& cur,
+                                              const float* __restrict__ lds, const int (&abase)[MT], int off,
+                                              const float* __restrict__ wq, int lhalf, f32x16 (&acc)[MT]) {
+  int a0[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a0[m] = conv_a0<2 * NK>(abase[m] + off, lhalf);
+  conv_load_b<NK>(nxt.b, wq);
+#pragma unroll
+  for (int kp = 0; kp < NK; ++kp) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) nxt.a[m][kp] = lds[a0[m] ^ kp];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[m][kp], cur.b[kp], acc[m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int MT, int NK>
+__device__ __forceinline__ void conv_chunk_compute(const float* __restrict__ lds, const int (&abase)[MT],
+                                                   const float* __restrict__ wq, int ntaps, int wstride,
+                                                   const TapWalk tw, int lhalf, f32x16 (&acc)[MT]) {
+  ConvFrag<MT, NK> f0, f1;
+  int off = 0, kw = 0, kh = 0, tap = 0;
+  auto advance = [&]() {   // move (off, wq) to the next tap; stays on the last tap at the end
+    if (tap + 1 < ntaps) {
+      off += tw.step_w;
+      if (++kw == tw.KW) { kw = 0; off += tw.step_h; if (++kh == tw.KH) { kh = 0; off += tw.step_d; } }
+      wq += wstride;
+    }
+    ++tap;
+  };
+  {  // prologue: fragments of tap 0
+    conv_load_b<NK>(f0.b, wq);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int a0 = conv_a0<2 * NK>(abase[m], lhalf);
+#pragma unroll
+      for (int kp = 0; kp < NK; ++kp) f0.a[m][kp] = lds[a0 ^ kp];
+    }
+  }
+  while (tap + 2 <= ntaps) {
+    advance();
+    __builtin_amdgcn_sched_barrier(0);
+    conv_tap_step<MT, NK>(f1, f0, lds, abase, off, wq, lhalf, acc);
+    advance();
+    __builtin_amdgcn_sched_barrier(0);
+    conv_tap_step<MT, NK>(f0, f1, lds, abase, off, wq, lhalf, acc);
+  }
+  if (tap < ntaps) {
+#pragma unroll
+    for (int kp = 0; kp < NK; ++kp)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.a[m][kp], f0.b[kp], acc[m], 0, 0, 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MW, int RH, int TD, int CK, bool FAST>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
   constexpr int MH = 32 / MW;
   constexpr int TH = MH * RH;
@@ -110,7 +299,6 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
   constexpr int NMT = TD * RH;
   static_assert(NMT % 4 == 0, "M tiles must split over 4 waves");
   constexpr int MT = NMT / 4;
-  constexpr int CKP = CK + 1;
   constexpr int NKP = CK / 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -128,9 +316,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
   const int nb = tile / P.tilesD;
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
 
-  const int LD = (TD - 1) * c.SD + c.KD, LH = (TH - 1) * c.SH + c.KH, LW = (TW - 1) * c.SW + c.KW;
+  // FAST: 3x3x3, stride 1, pad 1, no zero insertion -> the whole tile geometry is compile-time
+  const int KD = FAST ? 3 : c.KD, KH = FAST ? 3 : c.KH, KW = FAST ? 3 : c.KW;
+  const int SD = FAST ? 1 : c.SD, SH = FAST ? 1 : c.SH, SW = FAST ? 1 : c.SW;
+  const int LD = (TD - 1) * SD + KD, LH = (TH - 1) * SH + KH, LW = (TW - 1) * SW + KW;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
-  const int ud0 = od0 * c.SD - c.PD, uh0 = oh0 * c.SH - c.PH, uw0 = ow0 * c.SW - c.PW;
+  const int ud0 = od0 * SD - (FAST ? 1 : c.PD), uh0 = oh0 * SH - (FAST ? 1 : c.PH), uw0 = ow0 * SW - (FAST ? 1 : c.PW);
 
   // per-lane LDS base of each M tile: voxel (dm, row, col) of the tile, channel half lhalf
   int abase[MT];
@@ -140,7 +331,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
     const int dm = mt / RH, rh = mt % RH;
     const int r = li / MW, col = li % MW;
     const int row = rh * MH + r;
-    abase[m] = ((dm * c.SD * LH + row * c.SH) * LW + col * c.SW) * CKP + lhalf;
+    abase[m] = (dm * SD * LH + row * SH) * LW + col * SW;   // voxel index inside the LDS tile
   }
 
   f32x16 acc[MT];
@@ -149,42 +340,39 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[m][j] = 0.f;
 
-  const int ntaps = P.ntaps;
+  // De-phase the workgroups that share a CU: all workgroups have identical duration, so without this they stage
+  // together and then contend for the matrix pipe together.  The k-th initially resident workgroup of a CU (blocks
+  // are dealt round-robin: slot = blockIdx / 256) starts k*stagger later; later workgroups inherit the offset.
+  // Pure performance heuristic — correctness never depends on placement or timing.
+  if (P.stagger > 0 && blockIdx.y == 0) {
+    const int slot = blockIdx.x >> 8;
+    if (slot > 0 && slot < 4)
+      for (int i = 0; i < slot * P.stagger; ++i) __builtin_amdgcn_s_sleep(100);
+  }
+
+  long long* tsbuf = (P.dbg & 16) ? ((long long*)c.out1 + ((size_t)blockIdx.x * 4 + wave) * 16) : nullptr;
+  int tsn = 0;
+#define MT_STAMP() do { if (tsbuf && lane == 0 && tsn < 16) tsbuf[tsn++] = __builtin_readcyclecounter(); } while (0)
+  MT_STAMP();
+  const int ntaps = FAST ? 27 : P.ntaps;
   for (int ch = 0; ch < P.nchunks; ++ch) {
     const ConvChunk cc = P.chunk[ch];
-    const float* wq = c.wpack + ((size_t)(ntile * P.nchunks + ch) * ntaps) * (NKP * 64) + lane;
-    float bcur[NKP], bnxt[NKP];
-#pragma unroll
-    for (int kp = 0; kp < NKP; ++kp) bcur[kp] = wq[kp * 64];
-
+    const float* wq = c.wpack + ((size_t)(ntile * P.nchunks + ch) * ntaps) * (NKP * 64) + lane * 4;
     __syncthreads();  // previous chunk's LDS reads are done
-    mt_stage_input<CK>(lds, c, cc, nb, ud0, uh0, uw0, LD, LH, LW, lane, wave);
+    MT_STAMP();
+    if (!(P.dbg & 1)) {
+      if constexpr (FAST) mt_stage_fast<CK, TD + 2, TH + 2, TW + 2>(lds, c, cc, nb, ud0, uh0, uw0, lane, wave);
+      else mt_stage_input<CK>(lds, c, cc, nb, ud0, uh0, uw0, LD, LH, LW, lane, wave);
+    }
+    MT_STAMP();
     __syncthreads();
+    MT_STAMP();
 
-    const int nkp = (cc.ck + 1) >> 1;
-    int tap = 0;
-    for (int kd = 0; kd < c.KD; ++kd)
-      for (int kh = 0; kh < c.KH; ++kh)
-        for (int kw = 0; kw < c.KW; ++kw) {
-          const int tapoff = ((kd * LH + kh) * LW + kw) * CKP;
-          const int tnext = (tap + 1 < ntaps) ? tap + 1 : tap;
-          const float* wn = wq + (size_t)tnext * (NKP * 64);
-#pragma unroll
-          for (int kp = 0; kp < NKP; ++kp) bnxt[kp] = wn[kp * 64];
-#pragma unroll
-          for (int kp = 0; kp < NKP; ++kp) {
-            if (kp < nkp) {
-#pragma unroll
-              for (int m = 0; m < MT; ++m) {
-                const float a = lds[abase[m] + tapoff + 2 * kp];
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bcur[kp], acc[m], 0, 0, 0);
-              }
-            }
-          }
-#pragma unroll
-          for (int kp = 0; kp < NKP; ++kp) bcur[kp] = bnxt[kp];
-          ++tap;
-        }
+    // channels beyond cc.ck are zero both in LDS and in the packed weights: always run all NKP pairs (one
+    // straight-line code path keeps the register allocation small; <= 1/16 padded work for C = 30, 60, 120)
+    const TapWalk tw0{KH, KW, 1, LW - KW, (LH - KH) * LW};   // tap walk in voxels
+    if (!(P.dbg & 8)) conv_chunk_compute<MT, NKP>(lds, abase, wq, ntaps, (P.dbg & 2) ? 0 : NKP * 64, tw0, lhalf, acc);
+    MT_STAMP();
   }
 
   // ---- epilogue: bias, store, InstanceNorm partial statistics
@@ -206,7 +394,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
       const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf;
       const int r = iv / MW, col = iv % MW;
       const int oh = oh0 + rh * MH + r, ow = ow0 + col;
-      const bool ok = covalid && (od < c.Do) && (oh < c.Ho) && (ow < c.Wo);
+      const bool ok = covalid && (od < c.Do) && (oh < c.Ho) && (ow < c.Wo) && !(P.dbg & 4);
       if (ok) {
         const size_t idx = ((size_t)((size_t)((size_t)nb * c.Do + od) * c.Ho + oh) * c.Wo + ow) * ocs + cofs;
         float v = acc[m][j] + bv;
@@ -217,6 +405,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
       }
     }
   }
+  MT_STAMP();
   if (c.stats_part != nullptr) {
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
@@ -231,13 +420,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
       sp[0] = t1; sp[1] = t2;
     }
   }
+  MT_STAMP();
+#undef MT_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side of mt_conv3d_fwd
 struct ConvCfg { int MW, RH, TD, CK; };
 static const ConvCfg kCfgs[] = {
-  {32, 4, 2, 16}, {16, 2, 2, 16}, {8, 2, 2, 16}, {32, 4, 2, 8}, {16, 2, 2, 8}, {8, 2, 2, 8},
+  {32, 4, 2, 16}, {16, 2, 2, 16}, {8, 2, 2, 16}, {32, 4, 2, 8}, {16, 2, 2, 8}, {8, 2, 2, 8}, {32, 4, 4, 16},
 };
 
 static void cfg_tile(const ConvCfg& g, int* TD, int* TH, int* TW) {
@@ -246,11 +437,14 @@ static void cfg_tile(const ConvCfg& g, int* TD, int* TH, int* TW) {
 static size_t cfg_lds(const ConvCfg& g, const mt_conv3d_t* p) {
   int TD, TH, TW; cfg_tile(g, &TD, &TH, &TW);
   const size_t LD = (TD - 1) * p->SD + p->KD, LH = (TH - 1) * p->SH + p->KH, LW = (TW - 1) * p->SW + p->KW;
-  size_t b = LD * LH * LW * (g.CK + 1) * sizeof(float);
+  size_t b = LD * LH * LW * g.CK * sizeof(float);
   return b < 1024 ? 1024 : b;
 }
 // choose the tile shape with the least padded work that fits LDS; prefer >=2 workgroups per CU
 static int pick_cfg(const mt_conv3d_t* p) {
+  static int force = -2;
+  if (force == -2) { const char* e = getenv("MT_CONV_CFG"); force = e ? atoi(e) : -1; }
+  if (force >= 0 && cfg_lds(kCfgs[force], p) <= 160 * 1024) return force;
   int best = -1; double bestcost = 1e300;
   for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i) {
     const ConvCfg& g = kCfgs[i];
@@ -291,7 +485,15 @@ static int conv_validate(const mt_conv3d_t* p) {
   return MT_OK;
 }
 
-template <int MW, int RH, int TD, int CK>
+static bool conv_is_fast(const mt_conv3d_t* p) {
+  if (!(p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 1 && p->PH == 1 &&
+        p->PW == 1 && p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
+  for (int i = 0; i < p->nsrc; ++i)
+    if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 4.0 >= 2147483648.0) return false;  // 31-bit buffer offsets per sample
+  return true;
+}
+
+template <int MW, int RH, int TD, int CK, bool FAST>
 static int launch_conv(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
   ConvKParams P;
   P.c = *p;
@@ -302,9 +504,17 @@ static int launch_conv(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
   P.ntaps = p->KD * p->KH * p->KW;
   P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, CK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d, ck=%d)", p->Cin, CK);
+  {
+    static int stagger_env = -1;
+    if (stagger_env < 0) { const char* e = getenv("MT_CONV_STAGGER"); stagger_env = e ? atoi(e) : 0; }
+    P.stagger = stagger_env;
+    static int dbg_env = -1;
+    if (dbg_env < 0) { const char* e = getenv("MT_CONV_DBG"); dbg_env = e ? atoi(e) : 0; }
+    P.dbg = dbg_env;
+  }
   const size_t ldsb = cfg_lds(g, p);
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
-  auto kfn = conv_fwd_kernel<MW, RH, TD, CK>;
+  auto kfn = conv_fwd_kernel<MW, RH, TD, CK, FAST>;
   if (ldsb > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
@@ -321,13 +531,15 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   MT_REQUIRE(i >= 0, "conv3d: no tile configuration fits LDS");
   const ConvCfg& g = kCfgs[i];
   hipStream_t st = (hipStream_t)stream;
+  const bool fast = conv_is_fast(p);
   switch (i) {
-    case 0: return launch_conv<32, 4, 2, 16>(p, g, st);
-    case 1: return launch_conv<16, 2, 2, 16>(p, g, st);
-    case 2: return launch_conv<8, 2, 2, 16>(p, g, st);
-    case 3: return launch_conv<32, 4, 2, 8>(p, g, st);
-    case 4: return launch_conv<16, 2, 2, 8>(p, g, st);
-    case 5: return launch_conv<8, 2, 2, 8>(p, g, st);
+    case 0: return fast ? launch_conv<32, 4, 2, 16, true>(p, g, st) : launch_conv<32, 4, 2, 16, false>(p, g, st);
+    case 1: return fast ? launch_conv<16, 2, 2, 16, true>(p, g, st) : launch_conv<16, 2, 2, 16, false>(p, g, st);
+    case 2: return fast ? launch_conv<8, 2, 2, 16, true>(p, g, st) : launch_conv<8, 2, 2, 16, false>(p, g, st);
+    case 3: return fast ? launch_conv<32, 4, 2, 8, true>(p, g, st) : launch_conv<32, 4, 2, 8, false>(p, g, st);
+    case 4: return launch_conv<16, 2, 2, 8, false>(p, g, st);
+    case 5: return launch_conv<8, 2, 2, 8, false>(p, g, st);
+    case 6: return fast ? launch_conv<32, 4, 4, 16, true>(p, g, st) : launch_conv<32, 4, 4, 16, false>(p, g, st);
   }
   return MT_EINVAL;
 }
@@ -337,7 +549,7 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
 //   lane l holds W_eff[tap][ci = chunk.cglob + 2*kp + (l>>5)][co = ntile*32 + (l&31)]
 struct PackParams {
   const float* w; float* dst;
-  int Cout, KD, KH, KW, nkp, nchunks, ntiles, flip;
+  int Cout, KD, KH, KW, nkp, nchunks, ntiles, flip, layout;
   long s_ci, s_co, s_kd, s_kh, s_kw;
   ConvChunk chunk[MT_MAX_CHUNKS];
 };
@@ -345,15 +557,25 @@ __global__ void pack_weights_kernel(const PackParams P) {
   const long total = (long)P.ntiles * P.nchunks * P.KD * P.KH * P.KW * P.nkp * 64;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long r = i;
-    const int l = (int)(r % 64); r /= 64;
-    const int kp = (int)(r % P.nkp); r /= P.nkp;
+    int l, kp;
+    if (P.layout == 1) {      // [.. tap][kp/4][lane][4]: one float4 per lane carries 4 consecutive channel pairs
+      const int e = (int)(r % 4); r /= 4;
+      l = (int)(r % 64); r /= 64;
+      const int q = (int)(r % (P.nkp / 4)); r /= (P.nkp / 4);
+      kp = q * 4 + e;
+    } else {                  // [.. tap][kp][lane]
+      l = (int)(r % 64); r /= 64;
+      kp = (int)(r % P.nkp); r /= P.nkp;
+    }
     const int kw = (int)(r % P.KW); r /= P.KW;
     const int kh = (int)(r % P.KH); r /= P.KH;
     const int kd = (int)(r % P.KD); r /= P.KD;
     const int ch = (int)(r % P.nchunks); r /= P.nchunks;
     const int nt = (int)r;
     const ConvChunk cc = P.chunk[ch];
-    const int cin_local = 2 * kp + (l >> 5);
+    // layout 0: MFMA step kp contracts channels (2kp, 2kp+1); layout 1: channels (kp, nkp + kp) — each lane half
+    // then owns nkp CONTIGUOUS channels of a voxel, which the conv kernels fetch with two ds_read_b128
+    const int cin_local = (P.layout == 1) ? (l >> 5) * P.nkp + kp : 2 * kp + (l >> 5);
     const int co = nt * 32 + (l & 31);
     float v = 0.f;
     if (cin_local < cc.ck && co < P.Cout) {
@@ -367,8 +589,9 @@ __global__ void pack_weights_kernel(const PackParams P) {
 
 extern "C" int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats, int C0, int C1, int Cout,
                                     int KD, int KH, int KW, long s_ci, long s_co, long s_kd, long s_kh, long s_kw,
-                                    int flip, int ck, mt_stream_t stream) {
+                                    int flip, int ck, int layout, mt_stream_t stream) {
   MT_REQUIRE(ck >= 2 && (ck % 2) == 0, "pack: ck must be even (got %d)", ck);
+  MT_REQUIRE(layout == 0 || (layout == 1 && (ck % 8) == 0), "pack: layout 1 needs ck %% 8 == 0");
   PackParams P;
   P.nchunks = mt_build_chunks(C0, C1, ck, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "pack: too many chunks");
@@ -378,7 +601,7 @@ extern "C" int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_f
   if (packed_floats) *packed_floats = total;
   if (dst == nullptr) return MT_OK;
   MT_REQUIRE(w != nullptr, "pack: null weights");
-  P.w = w; P.dst = dst; P.Cout = Cout; P.KD = KD; P.KH = KH; P.KW = KW; P.flip = flip;
+  P.w = w; P.dst = dst; P.Cout = Cout; P.KD = KD; P.KH = KH; P.KW = KW; P.flip = flip; P.layout = layout;
   P.s_ci = s_ci; P.s_co = s_co; P.s_kd = s_kd; P.s_kh = s_kh; P.s_kw = s_kw;
   int blocks = mt_cdiv((long)total, 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
@@ -405,9 +628,45 @@ struct BwdWParams {
 #define BW_CK 16
 #define BW_YP 48
 #define BW_MAXT 7
+#define BW_YU 16
+
+// MFMA phase of one backward-weight tile: K = voxels (4 per v_mfma_f32_16x16x4_f32), NT taps of this wave x
+// 2 halves of 16 couts; operands of k-step i+1 are fetched from LDS while the MFMAs of k-step i issue.
+struct BwdwWalk { int wsteps, TH, dx_w, dx_h, dx_d, nsteps; };
+
+template <int NT>
+__device__ __forceinline__ void bwdw_tile_compute(const float* __restrict__ xl, const float* __restrict__ yl,
+                                                  const int (&tapoff)[BW_MAXT], int xb, int yb, const BwdwWalk wk,
+                                                  int li, f32x4 (&acc)[BW_MAXT][2]) {
+  float acur[NT], anxt[NT], b0c, b1c, b0n, b1n;
+  auto xaddr = [&](int lv) { return lv * BW_CK + (li ^ ((lv >> 1) & (BW_CK - 1))); };   // swizzled X tile (see mt_swz)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acur[t] = xl[xaddr(xb + tapoff[t])];
+  b0c = yl[yb]; b1c = yl[yb + 16];
+  int ws = 0, hs = 0;
+  for (int st = 0; st < wk.nsteps; ++st) {
+    int xn = xb, yn = yb;
+    if (st + 1 < wk.nsteps) {
+      xn += wk.dx_w; yn += 4 * BW_YP;
+      if (++ws == wk.wsteps) { ws = 0; xn += wk.dx_h; if (++hs == wk.TH) { hs = 0; xn += wk.dx_d; } }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) anxt[t] = xl[xaddr(xn + tapoff[t])];
+    b0n = yl[yn]; b1n = yl[yn + 16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[t], b0c, acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[t], b1c, acc[t][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acur[t] = anxt[t];
+    b0c = b0n; b1c = b1n;
+    xb = xn; yb = yn;
+  }
+}
 
 __global__ __launch_bounds__(256) void conv_bwdw_kernel(const BwdWParams P) {
-  constexpr int CK = BW_CK, CKP = CK + 1, YP = BW_YP;
+  constexpr int CK = BW_CK, YP = BW_YP;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -418,7 +677,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_kernel(const BwdWParams P) {
   const int TD = P.TD, TH = P.TH, TW = P.TW, TV = TD * TH * TW;
   const int LD = (TD - 1) * c.SD + c.KD, LH = (TH - 1) * c.SH + c.KH, LW = (TW - 1) * c.SW + c.KW;
   float* xl = lds;
-  float* yl = lds + (size_t)LD * LH * LW * CKP;
+  float* yl = lds + (size_t)LD * LH * LW * CK;
 
   // taps handled by this wave: wave, wave+4, ...
   int tapoff[BW_MAXT];
@@ -429,7 +688,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_kernel(const BwdWParams P) {
     tapoff[t] = 0;
     if (tap < P.ntaps) {
       const int kw = tap % c.KW, kh = (tap / c.KW) % c.KH, kd = tap / (c.KW * c.KH);
-      tapoff[t] = ((kd * LH + kh) * LW + kw) * CKP;
+      tapoff[t] = (kd * LH + kh) * LW + kw;   // in voxels
       mytaps = t + 1;
     }
   }
@@ -451,39 +710,58 @@ __global__ __launch_bounds__(256) void conv_bwdw_kernel(const BwdWParams P) {
     const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
     __syncthreads();
     mt_stage_input<CK>(xl, c, cc, nb, od0 * c.SD - c.PD, oh0 * c.SH - c.PH, ow0 * c.SW - c.PW, LD, LH, LW, lane, wave);
-    // stage Y tile: [TV][32 couts]
+    // stage Y tile: [TV][32 couts]; thread = (co = tid&31, voxel lane tid>>5), 8 voxels of a row per pass,
+    // BW_YU loads in flight before the LDS stores
     {
-      const int col = tid & 31;
+      const int col = tid & 31, wv = tid >> 5;
       const int co = cot * 32 + col;
       const bool cok = co < c.Cout;
       float ysc = 1.f, ysh = 0.f;
       const bool yaff = Y.scale != nullptr;
       if (yaff && cok) { ysc = Y.scale[(size_t)nb * Y.C + co]; ysh = Y.shift[(size_t)nb * Y.C + co]; }
-      for (int v = tid >> 5; v < TV; v += 8) {
-        const int w = v % TW, h = (v / TW) % TH, d = v / (TW * TH);
-        const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
-        float x = 0.f;
-        if (cok && od < c.Do && oh < c.Ho && ow < c.Wo) {
-          x = Y.ptr[((size_t)((size_t)((size_t)nb * c.Do + od) * c.Ho + oh) * c.Wo + ow) * Y.cs + co];
-          if (yaff) x = mt_lrelu(fmaf(x, ysc, ysh), Y.slope);
+      const int nrowsY = TD * TH, NP = (TW + 7) >> 3;
+      int rowy = 0, pass = 0;
+      while (rowy < nrowsY) {
+        float yv[BW_YU];
+        int yo[BW_YU];
+#pragma unroll
+        for (int u = 0; u < BW_YU; ++u) {
+          yo[u] = -1;
+          if (rowy < nrowsY) {
+            const int d = rowy / TH, h = rowy - d * TH;
+            const int w = pass * 8 + wv;
+            const int od = od0 + d, oh = oh0 + h, ow = ow0 + w;
+            const bool ok = cok && (w < TW) && od < c.Do && oh < c.Ho && ow < c.Wo;
+            float x = 0.f;
+            if (ok) x = Y.ptr[((size_t)((size_t)((size_t)nb * c.Do + od) * c.Ho + oh) * c.Wo + ow) * Y.cs + co];
+            yv[u] = x;
+            if (w < TW) yo[u] = ((rowy * TW + w) * YP + col) | (ok ? 0x40000000 : 0);
+            if (++pass == NP) { pass = 0; ++rowy; }
+          }
         }
-        yl[v * YP + col] = x;
+#pragma unroll
+        for (int u = 0; u < BW_YU; ++u) {
+          if (yo[u] >= 0) {
+            float x = yv[u];
+            if (yaff && (yo[u] & 0x40000000)) x = mt_lrelu(fmaf(x, ysc, ysh), Y.slope);
+            yl[yo[u] & 0x3fffffff] = x;
+          }
+        }
       }
     }
     __syncthreads();
-    for (int v0 = 0; v0 < TV; v0 += 4) {
-      const int v = v0 + lk;  // this lane's voxel (K index)
-      const int w = v % TW, h = (v / TW) % TH, d = v / (TW * TH);
-      const int xb = ((d * c.SD * LH + h * c.SH) * LW + w * c.SW) * CKP + li;
-      const float b0 = yl[v * YP + li];
-      const float b1 = yl[v * YP + 16 + li];
-#pragma unroll
-      for (int t = 0; t < BW_MAXT; ++t) {
-        if (t < mytaps) {
-          const float a = xl[xb + tapoff[t]];
-          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[t][1], 0, 0, 0);
-        }
+    {
+      const int xb0 = lk * c.SW, yb0 = lk * YP + li;   // X walk in voxels
+      const BwdwWalk wk{TW / 4, TH, 4 * c.SW, c.SH * LW - TW * c.SW, (c.SD * LH - TH * c.SH) * LW, TV / 4};
+      switch (mytaps) {
+        case 7: bwdw_tile_compute<7>(xl, yl, tapoff, xb0, yb0, wk, li, acc); break;
+        case 6: bwdw_tile_compute<6>(xl, yl, tapoff, xb0, yb0, wk, li, acc); break;
+        case 5: bwdw_tile_compute<5>(xl, yl, tapoff, xb0, yb0, wk, li, acc); break;
+        case 4: bwdw_tile_compute<4>(xl, yl, tapoff, xb0, yb0, wk, li, acc); break;
+        case 3: bwdw_tile_compute<3>(xl, yl, tapoff, xb0, yb0, wk, li, acc); break;
+        case 2: bwdw_tile_compute<2>(xl, yl, tapoff, xb0, yb0, wk, li, acc); break;
+        case 1: bwdw_tile_compute<1>(xl, yl, tapoff, xb0, yb0, wk, li, acc); break;
+        default: break;
       }
     }
   }
@@ -537,7 +815,7 @@ static void bwdw_plan(const mt_conv3d_t* p, BwdWParams* P) {
   // keep the haloed X tile within ~48 KiB for strided convs
   for (;;) {
     const size_t LD = (TD - 1) * p->SD + p->KD, LH = (TH - 1) * p->SH + p->KH, LW = (TW - 1) * p->SW + p->KW;
-    const size_t b = (LD * LH * LW * (BW_CK + 1) + (size_t)TD * TH * TW * BW_YP) * sizeof(float);
+    const size_t b = (LD * LH * LW * BW_CK + (size_t)TD * TH * TW * BW_YP) * sizeof(float);
     if (b <= 72 * 1024 || (TD == 1 && TH == 1)) break;
     if (TD > 1) TD = (TD + 1) / 2; else TH = (TH + 1) / 2;
   }
@@ -581,7 +859,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
   if (workspace == nullptr || workspace_bytes < need) { mt_set_error("bwd_weight: workspace %zu < %zu", workspace_bytes, need); return MT_EWORKSPACE; }
   P.part = (float*)workspace;
   const size_t LD = (P.TD - 1) * p->SD + p->KD, LH = (P.TH - 1) * p->SH + p->KH, LW = (P.TW - 1) * p->SW + p->KW;
-  const size_t ldsb = (LD * LH * LW * (BW_CK + 1) + (size_t)P.TD * P.TH * P.TW * BW_YP) * sizeof(float);
+  const size_t ldsb = (LD * LH * LW * BW_CK + (size_t)P.TD * P.TH * P.TW * BW_YP) * sizeof(float);
   MT_REQUIRE(ldsb <= 160 * 1024, "bwd_weight: LDS tile too large (%zu)", ldsb);
   hipStream_t st = (hipStream_t)stream;
   if (ldsb > 64 * 1024) {

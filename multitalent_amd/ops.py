@@ -133,17 +133,18 @@ def conv_stats_blocks(p):
     return _lib.load().mt_conv3d_stats_blocks(C.byref(p))
 
 
-def pack_conv_weights(w, C0, C1, Cout, kernel, strides, flip, ck, out=None):
-    """strides = (s_ci, s_co, s_kd, s_kh, s_kw) element strides of `w` for W_eff[tap][ci][co]."""
+def pack_conv_weights(w, C0, C1, Cout, kernel, strides, flip, ck, out=None, layout=1):
+    """strides = (s_ci, s_co, s_kd, s_kh, s_kw) element strides of `w` for W_eff[tap][ci][co].
+    layout 1 = conv kernels (mt_conv3d_fwd), layout 0 = pointwise kernels (mt_pointwise_fwd)."""
     lib = _lib.load()
     _check_dev(w)
     n = C.c_size_t(0)
     kd, kh, kw = kernel
-    _lib.check(lib.mt_pack_conv_weights(None, None, C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, None), 'pack(query)')
+    _lib.check(lib.mt_pack_conv_weights(None, None, C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, layout, None), 'pack(query)')
     if out is None:
         out = torch.empty(n.value, dtype=torch.float32, device=w.device)
     assert out.numel() >= n.value
-    _lib.check(lib.mt_pack_conv_weights(_ptr(w), _ptr(out), C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, _stream()), 'pack')
+    _lib.check(lib.mt_pack_conv_weights(_ptr(w), _ptr(out), C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, layout, _stream()), 'pack')
     return out
 
 

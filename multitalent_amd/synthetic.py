@@ -1,0 +1,41 @@
+"""Synthetic, device-resident training batches in the style of the reference's dummyLoad benchmarking trainer
+(nnUNet_variants/benchmarking/nnUNetTrainerV2_dummyLoad.py:26-64): CT-like intensities drawn from the Task100 plan's
+global statistics, clipped and z-scored like the CT preprocessing (preprocessing.py:275-285), and blocky integer label
+maps stored as float32 with a nearest-neighbour deep-supervision pyramid (downsampling.py:70-104)."""
+import numpy as np
+import torch
+
+from .plans import TASK100_CT_STATS
+
+
+def ds_scales(pool_op_kernel_sizes, skip_first=False):
+    """deep_supervision_scales (nnUNetTrainerV2.py:107-108; resenc variant MultiTalent_meets_resenc.py:107-116)."""
+    pools = np.vstack(pool_op_kernel_sizes[1:] if skip_first else pool_op_kernel_sizes)
+    return [[1, 1, 1]] + [list(i) for i in 1 / np.cumprod(pools, axis=0)][:-1]
+
+
+def synthetic_ct(B, patch, seed, device):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    s = TASK100_CT_STATS
+    hu = torch.randn((B, 1) + tuple(patch), generator=g) * s['sd'] + s['mean']
+    hu = hu.clamp_(s['percentile_00_5'], s['percentile_99_5'])
+    return ((hu - s['mean']) / s['sd']).float().to(device)
+
+
+def synthetic_targets(B, patch, scales, label_sets, seed, device, block=8):
+    """label_sets[b]: label values present in sample b.  Returns list of [B,1,...] float32 maps, highest res first."""
+    g = torch.Generator(device='cpu').manual_seed(seed + 7)
+    coarse_shape = tuple(max(p // block, 1) for p in patch)
+    maps = []
+    for b in range(B):
+        labs = torch.tensor([0] + list(label_sets[b]), dtype=torch.float32)
+        idx = torch.randint(0, len(labs), coarse_shape, generator=g)
+        keep = torch.rand(coarse_shape, generator=g) < 0.35      # mostly background, like real CT crops
+        maps.append(torch.where(keep, labs[idx], torch.zeros(())))
+    coarse = torch.stack(maps, 0)[:, None]
+    full = torch.nn.functional.interpolate(coarse, size=tuple(patch), mode='nearest')
+    out = []
+    for sc in scales:
+        size = tuple(int(np.round(p * f)) for p, f in zip(patch, sc))
+        out.append(torch.nn.functional.interpolate(full, size=size, mode='nearest').contiguous().to(device))
+    return out

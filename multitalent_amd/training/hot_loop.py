@@ -1,0 +1,108 @@
+"""The device side of `run_iteration` (MultiTalent_Trainer_DDP.py:324-370, nnUNetTrainerV2.py:225-274):
+forward -> loss -> backward (+ DDP gradient all-reduce overlapped with backward) -> clip_grad_norm_(12) ->
+SGD-Nesterov step, all on the HIP engine with flat parameter / gradient / momentum buffers.
+
+The network forward/backward bypass torch autograd entirely (engine.forward / engine.backward); autograd is only
+used for the few-hundred-float loss combination on top of the fused statistics kernels."""
+import torch
+import torch.distributed as dist
+
+from .. import ops
+
+
+class GradAllReducer:
+    """Bucketed gradient all-reduce (mean) over RCCL, launched on a side HIP stream as soon as a contiguous
+    slice of the flat gradient buffer is final (the buffer is laid out in backward-completion order), i.e.
+    overlapped with the rest of backward.  Replaces torch DDP's bucket hooks (nnUNetTrainerV2_DDP.py:200)."""
+
+    def __init__(self, engine, bucket_bytes=32 << 20):
+        self.eng = engine
+        self.bucket = bucket_bytes // 4
+        self.sent = 0
+        self.stream = None
+        self.handles = []
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def begin(self):
+        self.sent = 0
+        self.handles = []
+        if self.world > 1 and self.stream is None:
+            self.stream = torch.cuda.Stream()
+
+    def ready(self, lo, hi):
+        """all gradients in flat_grad[0:hi) are final."""
+        if self.world <= 1:
+            return
+        n = self.eng.flat_grad.numel()
+        final = hi >= n
+        while hi - self.sent >= self.bucket or (final and self.sent < n):
+            end = n if final and (n - self.sent) < 2 * self.bucket else self.sent + self.bucket
+            sl = self.eng.flat_grad[self.sent:end]
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                sl.div_(self.world)
+                self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+            self.sent = end
+
+    def finish(self):
+        if self.world <= 1:
+            return
+        for h in self.handles:
+            h.wait()
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class FusedTrainStep:
+    def __init__(self, network, loss_fn, lr=1e-2, weight_decay=3e-5, momentum=0.99, max_norm=12.0, ddp=False):
+        self.net = network
+        self.eng = network.engine()
+        self.loss_fn = loss_fn
+        self.lr, self.wd, self.mom, self.max_norm = lr, weight_decay, momentum, max_norm
+        self.buf = None
+        self.first = True
+        self.sumsq = None
+        self.ws = None
+        self.reducer = GradAllReducer(self.eng) if ddp else None
+
+    def _state(self, dev):
+        if self.buf is None or self.buf.device != dev or self.buf.numel() != self.eng.flat.numel():
+            self.buf = torch.zeros_like(self.eng.flat)
+            self.first = True
+            self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+            self.ws = torch.empty(ops.sumsq_workspace(self.eng.flat.numel()) // 4 + 16, dtype=torch.float32, device=dev)
+
+    def forward_loss(self, data, loss_args):
+        eng = self.eng
+        outs = eng.forward(data, need_grad=True, all_heads=True)
+        leaves = [o.permute(0, 4, 1, 2, 3).requires_grad_(True) for o in outs]
+        res = self.loss_fn(leaves, *loss_args)
+        return leaves, res
+
+    def __call__(self, data, *loss_args, do_backprop=True):
+        """Returns whatever loss_fn returns (loss first if a tuple), detached device tensors (no host sync)."""
+        eng = self.eng
+        if not do_backprop:
+            with torch.no_grad():
+                outs = eng.forward(data, need_grad=False, all_heads=True)
+                res = self.loss_fn([o.permute(0, 4, 1, 2, 3) for o in outs], *loss_args)
+            return res
+        leaves, res = self.forward_loss(data, loss_args)
+        loss = res[0] if isinstance(res, (tuple, list)) else res
+        loss.backward()
+        dl = [None if l.grad is None else l.grad.permute(0, 2, 3, 4, 1).contiguous() for l in leaves]
+        if self.reducer is not None:
+            self.reducer.begin()
+            eng.grad_ready_hook = self.reducer.ready
+        eng.backward(dl)
+        if self.reducer is not None:
+            self.reducer.finish()
+        self._state(eng.flat.device)
+        ops.sumsq(eng.flat_grad, self.sumsq, self.ws)
+        ops.sgd_nesterov(eng.flat, eng.flat_grad, self.buf, self.lr, self.wd, self.mom, self.first, self.sumsq, self.max_norm)
+        self.first = False
+        eng.mark_params_dirty()
+        if isinstance(res, (tuple, list)):
+            return tuple(r.detach() for r in res)
+        return res.detach()

@@ -197,7 +197,7 @@ def test_pointwise_tconv_and_heads(dev, Cin, Cout, base, so):
         wd = w.to(dev).contiguous()
         strides = ops.conv_weight_strides(wd, transposed_layout=True)
     ck = Cin + (Cin & 1)
-    wp = ops.pack_conv_weights(wd, Cin, 0, Cout, so, strides, False, ck)
+    wp = ops.pack_conv_weights(wd, Cin, 0, Cout, so, strides, False, ck, layout=0)
     outshape = tuple(b * s for b, s in zip(base, so))
     out = torch.full((N,) + outshape + (Cout + 3,), float('nan'), device=dev)   # write into a wider buffer (concat slot)
     oa = ops.Act(out, c0=0, C=Cout)

@@ -1,0 +1,65 @@
+"""Micro-benchmark of single convolution launches (forward kernel / backward-weight kernel) for profiling."""
+import argparse, sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+from multitalent_amd import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--cin', type=int, default=30); ap.add_argument('--cout', type=int, default=30)
+ap.add_argument('--shape', type=int, nargs=3, default=[48, 192, 192]); ap.add_argument('--n', type=int, default=2)
+ap.add_argument('--k', type=int, nargs=3, default=[3, 3, 3]); ap.add_argument('--stride', type=int, nargs=3, default=[1, 1, 1])
+ap.add_argument('--reps', type=int, default=5); ap.add_argument('--mode', default='fwd', choices=['fwd', 'bwdw'])
+ap.add_argument('--lazy', type=int, default=1)
+a = ap.parse_args()
+dev = torch.device('cuda:0')
+N, Cin, Cout = a.n, a.cin, a.cout
+x = torch.randn((N,) + tuple(a.shape) + (Cin,), device=dev)
+sc = torch.rand(N, Cin, device=dev) + 0.5; sh = torch.randn(N, Cin, device=dev)
+xa = ops.Act(x, scale=sc, shift=sh, slope=0.01) if a.lazy else ops.Act(x)
+w = torch.randn((Cout, Cin) + tuple(a.k), device=dev) * 0.05
+b = torch.randn(Cout, device=dev)
+geom = ops.ConvGeom(a.shape, a.k, a.stride)
+out = torch.empty((N,) + geom.out + (Cout,), device=dev)
+flops = 2.0 * N * geom.out[0] * geom.out[1] * geom.out[2] * Cin * Cout * a.k[0] * a.k[1] * a.k[2]
+if a.mode == 'fwd':
+    p = ops.fill_conv([xa], geom, Cout, bias=b, out0=ops.Act(out))
+    ck = ops.conv_ck(p)
+    wp = ops.pack_conv_weights(w, Cin, 0, Cout, a.k, ops.conv_weight_strides(w), False, ck)
+    p.wpack = wp.data_ptr()
+    part = torch.zeros((N, ops.conv_stats_blocks(p), Cout, 2), device=dev)
+    p.stats_part = part.data_ptr()
+    run = lambda: ops.conv3d_fwd(p)
+    import os
+    if int(os.environ.get('MT_CONV_DBG', '0')) & 16:
+        nblk = N * ops.conv_stats_blocks(p)
+        ts = torch.zeros((nblk, 4, 16), dtype=torch.int64, device=dev)
+        p.out1 = ts.data_ptr()
+        run(); torch.cuda.synchronize()
+        tsc = ts.cpu().numpy()
+        import numpy as np
+        t0 = tsc[:, :, 0].min()
+        names = ['start', 'bar0', 'staged0', 'sync0', 'comp0', 'bar1', 'staged1', 'sync1', 'comp1', 'epi_done', 'end']
+        d = np.diff(tsc[:, :, :11], axis=2).astype(float)
+        print('phase durations (cycles), median over waves/blocks:')
+        for i in range(10):
+            print('  %-9s -> %-9s %9.0f  (p10 %8.0f p90 %8.0f)' % (names[i], names[i + 1], np.median(d[:, :, i]), np.percentile(d[:, :, i], 10), np.percentile(d[:, :, i], 90)))
+        life = (tsc[:, :, 10] - tsc[:, :, 0]).astype(float)
+        print('  block wave lifetime median %.0f; kernel span %.0f cycles' % (np.median(life), tsc[:, :, 10].max() - t0))
+        # concurrency: how many blocks start within the first 1000 cycles
+        st = np.sort(tsc[:, 0, 0] - t0)
+        print('  blocks started in first 5k cycles: %d ; start times of blocks 500..520: %s' % ((st < 5000).sum(), st[500:520:4]))
+else:
+    dy = torch.randn_like(out)
+    p = ops.fill_conv([xa], geom, Cout)
+    ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
+    dw = torch.empty_like(w)
+    ya = ops.Act(dy)
+    run = lambda: ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
+run(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.reps):
+    run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.reps
+print("%s cin=%d cout=%d shape=%s k=%s s=%s: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)" % (a.mode, Cin, Cout, a.shape, a.k, a.stride, ms, flops / ms / 1e9, flops / ms / 1e9 / 1.573))
