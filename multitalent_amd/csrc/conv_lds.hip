@@ -424,6 +424,283 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
 #undef MT_STAMP
 }
 
+// ================================================================================================
+// FAST v2 forward kernel (3x3x3, stride 1, pad 1): ZERO vector-ALU instructions inside the MFMA loop.
+//
+// Measured on gfx950 (tools/ubench/mfma_fill.hip): v_mfma_f32_32x32x2_f32 runs on the FP32 vector datapath, so every
+// VALU instruction interleaved with it costs matrix time (+15 cycles for the first, ~6 per further one), while LDS
+// reads (~1 cycle), scalar ALU and s_waitcnt are free.  Hence:
+//   * LDS image [voxel][20 dwords] (16 channel slots + 4 pad): 16-byte aligned voxels, and the 80-byte stride makes
+//     ds_read_b128 over 16 consecutive voxels bank-conflict free (slot = 5*lv mod 16 is a bijection) without any XOR;
+//   * K-permutation (weight layout 1): lane half h contracts channels 8h..8h+7, i.e. 8 CONTIGUOUS floats of its voxel
+//     = two ds_read_b128 per M tile per tap;
+//   * the 27 taps are fully unrolled: every LDS address is (per-lane base) + compile-time immediate;
+//   * weights arrive as two global_load_dwordx4 per tap from a wave-uniform pointer + lane offset.
+// The staging pass uses 8-byte buffer loads (2 channels) with hardware bounds checking and ds_write_b64.
+#define FCK 16
+#define FCKP 20
+
+template <int LD, int LH, int LW, int VEC>
+__device__ __forceinline__ void mt_stage_fast2(float* __restrict__ lds, const mt_conv3d_t& c, const ConvChunk ch,
+                                               int nb, int ud0, int uh0, int uw0, int lane, int wave) {
+  constexpr int LPV = FCK / VEC;            // lanes per voxel
+  constexpr int VPS = 64 / LPV;             // voxels per wave step
+  constexpr int NI = (LW + VPS - 1) / VPS, R = LD * LH, RPW = (R + 3) / 4;
+  constexpr int RG = (RPW * NI * VEC > 32) ? ((32 / (NI * VEC)) > 0 ? (32 / (NI * VEC)) : 1) : RPW;   // rows per batch
+  const mt_src_t& S = c.src[ch.src];
+  const int cl = (lane % LPV) * VEC, vl = lane / LPV;
+  const bool has_aff = S.scale != nullptr;
+  float sc[VEC], sh[VEC];
+  bool cval[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    cval[e] = (cl + e) < ch.ck;
+    sc[e] = 1.f; sh[e] = 0.f;
+    if (has_aff && cval[e]) {
+      sc[e] = S.scale[(size_t)nb * S.C + ch.c0 + cl + e];
+      sh[e] = S.shift[(size_t)nb * S.C + ch.c0 + cl + e];
+    }
+  }
+  const float slope = S.slope;
+  const int cs = S.cs;
+  const size_t sample_elems = (size_t)c.Di * c.Hi * c.Wi * cs;
+  __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * sample_elems), 0, (int)(sample_elems * 4), 0x00020000);
+  int voff[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int lw = vl + i * VPS;
+    const int uw = uw0 + lw;
+    const bool ok = cval[0] && (lw < LW) && ((unsigned)uw < (unsigned)c.Wi);
+    voff[i] = ok ? (uw * cs + ch.c0 + cl) * 4 : (int)0x80000000;
+  }
+  float* lbase = lds + vl * FCKP + cl;      // + (row*LW + i*VPS)*FCKP : compile-time part
+  // block-uniform: the whole haloed tile lies inside the volume -> every in-tile lane is valid
+  const bool nosel = (ud0 >= 0) && (uh0 >= 0) && (uw0 >= 0) && (ud0 + LD <= c.Di) && (uh0 + LH <= c.Hi) && (uw0 + LW <= c.Wi) &&
+                     (slope >= 0.f) && (slope <= 1.f);
+#pragma unroll
+  for (int r0 = 0; r0 < RPW; r0 += RG) {
+    float v[RG][NI][VEC];
+    bool rv[RG];
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      const int row = wave + 4 * (r0 + q);
+      const int ld = row / LH, lhh = row % LH;
+      const int ud = ud0 + ld, uh = uh0 + lhh;
+      rv[q] = (r0 + q < RPW) && (row < R) && ((unsigned)ud < (unsigned)c.Di) && ((unsigned)uh < (unsigned)c.Hi);
+      if (rv[q]) {
+        const int srow = (ud * c.Hi + uh) * c.Wi * cs * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          if constexpr (VEC == 2) {
+            // NB: bit_cast the WHOLE 64-bit result; indexing the builtin's return type yields the first dword twice
+            const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[i] + srow, 0, 0));
+            v[q][i][0] = t.x;
+            v[q][i][1] = t.y;
+          } else {
+            v[q][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[i] + srow, 0, 0));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[q][i][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      const int row = wave + 4 * (r0 + q);   // wave-uniform; (row - wave) is a compile-time constant
+      if (r0 + q < RPW && row < R) {
+        float* lrow = lbase + wave * (LW * FCKP) + 4 * (r0 + q) * (LW * FCKP);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int lw = vl + i * VPS;
+          if ((i + 1) * VPS <= LW || lw < LW) {
+            float x[VEC];
+            const bool ok = rv[q] && voff[i] >= 0;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              x[e] = v[q][i][e];
+              if (has_aff) {
+                // LeakyReLU with 0 <= slope <= 1 is max(t, slope*t) (2 VALU).  Inside the volume no select is needed:
+                // a lane that loaded nothing (channel >= ck) holds lrelu(shift) — finite — and meets zero weights.
+                const float t = fmaf(x[e], sc[e], sh[e]);
+                const float a = fmaxf(t, t * slope);
+                x[e] = nosel ? a : ((ok && cval[e]) ? a : 0.f);
+              } else if (VEC == 2 && e == 1) x[e] = cval[e] ? x[e] : 0.f;
+            }
+            if constexpr (VEC == 2) {
+              float2 t; t.x = x[0]; t.y = x[1];
+              *(float2*)(lrow + i * VPS * FCKP) = t;
+            } else {
+              lrow[i * VPS * FCKP] = x[0];
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MT>
+struct FastFrag { f32x4 a[MT][2]; f32x4 b[2]; };
+
+template <int MT, int LH, int LW, int TAP>
+__device__ __forceinline__ void fast_frag_load(FastFrag<MT>& f, const float* __restrict__ lds, const int (&abase)[MT],
+                                               const float* __restrict__ wlane) {
+  constexpr int kd = TAP / 9, kh = (TAP / 3) % 3, kw = TAP % 3;
+  constexpr int toff = ((kd * LH + kh) * LW + kw) * FCKP;
+  f.b[0] = *(const f32x4*)(wlane + TAP * 512);
+  f.b[1] = *(const f32x4*)(wlane + TAP * 512 + 256);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    f.a[m][0] = *(const f32x4*)(lds + abase[m] + toff);
+    f.a[m][1] = *(const f32x4*)(lds + abase[m] + toff + 4);
+  }
+}
+template <int MT>
+__device__ __forceinline__ void fast_frag_mfma(const FastFrag<MT>& f, f32x16 (&acc)[MT]) {
+#pragma unroll
+  for (int kp = 0; kp < 8; ++kp)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[m][kp >> 2][kp & 3], f.b[kp >> 2][kp & 3], acc[m], 0, 0, 0);
+}
+template <int MT, int LH, int LW, int TAP>
+__device__ __forceinline__ void fast_taps(FastFrag<MT>& cur, FastFrag<MT>& nxt, const float* __restrict__ lds,
+                                          const int (&abase)[MT], const float* __restrict__ wlane, f32x16 (&acc)[MT]) {
+  // sched_barrier pins "loads of tap+1, THEN the MFMAs of tap": without it the scheduler sinks each load in front of its
+  // consumer (shortest live range) and every 8 MFMAs start with a fully exposed L2 + LDS latency.
+  if constexpr (TAP < 26) fast_frag_load<MT, LH, LW, TAP + 1>(nxt, lds, abase, wlane);
+  __builtin_amdgcn_sched_barrier(0);
+  fast_frag_mfma<MT>(cur, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (TAP < 26) fast_taps<MT, LH, LW, TAP + 1>(nxt, cur, lds, abase, wlane, acc);
+}
+
+template <int MW, int RH, int TD, int VEC>
+__global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
+  constexpr int MH = 32 / MW, TH = MH * RH, TW = MW, NMT = TD * RH, MT = NMT / 4;
+  constexpr int LD = TD + 2, LH = TH + 2, LW = TW + 2;
+  static_assert(NMT % 4 == 0, "M tiles must split over 4 waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const mt_conv3d_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = blockIdx.y;
+  const int tw = tile % P.tilesW; tile /= P.tilesW;
+  const int th = tile % P.tilesH; tile /= P.tilesH;
+  const int td = tile % P.tilesD;
+  const int nb = tile / P.tilesD;
+  const int sb = (td * P.tilesH + th) * P.tilesW + tw;
+  const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+
+  int abase[MT];   // dword index of (voxel of this lane in M tile m, channel 8*lhalf)
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mt = wave * MT + m;
+    const int dm = mt / RH, rh = mt % RH;
+    const int r = li / MW, col = li % MW;
+    abase[m] = ((dm * LH + rh * MH + r) * LW + col) * FCKP + lhalf * 8;
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[m][j] = 0.f;
+
+  for (int ch = 0; ch < P.nchunks; ++ch) {
+    const ConvChunk cc = P.chunk[ch];
+    const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
+    __syncthreads();
+    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+    __syncthreads();
+    FastFrag<MT> f0, f1;
+    fast_frag_load<MT, LH, LW, 0>(f0, lds, abase, wlane);
+    fast_taps<MT, LH, LW, 0>(f0, f1, lds, abase, wlane, acc);
+  }
+
+  // ---- epilogue: bias, store, statistics.  Stores go through a buffer descriptor: per-lane byte offset (column part)
+  // + wave-uniform scalar offset per (M tile, register) -> no vector address arithmetic; out-of-volume lanes of
+  // boundary tiles get offset 0x80000000 (dropped by the hardware bounds check).
+  const int co = ntile * 32 + li;
+  const bool covalid = co < c.Cout;
+  const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
+  float* optr; int ocs, cofs;
+  if (co < c.csplit) { optr = c.out0; ocs = c.ocs0; cofs = co; }
+  else               { optr = c.out1; ocs = c.ocs1; cofs = co - c.csplit; }
+  float s1 = 0.f, s2 = 0.f;
+  const bool interior = (od0 + TD <= c.Do) && (oh0 + TH <= c.Ho) && (ow0 + TW <= c.Wo);   // block-uniform
+  const size_t out_sample = (size_t)c.Do * c.Ho * c.Wo;
+  // two descriptors (out0 / out1 when the output is a split concat gradient); each lane uses the one of its channel
+  __amdgpu_buffer_rsrc_t r0d = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * c.ocs0), 0,
+                                                                 (int)(out_sample * c.ocs0 * 4), 0x00020000);
+  const bool split = c.csplit < c.Cout;
+  __amdgpu_buffer_rsrc_t r1d = r0d;
+  if (split) r1d = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out1 + (size_t)nb * out_sample * c.ocs1), 0,
+                                                     (int)(out_sample * c.ocs1 * 4), 0x00020000);
+  const bool use1 = split && !(co < c.csplit);
+  (void)optr;
+  const int lane_col = 4 * lhalf;    // column part of iv that depends on the lane
+  const int loff = covalid ? (lane_col * ocs + cofs) * 4 : (int)0x80000000;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mt = wave * MT + m;
+    const int dm = mt / RH, rh = mt % RH;
+    const int od = od0 + dm;
+    const int vox0 = ((od * c.Ho) + (oh0 + rh * MH)) * c.Wo + ow0;    // within the sample, wave-uniform
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      constexpr int dummy = 0; (void)dummy;
+      const int ivj = (j & 3) + 8 * (j >> 2);           // lane-independent part of the voxel index in the M tile
+      const int r = ivj / MW, colj = ivj % MW;          // (4*lhalf never crosses an MW boundary: MW >= 8)
+      int off = loff;
+      if (!interior) {
+        const bool ok = (od < c.Do) && (oh0 + rh * MH + r < c.Ho) && (ow0 + colj + lane_col < c.Wo);
+        off = ok ? loff : (int)0x80000000;
+      }
+      float v = acc[m][j] + bv;
+      // scalar offsets differ per destination only through ocs: compute both (SALU) and select per lane once
+      const int so0 = (vox0 + r * c.Wo + colj) * c.ocs0 * 4;
+      const int so1 = (vox0 + r * c.Wo + colj) * c.ocs1 * 4;
+      if (!split) {
+        if (c.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0d, off, so0, 0));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r0d, off, so0, 0);
+      } else {
+        // lanes of the two destinations take different descriptors: predicate by offset (OOB = no-op)
+        const int offa = use1 ? (int)0x80000000 : off, offb = use1 ? off : (int)0x80000000;
+        if (c.accumulate) {
+          const float o0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0d, offa, so0, 0));
+          const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1d, offb, so1, 0));
+          v += o0 + o1;
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r0d, offa, so0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r1d, offb, so1, 0);
+      }
+      if (interior) { s1 += v; s2 = fmaf(v, v, s2); }
+      else if (off >= 0) { s1 += v; s2 = fmaf(v, v, s2); }
+    }
+  }
+  if (!covalid) { s1 = 0.f; s2 = 0.f; }
+  if (c.stats_part != nullptr) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    __syncthreads();
+    if (lhalf == 0) { lds[(wave * 32 + li) * 2] = s1; lds[(wave * 32 + li) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 32 && (ntile * 32 + tid) < c.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += lds[(w * 32 + tid) * 2]; t2 += lds[(w * 32 + tid) * 2 + 1]; }
+      float* sp = c.stats_part + ((size_t)((size_t)nb * P.nsb + sb) * c.Cout + ntile * 32 + tid) * 2;
+      sp[0] = t1; sp[1] = t2;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side of mt_conv3d_fwd
 struct ConvCfg { int MW, RH, TD, CK; };
@@ -493,6 +770,44 @@ static bool conv_is_fast(const mt_conv3d_t* p) {
   return true;
 }
 
+// FAST v2 eligibility: FAST geometry + 8-byte alignment of every source for the 2-channel staging loads
+static int conv_fast_vec(const mt_conv3d_t* p) {
+  static int force1 = -1;
+  if (force1 < 0) { const char* e = getenv("MT_CONV_VEC1"); force1 = e ? atoi(e) : 0; }
+  if (force1) return 1;
+  for (int i = 0; i < p->nsrc; ++i) {
+    const mt_src_t& s = p->src[i];
+    if ((s.cs & 1) || (s.C & 1) || (((uintptr_t)s.ptr) & 7)) return 1;
+  }
+  return 2;
+}
+static size_t fast2_lds(const ConvCfg& g) {
+  int TD, TH, TW; TD = g.TD; TH = (32 / g.MW) * g.RH; TW = g.MW;
+  return (size_t)(TD + 2) * (TH + 2) * (TW + 2) * FCKP * sizeof(float);
+}
+template <int MW, int RH, int TD, int VEC>
+static int launch_fast2(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
+  ConvKParams P;
+  P.c = *p;
+  if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
+  int TDv, TH, TW; TDv = g.TD; TH = (32 / g.MW) * g.RH; TW = g.MW;
+  P.tilesD = mt_cdiv(p->Do, TDv); P.tilesH = mt_cdiv(p->Ho, TH); P.tilesW = mt_cdiv(p->Wo, TW);
+  P.nsb = P.tilesD * P.tilesH * P.tilesW;
+  P.ntaps = 27; P.dbg = 0; P.stagger = 0;
+  P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
+  MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
+  const size_t ldsb = fast2_lds(g);
+  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
+  auto kfn = conv_fast_kernel<MW, RH, TD, VEC>;
+  if (ldsb > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(256), ldsb, st, P);
+  MT_CHECK_LAUNCH("conv3d_fast");
+  return MT_OK;
+}
+
 template <int MW, int RH, int TD, int CK, bool FAST>
 static int launch_conv(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
   ConvKParams P;
@@ -532,6 +847,17 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   const ConvCfg& g = kCfgs[i];
   hipStream_t st = (hipStream_t)stream;
   const bool fast = conv_is_fast(p);
+  static int use_v2 = -1;
+  if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
+  if (fast && use_v2 && g.CK == 16) {
+    const int vec = conv_fast_vec(p);
+    switch (i) {
+      case 0: return vec == 2 ? launch_fast2<32, 4, 2, 2>(p, g, st) : launch_fast2<32, 4, 2, 1>(p, g, st);
+      case 1: return vec == 2 ? launch_fast2<16, 2, 2, 2>(p, g, st) : launch_fast2<16, 2, 2, 1>(p, g, st);
+      case 2: return vec == 2 ? launch_fast2<8, 2, 2, 2>(p, g, st) : launch_fast2<8, 2, 2, 1>(p, g, st);
+      default: break;
+    }
+  }
   switch (i) {
     case 0: return fast ? launch_conv<32, 4, 2, 16, true>(p, g, st) : launch_conv<32, 4, 2, 16, false>(p, g, st);
     case 1: return fast ? launch_conv<16, 2, 2, 16, true>(p, g, st) : launch_conv<16, 2, 2, 16, false>(p, g, st);
