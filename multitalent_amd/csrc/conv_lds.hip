@@ -1133,6 +1133,131 @@ __global__ void bwdw_reduce_kernel(const BwdWReduceParams P) {
   }
 }
 
+// ================================================================================================
+// FAST backward-weight kernel (3x3x3, stride 1, pad 1):  dW[tap][ci16][co32] += X(tile + tap)^T * Y(tile)
+// K (= voxels) is split across the 4 waves, every wave accumulates ALL 27 taps for its quarter of the tile
+// (216 accumulator registers), so all waves run the same straight-line code with compile-time LDS offsets:
+// ZERO vector-ALU instructions between the v_mfma_f32_16x16x4_f32 (see conv_fast_kernel for why that matters).
+// X tile: LDS [voxel][20] (same staging as the forward kernel).  Y fragments are wave-private, so they bypass LDS:
+// buffer loads straight into registers in B-fragment order.  A workgroup walks a strided list of tiles and writes
+// one partial per WAVE; bwdw_reduce_kernel sums them deterministically.
+template <int TH, int TW, int VEC>
+__global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P) {
+  constexpr int LD = 3, LH = TH + 2, LW = TW + 2, TV = TH * TW;
+  constexpr int KS = TV / 16;            // k-steps (4 voxels each) per wave
+  constexpr int SPR = TW / 4;            // k-steps per tile row
+  static_assert(TV == 128, "tile must hold 128 voxels");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const mt_conv3d_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int sg = blockIdx.x, cot = blockIdx.y, chi = blockIdx.z;
+  const ConvChunk cc = P.chunk[chi];
+  const mt_src_t& Y = P.y;
+
+  f32x4 acc[27][2];
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][h][j] = 0.f;
+
+  // this wave's first voxel inside the tile: k-step ks = wave*KS + s -> (row, w0) = (ks / SPR, 4*(ks % SPR))
+  const int row0 = (wave * KS) / SPR;
+  const int xbase = ((row0 * LW) + lk) * FCKP + li;      // + compile-time ((s/SPR)*LW + 4*(s%SPR) + tapvox)*FCKP
+  const int co = cot * 32 + li;
+  const bool yaff = Y.scale != nullptr;
+  const size_t ysample = (size_t)c.Do * c.Ho * c.Wo * Y.cs;
+
+  for (int tile = sg; tile < P.ntiles_total; tile += P.nsg) {
+    int r = tile;
+    const int tw = r % P.tilesW; r /= P.tilesW;
+    const int th = r % P.tilesH; r /= P.tilesH;
+    const int td = r % P.tilesD;
+    const int nb = r / P.tilesD;
+    const int od0 = td, oh0 = th * TH, ow0 = tw * TW;
+    // ---- Y fragments for this wave's KS k-steps (2 cout halves each), straight from global
+    float yb[KS][2];
+    {
+      __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(Y.ptr + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
+      float ysc0 = 1.f, ysh0 = 0.f, ysc1 = 1.f, ysh1 = 0.f;
+      if (yaff) {
+        if (co < c.Cout) { ysc0 = Y.scale[(size_t)nb * Y.C + co]; ysh0 = Y.shift[(size_t)nb * Y.C + co]; }
+        if (co + 16 < c.Cout) { ysc1 = Y.scale[(size_t)nb * Y.C + co + 16]; ysh1 = Y.shift[(size_t)nb * Y.C + co + 16]; }
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int ks = wave * KS + s;                    // wave-uniform
+        const int oh = oh0 + ks / SPR, ow = ow0 + 4 * (ks % SPR) + lk;
+        const bool vok = (oh < c.Ho) && (ow < c.Wo);
+        const int base = ((od0 * c.Ho + oh) * c.Wo + ow) * Y.cs + co;
+        const int o0 = (vok && co < c.Cout) ? base * 4 : (int)0x80000000;
+        const int o1 = (vok && co + 16 < c.Cout) ? (base + 16) * 4 : (int)0x80000000;
+        float v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, o0, 0, 0));
+        float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, o1, 0, 0));
+        if (yaff) {
+          v0 = (o0 >= 0) ? mt_lrelu(fmaf(v0, ysc0, ysh0), Y.slope) : 0.f;
+          v1 = (o1 >= 0) ? mt_lrelu(fmaf(v1, ysc1, ysh1), Y.slope) : 0.f;
+        }
+        yb[s][0] = v0; yb[s][1] = v1;
+      }
+    }
+    __syncthreads();     // previous tile's X reads are done
+    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+    __syncthreads();
+    // ---- MFMA phase: KS k-steps x 27 taps x 2 cout halves, all LDS offsets are immediates
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int svox = (s / SPR) * LW + 4 * (s % SPR);
+      float a[27];
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        const int tapvox = ((t / 9) * LH + (t / 3) % 3) * LW + (t % 3);
+        a[t] = lds[xbase + (svox + tapvox) * FCKP];
+      }
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], yb[s][0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], yb[s][1], acc[t][1], 0, 0, 0);
+      }
+    }
+  }
+  // one partial per wave: [chunk][cot][sg*4 + wave][tap][16][32]
+  float* pp = P.part + ((size_t)((size_t)(chi * P.ncot + cot) * (P.nsg * 4) + sg * 4 + wave) * 27) * 512;
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pp[(size_t)t * 512 + (lk * 4 + j) * 32 + h * 16 + li] = acc[t][h][j];
+}
+
+static bool bwdw_is_fast(const mt_conv3d_t* p, const mt_src_t* y) {
+  if (!(p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 1 && p->PH == 1 &&
+        p->PW == 1 && p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
+  for (int i = 0; i < p->nsrc; ++i)
+    if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 4.0 >= 2147483648.0) return false;
+  if ((double)p->Do * p->Ho * p->Wo * y->cs * 4.0 >= 2147483648.0) return false;
+  return true;
+}
+// plan for the fast kernel: tile 1 x TH x TW with (TH,TW) = (4,32) or (8,16)
+static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
+  const bool wide = p->Wo > 16;
+  P->TD = 1; P->TH = wide ? 4 : 8; P->TW = wide ? 32 : 16;
+  P->tilesD = p->Do; P->tilesH = mt_cdiv(p->Ho, P->TH); P->tilesW = mt_cdiv(p->Wo, P->TW);
+  P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N;
+  P->ntaps = 27;
+  P->nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, BW_CK, P->chunk);
+  P->ncot = mt_cdiv(p->Cout, 32);
+  int pairs = P->nchunks * P->ncot; if (pairs < 1) pairs = 1;
+  int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (216 accumulator registers per wave)
+  if (nsg > P->ntiles_total) nsg = P->ntiles_total;
+  if (nsg < 1) nsg = 1;
+  P->nsg = nsg;
+}
+
 static void bwdw_plan(const mt_conv3d_t* p, BwdWParams* P) {
   // tile: rows of up to 32 voxels in W (multiple of 4), ~128 voxels per tile
   int TW = p->Wo >= 32 ? 32 : ((p->Wo + 3) / 4) * 4;
@@ -1163,7 +1288,13 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
   if (p == nullptr) return 0;
   BwdWParams P; bwdw_plan(p, &P);
   if (P.nchunks <= 0) return 0;
-  return (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
+  size_t generic = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
+  if (p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1) {
+    BwdWParams F; bwdw_fast_plan(p, &F);
+    const size_t fast = (size_t)F.nchunks * F.ncot * F.nsg * 4 * 27 * 512 * sizeof(float);
+    if (fast > generic) generic = fast;
+  }
+  return generic;
 }
 
 extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, float* dw, long s_ci, long s_co,
@@ -1178,6 +1309,37 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
   P.c = *p;
   if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
   P.y = *ysrc;
+  static int use_fast = -1;
+  if (use_fast < 0) { const char* e = getenv("MT_BWDW_FAST"); use_fast = e ? atoi(e) : 1; }
+  if (use_fast && bwdw_is_fast(p, ysrc)) {
+    bwdw_fast_plan(p, &P);
+    MT_REQUIRE(P.nchunks > 0, "bwd_weight: too many channel chunks");
+    const size_t need = (size_t)P.nchunks * P.ncot * P.nsg * 4 * 27 * 512 * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need) { mt_set_error("bwd_weight: workspace %zu < %zu", workspace_bytes, need); return MT_EWORKSPACE; }
+    P.part = (float*)workspace;
+    const int vec = conv_fast_vec(p);
+    const size_t ldsb = (size_t)3 * (P.TH + 2) * (P.TW + 2) * FCKP * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(P.nsg, P.ncot, P.nchunks);
+    if (P.TW == 32) {
+      if (vec == 2) hipLaunchKernelGGL((conv_bwdw_fast_kernel<4, 32, 2>), grid, dim3(256), ldsb, st, P);
+      else hipLaunchKernelGGL((conv_bwdw_fast_kernel<4, 32, 1>), grid, dim3(256), ldsb, st, P);
+    } else {
+      if (vec == 2) hipLaunchKernelGGL((conv_bwdw_fast_kernel<8, 16, 2>), grid, dim3(256), ldsb, st, P);
+      else hipLaunchKernelGGL((conv_bwdw_fast_kernel<8, 16, 1>), grid, dim3(256), ldsb, st, P);
+    }
+    MT_CHECK_LAUNCH("conv_bwdw_fast");
+    BwdWReduceParams R;
+    R.part = P.part; R.dw = dw; R.Cin = p->Cin; R.Cout = p->Cout; R.KD = 3; R.KH = 3; R.KW = 3;
+    R.nchunks = P.nchunks; R.ncot = P.ncot; R.nsg = P.nsg * 4; R.ntaps = 27; R.accumulate = accumulate;
+    R.s_ci = s_ci; R.s_co = s_co; R.s_kd = s_kd; R.s_kh = s_kh; R.s_kw = s_kw;
+    for (int i = 0; i < P.nchunks; ++i) R.chunk[i] = P.chunk[i];
+    const long total = (long)P.nchunks * P.ncot * 27 * 512;
+    int blocks = mt_cdiv(total, 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bwdw_reduce_kernel, dim3(blocks), dim3(256), 0, st, R);
+    MT_CHECK_LAUNCH("bwdw_reduce");
+    return MT_OK;
+  }
   bwdw_plan(p, &P);
   MT_REQUIRE(P.nchunks > 0, "bwd_weight: too many channel chunks");
   MT_REQUIRE(P.ntaps <= 4 * BW_MAXT, "bwd_weight: too many taps");
