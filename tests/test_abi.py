@@ -1,0 +1,49 @@
+"""The C-ABI library loads and exports every symbol include/mtseg.h declares (no compute, no GPU)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'mtseg.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(mt_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_header_symbol():
+    from multitalent_amd import _lib
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 28
+    for s in syms:
+        assert hasattr(lib, s), "missing export: " + s
+    assert set(_lib.SIGNATURES) == set(syms), (set(_lib.SIGNATURES) ^ set(syms))
+    assert lib.mt_abi_version() == 1
+
+
+def test_struct_sizes_match_c_layout():
+    """ctypes mirrors of the ABI structs must have the C compiler's layout."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from multitalent_amd._lib import mt_conv3d_t, mt_pointwise_t, mt_src_t
+    src = '#include <stdio.h>\n#include "mtseg.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(mt_src_t), sizeof(mt_conv3d_t), sizeof(mt_pointwise_t));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 't.c'), 'w').write(src)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 't.c'), '-o', os.path.join(d, 't')])
+        out = subprocess.check_output([os.path.join(d, 't')]).decode().split()
+    assert [int(x) for x in out] == [C.sizeof(mt_src_t), C.sizeof(mt_conv3d_t), C.sizeof(mt_pointwise_t)]
+
+
+def test_cpu_call_fails_loudly():
+    """No silent fallback: the network refuses CPU tensors."""
+    import pytest
+    import torch
+    from torch import nn
+    from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
+    net = Generic_UNet(1, 4, 2, 1, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                       {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True}, True, False,
+                       lambda x: x, None, [[2, 2, 2]], [[3, 3, 3]] * 2, False, True, True)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        net(torch.zeros(1, 1, 4, 8, 8))
