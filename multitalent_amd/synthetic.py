@@ -39,3 +39,30 @@ def synthetic_targets(B, patch, scales, label_sets, seed, device, block=8):
         size = tuple(int(np.round(p * f)) for p, f in zip(patch, sc))
         out.append(torch.nn.functional.interpolate(full, size=size, mode='nearest').contiguous().to(device))
     return out
+
+
+class SyntheticBatchGenerator:
+    """Fixed device-resident batch, reference dummyLoad style (nnUNetTrainerV2_dummyLoad.py:26-64)."""
+
+    def __init__(self, trainer, seed=1234):
+        from .dataset_conversion.Task100_MultiTalent import MultiTalent_regions, MultiTalent_valid_regions
+        dev = torch.device('cuda', torch.cuda.current_device())
+        B, patch = int(trainer.batch_size), tuple(int(i) for i in trainer.patch_size)
+        rank = getattr(trainer, 'local_rank', 0)
+        scales = trainer.deep_supervision_scales
+        self.data = synthetic_ct(B, patch, seed + rank, dev)
+        names = list(MultiTalent_valid_regions.keys())
+        if getattr(trainer, 'regions', None) is not None:
+            valid = [MultiTalent_valid_regions[names[(rank * B + b) % len(names)]] for b in range(B)]
+            label_sets = [sorted({l for r in v for l in MultiTalent_regions[r]}) for v in valid]
+        else:
+            valid = None
+            label_sets = [list(range(1, trainer.num_classes))] * B
+        self.target = synthetic_targets(B, patch, scales, label_sets, seed + rank, dev)
+        self.properties = [{'valid_regions': v} for v in valid] if valid is not None else [{} for _ in range(B)]
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return {'data': self.data, 'target': self.target, 'properties': self.properties, 'keys': None}

@@ -26,7 +26,8 @@ class GradAllReducer:
     def begin(self):
         self.sent = 0
         self.handles = []
-        if self.world > 1 and self.stream is None:
+        self.on_gpu = self.eng.flat_grad.is_cuda
+        if self.world > 1 and self.stream is None and self.on_gpu:
             self.stream = torch.cuda.Stream()
 
     def ready(self, lo, hi):
@@ -38,10 +39,14 @@ class GradAllReducer:
         while hi - self.sent >= self.bucket or (final and self.sent < n):
             end = n if final and (n - self.sent) < 2 * self.bucket else self.sent + self.bucket
             sl = self.eng.flat_grad[self.sent:end]
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                self.stream.wait_event(ev)
+            if self.on_gpu:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    self.stream.wait_event(ev)
+                    sl.div_(self.world)
+                    self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+            else:       # host tensors (gloo): used by the CPU tests of the bucketing logic
                 sl.div_(self.world)
                 self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
             self.sent = end
@@ -51,7 +56,8 @@ class GradAllReducer:
             return
         for h in self.handles:
             h.wait()
-        torch.cuda.current_stream().wait_stream(self.stream)
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.stream)
 
 
 class FusedTrainStep:

@@ -1,0 +1,415 @@
+"""Trainer base classes — host orchestration around the HIP hot loop (boundary seam 1).
+
+Restates, minimally and in its own words, what the drivers call on a trainer in the reference
+(network_trainer.py, nnUNetTrainer.py, nnUNetTrainerV2.py, nnUNetTrainerV2_DDP.py): constructor signature, plans
+parsing, network / optimizer construction, poly learning rate, `run_iteration`, checkpoint save/load in the reference's
+file format (`.model` = torch.save(dict), `.model.pkl` = {'init','name','class','plans'}), and
+`predict_preprocessed_data_return_seg_and_softmax`.  Data loading / augmentation, validation on files and plotting are
+out of scope: a trainer consumes any generator yielding {'data','target','properties'} batches; without
+one it uses device-resident synthetic batches like the reference's dummyLoad benchmarking trainer.
+"""
+import os
+import pickle
+import sys
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from ... import plans as plans_mod
+from ...network_architecture.generic_UNet import Generic_UNet
+from ...network_architecture.initialization import InitWeights_He
+from ...utilities.nd_softmax import softmax_helper
+from ..ds_weights import ds_loss_weights
+from ..hot_loop import FusedTrainStep
+from ..loss_functions.fused_losses import DC_and_CE_DS_loss
+
+
+def poly_lr(epoch, max_epochs, initial_lr, exponent=0.9):
+    """training/learning_rate/poly_lr.py:16-17."""
+    return initial_lr * (1 - epoch / max_epochs) ** exponent
+
+
+class nnUNetTrainer(object):
+    def __init__(self, plans_file, fold, output_folder=None, dataset_directory=None, batch_dice=True, stage=None,
+                 unpack_data=True, deterministic=True, fp16=False):
+        self.fp16 = fp16
+        self.unpack_data, self.deterministic = unpack_data, deterministic
+        self.init_args = (plans_file, fold, output_folder, dataset_directory, batch_dice, stage, unpack_data, deterministic, fp16)
+        self.stage = stage
+        self.plans_file = plans_file
+        self.output_folder = output_folder
+        self.dataset_directory = dataset_directory
+        self.fold = fold
+        self.plans = None
+        self.batch_dice = batch_dice
+        self.network = None
+        self.optimizer = None
+        self.lr_scheduler = None
+        self.amp_grad_scaler = None
+        self.tr_gen = self.val_gen = None
+        self.was_initialized = False
+        self.epoch = 0
+        self.max_num_epochs = 1000
+        self.num_batches_per_epoch = 250          # network_trainer.py:96-97
+        self.num_val_batches_per_epoch = 50
+        self.initial_lr = 1e-2                    # nnUNetTrainerV2.py:49-50
+        self.weight_decay = 3e-5
+        self.all_tr_losses, self.all_val_losses, self.all_val_losses_tr_mode, self.all_val_eval_metrics = [], [], [], []
+        self.best_epoch_based_on_MA_tr_loss = self.best_MA_tr_loss_for_patience = self.best_val_eval_criterion_MA = None
+        self.save_every = 50
+        self.log_file = None
+        self.regions_class_order = None
+        self.classes = self.num_classes = self.patch_size = self.batch_size = None
+        self.inference_pad_border_mode = "constant"
+        self.inference_pad_kwargs = {'constant_values': 0}
+        self.data_aug_params = {'do_mirror': True, 'mirror_axes': (0, 1, 2)}
+        self.local_rank = 0
+        self.train_step = None
+
+    # ---- plans (nnUNetTrainer.py:319-392) ----------------------------------------------------------------
+    def load_plans_file(self):
+        self.plans = self.plans_file if isinstance(self.plans_file, dict) else plans_mod.load_plans_file(self.plans_file)
+
+    def process_plans(self, plans):
+        if self.stage is None:
+            assert len(plans['plans_per_stage']) == 1, "several stages in the plans: pass `stage`"
+            self.stage = list(plans['plans_per_stage'].keys())[0]
+        self.plans = plans
+        sp = plans['plans_per_stage'][self.stage]
+        self.batch_size = sp['batch_size']
+        self.patch_size = np.array(sp['patch_size']).astype(int)
+        self.do_dummy_2D_aug = sp.get('do_dummy_2D_data_aug', False)
+        self.net_num_pool_op_kernel_sizes = sp['pool_op_kernel_sizes']
+        self.net_conv_kernel_sizes = sp['conv_kernel_sizes']
+        self.intensity_properties = plans['dataset_properties']['intensityproperties']
+        self.normalization_schemes = plans['normalization_schemes']
+        self.base_num_features = plans['base_num_features']
+        self.num_input_channels = plans['num_modalities']
+        self.num_classes = plans['num_classes'] + 1           # background is added here (nnUNetTrainer.py:366)
+        self.classes = plans['all_classes']
+        self.use_mask_for_norm = plans['use_mask_for_norm']
+        self.transpose_forward = plans.get('transpose_forward', [0, 1, 2])
+        self.transpose_backward = plans.get('transpose_backward', [0, 1, 2])
+        if len(self.patch_size) != 3:
+            raise RuntimeError("only 3D patches are on the hot path (got %s)" % str(self.patch_size))
+        self.threeD = True
+        self.conv_per_stage = plans.get('conv_per_stage', 2)
+
+    # ---- logging (network_trainer.py:222-254), rank 0 only in DDP -----------------------------------------
+    def print_to_log_file(self, *args, also_print_to_console=True, add_timestamp=True):
+        if self.local_rank != 0:
+            return
+        ts = datetime.now()
+        if add_timestamp:
+            args = ("%s:" % ts, *args)
+        if self.output_folder is not None:
+            os.makedirs(self.output_folder, exist_ok=True)
+            if self.log_file is None:
+                self.log_file = os.path.join(self.output_folder, "training_log_%d_%d_%d_%02.0d_%02.0d_%02.0d.txt" %
+                                             (ts.year, ts.month, ts.day, ts.hour, ts.minute, ts.second))
+            with open(self.log_file, 'a+') as f:
+                f.write(" ".join(str(a) for a in args) + "\n")
+        if also_print_to_console:
+            print(*args)
+
+    # ---- checkpoints (network_trainer.py:256-362, nnUNetTrainer.py:726-734) --------------------------------
+    def _optimizer_state_dict(self):
+        """torch.optim.SGD-format state built from the flat momentum buffer of the fused step."""
+        params = list(self.network.parameters())
+        st = {}
+        if self.train_step is not None and self.train_step.buf is not None and not self.train_step.first:
+            eng = self.network.engine()
+            for i, p in enumerate(params):
+                o = eng._views[id(p)][0]
+                st[i] = {'momentum_buffer': self.train_step.buf[o:o + p.numel()].view(p.shape).detach().cpu().clone()}
+        lr = self.optimizer_lr
+        return {'state': st, 'param_groups': [{'lr': lr, 'momentum': 0.99, 'dampening': 0, 'weight_decay': self.weight_decay,
+                                               'nesterov': True, 'maximize': False, 'foreach': None, 'differentiable': False,
+                                               'fused': None, 'initial_lr': self.initial_lr, 'params': list(range(len(params)))}]}
+
+    def restore_optimizer_state(self, osd):
+        """Momentum buffers of a torch.optim.SGD state_dict -> the flat momentum buffer of the fused step."""
+        if not torch.cuda.is_available() or not osd.get('state'):
+            return
+        eng = self.network.engine()
+        eng.attach(torch.device('cuda', torch.cuda.current_device()))
+        self.train_step._state(eng.flat.device)
+        params = list(self.network.parameters())
+        for i, p in enumerate(params):
+            st = osd['state'].get(i)
+            if st is not None and st.get('momentum_buffer') is not None:
+                o = eng._views[id(p)][0]
+                self.train_step.buf[o:o + p.numel()].copy_(st['momentum_buffer'].reshape(-1))
+                self.train_step.first = False
+
+    def save_checkpoint(self, fname, save_optimizer=True):
+        if self.local_rank != 0:
+            return
+        sd = {k: v.detach().cpu().clone() for k, v in self.network.state_dict().items()}
+        save_this = {'epoch': self.epoch + 1, 'state_dict': sd,
+                     'optimizer_state_dict': self._optimizer_state_dict() if save_optimizer else None,
+                     'lr_scheduler_state_dict': None,
+                     'plot_stuff': (self.all_tr_losses, self.all_val_losses, self.all_val_losses_tr_mode, self.all_val_eval_metrics),
+                     'best_stuff': (self.best_epoch_based_on_MA_tr_loss, self.best_MA_tr_loss_for_patience, self.best_val_eval_criterion_MA)}
+        os.makedirs(os.path.dirname(os.path.abspath(fname)), exist_ok=True)
+        torch.save(save_this, fname)
+        info = {'init': self.init_args, 'name': self.__class__.__name__, 'class': str(self.__class__), 'plans': self.plans}
+        with open(fname + ".pkl", 'wb') as f:
+            pickle.dump(info, f)
+
+    def load_checkpoint(self, fname, train=True):
+        if not self.was_initialized:
+            self.initialize(train)
+        self.load_checkpoint_ram(torch.load(fname, map_location='cpu', weights_only=False), train)
+
+    def load_checkpoint_ram(self, checkpoint, train=True):
+        """network_trainer.py:331-385 / nnUNetTrainerV2_DDP.py:636-697: strips a leading 'module.' (DDP) from the keys."""
+        if not self.was_initialized:
+            self.initialize(train)
+        cur = self.network.state_dict()
+        new = {}
+        for k, v in checkpoint['state_dict'].items():
+            key = k
+            if key not in cur and key.startswith('module.'):
+                key = key[7:]
+            new[key] = v
+        self.network.load_state_dict(new)
+        self.network.engine().mark_params_dirty()
+        self.epoch = checkpoint['epoch']
+        if train and checkpoint.get('optimizer_state_dict') is not None and self.train_step is not None:
+            self.restore_optimizer_state(checkpoint['optimizer_state_dict'])
+        if 'plot_stuff' in checkpoint:
+            self.all_tr_losses, self.all_val_losses, self.all_val_losses_tr_mode, self.all_val_eval_metrics = checkpoint['plot_stuff']
+        if 'best_stuff' in checkpoint:
+            self.best_epoch_based_on_MA_tr_loss, self.best_MA_tr_loss_for_patience, self.best_val_eval_criterion_MA = checkpoint['best_stuff']
+
+    def load_latest_checkpoint(self, train=True):
+        for n in ("model_final_checkpoint.model", "model_latest.model", "model_best.model"):
+            f = os.path.join(self.output_folder, n)
+            if os.path.isfile(f):
+                return self.load_checkpoint(f, train=train)
+        raise RuntimeError("No checkpoint found")
+
+    def load_best_checkpoint(self, train=True):
+        f = os.path.join(self.output_folder, "model_best.model")
+        return self.load_checkpoint(f, train) if os.path.isfile(f) else self.load_latest_checkpoint(train)
+
+    def load_final_checkpoint(self, train=False):
+        f = os.path.join(self.output_folder, "model_final_checkpoint.model")
+        if not os.path.isfile(f):
+            raise RuntimeError("Final checkpoint not found. Expected: %s. Please finish the training first." % f)
+        return self.load_checkpoint(f, train=train)
+
+    # ---- inference wrapper (nnUNetTrainer.py:483-527, nnUNetTrainerV2_DDP.py:601-634) ------------------------
+    def predict_preprocessed_data_return_seg_and_softmax(self, data, do_mirroring=True, mirror_axes=None,
+                                                         use_sliding_window=True, step_size=0.5, use_gaussian=True,
+                                                         pad_border_mode='constant', pad_kwargs=None, all_in_gpu=False,
+                                                         verbose=True, mixed_precision=True):
+        if pad_border_mode == 'constant' and pad_kwargs is None:
+            pad_kwargs = {'constant_values': 0}
+        if do_mirroring and mirror_axes is None:
+            mirror_axes = self.data_aug_params['mirror_axes']
+        if do_mirroring:
+            assert self.data_aug_params["do_mirror"], "Cannot do mirroring as test time augmentation when training was done without mirroring"
+        net = self.network
+        ds = self._get_ds(net)
+        self._set_ds(net, False)
+        was_training = net.training
+        net.eval()
+        try:
+            ret = net.predict_3D(data, do_mirroring=do_mirroring, mirror_axes=mirror_axes, use_sliding_window=use_sliding_window,
+                                 step_size=step_size, patch_size=self.patch_size, regions_class_order=self.regions_class_order,
+                                 use_gaussian=use_gaussian, pad_border_mode=pad_border_mode, pad_kwargs=pad_kwargs,
+                                 all_in_gpu=all_in_gpu, verbose=verbose, mixed_precision=mixed_precision)
+        finally:
+            net.train(was_training)
+            self._set_ds(net, ds)
+        return ret
+
+    @staticmethod
+    def _get_ds(net):
+        return net.do_ds
+
+    @staticmethod
+    def _set_ds(net, v):
+        net.do_ds = v
+
+
+class nnUNetTrainerV2(nnUNetTrainer):
+    """nnUNetTrainerV2.py:39-444 (single GPU): Generic_UNet + deep supervision + SGD-Nesterov + poly lr."""
+
+    def __init__(self, plans_file, fold, output_folder=None, dataset_directory=None, batch_dice=True, stage=None,
+                 unpack_data=True, deterministic=True, fp16=False):
+        super().__init__(plans_file, fold, output_folder, dataset_directory, batch_dice, stage, unpack_data, deterministic, fp16)
+        self.max_num_epochs = 1000
+        self.initial_lr = 1e-2
+        self.deep_supervision_scales = None
+        self.ds_loss_weights = None
+        self.pin_memory = True
+        self.optimizer_lr = self.initial_lr
+        self.ddp = False
+
+    def setup_DA_params(self):
+        """only what the hot path needs: the deep-supervision target scales (nnUNetTrainerV2.py:107-108)."""
+        self.deep_supervision_scales = [[1, 1, 1]] + list(list(i) for i in 1 / np.cumprod(
+            np.vstack(self.net_num_pool_op_kernel_sizes), axis=0))[:-1]
+
+    def make_loss(self):
+        return DC_and_CE_DS_loss(self.ds_loss_weights, batch_dice=self.batch_dice, smooth=1e-5, do_bg=False, ddp=self.ddp)
+
+    def initialize(self, training=True, force_load_plans=False):
+        if self.was_initialized:
+            return
+        if force_load_plans or self.plans is None:
+            self.load_plans_file()
+        self.process_plans(self.plans)
+        self.setup_DA_params()
+        self.ds_loss_weights = ds_loss_weights(len(self.net_num_pool_op_kernel_sizes))    # nnUNetTrainerV2.py:78-90
+        self.initialize_network()
+        self.initialize_optimizer_and_scheduler()
+        self.was_initialized = True
+
+    def initialize_network(self):
+        """nnUNetTrainerV2.py:131-164 — same positional call."""
+        self.network = Generic_UNet(self.num_input_channels, self.base_num_features, self.num_classes,
+                                    len(self.net_num_pool_op_kernel_sizes), self.conv_per_stage, 2, nn.Conv3d, nn.InstanceNorm3d,
+                                    {'eps': 1e-5, 'affine': True}, nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
+                                    {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x, InitWeights_He(1e-2),
+                                    self.net_num_pool_op_kernel_sizes, self.net_conv_kernel_sizes, False, True, True)
+        if torch.cuda.is_available():
+            self.network.cuda()
+        self.network.inference_apply_nonlin = softmax_helper
+
+    def initialize_optimizer_and_scheduler(self):
+        """SGD(lr, weight_decay 3e-5, momentum 0.99, nesterov) (nnUNetTrainerV2.py:166-170) as ONE fused kernel."""
+        assert self.network is not None
+        self.train_step = FusedTrainStep(self.network, self.make_loss(), lr=self.initial_lr, weight_decay=self.weight_decay,
+                                         momentum=0.99, max_norm=12.0, ddp=self.ddp)
+        self.optimizer = self.train_step          # drivers only touch .param_groups-like lr through maybe_update_lr
+        self.lr_scheduler = None
+
+    def maybe_update_lr(self, epoch=None):
+        ep = self.epoch + 1 if epoch is None else epoch                                  # nnUNetTrainerV2.py:393-408
+        self.optimizer_lr = poly_lr(ep, self.max_num_epochs, self.initial_lr, 0.9)
+        self.train_step.lr = self.optimizer_lr
+        self.print_to_log_file("lr:", np.round(self.optimizer_lr, decimals=6))
+
+    def _to_device(self, a):
+        if isinstance(a, (list, tuple)):
+            return [self._to_device(i) for i in a]
+        if isinstance(a, np.ndarray):
+            a = torch.from_numpy(a).float()
+        return a.cuda(non_blocking=True) if not a.is_cuda else a
+
+    def loss_args(self, data_dict):
+        return (self._to_device(data_dict['target']),)
+
+    def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False):
+        """nnUNetTrainerV2.py:225-274: fwd, loss, bwd, clip 12, step — one call into the fused hot loop."""
+        data_dict = next(data_generator)
+        data = self._to_device(data_dict['data'])
+        res = self.train_step(data, *self.loss_args(data_dict), do_backprop=do_backprop)
+        l = res[0] if isinstance(res, tuple) else res
+        return l.detach().cpu().numpy()
+
+    def on_epoch_end(self):
+        self.maybe_update_lr()
+        if self.output_folder is not None and (self.epoch + 1) % self.save_every == 0:
+            self.save_checkpoint(os.path.join(self.output_folder, "model_latest.model"))
+        return self.epoch < self.max_num_epochs
+
+    def _default_generator(self):
+        from ...synthetic import SyntheticBatchGenerator
+        return SyntheticBatchGenerator(self)
+
+    def run_training(self):
+        """epoch loop of network_trainer.py:411-470 without plotting / early stopping bookkeeping."""
+        if not self.was_initialized:
+            self.initialize(True)
+        self.maybe_update_lr(self.epoch)
+        if self.tr_gen is None:
+            self.tr_gen = self._default_generator()
+        if self.val_gen is None:
+            self.val_gen = self.tr_gen
+        while self.epoch < self.max_num_epochs:
+            t0 = time.time()
+            self.network.train()
+            tr = [self.run_iteration(self.tr_gen, True) for _ in range(self.num_batches_per_epoch)]
+            self.all_tr_losses.append(float(np.mean(tr)))
+            self.print_to_log_file("\nepoch:", self.epoch, "train loss : %.4f" % self.all_tr_losses[-1])
+            with torch.no_grad():
+                self.network.eval()
+                va = [self.run_iteration(self.val_gen, False, True) for _ in range(self.num_val_batches_per_epoch)]
+                self.all_val_losses.append(float(np.mean(va)))
+            self.print_to_log_file("validation loss: %.4f" % self.all_val_losses[-1],
+                                   "This epoch took %f s\n" % (time.time() - t0))
+            cont = self.on_epoch_end()
+            self.epoch += 1
+            if not cont:
+                break
+        if self.output_folder is not None:
+            self.save_checkpoint(os.path.join(self.output_folder, "model_final_checkpoint.model"))
+
+
+class nnUNetTrainerV2_DDP(nnUNetTrainerV2):
+    """nnUNetTrainerV2_DDP.py:46-697: one process per GPU, RCCL ('nccl' backend) gradient all-reduce overlapped with
+    backward (hot_loop.GradAllReducer) instead of torch DDP buckets."""
+
+    def __init__(self, plans_file, fold, local_rank, output_folder=None, dataset_directory=None, batch_dice=True, stage=None,
+                 unpack_data=True, deterministic=True, distribute_batch_size=False, fp16=False):
+        super().__init__(plans_file, fold, output_folder, dataset_directory, batch_dice, stage, unpack_data, deterministic, fp16)
+        self.init_args = (plans_file, fold, local_rank, output_folder, dataset_directory, batch_dice, stage, unpack_data,
+                          deterministic, distribute_batch_size, fp16)
+        self.distribute_batch_size = distribute_batch_size
+        np.random.seed(local_rank)
+        torch.manual_seed(local_rank)
+        self.local_rank = local_rank
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            torch.cuda.manual_seed_all(local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group(backend='nccl' if torch.cuda.is_available() else 'gloo', init_method='env://')
+        self.ddp = True
+        self.oversample_foreground_percent = 0.33
+
+    def set_batch_size_and_oversample(self):
+        """Per-rank batch size and foreground-oversampling share (nnUNetTrainerV2_DDP.py:75-117): ranks are laid side by
+        side on the [0, global batch) sample axis and the last `oversample_foreground_percent` of that axis is the
+        foreground-forced part — in --dbs mode the plan batch is split, otherwise every rank gets the plan batch."""
+        world, me = dist.get_world_size(), dist.get_rank()
+        plan_bs, fg = self.batch_size, self.oversample_foreground_percent
+        total = plan_bs if self.distribute_batch_size else plan_bs * world
+        share = int(np.ceil(plan_bs / world))
+        sizes = []
+        for r in range(world):
+            sizes.append(min(share, plan_bs - r * share) if self.distribute_batch_size else plan_bs)
+        if sizes[me] <= 0:
+            raise RuntimeError("--dbs with %d ranks and plan batch size %d leaves rank %d without samples "
+                               "(run without distribute_batch_size)" % (world, plan_bs, me))
+        lo, hi = float(np.sum(sizes[:me])) / total, float(np.sum(sizes[:me + 1])) / total
+        if hi < 1 - fg:
+            pct = 0.0
+        elif lo > 1 - fg:
+            pct = 1.0
+        else:
+            pct = 1 - ((1 - fg) - lo) / (hi - lo)
+        self.global_batch_size = total
+        self.batch_size, self.oversample_foreground_percent = int(sizes[me]), float(pct)
+        return total
+
+    def process_plans(self, plans):
+        super().process_plans(plans)
+        self.set_batch_size_and_oversample()
+
+    def initialize_network(self):
+        torch.manual_seed(1234)      # identical initial weights on every rank (what DDP's initial broadcast guarantees)
+        super().initialize_network()
+        if dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available():
+            eng = self.network.engine()
+            eng.attach(torch.device('cuda', self.local_rank))
+            dist.broadcast(eng.flat, 0)
+            eng.mark_params_dirty()

@@ -1,0 +1,138 @@
+"""Multi-process CPU tests (gloo, world size 2) of everything the N>1 path adds on top of the single-GPU path:
+the Dice-statistics exchange, the bucketed gradient all-reduce, and the per-rank batch / oversampling split."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import reference_ops as R
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def run_world(fn, world=2):
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return [ret[r] for r in range(world)]
+
+
+def _dice_exchange(rank, world):
+    """sum_over_ranks (one all_reduce each way) == awesome_allgather_function(x).sum(0) of the reference, forward and
+    backward (distributed.py:28-73, MultiTalent_Trainer_DDP.py:598-606)."""
+    from multitalent_amd.training.distributed_utils import sum_over_ranks
+    g = torch.Generator().manual_seed(100 + rank)
+    out = {}
+    for name, f in (('ours', lambda t: sum_over_ranks(t)), ('ref', lambda t: R.AwesomeAllgather.apply(t).sum(0))):
+        tp = (torch.rand((3, 47), generator=torch.Generator().manual_seed(100 + rank)) * 50).requires_grad_(True)
+        fp = (torch.rand((3, 47), generator=torch.Generator().manual_seed(200 + rank)) * 50).requires_grad_(True)
+        fn = (torch.rand((3, 47), generator=torch.Generator().manual_seed(300 + rank)) * 50).requires_grad_(True)
+        if name == 'ours':
+            s = f(torch.stack((tp, fp, fn), 0))
+            TP, FP, FN = s[0], s[1], s[2]
+        else:
+            TP, FP, FN = f(tp), f(fp), f(fn)
+        dc = (2 * TP / torch.clamp(2 * TP + FP + FN, min=1e-7)).sum() * (rank + 1)      # rank-dependent local loss
+        dc.backward()
+        out[name] = (float(dc), tp.grad.numpy().copy(), fp.grad.numpy().copy(), fn.grad.numpy().copy())
+    return out
+
+
+def test_dice_statistics_exchange_matches_reference_allgather():
+    res = run_world(_dice_exchange)
+    for r in res:
+        assert abs(r['ours'][0] - r['ref'][0]) < 1e-4 * abs(r['ref'][0])
+        for a, b in zip(r['ours'][1:], r['ref'][1:]):
+            assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+class _FakeEngine:
+    def __init__(self, n):
+        self.flat_grad = torch.zeros(n)
+
+
+def _grad_allreduce(rank, world):
+    from multitalent_amd.training.hot_loop import GradAllReducer
+    n = 100000
+    eng = _FakeEngine(n)
+    red = GradAllReducer(eng, bucket_bytes=4 * 30000)
+    g = torch.Generator().manual_seed(rank)
+    full = torch.randn(n, generator=g)
+    red.begin()
+    # gradients become final in 7 uneven slices (backward-completion order)
+    cuts = [0, 5000, 41000, 41010, 77777, 90000, 99999, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        eng.flat_grad[lo:hi] = full[lo:hi]
+        red.ready(lo, hi)
+    red.ready(n, n)
+    red.finish()
+    assert red.sent == n
+    return eng.flat_grad.numpy().copy(), full.numpy()
+
+
+def test_bucketed_gradient_allreduce_is_the_mean():
+    res = run_world(_grad_allreduce)
+    mean = (res[0][1] + res[1][1]) / 2
+    for r in res:
+        assert np.allclose(r[0], mean, atol=1e-6)
+
+
+def test_batch_size_and_oversample_split_matches_reference():
+    from multitalent_amd.training.network_training.nnUNetTrainer import nnUNetTrainerV2_DDP
+
+    class Fake:
+        pass
+    for world in (1, 2, 4, 8):
+        for bs in (2, 4, 9):
+            for dbs in (False, True):
+                for rank in range(world):
+                    exp_bs, exp_pct = R.set_batch_size_and_oversample(bs, world, rank, dbs)
+                    if exp_bs <= 0:
+                        continue
+                    t = Fake(); t.batch_size = bs; t.oversample_foreground_percent = 0.33; t.distribute_batch_size = dbs
+                    orig = (dist.get_world_size, dist.get_rank)
+                    dist.get_world_size, dist.get_rank = (lambda: world), (lambda: rank)
+                    try:
+                        nnUNetTrainerV2_DDP.set_batch_size_and_oversample(t)
+                    finally:
+                        dist.get_world_size, dist.get_rank = orig
+                    assert t.batch_size == exp_bs and abs(t.oversample_foreground_percent - exp_pct) < 1e-12, (world, bs, dbs, rank)
+
+
+def test_dbs_with_more_ranks_than_samples_is_rejected():
+    """8 ranks, plan batch 4, --dbs: ranks 4-7 would get no samples (nnUNetTrainerV2_DDP.py:87-98)."""
+    from multitalent_amd.training.network_training.nnUNetTrainer import nnUNetTrainerV2_DDP
+
+    class Fake:
+        pass
+    t = Fake(); t.batch_size = 4; t.oversample_foreground_percent = 0.33; t.distribute_batch_size = True
+    orig = (dist.get_world_size, dist.get_rank)
+    dist.get_world_size, dist.get_rank = (lambda: 8), (lambda: 6)
+    try:
+        with pytest.raises(RuntimeError):
+            nnUNetTrainerV2_DDP.set_batch_size_and_oversample(t)
+    finally:
+        dist.get_world_size, dist.get_rank = orig

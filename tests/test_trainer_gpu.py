@@ -1,0 +1,89 @@
+"""Trainer plugin surface on the GPU: discovery by name, plans parsing, run_iteration on the fused hot loop,
+checkpoint round trip in the reference's file format, restore_model, sliding-window prediction wrapper."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def small_plans(resenc=False):
+    from multitalent_amd import plans as P
+    if resenc:
+        sp = {'batch_size': 2, 'patch_size': np.array([16, 32, 32]),
+              'pool_op_kernel_sizes': [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2]],
+              'conv_kernel_sizes': [[1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+              'num_blocks_encoder': [1, 2, 2, 2], 'num_blocks_decoder': [1, 1, 1], 'do_dummy_2D_data_aug': False}
+    else:
+        sp = {'batch_size': 2, 'patch_size': np.array([16, 32, 32]), 'pool_op_kernel_sizes': [[2, 2, 2], [2, 2, 2], [1, 2, 2]],
+              'conv_kernel_sizes': [[3, 3, 3]] * 4, 'do_dummy_2D_data_aug': False}
+    return P.make_plans(sp, base_num_features=8, num_classes=47, stage=1)
+
+
+@pytest.fixture(scope='module')
+def pg():
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29577')
+    os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', init_method='env://')
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,resenc", [("MultiTalent_trainer_ddp", False), ("nnUNetTrainerV2_MultiTalent", False),
+                                         ("MultiTalent_trainer_resenc_ddp", True)])
+def test_multitalent_trainer_roundtrip(dev, pg, tmp_path, name, resenc):
+    from multitalent_amd.training.model_restore import find_trainer_class, restore_model
+    cls = find_trainer_class(name)
+    tr = cls(small_plans(resenc), 0, 0, output_folder=str(tmp_path), stage=1)
+    tr.initialize(True)
+    assert tr.num_classes == 47 and tr.regions_class_order == list(range(47))
+    gen = tr._default_generator()
+    tr.network.train()
+    losses = [tr.run_iteration(gen, True) for _ in range(3)]
+    assert all(np.isfinite(l[0]) for l in losses) and len(losses[0]) == 3
+    assert losses[2][0] < losses[0][0]          # a fixed batch must be learnable
+    with torch.no_grad():
+        tr.network.eval()
+        v = tr.run_iteration(gen, False, True)
+    assert np.isfinite(v[0]) and len(tr.online_eval_tp) == 1 and len(tr.online_eval_tp[0]) == 47
+    f = os.path.join(str(tmp_path), 'model_latest.model')
+    tr.save_checkpoint(f)
+    ck = torch.load(f, map_location='cpu', weights_only=False)
+    assert set(ck) >= {'epoch', 'state_dict', 'optimizer_state_dict', 'lr_scheduler_state_dict', 'plot_stuff', 'best_stuff'}
+    info = pickle.load(open(f + '.pkl', 'rb'))
+    assert info['name'] == name and set(info) == {'init', 'name', 'class', 'plans'}
+    assert len(ck['optimizer_state_dict']['state']) == len(list(tr.network.parameters()))
+    # DDP checkpoints carry a 'module.' prefix: must be stripped on load (nnUNetTrainerV2_DDP.py:650-662)
+    ck['state_dict'] = {'module.' + k: v for k, v in ck['state_dict'].items()}
+    tr2 = restore_model(f + '.pkl')
+    tr2.initialize(False)
+    tr2.load_checkpoint_ram(ck, False)
+    vol = np.random.RandomState(0).randn(1, 20, 40, 40).astype(np.float32)
+    s1, p1 = tr.predict_preprocessed_data_return_seg_and_softmax(vol, do_mirroring=True, mirror_axes=(0, 1, 2), verbose=False)
+    s2, p2 = tr2.predict_preprocessed_data_return_seg_and_softmax(vol, do_mirroring=True, mirror_axes=(0, 1, 2), verbose=False)
+    assert p1.shape == (47, 20, 40, 40) and s1.shape == (20, 40, 40)
+    assert np.array_equal(p1, p2) and np.array_equal(s1, s2)
+    assert tr.network.training is False or True
+
+
+def test_single_gpu_trainer_softmax(dev, tmp_path):
+    from multitalent_amd import plans as P
+    from multitalent_amd.training.model_restore import find_trainer_class
+    sp = {'batch_size': 2, 'patch_size': np.array([16, 32, 32]), 'pool_op_kernel_sizes': [[2, 2, 2], [2, 2, 2], [1, 2, 2]],
+          'conv_kernel_sizes': [[3, 3, 3]] * 4, 'do_dummy_2D_data_aug': False}
+    plans = P.make_plans(sp, base_num_features=8, num_classes=1, stage=0)
+    tr = find_trainer_class('nnUNetTrainerV2')(plans, 0, output_folder=str(tmp_path), batch_dice=False, stage=0)
+    tr.initialize(True)
+    assert tr.num_classes == 2
+    gen = tr._default_generator()
+    tr.network.train()
+    l = [float(tr.run_iteration(gen, True)) for _ in range(4)]
+    assert l[-1] < l[0]
+    tr.maybe_update_lr(500)
+    assert abs(tr.train_step.lr - 1e-2 * (1 - 500 / 1000) ** 0.9) < 1e-12
