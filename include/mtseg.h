@@ -91,6 +91,7 @@ int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats,
 int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream);
 int mt_conv3d_stats_blocks(const mt_conv3d_t* p); /* spatial blocks per sample (size of stats_part dim 1) */
 int mt_conv3d_ck(const mt_conv3d_t* p);           /* channel chunk the kernel will use (pack weights with it) */
+int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n); /* device kernel that will run (profiler name) */
 
 /* ---- backward-weight -------------------------------------------------------------------------
  * dW[tap][ci][co] = sum_{n,o} X[n, o*S + t - P, ci] * Y[n, o, co]   (autograd of nn.Conv3d /

@@ -839,6 +839,23 @@ static int launch_conv(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
   return MT_OK;
 }
 
+// name of the device kernel mt_conv3d_fwd will launch for this problem (as rocprofv3 prints it) — lets the benchmark
+// attribute per-launch timings to the same kernel names the profiler reports
+extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) {
+  if (p == nullptr || buf == nullptr || n == 0) return MT_EINVAL;
+  const int i = pick_cfg(p);
+  if (i < 0) return MT_EINVAL;
+  const ConvCfg& g = kCfgs[i];
+  static int use_v2 = -1;
+  if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
+  const bool fast = conv_is_fast(p);
+  if (fast && use_v2 && g.CK == 16 && i <= 2)
+    snprintf(buf, n, "conv_fast_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
+  else
+    snprintf(buf, n, "conv_fwd_kernel<%d, %d, %d, %d, %s>", g.MW, g.RH, g.TD, g.CK, (fast && (i <= 3 || i == 6)) ? "true" : "false");
+  return MT_OK;
+}
+
 extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   int rc = conv_validate(p);
   if (rc != MT_OK) return rc;

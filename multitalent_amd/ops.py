@@ -129,6 +129,12 @@ def conv_ck(p):
     return ck
 
 
+def conv_kernel_name(p):
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.load().mt_conv3d_kernel_name(C.byref(p), buf, 128), 'conv3d_kernel_name')
+    return buf.value.decode()
+
+
 def conv_stats_blocks(p):
     return _lib.load().mt_conv3d_stats_blocks(C.byref(p))
 

@@ -165,3 +165,69 @@ def test_predict_3d_tiled_matches_reference_bit_exact_masks():
                 safe = (np.abs(probs - 0.5) > 1e-4).all(0)
             assert np.array_equal(seg[safe].astype(np.int16), ref_seg[safe])
             assert safe.mean() > 0.99
+
+
+# ---- the plain-C oracle (oracle/c/mt_oracle.c) against the same reference goldens ------------------------------
+def _c_oracle():
+    import ctypes as C
+    import subprocess
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', 'c')
+    so = os.path.join(d, 'libmt_oracle.so')
+    if not os.path.isfile(so):
+        subprocess.check_call(['make', '-C', d])
+    return C.CDLL(so)
+
+
+def _fp(a):
+    import ctypes as C
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def test_c_oracle_first_block_and_tconv_of_plain_unet():
+    """conv -> InstanceNorm -> LeakyReLU of the first two blocks, and a transposed conv, recomputed in plain C, must equal
+    the torch restatement (itself pinned to the reference goldens above)."""
+    import ctypes as C
+    lib = _c_oracle()
+    z = load('plain_unet.npz')
+    x = np.ascontiguousarray(z['x'])
+    N, Ci, D, H, W = x.shape
+    cur = x
+    t = torch.from_numpy(x)
+    for j in range(2):
+        w = np.ascontiguousarray(z['sd0/conv_blocks_context.0.blocks.%d.conv.weight' % j]); b = np.ascontiguousarray(z['sd0/conv_blocks_context.0.blocks.%d.conv.bias' % j])
+        g = np.ascontiguousarray(z['sd0/conv_blocks_context.0.blocks.%d.instnorm.weight' % j]); be = np.ascontiguousarray(z['sd0/conv_blocks_context.0.blocks.%d.instnorm.bias' % j])
+        Co = w.shape[0]
+        y = np.empty((N, Co, D, H, W), np.float32)
+        lib.mto_conv3d(_fp(cur), _fp(w), _fp(b), _fp(y), N, cur.shape[1], D, H, W, Co, 3, 3, 3, 1, 1, 1, 1, 1, 1)
+        lib.mto_instnorm_lrelu(_fp(y), _fp(g), _fp(be), N, Co, C.c_long(D * H * W), C.c_float(1e-5), C.c_float(1e-2))
+        t = R.conv_norm_nonlin(t, torch.from_numpy(w), torch.from_numpy(b), torch.from_numpy(g), torch.from_numpy(be))
+        assert np.abs(y - t.numpy()).max() < 2e-5
+        cur = y
+    wt = np.ascontiguousarray(z['sd0/tu.2.weight'])          # [Ci, Co, 2, 2, 2]
+    xin = np.ascontiguousarray(np.random.RandomState(0).randn(1, wt.shape[0], 2, 3, 4).astype(np.float32))
+    yo = np.empty((1, wt.shape[1], 2 * wt.shape[2], 3 * wt.shape[3], 4 * wt.shape[4]), np.float32)
+    lib.mto_tconv3d(_fp(xin), _fp(wt), _fp(yo), 1, wt.shape[0], 2, 3, 4, wt.shape[1], wt.shape[2], wt.shape[3], wt.shape[4])
+    ref = torch.nn.functional.conv_transpose3d(torch.from_numpy(xin), torch.from_numpy(wt), stride=tuple(wt.shape[2:]))
+    assert np.abs(yo - ref.numpy()).max() < 1e-5
+
+
+def test_c_oracle_multitalent_loss_statistics():
+    import ctypes as C
+    from multitalent_amd.dataset_conversion.Task100_MultiTalent import region_label_lut, valid_mask
+    lib = _c_oracle()
+    z = load('multitalent_loss.npz')
+    valid = json.load(open(os.path.join(G, 'multitalent_loss_valid.json')))['valid_regions']
+    lut = np.array(region_label_lut(), dtype=np.uint64)
+    vm = np.array([valid_mask(v) for v in valid], dtype=np.uint64)
+    total = 0.0
+    for i in range(2):
+        lg = np.ascontiguousarray(z['logits%d' % i]); tg = np.ascontiguousarray(z['target%d' % i])
+        B, Cn = lg.shape[:2]; V = int(np.prod(lg.shape[2:]))
+        st = np.zeros((B, Cn, 4), np.float64)
+        lib.mto_multitalent_stats(_fp(lg), _fp(tg), B, Cn, C.c_long(V), vm.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                  lut.ctypes.data_as(C.POINTER(C.c_uint64)), st.ctypes.data_as(C.POINTER(C.c_double)))
+        ce = st[..., 0].sum() / V
+        tp, fp, fn = st[..., 1], st[..., 2], st[..., 3]
+        dc = (2 * tp / np.maximum(2 * tp + fp + fn, 1e-7)).sum()
+        total += z['weights'][i] * (ce - dc)
+    assert abs(total - z['bd1/loss'][0]) < 1e-4 * abs(z['bd1/loss'][0])
