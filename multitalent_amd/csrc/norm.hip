@@ -197,6 +197,107 @@ __global__ __launch_bounds__(64) void colsum_kernel(const float* part, long rows
   if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)a : (float)a;
 }
 
+
+// ---- fast path for CONTIGUOUS tensors (cs == C): the whole [V][C] slab of a sample is one linear array.  A thread owns a
+// fixed group of VEC consecutive channels: with G = C/VEC groups, thread t < A = (256/G)*G handles flat vector index
+// base + t + k*A, whose channel group is (t mod G) for every k (A is a multiple of G) -> per-channel constants live in
+// registers, consecutive lanes read consecutive vectors (fully coalesced), 4 independent loads in flight per tensor.
+#define NF_UNROLL 4
+template <int VEC> struct VecT;
+template <> struct VecT<1> { typedef float T; };
+template <> struct VecT<2> { typedef float2 T; };
+template <> struct VecT<4> { typedef float4 T; };
+template <int VEC> __device__ __forceinline__ float vget(const typename VecT<VEC>::T& v, int e);
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+template <> __device__ __forceinline__ float vget<2>(const float2& v, int e) { return e ? v.y : v.x; }
+template <> __device__ __forceinline__ float vget<4>(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+template <int VEC> __device__ __forceinline__ void vset(typename VecT<VEC>::T& v, int e, float x);
+template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v = x; }
+template <> __device__ __forceinline__ void vset<2>(float2& v, int e, float x) { if (e) v.y = x; else v.x = x; }
+template <> __device__ __forceinline__ void vset<4>(float4& v, int e, float x) { if (e == 0) v.x = x; else if (e == 1) v.y = x; else if (e == 2) v.z = x; else v.w = x; }
+
+struct InBwdFast {
+  float* g; const float* y;
+  const float* mean; const float* rstd; const float* gamma; const float* beta; float slope;
+  long nvec;      // vectors per sample = V*C/VEC
+  int C, G, A, nblk;
+  float* part1;   // [N][nblk][C][2]
+  const float* m; // [N][C][2]
+  float* part2;   // [N][nblk][C] or null
+};
+
+template <int VEC, bool APPLY>
+__global__ __launch_bounds__(256) void inorm_bwd_fast_kernel(const InBwdFast P) {
+  typedef typename VecT<VEC>::T VT;
+  __shared__ float red[256 * VEC * 2];
+  const int n = blockIdx.y, t = threadIdx.x;
+  const bool act = t < P.A;
+  const int grp = t % P.G;
+  float mu[VEC], rs[VEC], ga[VEC], be[VEC], m1[VEC], m2[VEC], a0[VEC], a1[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const int c = grp * VEC + e;
+    mu[e] = P.mean[(size_t)n * P.C + c]; rs[e] = P.rstd[(size_t)n * P.C + c];
+    ga[e] = P.gamma ? P.gamma[c] : 1.f; be[e] = P.beta ? P.beta[c] : 0.f;
+    if (APPLY) { m1[e] = P.m[((size_t)n * P.C + c) * 2]; m2[e] = P.m[((size_t)n * P.C + c) * 2 + 1]; }
+    a0[e] = 0.f; a1[e] = 0.f;
+  }
+  // block range: vectors [blk*per, (blk+1)*per), per a multiple of A
+  const long per = ((P.nvec + P.nblk - 1) / P.nblk + P.A - 1) / P.A * P.A;
+  const long lo = (long)blockIdx.x * per;
+  long hi = lo + per; if (hi > P.nvec) hi = P.nvec;
+  VT* gp = (VT*)(P.g + (size_t)n * P.nvec * VEC);
+  const VT* yp = (const VT*)(P.y + (size_t)n * P.nvec * VEC);
+  if (act) {
+    for (long i0 = lo + t; i0 < hi; i0 += (long)P.A * NF_UNROLL) {
+      VT gv[NF_UNROLL], yv[NF_UNROLL];
+#pragma unroll
+      for (int u = 0; u < NF_UNROLL; ++u) {
+        const long i = i0 + (long)u * P.A;
+        if (i < hi) { gv[u] = gp[i]; yv[u] = yp[i]; }
+      }
+#pragma unroll
+      for (int u = 0; u < NF_UNROLL; ++u) {
+        const long i = i0 + (long)u * P.A;
+        if (i < hi) {
+          VT out;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float zh = (vget<VEC>(yv[u], e) - mu[e]) * rs[e];
+            const float z = fmaf(zh, ga[e], be[e]);
+            float dz = vget<VEC>(gv[u], e);
+            dz = z > 0.f ? dz : dz * P.slope;
+            if (APPLY) {
+              const float dy = ga[e] * rs[e] * (dz - m1[e] - zh * m2[e]);
+              vset<VEC>(out, e, dy);
+              a0[e] += dy;
+            } else {
+              a0[e] += dz;
+              a1[e] = fmaf(dz, zh, a1[e]);
+            }
+          }
+          if (APPLY) gp[i] = out;
+        }
+      }
+    }
+  }
+  if (APPLY && P.part2 == nullptr) return;
+  // reduce over the threads that share a channel group: threads t, t+G, t+2G, ...
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { red[(t * VEC + e) * 2] = act ? a0[e] : 0.f; red[(t * VEC + e) * 2 + 1] = act ? a1[e] : 0.f; }
+  __syncthreads();
+  if (t < P.G) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int k = t; k < P.A; k += P.G) { s0 += red[(k * VEC + e) * 2]; s1 += red[(k * VEC + e) * 2 + 1]; }
+      const int c = t * VEC + e;
+      if (APPLY) P.part2[((size_t)n * P.nblk + blockIdx.x) * P.C + c] = s0;
+      else { float* o = P.part1 + (((size_t)n * P.nblk + blockIdx.x) * P.C + c) * 2; o[0] = s0; o[1] = s1; }
+    }
+  }
+}
+
 extern "C" size_t mt_inorm_bwd_workspace(int N, long V, int C) {
   const size_t nvb = (size_t)nb_blocks(V);
   return ((size_t)N * nvb * C * 3 + (size_t)N * C * 2) * sizeof(float);
@@ -215,9 +316,28 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
   P.m = w; w += (size_t)N * C * 2;
   P.part2 = dbias ? w : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
-  hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, P, N, dgamma, dbeta);
-  hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
+  // contiguous tensors take the vectorised lane-constant-channel path
+  const int vec = (C % 4 == 0) ? 4 : (C % 2 == 0) ? 2 : 1;
+  const bool contig = (gcs == C) && (ycs == C) && (C / vec <= 256) && ((((uintptr_t)g) | ((uintptr_t)y)) & 15) == 0 &&
+                      (((long)V * C) % vec == 0) && ((((long)V * C) * 4) % 16 == 0);
+  if (contig) {
+    InBwdFast F;
+    F.g = g; F.y = y; F.mean = mean; F.rstd = rstd; F.gamma = gamma; F.beta = beta; F.slope = slope;
+    F.nvec = (long)V * C / vec; F.C = C; F.G = C / vec; F.A = (256 / F.G) * F.G; F.nblk = P.nvb;
+    F.part1 = P.part1; F.m = P.m; F.part2 = P.part2;
+    dim3 grid(P.nvb, N);
+    if (vec == 4) hipLaunchKernelGGL((inorm_bwd_fast_kernel<4, false>), grid, dim3(256), 0, st, F);
+    else if (vec == 2) hipLaunchKernelGGL((inorm_bwd_fast_kernel<2, false>), grid, dim3(256), 0, st, F);
+    else hipLaunchKernelGGL((inorm_bwd_fast_kernel<1, false>), grid, dim3(256), 0, st, F);
+    hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, P, N, dgamma, dbeta);
+    if (vec == 4) hipLaunchKernelGGL((inorm_bwd_fast_kernel<4, true>), grid, dim3(256), 0, st, F);
+    else if (vec == 2) hipLaunchKernelGGL((inorm_bwd_fast_kernel<2, true>), grid, dim3(256), 0, st, F);
+    else hipLaunchKernelGGL((inorm_bwd_fast_kernel<1, true>), grid, dim3(256), 0, st, F);
+  } else {
+    hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, P, N, dgamma, dbeta);
+    hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
+  }
   if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(64), 0, st, (const float*)P.part2, (long)N * P.nvb, C, dbias, 0);
   MT_CHECK_LAUNCH("inorm_lrelu_bwd");
   return MT_OK;
