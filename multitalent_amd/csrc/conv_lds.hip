@@ -543,6 +543,123 @@ __device__ __forceinline__ void mt_stage_fast2(float* __restrict__ lds, const mt
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split form of mt_stage_fast2 for software pipelining across tiles: stage2_load issues all global loads of a wave's
+// share of the tile into registers (no wait), stage2_store applies InstanceNorm+LeakyReLU and writes LDS later.
+template <int LD, int LH, int LW, int VEC>
+struct Stage2Regs {
+  static constexpr int LPV = FCK / VEC, VPS = 64 / LPV, NI = (LW + VPS - 1) / VPS, R = LD * LH, RPW = (R + 3) / 4;
+  float v[RPW][NI][VEC];
+  int voff[NI];
+  unsigned rvmask;     // bit r: row r of this wave is inside the volume
+  int nb;
+  bool nosel;
+};
+
+template <int LD, int LH, int LW, int VEC>
+__device__ __forceinline__ void stage2_load(Stage2Regs<LD, LH, LW, VEC>& g, const mt_conv3d_t& c, const ConvChunk ch, int nb,
+                                            int ud0, int uh0, int uw0, int lane, int wave) {
+  typedef Stage2Regs<LD, LH, LW, VEC> RG_;
+  constexpr int LPV = RG_::LPV, VPS = RG_::VPS, NI = RG_::NI, R = RG_::R, RPW = RG_::RPW;
+  const mt_src_t& S = c.src[ch.src];
+  const int cl = (lane % LPV) * VEC, vl = lane / LPV;
+  const bool cval0 = cl < ch.ck;
+  const int cs = S.cs;
+  const size_t sample_elems = (size_t)c.Di * c.Hi * c.Wi * cs;
+  __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * sample_elems), 0, (int)(sample_elems * 4), 0x00020000);
+  g.nb = nb;
+  g.nosel = (ud0 >= 0) && (uh0 >= 0) && (uw0 >= 0) && (ud0 + LD <= c.Di) && (uh0 + LH <= c.Hi) && (uw0 + LW <= c.Wi) &&
+            (S.slope >= 0.f) && (S.slope <= 1.f);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int lw = vl + i * VPS;
+    const int uw = uw0 + lw;
+    const bool ok = cval0 && (lw < LW) && ((unsigned)uw < (unsigned)c.Wi);
+    g.voff[i] = ok ? (uw * cs + ch.c0 + cl) * 4 : (int)0x80000000;
+  }
+  g.rvmask = 0;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = wave + 4 * r;
+    const int ld = row / LH, lhh = row % LH;
+    const int ud = ud0 + ld, uh = uh0 + lhh;
+    const bool rv = (row < R) && ((unsigned)ud < (unsigned)c.Di) && ((unsigned)uh < (unsigned)c.Hi);
+    if (rv) {
+      g.rvmask |= 1u << r;
+      const int srow = (ud * c.Hi + uh) * c.Wi * cs * 4;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if constexpr (VEC == 2) {
+          const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, g.voff[i] + srow, 0, 0));
+          g.v[r][i][0] = t.x; g.v[r][i][1] = t.y;
+        } else {
+          g.v[r][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, g.voff[i] + srow, 0, 0));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g.v[r][i][e] = 0.f;
+    }
+  }
+}
+
+template <int LD, int LH, int LW, int VEC>
+__device__ __forceinline__ void stage2_store(const Stage2Regs<LD, LH, LW, VEC>& g, float* __restrict__ lds, const mt_conv3d_t& c,
+                                             const ConvChunk ch, int lane, int wave) {
+  typedef Stage2Regs<LD, LH, LW, VEC> RG_;
+  constexpr int LPV = RG_::LPV, VPS = RG_::VPS, NI = RG_::NI, R = RG_::R, RPW = RG_::RPW;
+  const mt_src_t& S = c.src[ch.src];
+  const int cl = (lane % LPV) * VEC, vl = lane / LPV;
+  const bool has_aff = S.scale != nullptr;
+  float sc[VEC], sh[VEC];
+  bool cval[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    cval[e] = (cl + e) < ch.ck;
+    sc[e] = 1.f; sh[e] = 0.f;
+    if (has_aff && cval[e]) {
+      sc[e] = S.scale[(size_t)g.nb * S.C + ch.c0 + cl + e];
+      sh[e] = S.shift[(size_t)g.nb * S.C + ch.c0 + cl + e];
+    }
+  }
+  const float slope = S.slope;
+  float* lbase = lds + vl * FCKP + cl + wave * (LW * FCKP);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = wave + 4 * r;
+    if (row < R) {
+      const bool rv = (g.rvmask >> r) & 1u;
+      float* lrow = lbase + 4 * r * (LW * FCKP);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int lw = vl + i * VPS;
+        if ((i + 1) * VPS <= LW || lw < LW) {
+          float x[VEC];
+          const bool ok = rv && g.voff[i] >= 0;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            x[e] = g.v[r][i][e];
+            if (has_aff) {
+              const float t = fmaf(x[e], sc[e], sh[e]);
+              const float a = fmaxf(t, t * slope);
+              x[e] = g.nosel ? a : ((ok && cval[e]) ? a : 0.f);
+            } else if (VEC == 2 && e == 1) x[e] = cval[e] ? x[e] : 0.f;
+          }
+          if constexpr (VEC == 2) {
+            float2 t; t.x = x[0]; t.y = x[1];
+            *(float2*)(lrow + i * VPS * FCKP) = t;
+          } else {
+            lrow[i * VPS * FCKP] = x[0];
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int MT>
 struct FastFrag { f32x4 a[MT][2]; f32x4 b[2]; };
 
@@ -1188,57 +1305,96 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
   const bool yaff = Y.scale != nullptr;
   const size_t ysample = (size_t)c.Do * c.Ho * c.Wo * Y.cs;
 
-  for (int tile = sg; tile < P.ntiles_total; tile += P.nsg) {
+  // tile -> coordinates
+  auto tile_coords = [&](int tile, int& nb, int& od0, int& oh0, int& ow0) {
     int r = tile;
     const int tw = r % P.tilesW; r /= P.tilesW;
     const int th = r % P.tilesH; r /= P.tilesH;
-    const int td = r % P.tilesD;
-    const int nb = r / P.tilesD;
-    const int od0 = td, oh0 = th * TH, ow0 = tw * TW;
-    // ---- Y fragments for this wave's KS k-steps (2 cout halves each), straight from global
-    float yb[KS][2];
-    {
-      __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(Y.ptr + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
-      float ysc0 = 1.f, ysh0 = 0.f, ysc1 = 1.f, ysh1 = 0.f;
-      if (yaff) {
-        if (co < c.Cout) { ysc0 = Y.scale[(size_t)nb * Y.C + co]; ysh0 = Y.shift[(size_t)nb * Y.C + co]; }
-        if (co + 16 < c.Cout) { ysc1 = Y.scale[(size_t)nb * Y.C + co + 16]; ysh1 = Y.shift[(size_t)nb * Y.C + co + 16]; }
-      }
+    od0 = r % P.tilesD; nb = r / P.tilesD;
+    oh0 = th * TH; ow0 = tw * TW;
+  };
+  // Y fragments of this wave's KS k-steps (2 cout halves each), straight from global in B-fragment order.
+  // ISSUE ONLY: the optional lazy-activation transform is applied when the fragments are rotated in (finish_y), never
+  // right behind the loads — otherwise hipcc parks an s_waitcnt vmcnt(0) after every load pair and drains the prefetch.
+  auto issue_y = [&](float (&yb)[KS][2], unsigned& okmask, int nb, int od0, int oh0, int ow0) {
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(Y.ptr + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
+    okmask = 0;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int ks = wave * KS + s;                    // wave-uniform
-        const int oh = oh0 + ks / SPR, ow = ow0 + 4 * (ks % SPR) + lk;
-        const bool vok = (oh < c.Ho) && (ow < c.Wo);
-        const int base = ((od0 * c.Ho + oh) * c.Wo + ow) * Y.cs + co;
-        const int o0 = (vok && co < c.Cout) ? base * 4 : (int)0x80000000;
-        const int o1 = (vok && co + 16 < c.Cout) ? (base + 16) * 4 : (int)0x80000000;
-        float v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, o0, 0, 0));
-        float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, o1, 0, 0));
-        if (yaff) {
-          v0 = (o0 >= 0) ? mt_lrelu(fmaf(v0, ysc0, ysh0), Y.slope) : 0.f;
-          v1 = (o1 >= 0) ? mt_lrelu(fmaf(v1, ysc1, ysh1), Y.slope) : 0.f;
-        }
-        yb[s][0] = v0; yb[s][1] = v1;
-      }
+    for (int s2 = 0; s2 < KS; ++s2) {
+      const int ks = wave * KS + s2;                    // wave-uniform
+      const int oh = oh0 + ks / SPR, ow = ow0 + 4 * (ks % SPR) + lk;
+      const bool vok = (oh < c.Ho) && (ow < c.Wo);
+      const int base = ((od0 * c.Ho + oh) * c.Wo + ow) * Y.cs + co;
+      const bool k0 = vok && co < c.Cout, k1 = vok && co + 16 < c.Cout;
+      okmask |= (k0 ? 1u : 0u) << (2 * s2);
+      okmask |= (k1 ? 1u : 0u) << (2 * s2 + 1);
+      yb[s2][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, k0 ? base * 4 : (int)0x80000000, 0, 0));
+      yb[s2][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, k1 ? (base + 16) * 4 : (int)0x80000000, 0, 0));
     }
+  };
+  auto finish_y = [&](float (&dst)[KS][2], const float (&src)[KS][2], unsigned okmask, int nb) {
+    if (yaff) {
+      float ysc0 = 1.f, ysh0 = 0.f, ysc1 = 1.f, ysh1 = 0.f;
+      if (co < c.Cout) { ysc0 = Y.scale[(size_t)nb * Y.C + co]; ysh0 = Y.shift[(size_t)nb * Y.C + co]; }
+      if (co + 16 < c.Cout) { ysc1 = Y.scale[(size_t)nb * Y.C + co + 16]; ysh1 = Y.shift[(size_t)nb * Y.C + co + 16]; }
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        dst[s2][0] = ((okmask >> (2 * s2)) & 1u) ? mt_lrelu(fmaf(src[s2][0], ysc0, ysh0), Y.slope) : 0.f;
+        dst[s2][1] = ((okmask >> (2 * s2 + 1)) & 1u) ? mt_lrelu(fmaf(src[s2][1], ysc1, ysh1), Y.slope) : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) { dst[s2][0] = src[s2][0]; dst[s2][1] = src[s2][1]; }
+    }
+  };
+
+  // Software pipeline over tiles: while the MFMAs of tile i run, the global loads of tile i+1 (X share of this wave into
+  // registers, Y fragments) are in flight; between tiles only the register->LDS pass and two barriers are exposed.
+  Stage2Regs<LD, LH, LW, VEC> xr;
+  float ycur[KS][2], ynxt[KS][2];
+  unsigned yok = 0;
+  int ynb = 0;
+  int tile = sg;
+  if (tile < P.ntiles_total) {
+    int nb, od0, oh0, ow0; tile_coords(tile, nb, od0, oh0, ow0);
+    stage2_load<LD, LH, LW, VEC>(xr, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+    issue_y(ynxt, yok, nb, od0, oh0, ow0);
+    ynb = nb;
+  }
+  for (; tile < P.ntiles_total; tile += P.nsg) {
     __syncthreads();     // previous tile's X reads are done
-    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+    stage2_store<LD, LH, LW, VEC>(xr, lds, c, cc, lane, wave);
+    finish_y(ycur, ynxt, yok, ynb);
     __syncthreads();
-    // ---- MFMA phase: KS k-steps x 27 taps x 2 cout halves, all LDS offsets are immediates
+    const int tnext = tile + P.nsg;
+    if (tnext < P.ntiles_total) {
+      int nb, od0, oh0, ow0; tile_coords(tnext, nb, od0, oh0, ow0);
+      stage2_load<LD, LH, LW, VEC>(xr, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+      issue_y(ynxt, yok, nb, od0, oh0, ow0);
+      ynb = nb;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- MFMA phase: KS k-steps x 27 taps x 2 cout halves; all LDS offsets are immediates and the A fragments of
+    // k-step s+1 are fetched (ping-pong register sets) while the 54 MFMAs of k-step s issue
+    float a0[27], a1[27];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int svox = (s / SPR) * LW + 4 * (s % SPR);
-      float a[27];
+    for (int t = 0; t < 27; ++t) a0[t] = lds[xbase + (((t / 9) * LH + (t / 3) % 3) * LW + (t % 3)) * FCKP];
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      float (&ac)[27] = (s2 & 1) ? a1 : a0;
+      float (&an)[27] = (s2 & 1) ? a0 : a1;
+      if (s2 + 1 < KS) {
+        const int svox = ((s2 + 1) / SPR) * LW + 4 * ((s2 + 1) % SPR);
+#pragma unroll
+        for (int t = 0; t < 27; ++t) an[t] = lds[xbase + (svox + ((t / 9) * LH + (t / 3) % 3) * LW + (t % 3)) * FCKP];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 27; ++t) {
-        const int tapvox = ((t / 9) * LH + (t / 3) % 3) * LW + (t % 3);
-        a[t] = lds[xbase + (svox + tapvox) * FCKP];
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][1], acc[t][1], 0, 0, 0);
       }
-#pragma unroll
-      for (int t = 0; t < 27; ++t) {
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], yb[s][0], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], yb[s][1], acc[t][1], 0, 0, 0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // one partial per wave: [chunk][cot][sg*4 + wave][tap][16][32]
