@@ -4,9 +4,9 @@
 dummyLoad style (reference: nnUNet_variants/benchmarking/nnUNetTrainerV2_dummyLoad.py:26-64).
 
   python bench.py --gpus N --steps K --warmup W
-N == 1: BASELINE.json configs[1] = Task009_Spleen Generic_UNet, bs=2, patch 48x192x192, fp32 (softmax Dice+CE).
-N  > 1: launched by torch.distributed.run, one rank per GPU (RCCL); same per-GPU workload (weak scaling), gradients
-        all-reduced (mean) overlapped with backward on a side stream.
+Workload (every N): BASELINE.json configs[1] = Task009_Spleen Generic_UNet, bs=2 per GPU, patch 48x192x192, fp32, softmax
+Dice+CE with deep supervision.  N > 1: launched by torch.distributed.run, one rank per GPU (RCCL), weak scaling; gradients
+all-reduced (mean) overlapped with backward on a side stream.  --workload task100 selects the nc=47 MultiTalent loss, bs=4.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -168,11 +168,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    ddp = world > 1
+    ddp = world > 1 or ('RANK' in os.environ and int(os.environ.get('MT_FORCE_REDUCER', '0')))
     if ddp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', init_method='env://')
-    workload = args.workload or ('task009' if args.gpus == 1 else 'task100')
+    workload = args.workload or 'task009'      # same per-GPU workload at every N (weak scaling on BASELINE configs[1])
     B = args.batch or (2 if workload == 'task009' else 4)
 
     from multitalent_amd.training.hot_loop import FusedTrainStep

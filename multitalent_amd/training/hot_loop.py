@@ -22,17 +22,20 @@ class GradAllReducer:
         self.stream = None
         self.handles = []
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        # MT_FORCE_REDUCER=1 runs the full bucketed / side-stream code path even at world size 1 (single-GPU validation)
+        import os
+        self.force = bool(int(os.environ.get('MT_FORCE_REDUCER', '0'))) and dist.is_available() and dist.is_initialized()
 
     def begin(self):
         self.sent = 0
         self.handles = []
         self.on_gpu = self.eng.flat_grad.is_cuda
-        if self.world > 1 and self.stream is None and self.on_gpu:
+        if (self.world > 1 or self.force) and self.stream is None and self.on_gpu:
             self.stream = torch.cuda.Stream()
 
     def ready(self, lo, hi):
         """all gradients in flat_grad[0:hi) are final."""
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return
         n = self.eng.flat_grad.numel()
         final = hi >= n
@@ -52,7 +55,7 @@ class GradAllReducer:
             self.sent = end
 
     def finish(self):
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return
         for h in self.handles:
             h.wait()
