@@ -1275,9 +1275,12 @@ __global__ void bwdw_reduce_kernel(const BwdWReduceParams P) {
 // X tile: LDS [voxel][20] (same staging as the forward kernel).  Y fragments are wave-private, so they bypass LDS:
 // buffer loads straight into registers in B-fragment order.  A workgroup walks a strided list of tiles and writes
 // one partial per WAVE; bwdw_reduce_kernel sums them deterministically.
-template <int TH, int TW, int VEC>
+template <int KD, int KH, int KW, int SD, int SH, int SW, int TH, int TW, int VEC>
 __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P) {
-  constexpr int LD = 3, LH = TH + 2, LW = TW + 2, TV = TH * TW;
+  // compile-time geometry: kernel K, stride S, pad (K-1)/2 for odd K and 0 for K = 2 (transposed-conv weights); tile 1 x TH x TW
+  constexpr int NT = KD * KH * KW;
+  constexpr int PD = (KD == 3) ? 1 : 0, PH = (KH == 3) ? 1 : 0, PW = (KW == 3) ? 1 : 0;
+  constexpr int LD = KD, LH = (TH - 1) * SH + KH, LW = (TW - 1) * SW + KW, TV = TH * TW;
   constexpr int KS = TV / 16;            // k-steps (4 voxels each) per wave
   constexpr int SPR = TW / 4;            // k-steps per tile row
   static_assert(TV == 128, "tile must hold 128 voxels");
@@ -1290,9 +1293,9 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
   const ConvChunk cc = P.chunk[chi];
   const mt_src_t& Y = P.y;
 
-  f32x4 acc[27][2];
+  f32x4 acc[NT][2];
 #pragma unroll
-  for (int t = 0; t < 27; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1300,7 +1303,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
 
   // this wave's first voxel inside the tile: k-step ks = wave*KS + s -> (row, w0) = (ks / SPR, 4*(ks % SPR))
   const int row0 = (wave * KS) / SPR;
-  const int xbase = ((row0 * LW) + lk) * FCKP + li;      // + compile-time ((s/SPR)*LW + 4*(s%SPR) + tapvox)*FCKP
+  const int xbase = ((row0 * SH * LW) + lk * SW) * FCKP + li;      // + compile-time (step voxel + tap voxel) * FCKP
   const int co = cot * 32 + li;
   const bool yaff = Y.scale != nullptr;
   const size_t ysample = (size_t)c.Do * c.Ho * c.Wo * Y.cs;
@@ -1357,7 +1360,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
   int tile = sg;
   if (tile < P.ntiles_total) {
     int nb, od0, oh0, ow0; tile_coords(tile, nb, od0, oh0, ow0);
-    stage2_load<LD, LH, LW, VEC>(xr, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+    stage2_load<LD, LH, LW, VEC>(xr, c, cc, nb, od0 * SD - PD, oh0 * SH - PH, ow0 * SW - PW, lane, wave);
     issue_y(ynxt, yok, nb, od0, oh0, ow0);
     ynb = nb;
   }
@@ -1369,28 +1372,28 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
     const int tnext = tile + P.nsg;
     if (tnext < P.ntiles_total) {
       int nb, od0, oh0, ow0; tile_coords(tnext, nb, od0, oh0, ow0);
-      stage2_load<LD, LH, LW, VEC>(xr, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+      stage2_load<LD, LH, LW, VEC>(xr, c, cc, nb, od0 * SD - PD, oh0 * SH - PH, ow0 * SW - PW, lane, wave);
       issue_y(ynxt, yok, nb, od0, oh0, ow0);
       ynb = nb;
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- MFMA phase: KS k-steps x 27 taps x 2 cout halves; all LDS offsets are immediates and the A fragments of
     // k-step s+1 are fetched (ping-pong register sets) while the 54 MFMAs of k-step s issue
-    float a0[27], a1[27];
+    float a0[NT], a1[NT];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) a0[t] = lds[xbase + (((t / 9) * LH + (t / 3) % 3) * LW + (t % 3)) * FCKP];
+    for (int t = 0; t < NT; ++t) a0[t] = lds[xbase + (((t / (KH * KW)) * LH + (t / KW) % KH) * LW + (t % KW)) * FCKP];
 #pragma unroll
     for (int s2 = 0; s2 < KS; ++s2) {
-      float (&ac)[27] = (s2 & 1) ? a1 : a0;
-      float (&an)[27] = (s2 & 1) ? a0 : a1;
+      float (&ac)[NT] = (s2 & 1) ? a1 : a0;
+      float (&an)[NT] = (s2 & 1) ? a0 : a1;
       if (s2 + 1 < KS) {
-        const int svox = ((s2 + 1) / SPR) * LW + 4 * ((s2 + 1) % SPR);
+        const int svox = ((s2 + 1) / SPR) * SH * LW + 4 * ((s2 + 1) % SPR) * SW;
 #pragma unroll
-        for (int t = 0; t < 27; ++t) an[t] = lds[xbase + (svox + ((t / 9) * LH + (t / 3) % 3) * LW + (t % 3)) * FCKP];
+        for (int t = 0; t < NT; ++t) an[t] = lds[xbase + (svox + ((t / (KH * KW)) * LH + (t / KW) % KH) * LW + (t % KW)) * FCKP];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 27; ++t) {
+      for (int t = 0; t < NT; ++t) {
         acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][0], acc[t][0], 0, 0, 0);
         acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][1], acc[t][1], 0, 0, 0);
       }
@@ -1398,37 +1401,75 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
     }
   }
   // one partial per wave: [chunk][cot][sg*4 + wave][tap][16][32]
-  float* pp = P.part + ((size_t)((size_t)(chi * P.ncot + cot) * (P.nsg * 4) + sg * 4 + wave) * 27) * 512;
+  float* pp = P.part + ((size_t)((size_t)(chi * P.ncot + cot) * (P.nsg * 4) + sg * 4 + wave) * NT) * 512;
 #pragma unroll
-  for (int t = 0; t < 27; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int j = 0; j < 4; ++j) pp[(size_t)t * 512 + (lk * 4 + j) * 32 + h * 16 + li] = acc[t][h][j];
 }
 
-static bool bwdw_is_fast(const mt_conv3d_t* p, const mt_src_t* y) {
-  if (!(p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 1 && p->PH == 1 &&
-        p->PW == 1 && p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
+// compile-time geometries of the fast backward-weight kernel: (K, S) with pad (K-1)/2 for K=3/1 and 0 for K=2
+struct BwGeo { int KD, KH, KW, SD, SH, SW; };
+static const BwGeo kBwGeos[] = {
+  {3, 3, 3, 1, 1, 1},   // 0: all stride-1 3x3x3 convs
+  {3, 3, 3, 2, 2, 2},   // 1: strided stage convs (generic_UNet.py:263-278)
+  {3, 3, 3, 1, 2, 2},   // 2: anisotropic pooling stage
+  {2, 2, 2, 2, 2, 2},   // 3: ConvTranspose3d(k = s = 2) weights (X = dOut, Y = tconv input)
+  {1, 2, 2, 1, 2, 2},   // 4: ConvTranspose3d(k = s = (1,2,2))
+  {1, 1, 1, 1, 1, 1},   // 5: 1x1x1 heads
+  {1, 3, 3, 1, 1, 1},   // 6: residual-encoder stage 0
+};
+static int bwdw_fast_geo(const mt_conv3d_t* p, const mt_src_t* y) {
+  if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return -1;
   for (int i = 0; i < p->nsrc; ++i)
-    if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 4.0 >= 2147483648.0) return false;
-  if ((double)p->Do * p->Ho * p->Wo * y->cs * 4.0 >= 2147483648.0) return false;
-  return true;
+    if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 4.0 >= 2147483648.0) return -1;
+  if ((double)p->Do * p->Ho * p->Wo * y->cs * 4.0 >= 2147483648.0) return -1;
+  for (int g = 0; g < (int)(sizeof(kBwGeos) / sizeof(kBwGeos[0])); ++g) {
+    const BwGeo& b = kBwGeos[g];
+    if (p->KD == b.KD && p->KH == b.KH && p->KW == b.KW && p->SD == b.SD && p->SH == b.SH && p->SW == b.SW &&
+        p->PD == (b.KD == 3 ? 1 : 0) && p->PH == (b.KH == 3 ? 1 : 0) && p->PW == (b.KW == 3 ? 1 : 0)) return g;
+  }
+  return -1;
 }
+static bool bwdw_is_fast(const mt_conv3d_t* p, const mt_src_t* y) { return bwdw_fast_geo(p, y) >= 0; }
 // plan for the fast kernel: tile 1 x TH x TW with (TH,TW) = (4,32) or (8,16)
 static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   const bool wide = p->Wo > 16;
   P->TD = 1; P->TH = wide ? 4 : 8; P->TW = wide ? 32 : 16;
   P->tilesD = p->Do; P->tilesH = mt_cdiv(p->Ho, P->TH); P->tilesW = mt_cdiv(p->Wo, P->TW);
   P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N;
-  P->ntaps = 27;
+  P->ntaps = p->KD * p->KH * p->KW;
   P->nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, BW_CK, P->chunk);
   P->ncot = mt_cdiv(p->Cout, 32);
   int pairs = P->nchunks * P->ncot; if (pairs < 1) pairs = 1;
-  int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (216 accumulator registers per wave)
+  int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
   if (nsg > P->ntiles_total) nsg = P->ntiles_total;
   if (nsg < 1) nsg = 1;
   P->nsg = nsg;
+}
+
+template <int KD, int KH, int KW, int SD, int SH, int SW>
+static int launch_bwdw_fast(const BwdWParams& P, int vec, hipStream_t st) {
+  constexpr int LHa = 3 * SH + KH, LWa = 31 * SW + KW, LHb = 7 * SH + KH, LWb = 15 * SW + KW;
+  const size_t ldsb = (size_t)KD * (P.TW == 32 ? LHa * LWa : LHb * LWb) * FCKP * sizeof(float);
+  MT_REQUIRE(ldsb <= 160 * 1024, "bwd_weight: LDS tile too large (%zu)", ldsb);
+  dim3 grid(P.nsg, P.ncot, P.nchunks);
+#define MT_BW_LAUNCH(TH_, TW_, VEC_)                                                                          \
+  do {                                                                                                        \
+    auto kfn = conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, TH_, TW_, VEC_>;                                 \
+    if (ldsb > 64 * 1024) {                                                                                   \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
+      if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; } \
+    }                                                                                                         \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), ldsb, st, P);                                                    \
+  } while (0)
+  if (P.TW == 32) { if (vec == 2) MT_BW_LAUNCH(4, 32, 2); else MT_BW_LAUNCH(4, 32, 1); }
+  else            { if (vec == 2) MT_BW_LAUNCH(8, 16, 2); else MT_BW_LAUNCH(8, 16, 1); }
+#undef MT_BW_LAUNCH
+  MT_CHECK_LAUNCH("conv_bwdw_fast");
+  return MT_OK;
 }
 
 static void bwdw_plan(const mt_conv3d_t* p, BwdWParams* P) {
@@ -1462,10 +1503,12 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
   BwdWParams P; bwdw_plan(p, &P);
   if (P.nchunks <= 0) return 0;
   size_t generic = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
-  if (p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1) {
+  {
     BwdWParams F; bwdw_fast_plan(p, &F);
-    const size_t fast = (size_t)F.nchunks * F.ncot * F.nsg * 4 * 27 * 512 * sizeof(float);
-    if (fast > generic) generic = fast;
+    if (F.nchunks > 0) {
+      const size_t fast = (size_t)F.nchunks * F.ncot * F.nsg * 4 * F.ntaps * 512 * sizeof(float);
+      if (fast > generic) generic = fast;
+    }
   }
   return generic;
 }
@@ -1484,30 +1527,32 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
   P.y = *ysrc;
   static int use_fast = -1;
   if (use_fast < 0) { const char* e = getenv("MT_BWDW_FAST"); use_fast = e ? atoi(e) : 1; }
-  if (use_fast && bwdw_is_fast(p, ysrc)) {
+  const int geo = use_fast ? bwdw_fast_geo(p, ysrc) : -1;
+  if (geo >= 0) {
     bwdw_fast_plan(p, &P);
     MT_REQUIRE(P.nchunks > 0, "bwd_weight: too many channel chunks");
-    const size_t need = (size_t)P.nchunks * P.ncot * P.nsg * 4 * 27 * 512 * sizeof(float);
+    const size_t need = (size_t)P.nchunks * P.ncot * P.nsg * 4 * P.ntaps * 512 * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need) { mt_set_error("bwd_weight: workspace %zu < %zu", workspace_bytes, need); return MT_EWORKSPACE; }
     P.part = (float*)workspace;
     const int vec = conv_fast_vec(p);
-    const size_t ldsb = (size_t)3 * (P.TH + 2) * (P.TW + 2) * FCKP * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(P.nsg, P.ncot, P.nchunks);
-    if (P.TW == 32) {
-      if (vec == 2) hipLaunchKernelGGL((conv_bwdw_fast_kernel<4, 32, 2>), grid, dim3(256), ldsb, st, P);
-      else hipLaunchKernelGGL((conv_bwdw_fast_kernel<4, 32, 1>), grid, dim3(256), ldsb, st, P);
-    } else {
-      if (vec == 2) hipLaunchKernelGGL((conv_bwdw_fast_kernel<8, 16, 2>), grid, dim3(256), ldsb, st, P);
-      else hipLaunchKernelGGL((conv_bwdw_fast_kernel<8, 16, 1>), grid, dim3(256), ldsb, st, P);
+    int rc = MT_EINVAL;
+    switch (geo) {
+      case 0: rc = launch_bwdw_fast<3, 3, 3, 1, 1, 1>(P, vec, st); break;
+      case 1: rc = launch_bwdw_fast<3, 3, 3, 2, 2, 2>(P, vec, st); break;
+      case 2: rc = launch_bwdw_fast<3, 3, 3, 1, 2, 2>(P, vec, st); break;
+      case 3: rc = launch_bwdw_fast<2, 2, 2, 2, 2, 2>(P, vec, st); break;
+      case 4: rc = launch_bwdw_fast<1, 2, 2, 1, 2, 2>(P, vec, st); break;
+      case 5: rc = launch_bwdw_fast<1, 1, 1, 1, 1, 1>(P, vec, st); break;
+      case 6: rc = launch_bwdw_fast<1, 3, 3, 1, 1, 1>(P, vec, st); break;
     }
-    MT_CHECK_LAUNCH("conv_bwdw_fast");
+    if (rc != MT_OK) return rc;
     BwdWReduceParams R;
-    R.part = P.part; R.dw = dw; R.Cin = p->Cin; R.Cout = p->Cout; R.KD = 3; R.KH = 3; R.KW = 3;
-    R.nchunks = P.nchunks; R.ncot = P.ncot; R.nsg = P.nsg * 4; R.ntaps = 27; R.accumulate = accumulate;
+    R.part = P.part; R.dw = dw; R.Cin = p->Cin; R.Cout = p->Cout; R.KD = p->KD; R.KH = p->KH; R.KW = p->KW;
+    R.nchunks = P.nchunks; R.ncot = P.ncot; R.nsg = P.nsg * 4; R.ntaps = P.ntaps; R.accumulate = accumulate;
     R.s_ci = s_ci; R.s_co = s_co; R.s_kd = s_kd; R.s_kh = s_kh; R.s_kw = s_kw;
     for (int i = 0; i < P.nchunks; ++i) R.chunk[i] = P.chunk[i];
-    const long total = (long)P.nchunks * P.ncot * 27 * 512;
+    const long total = (long)P.nchunks * P.ncot * P.ntaps * 512;
     int blocks = mt_cdiv(total, 256); if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(bwdw_reduce_kernel, dim3(blocks), dim3(256), 0, st, R);
     MT_CHECK_LAUNCH("bwdw_reduce");
