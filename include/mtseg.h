@@ -70,6 +70,11 @@ typedef struct {
   int32_t csplit;
   int32_t accumulate;         /* 1: out += result (gradient accumulation on skip connections) */
   float* stats_part;          /* NULL or [N][nsb][Cout][2] per-block (sum, sumsq) partials, nsb = mt_conv3d_stats_blocks() */
+  /* Strided output placement (0 = dense): logical output position o is written at o*os + oo of a tensor with spatial dims
+   * (OD,OH,OW).  Used by the backward-data of a strided conv, which is computed as one exact stride-1 convolution per
+   * parity class of the input position instead of a convolution over a zero-inserted gradient. */
+  int32_t OD, OH, OW, osD, osH, osW, ooD, ooH, ooW;
+  int32_t _pad2;
 } mt_conv3d_t;
 
 const char* mt_last_error(void);
@@ -85,6 +90,8 @@ int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats,
                          long s_ci, long s_co, long s_kd, long s_kh, long s_kw, int flip, int ck,
                          int layout /* 0: pointwise kernels ([kp][lane], pair (2kp,2kp+1)); 1: conv kernels
                                        ([kp/4][lane][4], pair (kp, ck/2+kp)) */,
+                         const int32_t* tapmap /* NULL, or {tbD,tsD,tbH,tsH,tbW,tsW}: packed tap j of dim d takes source
+                                                  tap tb + ts*j (overrides flip) — sub-kernels of the parity classes */,
                          mt_stream_t stream);
 
 /* ---- convolution (N1/N2/N5 forward, and backward-data through flipped weights) --------------- */

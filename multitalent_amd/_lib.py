@@ -31,7 +31,10 @@ class mt_conv3d_t(C.Structure):
                 ('out0', C.c_void_p), ('ocs0', C.c_int32),
                 ('out1', C.c_void_p), ('ocs1', C.c_int32),
                 ('csplit', C.c_int32), ('accumulate', C.c_int32),
-                ('stats_part', C.c_void_p)]
+                ('stats_part', C.c_void_p),
+                ('OD', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
+                ('osD', C.c_int32), ('osH', C.c_int32), ('osW', C.c_int32),
+                ('ooD', C.c_int32), ('ooH', C.c_int32), ('ooW', C.c_int32), ('_pad2', C.c_int32)]
 
 
 class mt_pointwise_t(C.Structure):
@@ -53,7 +56,7 @@ _P = C.POINTER
 SIGNATURES = {
     'mt_last_error': (C.c_char_p, []),
     'mt_abi_version': (_i, []),
-    'mt_pack_conv_weights': (_i, [_vp, _vp, _P(_sz), _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _i, _vp]),
+    'mt_pack_conv_weights': (_i, [_vp, _vp, _P(_sz), _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _i, _vp, _vp]),
     'mt_conv3d_fwd': (_i, [_P(mt_conv3d_t), _vp]),
     'mt_conv3d_stats_blocks': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_ck': (_i, [_P(mt_conv3d_t)]),

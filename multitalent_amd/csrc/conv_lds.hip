@@ -818,6 +818,224 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
   }
 }
 
+// ================================================================================================
+// Runtime-geometry forward kernel on the FAST design (any kernel size 1..3, stride 1..2, pad, strided output placement):
+// LDS image [voxel][20], ds_read_b128 operands, float4 weights, buffer loads/stores.  The tap loop is a runtime loop
+// (unrolled by two with ping-pong fragments); the only vector-ALU work inside it is one address add per M tile and tap
+// (1 VALU per 16 MFMAs).  Serves strided stage convs, 1x3x3 and 1x1x1(strided) convs, the backward-data of transposed
+// convs (a k = s conv) and of strided convs (one launch per parity class with a sub-kernel and os = stride, oo = parity).
+template <int VEC>
+__device__ __forceinline__ void mt_stage_rt(float* __restrict__ lds, const mt_conv3d_t& c, const ConvChunk ch, int nb,
+                                            int ud0, int uh0, int uw0, int LD, int LH, int LW, int lane, int wave) {
+  constexpr int LPV = FCK / VEC, VPS = 64 / LPV, NIMAX = (66 + VPS - 1) / VPS;
+  const mt_src_t& S = c.src[ch.src];
+  const int cl = (lane % LPV) * VEC, vl = lane / LPV;
+  const bool has_aff = S.scale != nullptr;
+  float sc[VEC], sh[VEC];
+  bool cval[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    cval[e] = (cl + e) < ch.ck;
+    sc[e] = 1.f; sh[e] = 0.f;
+    if (has_aff && cval[e]) {
+      sc[e] = S.scale[(size_t)nb * S.C + ch.c0 + cl + e];
+      sh[e] = S.shift[(size_t)nb * S.C + ch.c0 + cl + e];
+    }
+  }
+  const float slope = S.slope;
+  const int cs = S.cs;
+  const size_t sample_elems = (size_t)c.Di * c.Hi * c.Wi * cs;
+  __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * sample_elems), 0, (int)(sample_elems * 4), 0x00020000);
+  const int NI = (LW + VPS - 1) / VPS;
+  int voff[NIMAX];
+#pragma unroll
+  for (int i = 0; i < NIMAX; ++i) {
+    const int lw = vl + i * VPS;
+    const int uw = uw0 + lw;
+    const bool ok = cval[0] && (i < NI) && (lw < LW) && ((unsigned)uw < (unsigned)c.Wi);
+    voff[i] = ok ? (uw * cs + ch.c0 + cl) * 4 : (int)0x80000000;
+  }
+  const bool lrelu_ok = (slope >= 0.f) && (slope <= 1.f);
+  const int nrows = LD * LH;
+  float* lbase = lds + vl * FCKP + cl;
+  for (int row = wave; row < nrows; row += 4) {
+    const int ld = row / LH, lhh = row - ld * LH;
+    const int ud = ud0 + ld, uh = uh0 + lhh;
+    const bool rv = ((unsigned)ud < (unsigned)c.Di) && ((unsigned)uh < (unsigned)c.Hi);
+    const int srow = rv ? (ud * c.Hi + uh) * c.Wi * cs * 4 : 0;
+    float v[NIMAX][VEC];
+#pragma unroll
+    for (int i = 0; i < NIMAX; ++i) {
+      if (i < NI && rv) {
+        if constexpr (VEC == 2) {
+          const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[i] + srow, 0, 0));
+          v[i][0] = t.x; v[i][1] = t.y;
+        } else {
+          v[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[i] + srow, 0, 0));
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[i][e] = 0.f;
+      }
+    }
+    float* lrow = lbase + row * LW * FCKP;
+#pragma unroll
+    for (int i = 0; i < NIMAX; ++i) {
+      const int lw = vl + i * VPS;
+      if (i < NI && lw < LW) {
+        float x[VEC];
+        const bool ok = rv && voff[i] >= 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          x[e] = v[i][e];
+          if (has_aff) {
+            const float t = fmaf(x[e], sc[e], sh[e]);
+            const float a = lrelu_ok ? fmaxf(t, t * slope) : mt_lrelu(t, slope);
+            x[e] = (ok && cval[e]) ? a : 0.f;
+          } else if (VEC == 2 && e == 1) x[e] = cval[e] ? x[e] : 0.f;
+        }
+        if constexpr (VEC == 2) {
+          float2 t; t.x = x[0]; t.y = x[1];
+          *(float2*)(lrow + i * VPS * FCKP) = t;
+        } else {
+          lrow[i * VPS * FCKP] = x[0];
+        }
+      }
+    }
+  }
+}
+
+template <int MT>
+__device__ __forceinline__ void rt_frag_load(FastFrag<MT>& f, const float* __restrict__ lds, const int (&abase)[MT], int off,
+                                             const float* __restrict__ wq) {
+  f.b[0] = *(const f32x4*)(wq);
+  f.b[1] = *(const f32x4*)(wq + 256);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const float* a = lds + abase[m] + off;
+    f.a[m][0] = *(const f32x4*)(a);
+    f.a[m][1] = *(const f32x4*)(a + 4);
+  }
+}
+
+template <int MW, int RH, int TD, int VEC>
+__global__ __launch_bounds__(256) void conv_rt_kernel(const ConvKParams P) {
+  constexpr int MH = 32 / MW, TH = MH * RH, TW = MW, NMT = TD * RH, MT = NMT / 4;
+  static_assert(NMT % 4 == 0, "M tiles must split over 4 waves");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const mt_conv3d_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = blockIdx.y;
+  const int tw = tile % P.tilesW; tile /= P.tilesW;
+  const int th = tile % P.tilesH; tile /= P.tilesH;
+  const int td = tile % P.tilesD;
+  const int nb = tile / P.tilesD;
+  const int sb = (td * P.tilesH + th) * P.tilesW + tw;
+  const int LD = (TD - 1) * c.SD + c.KD, LH = (TH - 1) * c.SH + c.KH, LW = (TW - 1) * c.SW + c.KW;
+  const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+
+  int abase[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mt = wave * MT + m;
+    const int dm = mt / RH, rh = mt % RH;
+    const int r = li / MW, col = li % MW;
+    abase[m] = ((dm * c.SD * LH + (rh * MH + r) * c.SH) * LW + col * c.SW) * FCKP + lhalf * 8;
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[m][j] = 0.f;
+
+  const int ntaps = P.ntaps;
+  const int step_w = FCKP, step_h = (LW - c.KW) * FCKP, step_d = (LH - c.KH) * LW * FCKP;
+  for (int ch = 0; ch < P.nchunks; ++ch) {
+    const ConvChunk cc = P.chunk[ch];
+    const float* wq = c.wpack + (size_t)(ntile * P.nchunks + ch) * ntaps * 512 + lane * 4;
+    __syncthreads();
+    mt_stage_rt<VEC>(lds, c, cc, nb, od0 * c.SD - c.PD, oh0 * c.SH - c.PH, ow0 * c.SW - c.PW, LD, LH, LW, lane, wave);
+    __syncthreads();
+    FastFrag<MT> f0, f1;
+    int off = 0, kw = 0, kh = 0, tap = 0;
+    auto advance = [&]() {
+      if (tap + 1 < ntaps) {
+        off += step_w;
+        if (++kw == c.KW) { kw = 0; off += step_h; if (++kh == c.KH) { kh = 0; off += step_d; } }
+        wq += 512;
+      }
+      ++tap;
+    };
+    rt_frag_load<MT>(f0, lds, abase, off, wq);
+    while (tap + 2 <= ntaps) {
+      advance();
+      __builtin_amdgcn_sched_barrier(0);
+      rt_frag_load<MT>(f1, lds, abase, off, wq);
+      __builtin_amdgcn_sched_barrier(0);
+      fast_frag_mfma<MT>(f0, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      advance();
+      __builtin_amdgcn_sched_barrier(0);
+      rt_frag_load<MT>(f0, lds, abase, off, wq);
+      __builtin_amdgcn_sched_barrier(0);
+      fast_frag_mfma<MT>(f1, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tap < ntaps) fast_frag_mfma<MT>(f0, acc);
+  }
+
+  // ---- epilogue (single destination; strided placement)
+  const int co = ntile * 32 + li;
+  const bool covalid = co < c.Cout;
+  const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
+  const int osD = c.osD > 0 ? c.osD : 1, osH = c.osH > 0 ? c.osH : 1, osW = c.osW > 0 ? c.osW : 1;
+  const int OD = c.osD > 0 ? c.OD : c.Do, OH = c.osD > 0 ? c.OH : c.Ho, OW = c.osD > 0 ? c.OW : c.Wo;
+  const int ooD = c.osD > 0 ? c.ooD : 0, ooH = c.osD > 0 ? c.ooH : 0, ooW = c.osD > 0 ? c.ooW : 0;
+  const int ocs = c.ocs0;
+  const size_t out_sample = (size_t)OD * OH * OW;
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
+                                                                (int)(out_sample * ocs * 4), 0x00020000);
+  const int lane_col = 4 * lhalf;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mt = wave * MT + m;
+    const int dm = mt / RH, rh = mt % RH;
+    const int od = od0 + dm;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int ivj = (j & 3) + 8 * (j >> 2);
+      const int r = ivj / MW, colj = ivj % MW;
+      const int oh = oh0 + rh * MH + r, ow = ow0 + colj + lane_col;
+      const bool ok = covalid && (od < c.Do) && (oh < c.Ho) && (ow < c.Wo);
+      const int vox = ((od * osD + ooD) * OH + (oh * osH + ooH)) * OW + (ow * osW + ooW);
+      const int off = ok ? (vox * ocs + co) * 4 : (int)0x80000000;
+      float v = acc[m][j] + bv;
+      if (c.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, 0);
+      if (ok) { s1 += v; s2 = fmaf(v, v, s2); }
+    }
+  }
+  if (c.stats_part != nullptr) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    __syncthreads();
+    if (lhalf == 0) { lds[(wave * 32 + li) * 2] = s1; lds[(wave * 32 + li) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 32 && (ntile * 32 + tid) < c.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += lds[(w * 32 + tid) * 2]; t2 += lds[(w * 32 + tid) * 2 + 1]; }
+      float* sp = c.stats_part + ((size_t)((size_t)nb * P.nsb + sb) * c.Cout + ntile * 32 + tid) * 2;
+      sp[0] = t1; sp[1] = t2;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side of mt_conv3d_fwd
 struct ConvCfg { int MW, RH, TD, CK; };
@@ -854,14 +1072,32 @@ static int pick_cfg(const mt_conv3d_t* p) {
   return best;
 }
 
+// which kernel family serves a problem, and with which tile shape
+enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2 };
+struct ConvPlan { int kind; int cfg; };
+static bool conv_is_fast(const mt_conv3d_t* p);
+static bool conv_rt_ok(const mt_conv3d_t* p);
+static int pick_rt_cfg(const mt_conv3d_t* p);
+static ConvPlan conv_plan(const mt_conv3d_t* p) {
+  static int use_v2 = -1, use_rt = -1;
+  if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
+  if (use_rt < 0) { const char* e = getenv("MT_CONV_RT"); use_rt = e ? atoi(e) : 1; }
+  ConvPlan pl; pl.kind = CONV_GENERIC; pl.cfg = pick_cfg(p);
+  if (conv_is_fast(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0) { pl.kind = CONV_FAST; return pl; }
+  if (use_rt && conv_rt_ok(p)) {
+    const int i = pick_rt_cfg(p);
+    if (i >= 0) { pl.kind = CONV_RT; pl.cfg = i; return pl; }
+  }
+  return pl;
+}
 extern "C" int mt_conv3d_ck(const mt_conv3d_t* p) {
-  const int i = pick_cfg(p);
-  return i < 0 ? -1 : kCfgs[i].CK;
+  const ConvPlan pl = conv_plan(p);
+  return pl.cfg < 0 ? -1 : kCfgs[pl.cfg].CK;
 }
 extern "C" int mt_conv3d_stats_blocks(const mt_conv3d_t* p) {
-  const int i = pick_cfg(p);
-  if (i < 0) return -1;
-  int TD, TH, TW; cfg_tile(kCfgs[i], &TD, &TH, &TW);
+  const ConvPlan pl = conv_plan(p);
+  if (pl.cfg < 0) return -1;
+  int TD, TH, TW; cfg_tile(kCfgs[pl.cfg], &TD, &TH, &TW);
   return mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW);
 }
 
@@ -925,6 +1161,58 @@ static int launch_fast2(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) 
   return MT_OK;
 }
 
+static size_t rt_lds(const ConvCfg& g, const mt_conv3d_t* p) {
+  int TD = g.TD, TH = (32 / g.MW) * g.RH, TW = g.MW;
+  const size_t LD = (TD - 1) * p->SD + p->KD, LH = (TH - 1) * p->SH + p->KH, LW = (TW - 1) * p->SW + p->KW;
+  size_t b = LD * LH * LW * FCKP * sizeof(float);
+  return b < 1024 ? 1024 : b;
+}
+static bool conv_rt_ok(const mt_conv3d_t* p) {
+  if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
+  if (p->csplit < p->Cout) return false;
+  for (int i = 0; i < p->nsrc; ++i)
+    if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 4.0 >= 2147483648.0) return false;
+  const double od = p->osD > 0 ? (double)p->OD * p->OH * p->OW : (double)p->Do * p->Ho * p->Wo;
+  if (od * p->ocs0 * 4.0 >= 2147483648.0) return false;
+  return true;
+}
+// tile shape for the runtime kernel: least padded work among the shapes whose LDS tile fits (prefer two workgroups per CU)
+static int pick_rt_cfg(const mt_conv3d_t* p) {
+  int best = -1; double bestcost = 1e300;
+  for (int i = 0; i < 3; ++i) {
+    const ConvCfg& g = kCfgs[i];
+    const size_t l = rt_lds(g, p);
+    if (l > 160 * 1024) continue;
+    int TD = g.TD, TH = (32 / g.MW) * g.RH, TW = g.MW;
+    double cost = (double)mt_cdiv(p->Do, TD) * TD * mt_cdiv(p->Ho, TH) * TH * mt_cdiv(p->Wo, TW) * TW;
+    if (l > 80 * 1024) cost *= 1.15;
+    if (cost < bestcost - 1e-9) { bestcost = cost; best = i; }
+  }
+  return best;
+}
+template <int MW, int RH, int TD, int VEC>
+static int launch_rt(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
+  ConvKParams P;
+  P.c = *p;
+  if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
+  int TDv = g.TD, TH = (32 / g.MW) * g.RH, TW = g.MW;
+  P.tilesD = mt_cdiv(p->Do, TDv); P.tilesH = mt_cdiv(p->Ho, TH); P.tilesW = mt_cdiv(p->Wo, TW);
+  P.nsb = P.tilesD * P.tilesH * P.tilesW;
+  P.ntaps = p->KD * p->KH * p->KW; P.dbg = 0; P.stagger = 0;
+  P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
+  MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
+  const size_t ldsb = rt_lds(g, p);
+  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
+  auto kfn = conv_rt_kernel<MW, RH, TD, VEC>;
+  if (ldsb > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(256), ldsb, st, P);
+  MT_CHECK_LAUNCH("conv3d_rt");
+  return MT_OK;
+}
+
 template <int MW, int RH, int TD, int CK, bool FAST>
 static int launch_conv(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
   ConvKParams P;
@@ -960,14 +1248,15 @@ static int launch_conv(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
 // attribute per-launch timings to the same kernel names the profiler reports
 extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) {
   if (p == nullptr || buf == nullptr || n == 0) return MT_EINVAL;
-  const int i = pick_cfg(p);
+  const ConvPlan pl = conv_plan(p);
+  const int i = pl.cfg;
   if (i < 0) return MT_EINVAL;
   const ConvCfg& g = kCfgs[i];
-  static int use_v2 = -1;
-  if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
   const bool fast = conv_is_fast(p);
-  if (fast && use_v2 && g.CK == 16 && i <= 2)
+  if (pl.kind == CONV_FAST)
     snprintf(buf, n, "conv_fast_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
+  else if (pl.kind == CONV_RT)
+    snprintf(buf, n, "conv_rt_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
   else
     snprintf(buf, n, "conv_fwd_kernel<%d, %d, %d, %d, %s>", g.MW, g.RH, g.TD, g.CK, (fast && (i <= 3 || i == 6)) ? "true" : "false");
   return MT_OK;
@@ -976,14 +1265,26 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
 extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   int rc = conv_validate(p);
   if (rc != MT_OK) return rc;
-  const int i = pick_cfg(p);
+  const ConvPlan pl = conv_plan(p);
+  const int i = pl.cfg;
   MT_REQUIRE(i >= 0, "conv3d: no tile configuration fits LDS");
   const ConvCfg& g = kCfgs[i];
   hipStream_t st = (hipStream_t)stream;
   const bool fast = conv_is_fast(p);
-  static int use_v2 = -1;
-  if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
-  if (fast && use_v2 && g.CK == 16) {
+  MT_REQUIRE(p->osD <= 0 || pl.kind == CONV_RT, "conv3d: strided output placement needs the runtime-geometry kernel");
+  MT_REQUIRE(p->osD <= 0 || (p->stats_part == nullptr && p->osH > 0 && p->osW > 0 &&
+             (p->Do - 1) * p->osD + p->ooD < p->OD && (p->Ho - 1) * p->osH + p->ooH < p->OH && (p->Wo - 1) * p->osW + p->ooW < p->OW),
+             "conv3d: bad strided output placement");
+  if (pl.kind == CONV_RT) {
+    const int vec = conv_fast_vec(p);
+    switch (i) {
+      case 0: return vec == 2 ? launch_rt<32, 4, 2, 2>(p, g, st) : launch_rt<32, 4, 2, 1>(p, g, st);
+      case 1: return vec == 2 ? launch_rt<16, 2, 2, 2>(p, g, st) : launch_rt<16, 2, 2, 1>(p, g, st);
+      case 2: return vec == 2 ? launch_rt<8, 2, 2, 2>(p, g, st) : launch_rt<8, 2, 2, 1>(p, g, st);
+      default: return MT_EINVAL;
+    }
+  }
+  if (pl.kind == CONV_FAST) {
     const int vec = conv_fast_vec(p);
     switch (i) {
       case 0: return vec == 2 ? launch_fast2<32, 4, 2, 2>(p, g, st) : launch_fast2<32, 4, 2, 1>(p, g, st);
@@ -1010,6 +1311,7 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
 struct PackParams {
   const float* w; float* dst;
   int Cout, KD, KH, KW, nkp, nchunks, ntiles, flip, layout;
+  int has_tm, tb[3], ts[3];
   long s_ci, s_co, s_kd, s_kh, s_kw;
   ConvChunk chunk[MT_MAX_CHUNKS];
 };
@@ -1040,7 +1342,8 @@ __global__ void pack_weights_kernel(const PackParams P) {
     float v = 0.f;
     if (cin_local < cc.ck && co < P.Cout) {
       const int ci = cc.cglob + cin_local;
-      const int zd = P.flip ? P.KD - 1 - kd : kd, zh = P.flip ? P.KH - 1 - kh : kh, zw = P.flip ? P.KW - 1 - kw : kw;
+      int zd = P.flip ? P.KD - 1 - kd : kd, zh = P.flip ? P.KH - 1 - kh : kh, zw = P.flip ? P.KW - 1 - kw : kw;
+      if (P.has_tm) { zd = P.tb[0] + P.ts[0] * kd; zh = P.tb[1] + P.ts[1] * kh; zw = P.tb[2] + P.ts[2] * kw; }
       v = P.w[ci * P.s_ci + co * P.s_co + zd * P.s_kd + zh * P.s_kh + zw * P.s_kw];
     }
     P.dst[i] = v;
@@ -1049,7 +1352,7 @@ __global__ void pack_weights_kernel(const PackParams P) {
 
 extern "C" int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats, int C0, int C1, int Cout,
                                     int KD, int KH, int KW, long s_ci, long s_co, long s_kd, long s_kh, long s_kw,
-                                    int flip, int ck, int layout, mt_stream_t stream) {
+                                    int flip, int ck, int layout, const int32_t* tapmap, mt_stream_t stream) {
   MT_REQUIRE(ck >= 2 && (ck % 2) == 0, "pack: ck must be even (got %d)", ck);
   MT_REQUIRE(layout == 0 || (layout == 1 && (ck % 8) == 0), "pack: layout 1 needs ck %% 8 == 0");
   PackParams P;
@@ -1062,6 +1365,8 @@ extern "C" int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_f
   if (dst == nullptr) return MT_OK;
   MT_REQUIRE(w != nullptr, "pack: null weights");
   P.w = w; P.dst = dst; P.Cout = Cout; P.KD = KD; P.KH = KH; P.KW = KW; P.flip = flip; P.layout = layout;
+  P.has_tm = tapmap != nullptr;
+  for (int d = 0; d < 3; ++d) { P.tb[d] = tapmap ? tapmap[2 * d] : 0; P.ts[d] = tapmap ? tapmap[2 * d + 1] : 1; }
   P.s_ci = s_ci; P.s_co = s_co; P.s_kd = s_kd; P.s_kh = s_kh; P.s_kw = s_kw;
   int blocks = mt_cdiv((long)total, 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);

@@ -112,9 +112,24 @@ class ConvNormOp(_Op):
         self.ck_f = ops.conv_ck(p)
         self.wf = ops.pack_conv_weights(w, C0, C1, Cout, self.kernel, _strides(w), False, self.ck_f, out=self.wf)
         if need_bwd and any(s.grad is not None for s in self.srcs):
+            if self._use_parity_classes():
+                cls = self._parity_classes()
+                if self.wb is None:
+                    self.wb = [None] * len(cls)
+                for i, (geomc, place, tapmap) in enumerate(cls):
+                    pb = ops.fill_conv([Act(self.out.act.buf)], geomc, C0, place=place)
+                    self.wb[i] = ops.pack_conv_weights(w, Cout, 0, C0, geomc.k, _strides(w, as_bwd_data=True), False,
+                                                       ops.conv_ck(pb), out=self.wb[i], tapmap=tapmap)
+                return
             pb = self._bwd_data_params(eng, None)
             self.ck_b = ops.conv_ck(pb)
             self.wb = ops.pack_conv_weights(w, Cout, 0, C0 + C1, self.kernel, _strides(w, as_bwd_data=True), True, self.ck_b, out=self.wb)
+
+    def _use_parity_classes(self):
+        return self.stride != (1, 1, 1) and len(self.srcs) == 1 and not self.pointwise
+
+    def _parity_classes(self):
+        return ops.bwd_data_parity_classes(self.geom)
 
     def forward(self, eng):
         p = self._fwd_params(eng)
@@ -171,6 +186,18 @@ class ConvNormOp(_Op):
             p = ops.fill_pointwise(gact, self.geom.out, self.geom.out, (1, 1, 1), (1, 1, 1), s0.C, self.wb, None,
                                    Act(s0.grad), accumulate=acc)
             ops.pointwise_fwd(p)
+        elif self._use_parity_classes():
+            s0 = self.srcs[0]
+            cls = self._parity_classes()
+            full = 1
+            for st in self.stride:
+                full *= st
+            if len(cls) < full and not acc:      # some input positions receive no gradient from this conv
+                s0.grad.zero_()
+                acc = True
+            for (geomc, place, _), wb in zip(cls, self.wb):
+                p = ops.fill_conv([gact], geomc, s0.C, wpack=wb, out0=Act(s0.grad), accumulate=acc, place=place)
+                ops.conv3d_fwd(p)
         else:
             p = self._bwd_data_params(eng, g)
             p.wpack = self.wb.data_ptr()

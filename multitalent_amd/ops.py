@@ -93,8 +93,9 @@ class ConvGeom:
 
 
 def fill_conv(srcs, geom, Cout, wpack=None, bias=None, out0=None, out1=None, csplit=None, accumulate=False,
-              stats_part=None):
-    """Build an mt_conv3d_t.  srcs: list of 1-2 Act; out0/out1: Act-like destination slices."""
+              stats_part=None, place=None):
+    """Build an mt_conv3d_t.  srcs: list of 1-2 Act; out0/out1: Act-like destination slices.
+    place = (stored_spatial, out_stride, out_offset): logical output o is written at o*stride + offset."""
     p = mt_conv3d_t()
     p.nsrc = len(srcs)
     for i, a in enumerate(srcs):
@@ -119,7 +120,39 @@ def fill_conv(srcs, geom, Cout, wpack=None, bias=None, out0=None, out1=None, csp
     p.csplit = Cout if csplit is None else csplit
     p.accumulate = 1 if accumulate else 0
     p.stats_part = stats_part.data_ptr() if stats_part is not None else None
+    if place is not None:
+        (p.OD, p.OH, p.OW), (p.osD, p.osH, p.osW), (p.ooD, p.ooH, p.ooW) = place
     return p
+
+
+def bwd_data_parity_classes(geom):
+    """Backward-data of a strided conv (geometry `geom`) as one exact stride-1 convolution per parity class of the input
+    position:  dX[S*m + par] = sum_j dY[m - pad' + j] * W[tmax - S*j]  over the taps t = tmax - S*j congruent to
+    par + P (mod S).  Returns [(ConvGeom on dY, placement, tapmap)] for fill_conv / pack_conv_weights; classes without taps
+    are omitted (their input positions receive no gradient from this conv)."""
+    dims = []
+    for d in range(3):
+        K, S, P, Di = geom.k[d], geom.s[d], geom.p[d], geom.inp[d]
+        opts = []
+        for par in range(S):
+            taps = [t for t in range(K) if (t - par - P) % S == 0]
+            cnt = (Di - par + S - 1) // S
+            if not taps or cnt <= 0:
+                continue
+            tmax = max(taps)
+            opts.append(dict(par=par, k=len(taps), pad=(tmax - par - P) // S, tb=tmax, ts=-S, cnt=cnt, S=S))
+        dims.append(opts)
+    out = []
+    for a in dims[0]:
+        for b in dims[1]:
+            for c in dims[2]:
+                sel = (a, b, c)
+                geomc = ConvGeom(geom.out, tuple(x['k'] for x in sel), (1, 1, 1), tuple(x['pad'] for x in sel),
+                                 out_spatial=tuple(x['cnt'] for x in sel))
+                place = (geom.inp, tuple(x['S'] for x in sel), tuple(x['par'] for x in sel))
+                tapmap = [v for x in sel for v in (x['tb'], x['ts'])]
+                out.append((geomc, place, tapmap))
+    return out
 
 
 def conv_ck(p):
@@ -139,18 +172,20 @@ def conv_stats_blocks(p):
     return _lib.load().mt_conv3d_stats_blocks(C.byref(p))
 
 
-def pack_conv_weights(w, C0, C1, Cout, kernel, strides, flip, ck, out=None, layout=1):
+def pack_conv_weights(w, C0, C1, Cout, kernel, strides, flip, ck, out=None, layout=1, tapmap=None):
     """strides = (s_ci, s_co, s_kd, s_kh, s_kw) element strides of `w` for W_eff[tap][ci][co].
     layout 1 = conv kernels (mt_conv3d_fwd), layout 0 = pointwise kernels (mt_pointwise_fwd)."""
     lib = _lib.load()
     _check_dev(w)
     n = C.c_size_t(0)
     kd, kh, kw = kernel
-    _lib.check(lib.mt_pack_conv_weights(None, None, C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, layout, None), 'pack(query)')
+    tm = (C.c_int32 * 6)(*[int(i) for i in tapmap]) if tapmap is not None else None
+    _lib.check(lib.mt_pack_conv_weights(None, None, C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, layout, None, None), 'pack(query)')
     if out is None:
         out = torch.empty(n.value, dtype=torch.float32, device=w.device)
     assert out.numel() >= n.value
-    _lib.check(lib.mt_pack_conv_weights(_ptr(w), _ptr(out), C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, layout, _stream()), 'pack')
+    _lib.check(lib.mt_pack_conv_weights(_ptr(w), _ptr(out), C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, layout,
+                                        C.cast(tm, C.c_void_p) if tm is not None else None, _stream()), 'pack')
     return out
 
 

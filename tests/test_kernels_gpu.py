@@ -117,6 +117,43 @@ def test_conv_fwd_two_lazy_sources(dev):
     assert relerr(to_ncdhw(out.cpu()), ref) < 1e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,shape,k,stride,pad", [
+    (30, 60, (6, 12, 34), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (32, 64, (7, 13, 33), (3, 3, 3), (2, 2, 2), (1, 1, 1)),       # odd input sizes: classes of different extent
+    (30, 60, (6, 12, 32), (3, 3, 3), (1, 2, 2), (1, 1, 1)),
+    (24, 40, (5, 8, 10), (1, 1, 1), (1, 2, 2), (0, 0, 0)),        # strided projection: three classes carry no taps
+    (16, 24, (4, 8, 8), (2, 2, 2), (2, 2, 2), (0, 0, 0)),
+])
+def test_conv_bwd_data_parity_classes(dev, Cin, Cout, shape, k, stride, pad):
+    """dX of a strided nn.Conv3d as one exact stride-1 convolution per parity class of the input position, written in place
+    with output stride/offset (no multiplication of inserted zeros)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(33)
+    N = 2
+    x = torch.randn((N, Cin) + shape, generator=g, requires_grad=True)
+    w = torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))
+    y = F.conv3d(x, w, None, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dyb = ops.Act(to_ndhwc(dy).to(dev))
+    fgeom = ops.ConvGeom(shape, k, stride, pad)
+    assert fgeom.out == tuple(dy.shape[2:])
+    base = torch.randn((N,) + shape + (Cin,), generator=g)
+    dx = base.to(dev)                                   # accumulate on top of an existing gradient
+    wd = w.to(dev).contiguous()
+    keep = []
+    for geomc, place, tapmap in ops.bwd_data_parity_classes(fgeom):
+        p = ops.fill_conv([dyb], geomc, Cin, out0=ops.Act(dx), accumulate=True, place=place)
+        wp = ops.pack_conv_weights(wd, Cout, 0, Cin, geomc.k, ops.conv_weight_strides(wd, as_bwd_data=True), False,
+                                   ops.conv_ck(p), tapmap=tapmap)
+        keep.append(wp)
+        p.wpack = wp.data_ptr()
+        assert ops.conv_kernel_name(p).startswith('conv_rt_kernel')
+        ops.conv3d_fwd(p)
+    torch.cuda.synchronize()
+    assert relerr(to_ncdhw(dx.cpu()) - to_ncdhw(base), x.grad) < 1e-5
+
+
 @pytest.mark.parametrize("Cin,Cout,shape,k,stride", [
     (30, 30, (4, 8, 32), (3, 3, 3), (1, 1, 1)),
     (30, 60, (6, 12, 34), (3, 3, 3), (2, 2, 2)),
