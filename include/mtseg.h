@@ -88,8 +88,8 @@ int mt_abi_version(void);
 int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats,
                          int C0, int C1, int Cout, int KD, int KH, int KW,
                          long s_ci, long s_co, long s_kd, long s_kh, long s_kw, int flip, int ck,
-                         int layout /* 0: pointwise kernels ([kp][lane], pair (2kp,2kp+1)); 1: conv kernels
-                                       ([kp/4][lane][4], pair (kp, ck/2+kp)) */,
+                         int layout /* 1: all MFMA kernels ([kp/4][lane][4], pair (kp, ck/2+kp)); mt_pointwise_fwd takes ck = 16;
+                                       0: legacy [kp][lane], pair (2kp,2kp+1) */,
                          const int32_t* tapmap /* NULL, or {tbD,tsD,tbH,tsH,tbW,tsW}: packed tap j of dim d takes source
                                                   tap tb + ts*j (overrides flip) — sub-kernels of the parity classes */,
                          mt_stream_t stream);

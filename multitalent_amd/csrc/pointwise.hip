@@ -5,79 +5,140 @@
 // (generic_UNet.py:335-336; generic_modular_UNet.py:236-237) and, with transposed packed weights,
 // the backward-data of the 1x1x1 convs.
 //
-// One wave = 32 base voxels x 32 output channels; A (32 voxels x 2 channels) is gathered straight
-// from global memory with the lazy InstanceNorm+LeakyReLU applied on load, B comes from the packed
-// weights; for a transposed conv every tap is an independent GEMM whose rows are scattered to
-// out[base*so + tap] — written directly into the first half of the skip-concat buffer (ocs).
+// For a transposed conv every tap is an independent GEMM whose rows are scattered to out[base*so + tap] — written
+// directly into the first half of the skip-concat buffer (ocs).  Weights: mt_pack_conv_weights(layout 1, ck 16).
 #include "mt_common.h"
 
 struct PwKParams {
   mt_pointwise_t c;
-  int ntaps, nkp, nsb;
+  int ntaps, nchunks, nsb;
   long Vb;
 };
 
-__global__ __launch_bounds__(256) void pointwise_kernel(const PwKParams P) {
+#define PW_CK 16   // channels per K chunk (packed weight layout 1, ck = 16 — the conv kernels' layout)
+
+// One wave = 32 base voxels x 32 output channels x NT taps.  Lane (i, h) holds channels 8h..8h+7 of voxel i for the current
+// 16-channel chunk (one 32-byte vector straight from global memory, lazy InstanceNorm+LeakyReLU applied in registers), so a
+// chunk costs 8 MFMAs per tap with no LDS traffic at all; every tap of a transposed conv accumulates into its own
+// accumulator tile (NT*16 AGPRs) and the input is read exactly once.  Outputs leave through buffer stores whose per-row
+// offsets are computed once (out-of-range rows carry the hardware-masked offset).
+template <int NT, int VEC>
+__global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   const mt_pointwise_t& c = P.c;
   __shared__ float red[4 * 32 * 2];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lhalf = lane >> 5;
-  const int nb = blockIdx.x / P.nsb, sb = blockIdx.x % P.nsb;
+  const int bx = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const int nb = bx / P.nsb, sb = bx % P.nsb;
   const int ntile = blockIdx.y;
   const long m0 = (long)sb * 128 + wave * 32;
   const mt_src_t& S = c.src;
 
-  // A operand addressing: this lane's base voxel
+  // ---- A operand: this lane's base voxel, channels 8*lhalf .. +7 of each chunk
   const long bv = m0 + li;
   const bool vok = bv < P.Vb;
   const int wb = (int)(bv % c.Wb), hb = (int)((bv / c.Wb) % c.Hb), db = (int)(bv / ((long)c.Wb * c.Hb));
-  const float* ap = S.ptr + ((size_t)((size_t)((size_t)nb * c.Di + db * c.siD) * c.Hi + hb * c.siH) * c.Wi + wb * c.siW) * S.cs;
+  const size_t in_sample = (size_t)c.Di * c.Hi * c.Wi * S.cs;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0,
+                                                                (int)(in_sample * 4), 0x00020000);
+  const int aoff = vok ? ((((db * c.siD) * c.Hi + hb * c.siH) * c.Wi + wb * c.siW) * S.cs + 8 * lhalf) * 4 : (int)0x80000000;
   const bool aff = S.scale != nullptr;
-  const float* scp = aff ? S.scale + (size_t)nb * S.C : nullptr;
-  const float* shp = aff ? S.shift + (size_t)nb * S.C : nullptr;
+  const float slope = S.slope;
+  const bool lrelu_ok = (slope >= 0.f) && (slope <= 1.f);
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(aff ? S.scale + (size_t)nb * S.C : S.ptr), 0, aff ? S.C * 4 : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)(aff ? S.shift + (size_t)nb * S.C : S.ptr), 0, aff ? S.C * 4 : 0, 0x00020000);
 
+  auto load_a = [&](int ch, float (&x)[8]) {
+    const int o = aoff + ch * (PW_CK * 4);
+    if constexpr (VEC == 4) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, o + g * 16, 0, 0));
+        x[4 * g] = t[0]; x[4 * g + 1] = t[1]; x[4 * g + 2] = t[2]; x[4 * g + 3] = t[3];
+      }
+    } else if constexpr (VEC == 2) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra, o + g * 8, 0, 0));
+        x[2 * g] = t.x; x[2 * g + 1] = t.y;
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) x[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, o + g * 4, 0, 0));
+    }
+  };
+  // channels beyond Cin inside the last chunk may hold neighbouring data: zero them (and apply the lazy activation)
+  auto finish_a = [&](int ch, float (&x)[8]) {
+    const int cb = ch * PW_CK + 8 * lhalf;
+    if (aff) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (cb + e) * 4, 0, 0));
+        const float sh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (cb + e) * 4, 0, 0));
+        const float t = fmaf(x[e], sc, sh);
+        x[e] = lrelu_ok ? fmaxf(t, t * slope) : mt_lrelu(t, slope);
+      }
+    }
+    if (cb + 8 > c.Cin || !vok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = (vok && cb + e < c.Cin) ? x[e] : 0.f;
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  float xa[8], xn[8];
+  load_a(0, xa);
+  for (int ch = 0; ch < P.nchunks; ++ch) {
+    if (ch + 1 < P.nchunks) load_a(ch + 1, xn);
+    finish_a(ch, xa);
+    const float* wq = c.wpack + (size_t)(ntile * P.nchunks + ch) * NT * 512 + lane * 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 b0 = *(const f32x4*)(wq + t * 512);
+      const f32x4 b1 = *(const f32x4*)(wq + t * 512 + 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], b0[e], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[4 + e], b1[e], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xa[e] = xn[e];
+  }
+
+  // ---- epilogue
   const int co = ntile * 32 + li;
   const bool covalid = co < c.Cout;
   const float bias = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
   const int Ho = c.Hb * c.soH, Wo = c.Wb * c.soW, Do = c.Db * c.soD;
+  const size_t out_sample = (size_t)Do * Ho * Wo * c.ocs;
+  __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out + (size_t)nb * out_sample), 0,
+                                                                (int)(out_sample * 4), 0x00020000);
+  int obase[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+    const long v = m0 + iv;
+    const int w2 = (int)(v % c.Wb), h2 = (int)((v / c.Wb) % c.Hb), d2 = (int)(v / ((long)c.Wb * c.Hb));
+    const bool ok = covalid && v < P.Vb;
+    obase[j] = ok ? ((((d2 * c.soD) * Ho + h2 * c.soH) * Wo + w2 * c.soW) * c.ocs + co) * 4 : (int)0x80000000;
+  }
   float s1 = 0.f, s2 = 0.f;
-
-  for (int tap = 0; tap < P.ntaps; ++tap) {
-    const int tw = tap % c.soW, th = (tap / c.soW) % c.soH, tdd = tap / (c.soW * c.soH);
-    const float* wq = c.wpack + ((size_t)ntile * P.ntaps + tap) * ((size_t)P.nkp * 64) + lane;
-    f32x16 acc;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    for (int kp0 = 0; kp0 < P.nkp; kp0 += 4) {
-      float a[4], b[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kp = kp0 + u;
-        const int ci = 2 * kp + lhalf;
-        float x = 0.f;
-        if (vok && kp < P.nkp && ci < c.Cin) {
-          x = ap[ci];
-          if (aff) x = mt_lrelu(fmaf(x, scp[ci], shp[ci]), S.slope);
-        }
-        a[u] = x;
-        b[u] = (kp < P.nkp) ? wq[(size_t)kp * 64] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
-    }
+  for (int t = 0; t < NT; ++t) {
+    const int tw = t % c.soW, th = (t / c.soW) % c.soH, tdd = t / (c.soW * c.soH);
+    const int toff = ((tdd * Ho + th) * Wo + tw) * c.ocs * 4;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf;
-      const long v = m0 + iv;
-      if (covalid && v < P.Vb) {
-        const int w2 = (int)(v % c.Wb), h2 = (int)((v / c.Wb) % c.Hb), d2 = (int)(v / ((long)c.Wb * c.Hb));
-        const size_t idx = ((size_t)((size_t)((size_t)nb * Do + d2 * c.soD + tdd) * Ho + h2 * c.soH + th) * Wo + w2 * c.soW + tw) * c.ocs + co;
-        float val = acc[j] + bias;
-        if (c.accumulate) val += c.out[idx];
-        c.out[idx] = val;
-        s1 += val; s2 += val * val;
-      }
+      float val = acc[t][j] + bias;
+      if (c.accumulate) val += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro, obase[j], toff, 0));
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, obase[j], toff, 0);
+      if (c.stats_part != nullptr && obase[j] >= 0) { s1 += val; s2 = fmaf(val, val, s2); }
     }
   }
   if (c.stats_part != nullptr) {
@@ -111,11 +172,31 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   PwKParams P;
   P.c = *p;
   P.ntaps = p->soD * p->soH * p->soW;
-  P.nkp = (p->Cin + 1) / 2;
+  P.nchunks = mt_cdiv(p->Cin, PW_CK);
   P.Vb = (long)p->Db * p->Hb * p->Wb;
   P.nsb = mt_cdiv(P.Vb, 128);
+  MT_REQUIRE((double)p->Di * p->Hi * p->Wi * p->src.cs * 4.0 < 2147483648.0 &&
+             (double)P.Vb * P.ntaps * p->ocs * 4.0 < 2147483648.0, "pointwise: sample larger than 2 GiB");
+  MT_REQUIRE(P.ntaps == 1 || P.ntaps == 2 || P.ntaps == 4 || P.ntaps == 8, "pointwise: unsupported tap count %d", P.ntaps);
+  const mt_src_t& S = p->src;
+  int vec = 1;
+  if ((S.cs % 4) == 0 && (((uintptr_t)S.ptr) & 15) == 0) vec = 4;
+  else if ((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0) vec = 2;
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
-  hipLaunchKernelGGL(pointwise_kernel, grid, dim3(256), 0, (hipStream_t)stream, P);
+  hipStream_t st = (hipStream_t)stream;
+#define PW_LAUNCH(NT)                                                                              \
+  do {                                                                                             \
+    if (vec == 4) hipLaunchKernelGGL((pw_fast_kernel<NT, 4>), grid, dim3(256), 0, st, P);           \
+    else if (vec == 2) hipLaunchKernelGGL((pw_fast_kernel<NT, 2>), grid, dim3(256), 0, st, P);      \
+    else hipLaunchKernelGGL((pw_fast_kernel<NT, 1>), grid, dim3(256), 0, st, P);                    \
+  } while (0)
+  switch (P.ntaps) {
+    case 1: PW_LAUNCH(1); break;
+    case 2: PW_LAUNCH(2); break;
+    case 4: PW_LAUNCH(4); break;
+    default: PW_LAUNCH(8); break;
+  }
+#undef PW_LAUNCH
   MT_CHECK_LAUNCH("pointwise");
   return MT_OK;
 }

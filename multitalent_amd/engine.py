@@ -102,11 +102,9 @@ class ConvNormOp(_Op):
         C0 = self.srcs[0].C
         C1 = self.srcs[1].C if len(self.srcs) > 1 else 0
         if self.pointwise:
-            ck = C0 + (C0 & 1)
-            self.wf = ops.pack_conv_weights(w, C0, 0, Cout, (1, 1, 1), _strides(w), False, ck, out=self.wf, layout=0)
+            self.wf = ops.pack_conv_weights(w, C0, 0, Cout, (1, 1, 1), _strides(w), False, ops.POINTWISE_CK, out=self.wf)
             if need_bwd and self.srcs[0].grad is not None and self.stride == (1, 1, 1):
-                ckb = Cout + (Cout & 1)
-                self.wb = ops.pack_conv_weights(w, Cout, 0, C0, (1, 1, 1), _strides(w, as_bwd_data=True), False, ckb, out=self.wb, layout=0)
+                self.wb = ops.pack_conv_weights(w, Cout, 0, C0, (1, 1, 1), _strides(w, as_bwd_data=True), False, ops.POINTWISE_CK, out=self.wb)
             return
         p = self._fwd_params(eng)
         self.ck_f = ops.conv_ck(p)
@@ -234,7 +232,7 @@ class TConvOp(_Op):
     def pack(self, eng, need_bwd):
         w = self.tu.weight
         Cin, Cout = self.tu.in_channels, self.tu.out_channels
-        self.wf = ops.pack_conv_weights(w, Cin, 0, Cout, self.k, _strides(w, transposed_layout=True), False, Cin + (Cin & 1), out=self.wf, layout=0)
+        self.wf = ops.pack_conv_weights(w, Cin, 0, Cout, self.k, _strides(w, transposed_layout=True), False, ops.POINTWISE_CK, out=self.wf)
         if need_bwd and self.src.grad is not None:
             p = self._bwd_params()
             self.ck_b = ops.conv_ck(p)

@@ -174,7 +174,7 @@ def conv_stats_blocks(p):
 
 def pack_conv_weights(w, C0, C1, Cout, kernel, strides, flip, ck, out=None, layout=1, tapmap=None):
     """strides = (s_ci, s_co, s_kd, s_kh, s_kw) element strides of `w` for W_eff[tap][ci][co].
-    layout 1 = conv kernels (mt_conv3d_fwd), layout 0 = pointwise kernels (mt_pointwise_fwd)."""
+    layout 1 = every MFMA kernel (mt_conv3d_fwd with ck = mt_conv3d_ck, mt_pointwise_fwd with ck = POINTWISE_CK)."""
     lib = _lib.load()
     _check_dev(w)
     n = C.c_size_t(0)
@@ -216,6 +216,9 @@ def conv3d_bwd_weight(p, y, dw, strides, accumulate, ws):
     ys = y.src()
     _lib.check(_lib.load().mt_conv3d_bwd_weight(C.byref(p), C.byref(ys), _ptr(dw), *strides, int(accumulate), _ptr(ws),
                                                 ws.numel() * ws.element_size(), _stream()), 'conv3d_bwd_weight')
+
+
+POINTWISE_CK = 16   # mt_pointwise_fwd takes weights packed with layout 1, ck 16
 
 
 def fill_pointwise(src, base, in_spatial, si, so, Cout, wpack, bias, out, accumulate=False, stats_part=None):

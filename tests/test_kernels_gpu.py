@@ -233,8 +233,7 @@ def test_pointwise_tconv_and_heads(dev, Cin, Cout, base, so):
         ref = F.conv_transpose3d(x, w, stride=so)
         wd = w.to(dev).contiguous()
         strides = ops.conv_weight_strides(wd, transposed_layout=True)
-    ck = Cin + (Cin & 1)
-    wp = ops.pack_conv_weights(wd, Cin, 0, Cout, so, strides, False, ck, layout=0)
+    wp = ops.pack_conv_weights(wd, Cin, 0, Cout, so, strides, False, ops.POINTWISE_CK)
     outshape = tuple(b * s for b, s in zip(base, so))
     out = torch.full((N,) + outshape + (Cout + 3,), float('nan'), device=dev)   # write into a wider buffer (concat slot)
     oa = ops.Act(out, c0=0, C=Cout)
