@@ -606,7 +606,7 @@ __device__ __forceinline__ void stage2_load(Stage2Regs<LD, LH, LW, VEC>& g, cons
   }
 }
 
-template <int LD, int LH, int LW, int VEC>
+template <int LD, int LH, int LW, int VEC, int PITCH = FCKP>
 __device__ __forceinline__ void stage2_store(const Stage2Regs<LD, LH, LW, VEC>& g, float* __restrict__ lds, const mt_conv3d_t& c,
                                              const ConvChunk ch, int lane, int wave) {
   typedef Stage2Regs<LD, LH, LW, VEC> RG_;
@@ -626,13 +626,13 @@ __device__ __forceinline__ void stage2_store(const Stage2Regs<LD, LH, LW, VEC>& 
     }
   }
   const float slope = S.slope;
-  float* lbase = lds + vl * FCKP + cl + wave * (LW * FCKP);
+  float* lbase = lds + vl * PITCH + cl + wave * (LW * PITCH);
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const int row = wave + 4 * r;
     if (row < R) {
       const bool rv = (g.rvmask >> r) & 1u;
-      float* lrow = lbase + 4 * r * (LW * FCKP);
+      float* lrow = lbase + 4 * r * (LW * PITCH);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int lw = vl + i * VPS;
@@ -650,9 +650,9 @@ __device__ __forceinline__ void stage2_store(const Stage2Regs<LD, LH, LW, VEC>& 
           }
           if constexpr (VEC == 2) {
             float2 t; t.x = x[0]; t.y = x[1];
-            *(float2*)(lrow + i * VPS * FCKP) = t;
+            *(float2*)(lrow + i * VPS * PITCH) = t;
           } else {
-            lrow[i * VPS * FCKP] = x[0];
+            lrow[i * VPS * PITCH] = x[0];
           }
         }
       }
@@ -1386,11 +1386,15 @@ struct BwdWParams {
   int TD, TH, TW;     // spatial tile (TW % 4 == 0)
   int tilesD, tilesH, tilesW, ntiles_total;
   int nchunks, ntaps, ncot, nsg;
+  int nsg_cap, nunits, nseg, dseg;   // marching kernel: units = (sample, h-tile, w-tile, D segment of dseg planes)
   float* part;        // [chunk][cot][sg][tap][16][32]
   ConvChunk chunk[MT_MAX_CHUNKS];
 };
 
 #define BW_CK 16
+#ifndef BW_ABL
+#define BW_ABL 0   // compile-time timing ablations of the fast backward-weight kernel: 1 skip X staging, 2 skip Y, 8 skip MFMA
+#endif
 #define BW_YP 48
 #define BW_MAXT 7
 #define BW_YU 16
@@ -1671,16 +1675,17 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
   }
   for (; tile < P.ntiles_total; tile += P.nsg) {
     __syncthreads();     // previous tile's X reads are done
-    stage2_store<LD, LH, LW, VEC>(xr, lds, c, cc, lane, wave);
-    finish_y(ycur, ynxt, yok, ynb);
+    if (!(BW_ABL & 1)) stage2_store<LD, LH, LW, VEC>(xr, lds, c, cc, lane, wave);
+    if (!(BW_ABL & 2)) finish_y(ycur, ynxt, yok, ynb);
     __syncthreads();
     const int tnext = tile + P.nsg;
     if (tnext < P.ntiles_total) {
       int nb, od0, oh0, ow0; tile_coords(tnext, nb, od0, oh0, ow0);
-      stage2_load<LD, LH, LW, VEC>(xr, c, cc, nb, od0 * SD - PD, oh0 * SH - PH, ow0 * SW - PW, lane, wave);
-      issue_y(ynxt, yok, nb, od0, oh0, ow0);
+      if (!(BW_ABL & 1)) stage2_load<LD, LH, LW, VEC>(xr, c, cc, nb, od0 * SD - PD, oh0 * SH - PH, ow0 * SW - PW, lane, wave);
+      if (!(BW_ABL & 2)) issue_y(ynxt, yok, nb, od0, oh0, ow0);
       ynb = nb;
     }
+    if (BW_ABL & 8) continue;
     __builtin_amdgcn_sched_barrier(0);
     // ---- MFMA phase: KS k-steps x 27 taps x 2 cout halves; all LDS offsets are immediates and the A fragments of
     // k-step s+1 are fetched (ping-pong register sets) while the 54 MFMAs of k-step s issue
@@ -1691,21 +1696,154 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
     for (int s2 = 0; s2 < KS; ++s2) {
       float (&ac)[NT] = (s2 & 1) ? a1 : a0;
       float (&an)[NT] = (s2 & 1) ? a0 : a1;
-      if (s2 + 1 < KS) {
-        const int svox = ((s2 + 1) / SPR) * SH * LW + 4 * ((s2 + 1) % SPR) * SW;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) an[t] = lds[xbase + (svox + ((t / (KH * KW)) * LH + (t / KW) % KH) * LW + (t % KW)) * FCKP];
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      // one A read of the next k-step rides behind every MFMA pair: the LDS queue never fills, so MFMA issue never waits
+      // on a burst of reads
+      const int svox = ((s2 + 1) / SPR) * SH * LW + 4 * ((s2 + 1) % SPR) * SW;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
+        if (s2 + 1 < KS) an[t] = lds[xbase + (svox + ((t / (KH * KW)) * LH + (t / KW) % KH) * LW + (t % KW)) * FCKP];
         acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][0], acc[t][0], 0, 0, 0);
         acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][1], acc[t][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // one partial per wave: [chunk][cot][sg*4 + wave][tap][16][32]
+  float* pp = P.part + ((size_t)((size_t)(chi * P.ncot + cot) * (P.nsg * 4) + sg * 4 + wave) * NT) * 512;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pp[(size_t)t * 512 + (lk * 4 + j) * 32 + h * 16 + li] = acc[t][h][j];
+}
+
+
+// ================================================================================================
+// Marching backward-weight kernel (KD = 3, SD = 1): a workgroup owns a column (sample, h-tile, w-tile) and walks it plane by
+// plane along D.  The X planes live in a ring of 4 LDS slots, so every input plane is fetched from memory and transformed ONCE
+// per column instead of once per output plane (the tile kernel above re-stages all three planes of every tile); one barrier per
+// plane.  While the 432 MFMAs of plane d issue, plane d+2 of X and the Y fragments of plane d+1 are in flight.
+// Voxel pitch 16 (SW = 1) / 24 (SW = 2) dwords makes the four k-groups of an A-fragment ds_read_b32 land on disjoint banks.
+template <int KH, int KW, int SH, int SW, int TH, int TW, int VEC>
+__global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P) {
+  constexpr int KD = 3, NT = KD * KH * KW;
+  constexpr int PH = (KH == 3) ? 1 : 0, PW = (KW == 3) ? 1 : 0;
+  constexpr int LH = (TH - 1) * SH + KH, LW = (TW - 1) * SW + KW, TV = TH * TW;
+  constexpr int KS = TV / 16, SPR = TW / 4;
+  constexpr int PITCH = (SW == 1) ? 16 : 24;
+  constexpr int PLANE = LH * LW * PITCH;
+  static_assert(TV == 128, "tile must hold 128 voxels");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const mt_conv3d_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int sg = blockIdx.x, cot = blockIdx.y, chi = blockIdx.z;
+  const ConvChunk cc = P.chunk[chi];
+  const mt_src_t& Y = P.y;
+
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][h][j] = 0.f;
+
+  const int row0 = (wave * KS) / SPR;
+  const int xlane = ((row0 * SH * LW) + lk * SW) * PITCH + li;
+  const int co = cot * 32 + li;
+  const bool yaff = Y.scale != nullptr;
+  const size_t ysample = (size_t)c.Do * c.Ho * c.Wo * Y.cs;
+
+  auto issue_y = [&](float (&yb)[KS][2], unsigned& okmask, int nb, int od, int oh0, int ow0) {
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(Y.ptr + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
+    okmask = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      const int ks = wave * KS + s2;
+      const int oh = oh0 + ks / SPR, ow = ow0 + 4 * (ks % SPR) + lk;
+      const bool vok = (oh < c.Ho) && (ow < c.Wo);
+      const int base = ((od * c.Ho + oh) * c.Wo + ow) * Y.cs + co;
+      const bool k0 = vok && co < c.Cout, k1 = vok && co + 16 < c.Cout;
+      okmask |= (k0 ? 1u : 0u) << (2 * s2);
+      okmask |= (k1 ? 1u : 0u) << (2 * s2 + 1);
+      yb[s2][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, k0 ? base * 4 : (int)0x80000000, 0, 0));
+      yb[s2][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, k1 ? (base + 16) * 4 : (int)0x80000000, 0, 0));
+    }
+  };
+  auto finish_y = [&](float (&dst)[KS][2], const float (&src)[KS][2], unsigned okmask, int nb) {
+    if (yaff) {
+      float ysc0 = 1.f, ysh0 = 0.f, ysc1 = 1.f, ysh1 = 0.f;
+      if (co < c.Cout) { ysc0 = Y.scale[(size_t)nb * Y.C + co]; ysh0 = Y.shift[(size_t)nb * Y.C + co]; }
+      if (co + 16 < c.Cout) { ysc1 = Y.scale[(size_t)nb * Y.C + co + 16]; ysh1 = Y.shift[(size_t)nb * Y.C + co + 16]; }
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        dst[s2][0] = ((okmask >> (2 * s2)) & 1u) ? mt_lrelu(fmaf(src[s2][0], ysc0, ysh0), Y.slope) : 0.f;
+        dst[s2][1] = ((okmask >> (2 * s2 + 1)) & 1u) ? mt_lrelu(fmaf(src[s2][1], ysc1, ysh1), Y.slope) : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) { dst[s2][0] = src[s2][0]; dst[s2][1] = src[s2][1]; }
+    }
+  };
+
+  Stage2Regs<1, LH, LW, VEC> xr, xq;
+  float ycur[KS][2], ynxt[KS][2];
+  unsigned yok = 0;
+
+  for (int unit = sg; unit < P.nunits; unit += P.nsg) {
+    int r = unit;
+    const int seg = r % P.nseg; r /= P.nseg;
+    const int tw = r % P.tilesW; r /= P.tilesW;
+    const int th = r % P.tilesH;
+    const int nb = r / P.tilesH;
+    const int oh0 = th * TH, ow0 = tw * TW;
+    const int uh0 = oh0 * SH - PH, uw0 = ow0 * SW - PW;
+    const int d0 = seg * P.dseg;
+    const int d1 = (d0 + P.dseg < c.Do) ? d0 + P.dseg : c.Do;
+    // ---- prologue: planes d0-1 and d0 into the ring, plane d0+1 and the Y fragments of plane d0 in flight
+    stage2_load<1, LH, LW, VEC>(xq, c, cc, nb, d0 - 1, uh0, uw0, lane, wave);
+    stage2_load<1, LH, LW, VEC>(xr, c, cc, nb, d0, uh0, uw0, lane, wave);
+    __syncthreads();       // the previous unit's A reads are done
+    stage2_store<1, LH, LW, VEC, PITCH>(xq, lds + ((d0 + 3) & 3) * PLANE, c, cc, lane, wave);
+    stage2_store<1, LH, LW, VEC, PITCH>(xr, lds + (d0 & 3) * PLANE, c, cc, lane, wave);
+    stage2_load<1, LH, LW, VEC>(xr, c, cc, nb, d0 + 1, uh0, uw0, lane, wave);
+    issue_y(ynxt, yok, nb, d0, oh0, ow0);
+
+    for (int d = d0; d < d1; ++d) {
+      // slot (d+1)&3 was last read for plane d-3+... (step d-2 at the latest): every wave has passed the barrier of step d-1 since
+      stage2_store<1, LH, LW, VEC, PITCH>(xr, lds + ((d + 1) & 3) * PLANE, c, cc, lane, wave);
+      finish_y(ycur, ynxt, yok, nb);
+      __syncthreads();
+      if (d + 1 < d1) {
+        stage2_load<1, LH, LW, VEC>(xr, c, cc, nb, d + 2, uh0, uw0, lane, wave);
+        issue_y(ynxt, yok, nb, d + 1, oh0, ow0);
+      }
+      if (BW_ABL & 8) continue;
+      int xb[3];
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) xb[kd] = ((d + 3 + kd) & 3) * PLANE + xlane;      // plane d-1+kd
+      __builtin_amdgcn_sched_barrier(0);
+      float a0[NT], a1[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a0[t] = lds[xb[t / (KH * KW)] + (((t / KW) % KH) * LW + (t % KW)) * PITCH];
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        float (&ac)[NT] = (s2 & 1) ? a1 : a0;
+        float (&an)[NT] = (s2 & 1) ? a0 : a1;
+        const int svox = ((s2 + 1) / SPR) * SH * LW + 4 * ((s2 + 1) % SPR) * SW;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (s2 + 1 < KS) an[t] = lds[xb[t / (KH * KW)] + (svox + ((t / KW) % KH) * LW + (t % KW)) * PITCH];
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][0], acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][1], acc[t][1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
   float* pp = P.part + ((size_t)((size_t)(chi * P.ncot + cot) * (P.nsg * 4) + sg * 4 + wave) * NT) * 512;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -1739,6 +1877,12 @@ static int bwdw_fast_geo(const mt_conv3d_t* p, const mt_src_t* y) {
   return -1;
 }
 static bool bwdw_is_fast(const mt_conv3d_t* p, const mt_src_t* y) { return bwdw_fast_geo(p, y) >= 0; }
+static bool bwdw_use_march(const mt_conv3d_t* p) {
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_BWDW_MARCH"); use = e ? atoi(e) : 1; }
+  return use && p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 1 && p->Do >= 3;
+}
+static void bwdw_march_plan(const mt_conv3d_t* p, BwdWParams* P);
 // plan for the fast kernel: tile 1 x TH x TW with (TH,TW) = (4,32) or (8,16)
 static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   const bool wide = p->Wo > 16;
@@ -1750,9 +1894,50 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   P->ncot = mt_cdiv(p->Cout, 32);
   int pairs = P->nchunks * P->ncot; if (pairs < 1) pairs = 1;
   int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
+  P->nsg_cap = nsg;
   if (nsg > P->ntiles_total) nsg = P->ntiles_total;
   if (nsg < 1) nsg = 1;
   P->nsg = nsg;
+  P->nunits = 0; P->nseg = 1; P->dseg = p->Do;
+  if (bwdw_use_march(p)) bwdw_march_plan(p, P);
+}
+
+// marching plan: columns x D segments; the segment count balances the units over the workgroups of a (chunk, cout tile) pair
+static void bwdw_march_plan(const mt_conv3d_t* p, BwdWParams* P) {
+  const int cols = p->N * P->tilesH * P->tilesW;
+  int best = 1; double bestcost = 1e300;
+  for (int nseg = 1; nseg <= p->Do; ++nseg) {
+    const int dseg = mt_cdiv(p->Do, nseg);
+    if (mt_cdiv(p->Do, dseg) != nseg) continue;
+    const long units = (long)cols * nseg;
+    const double cost = (double)mt_cdiv(units, P->nsg_cap) * (dseg + 2.0);   // +2: prologue planes of every unit
+    if (cost < bestcost - 1e-9) { bestcost = cost; best = nseg; }
+  }
+  P->nseg = best; P->dseg = mt_cdiv(p->Do, best);
+  P->nunits = cols * best;
+  P->nsg = P->nsg_cap < P->nunits ? P->nsg_cap : P->nunits;
+}
+template <int KH, int KW, int SH, int SW>
+static int launch_bwdw_march(const BwdWParams& P, int vec, hipStream_t st) {
+  constexpr int PITCH = (SW == 1) ? 16 : 24;
+  constexpr int LHa = 3 * SH + KH, LWa = 31 * SW + KW, LHb = 7 * SH + KH, LWb = 15 * SW + KW;
+  const size_t ldsb = (size_t)4 * (P.TW == 32 ? LHa * LWa : LHb * LWb) * PITCH * sizeof(float);
+  MT_REQUIRE(ldsb <= 160 * 1024, "bwd_weight: LDS ring too large (%zu)", ldsb);
+  dim3 grid(P.nsg, P.ncot, P.nchunks);
+#define MT_BW_LAUNCH(TH_, TW_, VEC_)                                                                          \
+  do {                                                                                                        \
+    auto kfn = conv_bwdw_march_kernel<KH, KW, SH, SW, TH_, TW_, VEC_>;                                        \
+    if (ldsb > 64 * 1024) {                                                                                   \
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
+      if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; } \
+    }                                                                                                         \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), ldsb, st, P);                                                    \
+  } while (0)
+  if (P.TW == 32) { if (vec == 2) MT_BW_LAUNCH(4, 32, 2); else MT_BW_LAUNCH(4, 32, 1); }
+  else            { if (vec == 2) MT_BW_LAUNCH(8, 16, 2); else MT_BW_LAUNCH(8, 16, 1); }
+#undef MT_BW_LAUNCH
+  MT_CHECK_LAUNCH("conv_bwdw_march");
+  return MT_OK;
 }
 
 template <int KD, int KH, int KW, int SD, int SH, int SW>
@@ -1843,7 +2028,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     hipStream_t st = (hipStream_t)stream;
     int rc = MT_EINVAL;
     switch (geo) {
-      case 0: rc = launch_bwdw_fast<3, 3, 3, 1, 1, 1>(P, vec, st); break;
+      case 0: rc = bwdw_use_march(p) ? launch_bwdw_march<3, 3, 1, 1>(P, vec, st) : launch_bwdw_fast<3, 3, 3, 1, 1, 1>(P, vec, st); break;
       case 1: rc = launch_bwdw_fast<3, 3, 3, 2, 2, 2>(P, vec, st); break;
       case 2: rc = launch_bwdw_fast<3, 3, 3, 1, 2, 2>(P, vec, st); break;
       case 3: rc = launch_bwdw_fast<2, 2, 2, 2, 2, 2>(P, vec, st); break;

@@ -1,0 +1,7 @@
+#!/bin/bash
+# build an instrumented variant of the library: tools/build_variant.sh NAME "-DBW_ABL=3 ..."  ->  multitalent_amd/libmtseg_hip_NAME.so
+set -e
+cd "$(dirname "$0")/../multitalent_amd/csrc"
+name=$1; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c conv_lds.hip -o /tmp/conv_lds_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmtseg_hip_$name.so /tmp/conv_lds_$name.o pointwise.o norm.o loss.o optim.o infer.o errors.o
