@@ -1732,7 +1732,11 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
   constexpr int LH = (TH - 1) * SH + KH, LW = (TW - 1) * SW + KW, TV = TH * TW;
   constexpr int KS = TV / 16, SPR = TW / 4;
   constexpr int PITCH = (SW == 1) ? 16 : 24;
-  constexpr int PLANE = LH * LW * PITCH;
+  // staging geometry: 64 lanes = VPS voxels x LPV channel groups; NI steps cover a row, RPW rows per wave.  Rows are padded to
+  // LWP = NI*VPS voxels in LDS so that every lane of every step may store unconditionally.
+  constexpr int LPV = FCK / VEC, VPS = 64 / LPV, NI = (LW + VPS - 1) / VPS, RPW = (LH + 3) / 4, LWP = NI * VPS;
+  constexpr int LHP = RPW * 4;                 // rows padded likewise: every wave stores RPW rows unconditionally
+  constexpr int PLANE = LHP * LWP * PITCH;
   static_assert(TV == 128, "tile must hold 128 voxels");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
@@ -1742,6 +1746,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
   const int sg = blockIdx.x, cot = blockIdx.y, chi = blockIdx.z;
   const ConvChunk cc = P.chunk[chi];
   const mt_src_t& Y = P.y;
+  const mt_src_t& S = c.src[cc.src];
 
   f32x4 acc[NT][2];
 #pragma unroll
@@ -1752,46 +1757,24 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
       for (int j = 0; j < 4; ++j) acc[t][h][j] = 0.f;
 
   const int row0 = (wave * KS) / SPR;
-  const int xlane = ((row0 * SH * LW) + lk * SW) * PITCH + li;
+  const int xlane = ((row0 * SH * LWP) + lk * SW) * PITCH + li;
   const int co = cot * 32 + li;
   const bool yaff = Y.scale != nullptr;
   const size_t ysample = (size_t)c.Do * c.Ho * c.Wo * Y.cs;
+  const size_t xsample = (size_t)c.Di * c.Hi * c.Wi * S.cs;
+  const int xplane_bytes = c.Hi * c.Wi * S.cs * 4, yplane_bytes = c.Ho * c.Wo * Y.cs * 4;
 
-  auto issue_y = [&](float (&yb)[KS][2], unsigned& okmask, int nb, int od, int oh0, int ow0) {
-    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(Y.ptr + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
-    okmask = 0;
+  // staging lane constants
+  const int cl = (lane % LPV) * VEC, vl = lane / LPV;
+  const bool xaff = S.scale != nullptr;
+  const float xslope = xaff ? S.slope : 1.f;
+  bool cval[VEC];
 #pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) {
-      const int ks = wave * KS + s2;
-      const int oh = oh0 + ks / SPR, ow = ow0 + 4 * (ks % SPR) + lk;
-      const bool vok = (oh < c.Ho) && (ow < c.Wo);
-      const int base = ((od * c.Ho + oh) * c.Wo + ow) * Y.cs + co;
-      const bool k0 = vok && co < c.Cout, k1 = vok && co + 16 < c.Cout;
-      okmask |= (k0 ? 1u : 0u) << (2 * s2);
-      okmask |= (k1 ? 1u : 0u) << (2 * s2 + 1);
-      yb[s2][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, k0 ? base * 4 : (int)0x80000000, 0, 0));
-      yb[s2][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, k1 ? (base + 16) * 4 : (int)0x80000000, 0, 0));
-    }
-  };
-  auto finish_y = [&](float (&dst)[KS][2], const float (&src)[KS][2], unsigned okmask, int nb) {
-    if (yaff) {
-      float ysc0 = 1.f, ysh0 = 0.f, ysc1 = 1.f, ysh1 = 0.f;
-      if (co < c.Cout) { ysc0 = Y.scale[(size_t)nb * Y.C + co]; ysh0 = Y.shift[(size_t)nb * Y.C + co]; }
-      if (co + 16 < c.Cout) { ysc1 = Y.scale[(size_t)nb * Y.C + co + 16]; ysh1 = Y.shift[(size_t)nb * Y.C + co + 16]; }
-#pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) {
-        dst[s2][0] = ((okmask >> (2 * s2)) & 1u) ? mt_lrelu(fmaf(src[s2][0], ysc0, ysh0), Y.slope) : 0.f;
-        dst[s2][1] = ((okmask >> (2 * s2 + 1)) & 1u) ? mt_lrelu(fmaf(src[s2][1], ysc1, ysh1), Y.slope) : 0.f;
-      }
-    } else {
-#pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) { dst[s2][0] = src[s2][0]; dst[s2][1] = src[s2][1]; }
-    }
-  };
+  for (int e = 0; e < VEC; ++e) cval[e] = (cl + e) < cc.ck;
+  const int swlane = vl * PITCH + cl + wave * (LWP * PITCH);      // this lane's LDS store offset inside a plane (row r: + 4r rows)
 
-  Stage2Regs<1, LH, LW, VEC> xr, xq;
+  float xv[RPW][NI][VEC];      // the X plane in flight
   float ycur[KS][2], ynxt[KS][2];
-  unsigned yok = 0;
 
   for (int unit = sg; unit < P.nunits; unit += P.nsg) {
     int r = unit;
@@ -1803,23 +1786,128 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
     const int uh0 = oh0 * SH - PH, uw0 = ow0 * SW - PW;
     const int d0 = seg * P.dseg;
     const int d1 = (d0 + P.dseg < c.Do) ? d0 + P.dseg : c.Do;
+
+    // ---- per-unit constants: every per-plane load below is (constant VGPR offset, scalar plane/row offset)
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * xsample), 0, (int)(xsample * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Y.ptr + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
+    // validity is carried as data (masks / out-of-range offsets), never as control flow: uniform conditions would otherwise
+    // become dozens of scalar branches around single loads and stores
+    int xvo[NI];
+    unsigned mval[NI][VEC];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int lw = vl + i * VPS, uw = uw0 + lw;
+      const bool ok = (lw < LW) && ((unsigned)uw < (unsigned)c.Wi);
+      xvo[i] = (ok && cval[0]) ? (uw * S.cs + cc.c0 + cl) * 4 : (int)0x80000000;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) mval[i][e] = (ok && cval[e]) ? 0xffffffffu : 0u;
+    }
+    int rowm[RPW], rowoff[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+      const int row = wave + 4 * q, uh = uh0 + row;
+      const bool ok = (row < LH) && ((unsigned)uh < (unsigned)c.Hi);
+      rowm[q] = ok ? -1 : 0;
+      rowoff[q] = ok ? uh * c.Wi * S.cs * 4 : 0;
+    }
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      sc[e] = 1.f; sh[e] = 0.f;
+      if (xaff && cval[e]) { sc[e] = S.scale[(size_t)nb * S.C + cc.c0 + cl + e]; sh[e] = S.shift[(size_t)nb * S.C + cc.c0 + cl + e]; }
+    }
+    int yvo[KS][2];
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      const int ks = wave * KS + s2;
+      const int oh = oh0 + ks / SPR, ow = ow0 + 4 * (ks % SPR) + lk;
+      const bool vok = (oh < c.Ho) && (ow < c.Wo);
+      const int base = ((oh * c.Wo + ow) * Y.cs + co) * 4;
+      yvo[s2][0] = (vok && co < c.Cout) ? base : (int)0x80000000;
+      yvo[s2][1] = (vok && co + 16 < c.Cout) ? base + 64 : (int)0x80000000;
+    }
+    float ysc0 = 1.f, ysh0 = 0.f, ysc1 = 1.f, ysh1 = 0.f;
+    if (yaff) {
+      if (co < c.Cout) { ysc0 = Y.scale[(size_t)nb * Y.C + co]; ysh0 = Y.shift[(size_t)nb * Y.C + co]; }
+      if (co + 16 < c.Cout) { ysc1 = Y.scale[(size_t)nb * Y.C + co + 16]; ysh1 = Y.shift[(size_t)nb * Y.C + co + 16]; }
+    }
+
+    auto load_x = [&](int ud) {            // issue only
+      const int pvm = ((unsigned)ud < (unsigned)c.Di) ? -1 : 0;
+      const int poff = (ud & pvm) * xplane_bytes;
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int oob = ~(pvm & rowm[q]) & (int)0x80000000;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int vo = xvo[i] | oob;
+          if constexpr (VEC == 2) {
+            const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(xrs, vo, poff + rowoff[q], 0));
+            xv[q][i][0] = t.x; xv[q][i][1] = t.y;
+          } else {
+            xv[q][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo, poff + rowoff[q], 0));
+          }
+        }
+      }
+    };
+    auto store_x = [&](int ud, int slot) {
+      const int pvm = ((unsigned)ud < (unsigned)c.Di) ? -1 : 0;
+      float* lp = lds + slot * PLANE + swlane;
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const unsigned rvm = (unsigned)(pvm & rowm[q]);
+        float scq[VEC], shq[VEC];      // a row outside the volume gets scale = shift = 0: its voxels stage as exact zeros
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          scq[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sc[e]) & rvm);
+          shq[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sh[e]) & rvm);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          float x[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float t = fmaf(xv[q][i][e], scq[e], shq[e]);
+            const float a = mt_lrelu(t, xslope);
+            x[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & mval[i][e]);
+          }
+          float* d = lp + (4 * q * LWP + i * VPS) * PITCH;
+          if constexpr (VEC == 2) { float2 t; t.x = x[0]; t.y = x[1]; *(float2*)d = t; }
+          else *d = x[0];
+        }
+      }
+    };
+    auto load_y = [&](int od) {
+      const int poff = od * yplane_bytes;
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        ynxt[s2][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yvo[s2][0], poff, 0));
+        ynxt[s2][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yvo[s2][1], poff, 0));
+      }
+    };
+    auto rotate_y = [&]() {
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        if (yaff) {
+          ycur[s2][0] = (yvo[s2][0] >= 0) ? mt_lrelu(fmaf(ynxt[s2][0], ysc0, ysh0), Y.slope) : 0.f;
+          ycur[s2][1] = (yvo[s2][1] >= 0) ? mt_lrelu(fmaf(ynxt[s2][1], ysc1, ysh1), Y.slope) : 0.f;
+        } else { ycur[s2][0] = ynxt[s2][0]; ycur[s2][1] = ynxt[s2][1]; }
+      }
+    };
+
     // ---- prologue: planes d0-1 and d0 into the ring, plane d0+1 and the Y fragments of plane d0 in flight
-    stage2_load<1, LH, LW, VEC>(xq, c, cc, nb, d0 - 1, uh0, uw0, lane, wave);
-    stage2_load<1, LH, LW, VEC>(xr, c, cc, nb, d0, uh0, uw0, lane, wave);
     __syncthreads();       // the previous unit's A reads are done
-    stage2_store<1, LH, LW, VEC, PITCH>(xq, lds + ((d0 + 3) & 3) * PLANE, c, cc, lane, wave);
-    stage2_store<1, LH, LW, VEC, PITCH>(xr, lds + (d0 & 3) * PLANE, c, cc, lane, wave);
-    stage2_load<1, LH, LW, VEC>(xr, c, cc, nb, d0 + 1, uh0, uw0, lane, wave);
-    issue_y(ynxt, yok, nb, d0, oh0, ow0);
+    if (!(BW_ABL & 1)) { load_x(d0 - 1); store_x(d0 - 1, (d0 + 3) & 3); load_x(d0); store_x(d0, d0 & 3); load_x(d0 + 1); }
+    if (!(BW_ABL & 2)) load_y(d0);
 
     for (int d = d0; d < d1; ++d) {
-      // slot (d+1)&3 was last read for plane d-3+... (step d-2 at the latest): every wave has passed the barrier of step d-1 since
-      stage2_store<1, LH, LW, VEC, PITCH>(xr, lds + ((d + 1) & 3) * PLANE, c, cc, lane, wave);
-      finish_y(ycur, ynxt, yok, nb);
+      // slot (d+1)&3 last held plane d-3, read no later than step d-2: every wave has passed the barrier of step d-1 since
+      if (!(BW_ABL & 1)) store_x(d + 1, (d + 1) & 3);
+      if (!(BW_ABL & 2)) rotate_y();
       __syncthreads();
       if (d + 1 < d1) {
-        stage2_load<1, LH, LW, VEC>(xr, c, cc, nb, d + 2, uh0, uw0, lane, wave);
-        issue_y(ynxt, yok, nb, d + 1, oh0, ow0);
+        if (!(BW_ABL & 1)) load_x(d + 2);
+        if (!(BW_ABL & 2)) load_y(d + 1);
       }
       if (BW_ABL & 8) continue;
       int xb[3];
@@ -1828,15 +1916,15 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
       __builtin_amdgcn_sched_barrier(0);
       float a0[NT], a1[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) a0[t] = lds[xb[t / (KH * KW)] + (((t / KW) % KH) * LW + (t % KW)) * PITCH];
+      for (int t = 0; t < NT; ++t) a0[t] = lds[xb[t / (KH * KW)] + (((t / KW) % KH) * LWP + (t % KW)) * PITCH];
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) {
         float (&ac)[NT] = (s2 & 1) ? a1 : a0;
         float (&an)[NT] = (s2 & 1) ? a0 : a1;
-        const int svox = ((s2 + 1) / SPR) * SH * LW + 4 * ((s2 + 1) % SPR) * SW;
+        const int svox = ((s2 + 1) / SPR) * SH * LWP + 4 * ((s2 + 1) % SPR) * SW;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          if (s2 + 1 < KS) an[t] = lds[xb[t / (KH * KW)] + (svox + ((t / KW) % KH) * LW + (t % KW)) * PITCH];
+          if (s2 + 1 < KS) an[t] = lds[xb[t / (KH * KW)] + (svox + ((t / KW) % KH) * LWP + (t % KW)) * PITCH];
           acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][0], acc[t][0], 0, 0, 0);
           acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][1], acc[t][1], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
@@ -1921,7 +2009,10 @@ template <int KH, int KW, int SH, int SW>
 static int launch_bwdw_march(const BwdWParams& P, int vec, hipStream_t st) {
   constexpr int PITCH = (SW == 1) ? 16 : 24;
   constexpr int LHa = 3 * SH + KH, LWa = 31 * SW + KW, LHb = 7 * SH + KH, LWb = 15 * SW + KW;
-  const size_t ldsb = (size_t)4 * (P.TW == 32 ? LHa * LWa : LHb * LWb) * PITCH * sizeof(float);
+  const int vps = vec == 2 ? 8 : 4;                                 // voxels per staging step; rows are padded to a multiple
+  const int lwa = mt_cdiv(LWa, vps) * vps, lwb = mt_cdiv(LWb, vps) * vps;
+  const int lha = mt_cdiv(LHa, 4) * 4, lhb = mt_cdiv(LHb, 4) * 4;
+  const size_t ldsb = (size_t)4 * (P.TW == 32 ? lha * lwa : lhb * lwb) * PITCH * sizeof(float);
   MT_REQUIRE(ldsb <= 160 * 1024, "bwd_weight: LDS ring too large (%zu)", ldsb);
   dim3 grid(P.nsg, P.ncot, P.nchunks);
 #define MT_BW_LAUNCH(TH_, TW_, VEC_)                                                                          \
