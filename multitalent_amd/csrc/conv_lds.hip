@@ -1576,6 +1576,56 @@ __global__ void bwdw_reduce_kernel(const BwdWReduceParams P) {
   }
 }
 
+// Deterministic in-workgroup reduction of the four waves' accumulator tiles through LDS (waves 2,3 -> 0,1, then 1 -> 0) and
+// ONE partial per workgroup in global memory: [chunk][cot][sg][tap][16 ci][32 co].  Needs 2 * NT * 512 floats of LDS.
+#define BW_RED_LDS(NT_) ((size_t)2 * (NT_) * 512 * sizeof(float))
+template <int NT>
+__device__ __forceinline__ void bwdw_wg_reduce_store(f32x4 (&acc)[NT][2], float* __restrict__ lds, float* __restrict__ pp,
+                                                     int wave, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
+  __syncthreads();                     // every wave is done with the X tiles
+  if (wave >= 2) {
+    float* b = lds + (wave - 2) * (NT * 512) + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[((t * 2 + h) * 4 + j) * 64] = acc[t][h][j];
+  }
+  __syncthreads();
+  if (wave < 2) {
+    const float* b = lds + wave * (NT * 512) + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][h][j] += b[((t * 2 + h) * 4 + j) * 64];
+  }
+  __syncthreads();
+  if (wave == 1) {
+    float* b = lds + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[((t * 2 + h) * 4 + j) * 64] = acc[t][h][j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float* b = lds + lane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          pp[(size_t)t * 512 + (lk * 4 + j) * 32 + h * 16 + li] = acc[t][h][j] + b[((t * 2 + h) * 4 + j) * 64];
+  }
+}
+
 // ================================================================================================
 // FAST backward-weight kernel (3x3x3, stride 1, pad 1):  dW[tap][ci16][co32] += X(tile + tap)^T * Y(tile)
 // K (= voxels) is split across the 4 waves, every wave accumulates ALL 27 taps for its quarter of the tile
@@ -1708,14 +1758,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
       }
     }
   }
-  // one partial per wave: [chunk][cot][sg*4 + wave][tap][16][32]
-  float* pp = P.part + ((size_t)((size_t)(chi * P.ncot + cot) * (P.nsg * 4) + sg * 4 + wave) * NT) * 512;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pp[(size_t)t * 512 + (lk * 4 + j) * 32 + h * 16 + li] = acc[t][h][j];
+  bwdw_wg_reduce_store<NT>(acc, lds, P.part + ((size_t)((size_t)(chi * P.ncot + cot) * P.nsg + sg) * NT) * 512, wave, lane);
 }
 
 
@@ -1932,13 +1975,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
       }
     }
   }
-  float* pp = P.part + ((size_t)((size_t)(chi * P.ncot + cot) * (P.nsg * 4) + sg * 4 + wave) * NT) * 512;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pp[(size_t)t * 512 + (lk * 4 + j) * 32 + h * 16 + li] = acc[t][h][j];
+  bwdw_wg_reduce_store<NT>(acc, lds, P.part + ((size_t)((size_t)(chi * P.ncot + cot) * P.nsg + sg) * NT) * 512, wave, lane);
 }
 
 // compile-time geometries of the fast backward-weight kernel: (K, S) with pad (K-1)/2 for K=3/1 and 0 for K=2
@@ -2012,7 +2049,8 @@ static int launch_bwdw_march(const BwdWParams& P, int vec, hipStream_t st) {
   const int vps = vec == 2 ? 8 : 4;                                 // voxels per staging step; rows are padded to a multiple
   const int lwa = mt_cdiv(LWa, vps) * vps, lwb = mt_cdiv(LWb, vps) * vps;
   const int lha = mt_cdiv(LHa, 4) * 4, lhb = mt_cdiv(LHb, 4) * 4;
-  const size_t ldsb = (size_t)4 * (P.TW == 32 ? lha * lwa : lhb * lwb) * PITCH * sizeof(float);
+  size_t ldsb = (size_t)4 * (P.TW == 32 ? lha * lwa : lhb * lwb) * PITCH * sizeof(float);
+  if (ldsb < BW_RED_LDS(3 * KH * KW)) ldsb = BW_RED_LDS(3 * KH * KW);
   MT_REQUIRE(ldsb <= 160 * 1024, "bwd_weight: LDS ring too large (%zu)", ldsb);
   dim3 grid(P.nsg, P.ncot, P.nchunks);
 #define MT_BW_LAUNCH(TH_, TW_, VEC_)                                                                          \
@@ -2034,7 +2072,8 @@ static int launch_bwdw_march(const BwdWParams& P, int vec, hipStream_t st) {
 template <int KD, int KH, int KW, int SD, int SH, int SW>
 static int launch_bwdw_fast(const BwdWParams& P, int vec, hipStream_t st) {
   constexpr int LHa = 3 * SH + KH, LWa = 31 * SW + KW, LHb = 7 * SH + KH, LWb = 15 * SW + KW;
-  const size_t ldsb = (size_t)KD * (P.TW == 32 ? LHa * LWa : LHb * LWb) * FCKP * sizeof(float);
+  size_t ldsb = (size_t)KD * (P.TW == 32 ? LHa * LWa : LHb * LWb) * FCKP * sizeof(float);
+  if (ldsb < BW_RED_LDS(KD * KH * KW)) ldsb = BW_RED_LDS(KD * KH * KW);
   MT_REQUIRE(ldsb <= 160 * 1024, "bwd_weight: LDS tile too large (%zu)", ldsb);
   dim3 grid(P.nsg, P.ncot, P.nchunks);
 #define MT_BW_LAUNCH(TH_, TW_, VEC_)                                                                          \
@@ -2087,7 +2126,7 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
   {
     BwdWParams F; bwdw_fast_plan(p, &F);
     if (F.nchunks > 0) {
-      const size_t fast = (size_t)F.nchunks * F.ncot * F.nsg * 4 * F.ntaps * 512 * sizeof(float);
+      const size_t fast = (size_t)F.nchunks * F.ncot * F.nsg * F.ntaps * 512 * sizeof(float);
       if (fast > generic) generic = fast;
     }
   }
@@ -2112,7 +2151,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
   if (geo >= 0) {
     bwdw_fast_plan(p, &P);
     MT_REQUIRE(P.nchunks > 0, "bwd_weight: too many channel chunks");
-    const size_t need = (size_t)P.nchunks * P.ncot * P.nsg * 4 * P.ntaps * 512 * sizeof(float);
+    const size_t need = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need) { mt_set_error("bwd_weight: workspace %zu < %zu", workspace_bytes, need); return MT_EWORKSPACE; }
     P.part = (float*)workspace;
     const int vec = conv_fast_vec(p);
@@ -2130,7 +2169,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     if (rc != MT_OK) return rc;
     BwdWReduceParams R;
     R.part = P.part; R.dw = dw; R.Cin = p->Cin; R.Cout = p->Cout; R.KD = p->KD; R.KH = p->KH; R.KW = p->KW;
-    R.nchunks = P.nchunks; R.ncot = P.ncot; R.nsg = P.nsg * 4; R.ntaps = P.ntaps; R.accumulate = accumulate;
+    R.nchunks = P.nchunks; R.ncot = P.ncot; R.nsg = P.nsg; R.ntaps = P.ntaps; R.accumulate = accumulate;
     R.s_ci = s_ci; R.s_co = s_co; R.s_kd = s_kd; R.s_kh = s_kh; R.s_kw = s_kw;
     for (int i = 0; i < P.nchunks; ++i) R.chunk[i] = P.chunk[i];
     const long total = (long)P.nchunks * P.ncot * P.ntaps * 512;
