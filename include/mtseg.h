@@ -98,6 +98,14 @@ int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats,
 int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream);
 int mt_conv3d_stats_blocks(const mt_conv3d_t* p); /* spatial blocks per sample (size of stats_part dim 1) */
 int mt_conv3d_ck(const mt_conv3d_t* p);           /* channel chunk the kernel will use (pack weights with it) */
+/* Backward-data of a strided 3x3x3 convolution (pad 1, stride (2,2,2) or (1,2,2)) in one launch — replaces autograd's
+ * conv_transpose for the strided stage convs (generic_UNet.py:263-278 `first_stride`, generic_modular_UNet.py:69-77).
+ * p carries the FORWARD geometry: Di/Hi/Wi = X dims, Do/Ho/Wo = Y dims, K, S, P, Cin, Cout; src[0] = dY (C = Cout, may be lazy);
+ * out0/ocs0 = dX (Cin channels), accumulate adds to it.  wpack = mt_pack_conv_weights(w, C0 = Cout, C1 = 0, Cout_arg = Cin,
+ * kernel 3x3x3, strides with the ci/co roles swapped, flip = 0, ck = 16, layout 1).  Each of the 27 taps is one MFMA block
+ * into the accumulator of the parity class (x mod stride) it reaches: no work on inserted zeros. */
+int mt_conv3d_bwd_data_strided(const mt_conv3d_t* p, mt_stream_t stream);
+int mt_conv3d_bwd_data_strided_supported(const mt_conv3d_t* p);   /* 1 when the geometry is handled, else 0 */
 int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n); /* device kernel that will run (profiler name) */
 
 /* ---- backward-weight -------------------------------------------------------------------------

@@ -1036,6 +1036,102 @@ __global__ __launch_bounds__(256) void conv_rt_kernel(const ConvKParams P) {
   }
 }
 
+// ================================================================================================
+// Backward-data of a strided 3x3x3 convolution (stride 2 in the dims given by SD/SH/SW, pad 1) in ONE launch:
+//   dX[S*m + par] = sum over the taps k congruent to par+1 (mod S) of dY[m + j(k)] * W[k]
+// A workgroup stages one dY tile (with a +1 halo in strided dims, +-1 in stride-1 dims) and keeps one accumulator tile per
+// parity class (8 for stride (2,2,2), 4 for (1,2,2)): every one of the 27 taps is exactly one 16-channel MFMA block into the
+// class it belongs to, so the MFMA work equals the algorithmic FLOPs — no multiplication of inserted zeros, no re-staging
+// of dY per class.  Per dim:  S = 2: k=1 -> (par 0, j 0), k=2 -> (par 1, j 0), k=0 -> (par 1, j 1);   S = 1: (par 0, j 2-k)
+// with the tile origin at m0-1.
+template <int S> __host__ __device__ constexpr int bd_par(int k) { return S == 2 ? (k == 1 ? 0 : 1) : 0; }
+template <int S> __host__ __device__ constexpr int bd_off(int k) { return S == 2 ? (k == 0 ? 1 : 0) : 2 - k; }
+
+template <int SD, int SH, int SW, int VEC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_bwdd_strided_kernel(const ConvKParams P) {
+  constexpr int TD = 2, TH = 4, TW = 16;                       // dY positions per workgroup: 4 waves x 32
+  constexpr int LD = TD + (SD == 2 ? 1 : 2), LH = TH + (SH == 2 ? 1 : 2), LW = TW + (SW == 2 ? 1 : 2);
+  constexpr int NC = SD * SH * SW;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const mt_conv3d_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = blockIdx.y;
+  const int tw = tile % P.tilesW; tile /= P.tilesW;
+  const int th = tile % P.tilesH; tile /= P.tilesH;
+  const int td = tile % P.tilesD;
+  const int nb = tile / P.tilesD;
+  const int md0 = td * TD, mh0 = th * TH, mw0 = tw * TW;
+
+  // this wave's M tile: dm = wave/2, rows (wave%2)*2 + {0,1}, 16 columns
+  const int dm = wave >> 1, rbase = (wave & 1) * 2;
+  const int abase = ((dm * LH + rbase + (li >> 4)) * LW + (li & 15)) * FCKP + lhalf * 8;
+
+  f32x16 acc[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
+
+  for (int ch = 0; ch < P.nchunks; ++ch) {
+    const ConvChunk cc = P.chunk[ch];
+    const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
+    __syncthreads();
+    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
+    __syncthreads();
+    // offsets outer (A fragment fetched once per offset), taps of that offset inner
+#pragma unroll
+    for (int jd = 0; jd < LD - TD + 1; ++jd)
+#pragma unroll
+      for (int jh = 0; jh < LH - TH + 1; ++jh)
+#pragma unroll
+        for (int jw = 0; jw < LW - TW + 1; ++jw) {
+          const float* ap = lds + abase + ((jd * LH + jh) * LW + jw) * FCKP;
+          const f32x4 a0 = *(const f32x4*)(ap);
+          const f32x4 a1 = *(const f32x4*)(ap + 4);
+#pragma unroll
+          for (int tap = 0; tap < 27; ++tap) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            if (bd_off<SD>(kd) == jd && bd_off<SH>(kh) == jh && bd_off<SW>(kw) == jw) {
+              const int q = (bd_par<SD>(kd) * SH + bd_par<SH>(kh)) * SW + bd_par<SW>(kw);
+              const f32x4 b0 = *(const f32x4*)(wlane + tap * 512);
+              const f32x4 b1 = *(const f32x4*)(wlane + tap * 512 + 256);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[q], 0, 0, 0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[q], 0, 0, 0);
+            }
+          }
+        }
+  }
+
+  // ---- epilogue: class (pd,ph,pw) of dY position m lands at dX[S*m + par]
+  const int co = ntile * 32 + li;
+  const bool covalid = co < c.Cout;
+  const int ocs = c.ocs0;
+  const size_t out_sample = (size_t)c.OD * c.OH * c.OW;
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
+                                                                (int)(out_sample * ocs * 4), 0x00020000);
+  const int md = md0 + dm;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+    const int mh = mh0 + rbase + (iv >> 4), mw = mw0 + (iv & 15);
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      const int pd = q / (SH * SW), ph = (q / SW) % SH, pw = q % SW;
+      const int xd = md * SD + pd, xh = mh * SH + ph, xw = mw * SW + pw;
+      const bool ok = covalid && xd < c.OD && xh < c.OH && xw < c.OW;
+      const int off = ok ? (((xd * c.OH + xh) * c.OW + xw) * ocs + co) * 4 : (int)0x80000000;
+      float v = acc[q][j];
+      if (c.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, 0);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side of mt_conv3d_fwd
 struct ConvCfg { int MW, RH, TD, CK; };
@@ -1303,6 +1399,54 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
     case 6: return fast ? launch_conv<32, 4, 4, 16, true>(p, g, st) : launch_conv<32, 4, 4, 16, false>(p, g, st);
   }
   return MT_EINVAL;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// mt_conv3d_bwd_data_strided: see include/mtseg.h.  p carries the FORWARD geometry (Di.. = X dims, Do.. = Y dims, K = 3,
+// S in {(2,2,2), (1,2,2)}, P = 1); src[0] = dY (C = Cout of the conv), out0 = dX (Cin channels).
+template <int SD, int SH, int SW>
+static int launch_bwdd_strided(const mt_conv3d_t* p, hipStream_t st) {
+  constexpr int TD = 2, TH = 4, TW = 16;
+  constexpr int LD = TD + (SD == 2 ? 1 : 2), LH = TH + (SH == 2 ? 1 : 2), LW = TW + (SW == 2 ? 1 : 2);
+  ConvKParams P;
+  P.c = *p;
+  // the kernel sees a stride-1 problem over the dY grid: input = dY (dims Do,Ho,Wo), channels Cout -> Cin
+  P.c.Di = p->Do; P.c.Hi = p->Ho; P.c.Wi = p->Wo;
+  P.c.OD = p->Di; P.c.OH = p->Hi; P.c.OW = p->Wi;
+  P.c.Cin = p->Cout; P.c.Cout = p->Cin;
+  P.c.nsrc = 1; P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0;
+  const int gD = mt_cdiv(p->Di, SD), gH = mt_cdiv(p->Hi, SH), gW = mt_cdiv(p->Wi, SW);   // dY positions that reach some dX
+  P.tilesD = mt_cdiv(gD, TD); P.tilesH = mt_cdiv(gH, TH); P.tilesW = mt_cdiv(gW, TW);
+  P.nsb = P.tilesD * P.tilesH * P.tilesW;
+  P.ntaps = 27; P.dbg = 0; P.stagger = 0;
+  P.nchunks = mt_build_chunks(p->Cout, 0, FCK, P.chunk);
+  MT_REQUIRE(P.nchunks > 0, "bwd_data_strided: too many channel chunks (Cout=%d)", p->Cout);
+  const size_t ldsb = (size_t)LD * LH * LW * FCKP * sizeof(float);
+  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cin, 32), 1);
+  const mt_src_t& s0 = p->src[0];
+  const bool v2 = !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7));
+  if (v2) hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2>), grid, dim3(256), ldsb, st, P);
+  else    hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 1>), grid, dim3(256), ldsb, st, P);
+  MT_CHECK_LAUNCH("conv_bwdd_strided");
+  return MT_OK;
+}
+extern "C" int mt_conv3d_bwd_data_strided_supported(const mt_conv3d_t* p) {
+  if (p == nullptr || p->nsrc != 1) return 0;
+  if (!(p->KD == 3 && p->KH == 3 && p->KW == 3 && p->PD == 1 && p->PH == 1 && p->PW == 1)) return 0;
+  if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return 0;
+  if (!(p->SH == 2 && p->SW == 2 && (p->SD == 1 || p->SD == 2))) return 0;
+  if ((double)p->Do * p->Ho * p->Wo * p->src[0].cs * 4.0 >= 2147483648.0) return 0;
+  if ((double)p->Di * p->Hi * p->Wi * p->ocs0 * 4.0 >= 2147483648.0) return 0;
+  return 1;
+}
+extern "C" int mt_conv3d_bwd_data_strided(const mt_conv3d_t* p, mt_stream_t stream) {
+  MT_REQUIRE(p != nullptr, "bwd_data_strided: null params");
+  MT_REQUIRE(mt_conv3d_bwd_data_strided_supported(p), "bwd_data_strided: unsupported geometry (needs 3x3x3, pad 1, stride (1|2,2,2), one source)");
+  MT_REQUIRE(p->src[0].C == p->Cout, "bwd_data_strided: src[0].C (%d) != Cout (%d)", p->src[0].C, p->Cout);
+  MT_REQUIRE(p->wpack != nullptr && p->out0 != nullptr && p->src[0].ptr != nullptr, "bwd_data_strided: null pointers");
+  hipStream_t st = (hipStream_t)stream;
+  return p->SD == 2 ? launch_bwdd_strided<2, 2, 2>(p, st) : launch_bwdd_strided<1, 2, 2>(p, st);
 }
 
 // ------------------------------------------------------------------------------------------------

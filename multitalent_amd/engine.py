@@ -110,6 +110,9 @@ class ConvNormOp(_Op):
         self.ck_f = ops.conv_ck(p)
         self.wf = ops.pack_conv_weights(w, C0, C1, Cout, self.kernel, _strides(w), False, self.ck_f, out=self.wf)
         if need_bwd and any(s.grad is not None for s in self.srcs):
+            if self._use_strided_bwd(eng):
+                self.wb = ops.pack_conv_weights(w, Cout, 0, C0, self.kernel, _strides(w, as_bwd_data=True), False, 16, out=self.wb)
+                return
             if self._use_parity_classes():
                 cls = self._parity_classes()
                 if self.wb is None:
@@ -122,6 +125,20 @@ class ConvNormOp(_Op):
             pb = self._bwd_data_params(eng, None)
             self.ck_b = ops.conv_ck(pb)
             self.wb = ops.pack_conv_weights(w, Cout, 0, C0 + C1, self.kernel, _strides(w, as_bwd_data=True), True, self.ck_b, out=self.wb)
+
+    def _strided_bwd_params(self, g):
+        """mt_conv3d_bwd_data_strided takes the FORWARD geometry with src[0] = dY and out0 = dX."""
+        gact = Act(g) if g is not None else Act(self.out.act.buf)
+        p = ops.fill_conv([gact], self.geom, self.conv.out_channels)
+        p.Cin = self.srcs[0].C
+        return p
+
+    def _use_strided_bwd(self, eng):
+        if self.stride == (1, 1, 1) or len(self.srcs) != 1 or self.pointwise:
+            return False
+        p = self._strided_bwd_params(None)
+        p.ocs0 = self.srcs[0].C
+        return ops.conv3d_bwd_data_strided_supported(p)
 
     def _use_parity_classes(self):
         return self.stride != (1, 1, 1) and len(self.srcs) == 1 and not self.pointwise
@@ -184,6 +201,14 @@ class ConvNormOp(_Op):
             p = ops.fill_pointwise(gact, self.geom.out, self.geom.out, (1, 1, 1), (1, 1, 1), s0.C, self.wb, None,
                                    Act(s0.grad), accumulate=acc)
             ops.pointwise_fwd(p)
+        elif self._use_strided_bwd(eng):
+            s0 = self.srcs[0]
+            p = self._strided_bwd_params(g)
+            p.wpack = self.wb.data_ptr()
+            p.out0 = s0.grad.data_ptr()
+            p.ocs0 = s0.C
+            p.accumulate = 1 if acc else 0
+            ops.conv3d_bwd_data_strided(p)
         elif self._use_parity_classes():
             s0 = self.srcs[0]
             cls = self._parity_classes()

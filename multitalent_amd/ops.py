@@ -208,6 +208,15 @@ def conv3d_fwd(p):
     _lib.check(_lib.load().mt_conv3d_fwd(C.byref(p), _stream()), 'conv3d_fwd')
 
 
+def conv3d_bwd_data_strided_supported(p):
+    return bool(_lib.load().mt_conv3d_bwd_data_strided_supported(C.byref(p)))
+
+
+def conv3d_bwd_data_strided(p):
+    """dX of a strided 3x3x3 conv in one launch; p = FORWARD geometry with src[0] = dY, out0 = dX (see include/mtseg.h)."""
+    _lib.check(_lib.load().mt_conv3d_bwd_data_strided(C.byref(p), _stream()), 'conv3d_bwd_data_strided')
+
+
 def conv3d_bwd_weight_workspace(p):
     return _lib.load().mt_conv3d_bwd_weight_workspace(C.byref(p))
 

@@ -154,6 +154,42 @@ def test_conv_bwd_data_parity_classes(dev, Cin, Cout, shape, k, stride, pad):
     assert relerr(to_ncdhw(dx.cpu()) - to_ncdhw(base), x.grad) < 1e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,shape,stride,acc", [
+    (30, 60, (6, 12, 34), (2, 2, 2), False),
+    (32, 64, (7, 13, 33), (2, 2, 2), True),        # odd input sizes: the last parity class is one position shorter
+    (30, 60, (6, 12, 32), (1, 2, 2), False),
+    (64, 33, (5, 9, 40), (1, 2, 2), True),
+    (17, 20, (3, 5, 7), (2, 2, 2), False),
+])
+def test_conv_bwd_data_strided_one_launch(dev, Cin, Cout, shape, stride, acc):
+    """mt_conv3d_bwd_data_strided: all parity classes of dX from one staged dY tile, vs autograd of F.conv3d."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(34)
+    N, k, pad = 2, (3, 3, 3), (1, 1, 1)
+    x = torch.randn((N, Cin) + shape, generator=g, requires_grad=True)
+    w = torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * 27)
+    y = F.conv3d(x, w, None, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    # dY arrives lazily activated in the residual encoder; exercise that path too: dy = lrelu(raw*sc+sh)
+    dyb = ops.Act(to_ndhwc(dy).to(dev))
+    fgeom = ops.ConvGeom(shape, k, stride, pad)
+    base = torch.randn((N,) + shape + (Cin,), generator=g) if acc else torch.full((N,) + shape + (Cin,), float('nan'))
+    dx = base.to(dev)
+    wd = w.to(dev).contiguous()
+    p = ops.fill_conv([dyb], fgeom, Cout, out0=ops.Act(dx), accumulate=acc)
+    p.Cin = Cin
+    assert ops.conv3d_bwd_data_strided_supported(p)
+    wp = ops.pack_conv_weights(wd, Cout, 0, Cin, k, ops.conv_weight_strides(wd, as_bwd_data=True), False, 16)
+    p.wpack = wp.data_ptr()
+    ops.conv3d_bwd_data_strided(p)
+    torch.cuda.synchronize()
+    got = to_ncdhw(dx.cpu())
+    if acc:
+        got = got - to_ncdhw(base)
+    assert relerr(got, x.grad) < 1e-5
+
+
 @pytest.mark.parametrize("Cin,Cout,shape,k,stride", [
     (30, 30, (4, 8, 32), (3, 3, 3), (1, 1, 1)),
     (30, 60, (6, 12, 34), (3, 3, 3), (2, 2, 2)),
