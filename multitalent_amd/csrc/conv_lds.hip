@@ -819,6 +819,88 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
 }
 
 // ================================================================================================
+// Forward 3x3x3 convolution with stride (2,2,2) or (1,2,2), pad 1 (the first conv of every encoder stage,
+// generic_UNet.py:263-278) on the FAST design with compile-time taps.  Tile = 2 x 4 x 8 outputs x 64 output channels:
+// the haloed input tile ((TD-1)*SD+3) x 9 x 17 voxels x 16 channels stays under 64 KiB so two workgroups share a CU; the four
+// waves are 2 M tiles (one output plane each) x 2 N tiles, so every staged voxel feeds 64 output channels.
+template <int SD, int SH, int SW, int VEC>
+__global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParams P) {
+  constexpr int TD = 2, TH = 4, TW = 8;
+  constexpr int LD = (TD - 1) * SD + 3, LH = (TH - 1) * SH + 3, LW = (TW - 1) * SW + 3;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const mt_conv3d_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const int dm = wave & 1, nt2 = wave >> 1;
+  const int ntile_raw = blockIdx.y * 2 + nt2;
+  const bool nt_ok = ntile_raw * 32 < c.Cout;           // wave-uniform: an odd number of 32-channel tiles leaves one wave idle
+  const int ntile = nt_ok ? ntile_raw : 0;
+  const int tw = tile % P.tilesW; tile /= P.tilesW;
+  const int th = tile % P.tilesH; tile /= P.tilesH;
+  const int td = tile % P.tilesD;
+  const int nb = tile / P.tilesD;
+  const int sb = (td * P.tilesH + th) * P.tilesW + tw;
+  const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+
+  int abase[1];
+  abase[0] = ((dm * SD * LH + (li >> 3) * SH) * LW + (li & 7) * SW) * FCKP + lhalf * 8;
+  f32x16 acc[1];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[0][j] = 0.f;
+
+  for (int ch = 0; ch < P.nchunks; ++ch) {
+    const ConvChunk cc = P.chunk[ch];
+    const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
+    __syncthreads();
+    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
+    __syncthreads();
+    FastFrag<1> f0, f1;
+    fast_frag_load<1, LH, LW, 0>(f0, lds, abase, wlane);
+    fast_taps<1, LH, LW, 0>(f0, f1, lds, abase, wlane, acc);
+  }
+
+  const int co = ntile_raw * 32 + li;
+  const bool covalid = nt_ok && co < c.Cout;
+  const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
+  const int ocs = c.ocs0;
+  const size_t out_sample = (size_t)c.Do * c.Ho * c.Wo;
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
+                                                                (int)(out_sample * ocs * 4), 0x00020000);
+  const int od = od0 + dm;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+    const int oh = oh0 + (iv >> 3), ow = ow0 + (iv & 7);
+    const bool ok = covalid && (od < c.Do) && (oh < c.Ho) && (ow < c.Wo);
+    const int off = ok ? (((od * c.Ho + oh) * c.Wo + ow) * ocs + co) * 4 : (int)0x80000000;
+    float v = acc[0][j] + bv;
+    if (c.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, 0);
+    if (ok) { s1 += v; s2 = fmaf(v, v, s2); }
+  }
+  if (c.stats_part != nullptr) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    __syncthreads();
+    if (lhalf == 0) { lds[(wave * 32 + li) * 2] = s1; lds[(wave * 32 + li) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 64) {                                      // thread t: N tile t/32 of this pair, channel t%32
+      const int n2 = tid >> 5, cl = tid & 31;
+      const int cg = (blockIdx.y * 2 + n2) * 32 + cl;
+      if (cg < c.Cout) {
+        const float t1 = lds[((n2 * 2) * 32 + cl) * 2] + lds[((n2 * 2 + 1) * 32 + cl) * 2];
+        const float t2 = lds[((n2 * 2) * 32 + cl) * 2 + 1] + lds[((n2 * 2 + 1) * 32 + cl) * 2 + 1];
+        float* sp = c.stats_part + ((size_t)((size_t)nb * P.nsb + sb) * c.Cout + cg) * 2;
+        sp[0] = t1; sp[1] = t2;
+      }
+    }
+  }
+}
+
+// ================================================================================================
 // Runtime-geometry forward kernel on the FAST design (any kernel size 1..3, stride 1..2, pad, strided output placement):
 // LDS image [voxel][20], ds_read_b128 operands, float4 weights, buffer loads/stores.  The tap loop is a runtime loop
 // (unrolled by two with ping-pong fragments); the only vector-ALU work inside it is one address add per M tile and tap
@@ -1169,17 +1251,19 @@ static int pick_cfg(const mt_conv3d_t* p) {
 }
 
 // which kernel family serves a problem, and with which tile shape
-enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2 };
+enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2, CONV_FAST_STRIDED = 3 };
 struct ConvPlan { int kind; int cfg; };
 static bool conv_is_fast(const mt_conv3d_t* p);
 static bool conv_rt_ok(const mt_conv3d_t* p);
 static int pick_rt_cfg(const mt_conv3d_t* p);
+static bool conv_fast_strided_ok(const mt_conv3d_t* p);
 static ConvPlan conv_plan(const mt_conv3d_t* p) {
   static int use_v2 = -1, use_rt = -1;
   if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
   if (use_rt < 0) { const char* e = getenv("MT_CONV_RT"); use_rt = e ? atoi(e) : 1; }
   ConvPlan pl; pl.kind = CONV_GENERIC; pl.cfg = pick_cfg(p);
   if (conv_is_fast(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0) { pl.kind = CONV_FAST; return pl; }
+  if (use_rt && conv_fast_strided_ok(p)) { pl.kind = CONV_FAST_STRIDED; pl.cfg = 0; return pl; }
   if (use_rt && conv_rt_ok(p)) {
     const int i = pick_rt_cfg(p);
     if (i >= 0) { pl.kind = CONV_RT; pl.cfg = i; return pl; }
@@ -1193,6 +1277,7 @@ extern "C" int mt_conv3d_ck(const mt_conv3d_t* p) {
 extern "C" int mt_conv3d_stats_blocks(const mt_conv3d_t* p) {
   const ConvPlan pl = conv_plan(p);
   if (pl.cfg < 0) return -1;
+  if (pl.kind == CONV_FAST_STRIDED) return mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 8);
   int TD, TH, TW; cfg_tile(kCfgs[pl.cfg], &TD, &TH, &TW);
   return mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW);
 }
@@ -1255,6 +1340,37 @@ static int launch_fast2(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) 
   hipLaunchKernelGGL(kfn, grid, dim3(256), ldsb, st, P);
   MT_CHECK_LAUNCH("conv3d_fast");
   return MT_OK;
+}
+
+static bool conv_fast_strided_ok(const mt_conv3d_t* p) {
+  if (!(p->KD == 3 && p->KH == 3 && p->KW == 3 && p->PD == 1 && p->PH == 1 && p->PW == 1)) return false;
+  if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1 && p->SH == 2 && p->SW == 2 && (p->SD == 1 || p->SD == 2))) return false;
+  if (p->csplit < p->Cout || p->osD > 0) return false;
+  for (int i = 0; i < p->nsrc; ++i)
+    if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 4.0 >= 2147483648.0) return false;
+  if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return false;
+  return true;
+}
+template <int SD>
+static int launch_fast_strided_t(const mt_conv3d_t* p, hipStream_t st) {
+  constexpr int TD = 2, TH = 4, TW = 8, LD = (TD - 1) * SD + 3, LH = (TH - 1) * 2 + 3, LW = (TW - 1) * 2 + 3;
+  ConvKParams P;
+  P.c = *p;
+  if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
+  P.tilesD = mt_cdiv(p->Do, TD); P.tilesH = mt_cdiv(p->Ho, TH); P.tilesW = mt_cdiv(p->Wo, TW);
+  P.nsb = P.tilesD * P.tilesH * P.tilesW;
+  P.ntaps = 27; P.dbg = 0; P.stagger = 0;
+  P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
+  MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
+  const size_t ldsb = (size_t)LD * LH * LW * FCKP * sizeof(float);
+  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 64), 1);
+  if (conv_fast_vec(p) == 2) hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2>), grid, dim3(256), ldsb, st, P);
+  else                       hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 1>), grid, dim3(256), ldsb, st, P);
+  MT_CHECK_LAUNCH("conv3d_fast_strided");
+  return MT_OK;
+}
+static int launch_fast_strided(const mt_conv3d_t* p, hipStream_t st) {
+  return p->SD == 2 ? launch_fast_strided_t<2>(p, st) : launch_fast_strided_t<1>(p, st);
 }
 
 static size_t rt_lds(const ConvCfg& g, const mt_conv3d_t* p) {
@@ -1351,6 +1467,8 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   const bool fast = conv_is_fast(p);
   if (pl.kind == CONV_FAST)
     snprintf(buf, n, "conv_fast_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
+  else if (pl.kind == CONV_FAST_STRIDED)
+    snprintf(buf, n, "conv_fast_strided_kernel<%d, %d, %d, %d>", p->SD, p->SH, p->SW, conv_fast_vec(p));
   else if (pl.kind == CONV_RT)
     snprintf(buf, n, "conv_rt_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
   else
@@ -1371,6 +1489,7 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   MT_REQUIRE(p->osD <= 0 || (p->stats_part == nullptr && p->osH > 0 && p->osW > 0 &&
              (p->Do - 1) * p->osD + p->ooD < p->OD && (p->Ho - 1) * p->osH + p->ooH < p->OH && (p->Wo - 1) * p->osW + p->ooW < p->OW),
              "conv3d: bad strided output placement");
+  if (pl.kind == CONV_FAST_STRIDED) return launch_fast_strided(p, st);
   if (pl.kind == CONV_RT) {
     const int vec = conv_fast_vec(p);
     switch (i) {
