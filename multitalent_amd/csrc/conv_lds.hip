@@ -439,97 +439,112 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
 // The staging pass uses 8-byte buffer loads (2 channels) with hardware bounds checking and ds_write_b64.
 #define FCK 16
 #define FCKP 20
+#ifndef CF_ABL
+#define CF_ABL 0   // compile-time timing ablations of conv_fast_kernel: 1 skip staging, 4 skip epilogue, 8 skip MFMA
+#endif
+
+// Lean staging of a haloed input tile (LD x LH x LW voxels x 16 channels) into the LDS image [row][LWP voxels][20 dwords].
+// 64 lanes = VPS voxels x LPV channel groups; a wave owns rows wave, wave+4, ...; NI steps cover a row.  Validity is carried as
+// DATA, never as control flow: out-of-volume rows/voxels load through the buffer descriptor's bounds check (offset
+// 0x80000000 -> 0) and are zeroed by scale = shift = 0 (rows, channel slots) or an AND mask (voxels); every load is
+// (per-lane constant offset, scalar row offset) and every store (one base VGPR + immediate).  All loads of a batch are issued
+// before the first store.  The staging VALU work matters twice: it delays this wave AND it steals issue cycles from the
+// other workgroup's MFMAs on the same SIMD.
+// LDS rows are padded to a multiple of 4 (stage_rows) so that every wave stores RPW rows; LWP >= NI*VPS makes the last step
+// of a row unconditional, otherwise (LDS too small for the padding) it is predicated.
+template <int VEC> __host__ __device__ constexpr int stage_vps() { return 64 / (FCK / VEC); }
+template <int LD, int LH> __host__ __device__ constexpr int stage_rows() { return ((LD * LH + 3) / 4) * 4; }
+template <int LD, int LH, int LW, int VEC> __host__ __device__ constexpr int stage_lwp() {
+  constexpr int padded = ((LW + stage_vps<VEC>() - 1) / stage_vps<VEC>()) * stage_vps<VEC>();
+  return ((size_t)stage_rows<LD, LH>() * padded * FCKP * 4 <= 80 * 1024) ? padded : LW;
+}
+template <int LD, int LH, int LW, int VEC> __host__ __device__ constexpr size_t stage_lds_bytes() {
+  return (size_t)stage_rows<LD, LH>() * stage_lwp<LD, LH, LW, VEC>() * FCKP * sizeof(float);
+}
 
 template <int LD, int LH, int LW, int VEC>
 __device__ __forceinline__ void mt_stage_fast2(float* __restrict__ lds, const mt_conv3d_t& c, const ConvChunk ch,
                                                int nb, int ud0, int uh0, int uw0, int lane, int wave) {
-  constexpr int LPV = FCK / VEC;            // lanes per voxel
-  constexpr int VPS = 64 / LPV;             // voxels per wave step
-  constexpr int NI = (LW + VPS - 1) / VPS, R = LD * LH, RPW = (R + 3) / 4;
-  constexpr int RG = (RPW * NI * VEC > 32) ? ((32 / (NI * VEC)) > 0 ? (32 / (NI * VEC)) : 1) : RPW;   // rows per batch
+  constexpr int LPV = FCK / VEC, VPS = 64 / LPV, NI = (LW + VPS - 1) / VPS, R = LD * LH, RPW = (R + 3) / 4;
+  constexpr int LWP = stage_lwp<LD, LH, LW, VEC>();
+  constexpr bool PADW = LWP >= NI * VPS;
+  constexpr int RG = (RPW * NI * VEC > 64) ? (RPW + 1) / 2 : RPW;      // rows per batch (<= ~64 registers in flight)
   const mt_src_t& S = c.src[ch.src];
   const int cl = (lane % LPV) * VEC, vl = lane / LPV;
   const bool has_aff = S.scale != nullptr;
   float sc[VEC], sh[VEC];
-  bool cval[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
-    cval[e] = (cl + e) < ch.ck;
-    sc[e] = 1.f; sh[e] = 0.f;
-    if (has_aff && cval[e]) {
+    const bool cv = (cl + e) < ch.ck;
+    sc[e] = cv ? 1.f : 0.f; sh[e] = 0.f;                    // channel slots beyond the chunk stage as zeros
+    if (has_aff && cv) {
       sc[e] = S.scale[(size_t)nb * S.C + ch.c0 + cl + e];
       sh[e] = S.shift[(size_t)nb * S.C + ch.c0 + cl + e];
     }
   }
-  const float slope = S.slope;
+  const float slope = has_aff ? S.slope : 1.f;
   const int cs = S.cs;
   const size_t sample_elems = (size_t)c.Di * c.Hi * c.Wi * cs;
   __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * sample_elems), 0, (int)(sample_elems * 4), 0x00020000);
   int voff[NI];
+  unsigned mval[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int lw = vl + i * VPS;
     const int uw = uw0 + lw;
-    const bool ok = cval[0] && (lw < LW) && ((unsigned)uw < (unsigned)c.Wi);
+    const bool ok = (lw < LW) && ((unsigned)uw < (unsigned)c.Wi);
     voff[i] = ok ? (uw * cs + ch.c0 + cl) * 4 : (int)0x80000000;
+    mval[i] = ok ? 0xffffffffu : 0u;
   }
-  float* lbase = lds + vl * FCKP + cl;      // + (row*LW + i*VPS)*FCKP : compile-time part
-  // block-uniform: the whole haloed tile lies inside the volume -> every in-tile lane is valid
-  const bool nosel = (ud0 >= 0) && (uh0 >= 0) && (uw0 >= 0) && (ud0 + LD <= c.Di) && (uh0 + LH <= c.Hi) && (uw0 + LW <= c.Wi) &&
-                     (slope >= 0.f) && (slope <= 1.f);
+  float* lbase = lds + (wave * LWP + vl) * FCKP + cl;
+  const int rowbytes = c.Wi * cs * 4;
 #pragma unroll
   for (int r0 = 0; r0 < RPW; r0 += RG) {
     float v[RG][NI][VEC];
-    bool rv[RG];
+    int rowm[RG];
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
-      const int row = wave + 4 * (r0 + q);
-      const int ld = row / LH, lhh = row % LH;
-      const int ud = ud0 + ld, uh = uh0 + lhh;
-      rv[q] = (r0 + q < RPW) && (row < R) && ((unsigned)ud < (unsigned)c.Di) && ((unsigned)uh < (unsigned)c.Hi);
-      if (rv[q]) {
-        const int srow = (ud * c.Hi + uh) * c.Wi * cs * 4;
+      if (r0 + q < RPW) {
+        const int row = wave + 4 * (r0 + q);
+        const int ld = row / LH, lhh = row - ld * LH;
+        const int ud = ud0 + ld, uh = uh0 + lhh;
+        rowm[q] = ((row < R) && ((unsigned)ud < (unsigned)c.Di) && ((unsigned)uh < (unsigned)c.Hi)) ? -1 : 0;
+        const int srow = ((ud * c.Hi + uh) & rowm[q]) * rowbytes;
+        const int oob = ~rowm[q] & (int)0x80000000;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           if constexpr (VEC == 2) {
             // NB: bit_cast the WHOLE 64-bit result; indexing the builtin's return type yields the first dword twice
-            const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[i] + srow, 0, 0));
+            const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff[i] | oob, srow, 0));
             v[q][i][0] = t.x;
             v[q][i][1] = t.y;
           } else {
-            v[q][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[i] + srow, 0, 0));
+            v[q][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[i] | oob, srow, 0));
           }
         }
-      } else {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) v[q][i][e] = 0.f;
       }
     }
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
-      const int row = wave + 4 * (r0 + q);   // wave-uniform; (row - wave) is a compile-time constant
-      if (r0 + q < RPW && row < R) {
-        float* lrow = lbase + wave * (LW * FCKP) + 4 * (r0 + q) * (LW * FCKP);
+      if (r0 + q < RPW) {
+        float scq[VEC], shq[VEC];        // a row outside the volume: scale = shift = 0 -> exact zeros
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          scq[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sc[e]) & (unsigned)rowm[q]);
+          shq[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sh[e]) & (unsigned)rowm[q]);
+        }
+        float* lrow = lbase + 4 * (r0 + q) * (LWP * FCKP);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-          const int lw = vl + i * VPS;
-          if ((i + 1) * VPS <= LW || lw < LW) {
-            float x[VEC];
-            const bool ok = rv[q] && voff[i] >= 0;
+          float x[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-              x[e] = v[q][i][e];
-              if (has_aff) {
-                // LeakyReLU with 0 <= slope <= 1 is max(t, slope*t) (2 VALU).  Inside the volume no select is needed:
-                // a lane that loaded nothing (channel >= ck) holds lrelu(shift) — finite — and meets zero weights.
-                const float t = fmaf(x[e], sc[e], sh[e]);
-                const float a = fmaxf(t, t * slope);
-                x[e] = nosel ? a : ((ok && cval[e]) ? a : 0.f);
-              } else if (VEC == 2 && e == 1) x[e] = cval[e] ? x[e] : 0.f;
-            }
+          for (int e = 0; e < VEC; ++e) {
+            const float t = fmaf(v[q][i][e], scq[e], shq[e]);
+            const float a = mt_lrelu(t, slope);
+            x[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & mval[i]);
+          }
+          if (PADW || (i + 1) * VPS <= LW || vl + i * VPS < LW) {
             if constexpr (VEC == 2) {
               float2 t; t.x = x[0]; t.y = x[1];
               *(float2*)(lrow + i * VPS * FCKP) = t;
@@ -663,19 +678,6 @@ __device__ __forceinline__ void stage2_store(const Stage2Regs<LD, LH, LW, VEC>& 
 template <int MT>
 struct FastFrag { f32x4 a[MT][2]; f32x4 b[2]; };
 
-template <int MT, int LH, int LW, int TAP>
-__device__ __forceinline__ void fast_frag_load(FastFrag<MT>& f, const float* __restrict__ lds, const int (&abase)[MT],
-                                               const float* __restrict__ wlane) {
-  constexpr int kd = TAP / 9, kh = (TAP / 3) % 3, kw = TAP % 3;
-  constexpr int toff = ((kd * LH + kh) * LW + kw) * FCKP;
-  f.b[0] = *(const f32x4*)(wlane + TAP * 512);
-  f.b[1] = *(const f32x4*)(wlane + TAP * 512 + 256);
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    f.a[m][0] = *(const f32x4*)(lds + abase[m] + toff);
-    f.a[m][1] = *(const f32x4*)(lds + abase[m] + toff + 4);
-  }
-}
 template <int MT>
 __device__ __forceinline__ void fast_frag_mfma(const FastFrag<MT>& f, f32x16 (&acc)[MT]) {
 #pragma unroll
@@ -684,22 +686,57 @@ __device__ __forceinline__ void fast_frag_mfma(const FastFrag<MT>& f, f32x16 (&a
     for (int m = 0; m < MT; ++m)
       acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[m][kp >> 2][kp & 3], f.b[kp >> 2][kp & 3], acc[m], 0, 0, 0);
 }
-template <int MT, int LH, int LW, int TAP>
-__device__ __forceinline__ void fast_taps(FastFrag<MT>& cur, FastFrag<MT>& nxt, const float* __restrict__ lds,
-                                          const int (&abase)[MT], const float* __restrict__ wlane, f32x16 (&acc)[MT]) {
-  // sched_barrier pins "loads of tap+1, THEN the MFMAs of tap": without it the scheduler sinks each load in front of its
-  // consumer (shortest live range) and every 8 MFMAs start with a fully exposed L2 + LDS latency.
-  if constexpr (TAP < 26) fast_frag_load<MT, LH, LW, TAP + 1>(nxt, lds, abase, wlane);
-  __builtin_amdgcn_sched_barrier(0);
-  fast_frag_mfma<MT>(cur, acc);
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (TAP < 26) fast_taps<MT, LH, LW, TAP + 1>(nxt, cur, lds, abase, wlane, acc);
+// One 16-channel chunk of a 3x3x3 conv, all 27 taps unrolled with compile-time LDS offsets.  The weight (B) fragments come from
+// L2 with a latency of more than one tap's worth of MFMAs, so they are prefetched BPF taps ahead through a small register ring;
+// the A fragments (LDS) one tap ahead.
+#ifndef CF_BPF
+#define CF_BPF 3
+#endif
+template <int MT, int LH, int LW>
+__device__ __forceinline__ void fast_chunk(const float* __restrict__ lds, const int (&abase)[MT], const float* __restrict__ wlane,
+                                           f32x16 (&acc)[MT]) {
+  constexpr int NB = CF_BPF + 1;
+  f32x4 b[NB][2];
+  f32x4 a[2][MT][2];
+#pragma unroll
+  for (int t = 0; t < CF_BPF; ++t) {
+    b[t][0] = *(const f32x4*)(wlane + t * 512);
+    b[t][1] = *(const f32x4*)(wlane + t * 512 + 256);
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    a[0][m][0] = *(const f32x4*)(lds + abase[m]);
+    a[0][m][1] = *(const f32x4*)(lds + abase[m] + 4);
+  }
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    if (t + CF_BPF < 27 && !(CF_ABL & 64)) {
+      b[(t + CF_BPF) % NB][0] = *(const f32x4*)(wlane + (t + CF_BPF) * 512);
+      b[(t + CF_BPF) % NB][1] = *(const f32x4*)(wlane + (t + CF_BPF) * 512 + 256);
+    }
+    if (t + 1 < 27 && !(CF_ABL & 32)) {
+      const int t1 = t + 1;
+      const int toff = (((t1 / 9) * LH + (t1 / 3) % 3) * LW + t1 % 3) * FCKP;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        a[t1 & 1][m][0] = *(const f32x4*)(lds + abase[m] + toff);
+        a[t1 & 1][m][1] = *(const f32x4*)(lds + abase[m] + toff + 4);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kp = 0; kp < 8; ++kp)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(CF_ABL & 32) ? 0 : (t & 1)][m][kp >> 2][kp & 3], b[(CF_ABL & 64) ? 0 : (t % NB)][kp >> 2][kp & 3], acc[m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 template <int MW, int RH, int TD, int VEC>
 __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
   constexpr int MH = 32 / MW, TH = MH * RH, TW = MW, NMT = TD * RH, MT = NMT / 4;
-  constexpr int LD = TD + 2, LH = TH + 2, LW = TW + 2;
+  constexpr int LD = TD + 2, LH = TH + 2, LW = TW + 2, LWP = stage_lwp<LD, LH, LW, VEC>();
   static_assert(NMT % 4 == 0, "M tiles must split over 4 waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
@@ -721,7 +758,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
     const int mt = wave * MT + m;
     const int dm = mt / RH, rh = mt % RH;
     const int r = li / MW, col = li % MW;
-    abase[m] = ((dm * LH + rh * MH + r) * LW + col) * FCKP + lhalf * 8;
+    abase[m] = ((dm * LH + rh * MH + r) * LWP + col) * FCKP + lhalf * 8;
   }
   f32x16 acc[MT];
 #pragma unroll
@@ -732,17 +769,16 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
   for (int ch = 0; ch < P.nchunks; ++ch) {
     const ConvChunk cc = P.chunk[ch];
     const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
-    __syncthreads();
-    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
-    __syncthreads();
-    FastFrag<MT> f0, f1;
-    fast_frag_load<MT, LH, LW, 0>(f0, lds, abase, wlane);
-    fast_taps<MT, LH, LW, 0>(f0, f1, lds, abase, wlane, acc);
+    if (!(CF_ABL & 16)) __syncthreads();
+    if (!(CF_ABL & 1)) mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+    if (!(CF_ABL & 16)) __syncthreads();
+    if (!(CF_ABL & 8)) fast_chunk<MT, LH, LWP>(lds, abase, wlane, acc);
   }
 
   // ---- epilogue: bias, store, statistics.  Stores go through a buffer descriptor: per-lane byte offset (column part)
   // + wave-uniform scalar offset per (M tile, register) -> no vector address arithmetic; out-of-volume lanes of
   // boundary tiles get offset 0x80000000 (dropped by the hardware bounds check).
+  if (CF_ABL & 4) { if (acc[0][0] == 12345.678f) c.out0[0] = acc[MT - 1][3]; return; }
   const int co = ntile * 32 + li;
   const bool covalid = co < c.Cout;
   const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
@@ -826,7 +862,7 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
 template <int SD, int SH, int SW, int VEC>
 __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParams P) {
   constexpr int TD = 2, TH = 4, TW = 8;
-  constexpr int LD = (TD - 1) * SD + 3, LH = (TH - 1) * SH + 3, LW = (TW - 1) * SW + 3;
+  constexpr int LD = (TD - 1) * SD + 3, LH = (TH - 1) * SH + 3, LW = (TW - 1) * SW + 3, LWP = stage_lwp<LD, LH, LW, VEC>();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -845,7 +881,7 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
 
   int abase[1];
-  abase[0] = ((dm * SD * LH + (li >> 3) * SH) * LW + (li & 7) * SW) * FCKP + lhalf * 8;
+  abase[0] = ((dm * SD * LH + (li >> 3) * SH) * LWP + (li & 7) * SW) * FCKP + lhalf * 8;
   f32x16 acc[1];
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[0][j] = 0.f;
@@ -856,9 +892,7 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
     __syncthreads();
     mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
     __syncthreads();
-    FastFrag<1> f0, f1;
-    fast_frag_load<1, LH, LW, 0>(f0, lds, abase, wlane);
-    fast_taps<1, LH, LW, 0>(f0, f1, lds, abase, wlane, acc);
+    fast_chunk<1, LH, LWP>(lds, abase, wlane, acc);
   }
 
   const int co = ntile_raw * 32 + li;
@@ -1133,7 +1167,7 @@ template <int SD, int SH, int SW, int VEC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_bwdd_strided_kernel(const ConvKParams P) {
   constexpr int TD = 2, TH = 4, TW = 16;                       // dY positions per workgroup: 4 waves x 32
   constexpr int LD = TD + (SD == 2 ? 1 : 2), LH = TH + (SH == 2 ? 1 : 2), LW = TW + (SW == 2 ? 1 : 2);
-  constexpr int NC = SD * SH * SW;
+  constexpr int NC = SD * SH * SW, LWP = stage_lwp<LD, LH, LW, VEC>();
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1149,7 +1183,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 
   // this wave's M tile: dm = wave/2, rows (wave%2)*2 + {0,1}, 16 columns
   const int dm = wave >> 1, rbase = (wave & 1) * 2;
-  const int abase = ((dm * LH + rbase + (li >> 4)) * LW + (li & 15)) * FCKP + lhalf * 8;
+  const int abase = ((dm * LH + rbase + (li >> 4)) * LWP + (li & 15)) * FCKP + lhalf * 8;
 
   f32x16 acc[NC];
 #pragma unroll
@@ -1170,7 +1204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       for (int jh = 0; jh < LH - TH + 1; ++jh)
 #pragma unroll
         for (int jw = 0; jw < LW - TW + 1; ++jw) {
-          const float* ap = lds + abase + ((jd * LH + jh) * LW + jw) * FCKP;
+          const float* ap = lds + abase + ((jd * LH + jh) * LWP + jw) * FCKP;
           const f32x4 a0 = *(const f32x4*)(ap);
           const f32x4 a1 = *(const f32x4*)(ap + 4);
 #pragma unroll
@@ -1315,10 +1349,7 @@ static int conv_fast_vec(const mt_conv3d_t* p) {
   }
   return 2;
 }
-static size_t fast2_lds(const ConvCfg& g) {
-  int TD, TH, TW; TD = g.TD; TH = (32 / g.MW) * g.RH; TW = g.MW;
-  return (size_t)(TD + 2) * (TH + 2) * (TW + 2) * FCKP * sizeof(float);
-}
+
 template <int MW, int RH, int TD, int VEC>
 static int launch_fast2(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
   ConvKParams P;
@@ -1330,7 +1361,8 @@ static int launch_fast2(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) 
   P.ntaps = 27; P.dbg = 0; P.stagger = 0;
   P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
-  const size_t ldsb = fast2_lds(g);
+  constexpr int TH_ = (32 / MW) * RH;
+  const size_t ldsb = stage_lds_bytes<TD + 2, TH_ + 2, MW + 2, VEC>();
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
   auto kfn = conv_fast_kernel<MW, RH, TD, VEC>;
   if (ldsb > 64 * 1024) {
@@ -1362,10 +1394,18 @@ static int launch_fast_strided_t(const mt_conv3d_t* p, hipStream_t st) {
   P.ntaps = 27; P.dbg = 0; P.stagger = 0;
   P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
-  const size_t ldsb = (size_t)LD * LH * LW * FCKP * sizeof(float);
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 64), 1);
-  if (conv_fast_vec(p) == 2) hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2>), grid, dim3(256), ldsb, st, P);
-  else                       hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 1>), grid, dim3(256), ldsb, st, P);
+  if (conv_fast_vec(p) == 2) {
+    hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 2>()), st, P);
+  } else {
+    constexpr size_t l1 = stage_lds_bytes<LD, LH, LW, 1>();
+    auto kfn = conv_fast_strided_kernel<SD, 2, 2, 1>;
+    if (l1 > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+      if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(256), l1, st, P);
+  }
   MT_CHECK_LAUNCH("conv3d_fast_strided");
   return MT_OK;
 }
@@ -1541,12 +1581,11 @@ static int launch_bwdd_strided(const mt_conv3d_t* p, hipStream_t st) {
   P.ntaps = 27; P.dbg = 0; P.stagger = 0;
   P.nchunks = mt_build_chunks(p->Cout, 0, FCK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "bwd_data_strided: too many channel chunks (Cout=%d)", p->Cout);
-  const size_t ldsb = (size_t)LD * LH * LW * FCKP * sizeof(float);
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cin, 32), 1);
   const mt_src_t& s0 = p->src[0];
   const bool v2 = !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7));
-  if (v2) hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2>), grid, dim3(256), ldsb, st, P);
-  else    hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 1>), grid, dim3(256), ldsb, st, P);
+  if (v2) hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 2>()), st, P);
+  else    hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 1>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 1>()), st, P);
   MT_CHECK_LAUNCH("conv_bwdd_strided");
   return MT_OK;
 }
