@@ -538,11 +538,19 @@ __device__ __forceinline__ void mt_stage_fast2(float* __restrict__ lds, const mt
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
           float x[VEC];
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            const float t = fmaf(v[q][i][e], scq[e], shq[e]);
-            const float a = mt_lrelu(t, slope);
-            x[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & mval[i]);
+          if constexpr (VEC == 2) {       // packed fp32 math: one v_pk_fma_f32 + one v_pk_mul_f32 per two channels
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 xv2, sc2, sh2, sl2;
+            xv2[0] = v[q][i][0]; xv2[1] = v[q][i][1]; sc2[0] = scq[0]; sc2[1] = scq[1]; sh2[0] = shq[0]; sh2[1] = shq[1];
+            sl2[0] = slope; sl2[1] = slope;
+            const f32x2 t = __builtin_elementwise_fma(xv2, sc2, sh2);
+            const f32x2 u = t * sl2;
+            // LeakyReLU with 0 <= slope <= 1 (checked on the host for these kernels) is max(t, slope*t)
+            x[0] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, fmaxf(t[0], u[0])) & mval[i]);
+            x[1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, fmaxf(t[1], u[1])) & mval[i]);
+          } else {
+            const float t = fmaf(v[q][i][0], scq[0], shq[0]);
+            x[0] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, fmaxf(t, t * slope)) & mval[i]);
           }
           if (PADW || (i + 1) * VPS <= LW || vl + i * VPS < LW) {
             if constexpr (VEC == 2) {
@@ -1330,7 +1338,13 @@ static int conv_validate(const mt_conv3d_t* p) {
   return MT_OK;
 }
 
+static bool conv_slopes_ok(const mt_conv3d_t* p) {     // the lean staging computes LeakyReLU as max(t, slope*t)
+  for (int i = 0; i < p->nsrc; ++i)
+    if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
+  return true;
+}
 static bool conv_is_fast(const mt_conv3d_t* p) {
+  if (!conv_slopes_ok(p)) return false;
   if (!(p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 1 && p->PH == 1 &&
         p->PW == 1 && p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
   for (int i = 0; i < p->nsrc; ++i)
@@ -1375,6 +1389,7 @@ static int launch_fast2(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) 
 }
 
 static bool conv_fast_strided_ok(const mt_conv3d_t* p) {
+  if (!conv_slopes_ok(p)) return false;
   if (!(p->KD == 3 && p->KH == 3 && p->KW == 3 && p->PD == 1 && p->PH == 1 && p->PW == 1)) return false;
   if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1 && p->SH == 2 && p->SW == 2 && (p->SD == 1 || p->SD == 2))) return false;
   if (p->csplit < p->Cout || p->osD > 0) return false;
@@ -1591,6 +1606,7 @@ static int launch_bwdd_strided(const mt_conv3d_t* p, hipStream_t st) {
 }
 extern "C" int mt_conv3d_bwd_data_strided_supported(const mt_conv3d_t* p) {
   if (p == nullptr || p->nsrc != 1) return 0;
+  if (p->src[0].scale != nullptr && !(p->src[0].slope >= 0.f && p->src[0].slope <= 1.f)) return 0;
   if (!(p->KD == 3 && p->KH == 3 && p->KW == 3 && p->PD == 1 && p->PH == 1 && p->PW == 1)) return 0;
   if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return 0;
   if (!(p->SH == 2 && p->SW == 2 && (p->SD == 1 || p->SD == 2))) return 0;
