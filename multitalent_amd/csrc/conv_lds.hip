@@ -943,6 +943,115 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
 }
 
 // ================================================================================================
+// 3x3x3 stride-1 convolution for the LOW-RESOLUTION stages (<= 6x24x24 voxels, 256-320 channels): the standard tiling yields
+// fewer workgroups than the chip has CUs and each wave walks Cin/16 x 27 taps serially.  Here a workgroup owns ONE 32-voxel
+// M tile (2x4x4) x 32 output channels and its four waves split the 27 TAPS (t = wave, wave+4, ...), so the serial chain per wave
+// is 4x shorter and the grid 4x larger; the four accumulator tiles are summed through LDS in a fixed order (deterministic).
+template <int VEC>
+__global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P) {
+  constexpr int TD = 2, TH = 4, TW = 4, LD = TD + 2, LH = TH + 2, LW = TW + 2;
+  constexpr int LWP = stage_lwp<LD, LH, LW, VEC>();
+  constexpr int TILE = stage_rows<LD, LH>() * LWP * FCKP;       // floats
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const mt_conv3d_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = blockIdx.y;
+  const int tw = tile % P.tilesW; tile /= P.tilesW;
+  const int th = tile % P.tilesH; tile /= P.tilesH;
+  const int td = tile % P.tilesD;
+  const int nb = tile / P.tilesD;
+  const int sb = (td * P.tilesH + th) * P.tilesW + tw;
+  const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+  // M tile row li -> voxel (dm, r, col) = (li>>4, (li>>2)&3, li&3)
+  const int abase = (((li >> 4) * LH + ((li >> 2) & 3)) * LWP + (li & 3)) * FCKP + lhalf * 8;
+
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+
+  for (int ch = 0; ch < P.nchunks; ++ch) {
+    const ConvChunk cc = P.chunk[ch];
+    const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
+    __syncthreads();
+    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+    __syncthreads();
+    // this wave's taps: wave, wave+4, ... (7 or 6 of them); the next tap's fragments are fetched behind the current MFMAs
+    f32x4 a[2][2], b[2][2];
+    {
+      const int t = wave;
+      const int toff = (((t / 9) * LH + (t / 3) % 3) * LWP + t % 3) * FCKP;
+      a[0][0] = *(const f32x4*)(lds + abase + toff); a[0][1] = *(const f32x4*)(lds + abase + toff + 4);
+      b[0][0] = *(const f32x4*)(wlane + t * 512);    b[0][1] = *(const f32x4*)(wlane + t * 512 + 256);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int t = wave + 4 * i, t1 = t + 4;
+      if (i + 1 < 7) {
+        const int tt = t1 < 27 ? t1 : 26;                 // wave 3 has 6 taps: its 7th fetch is a harmless repeat
+        const int toff = (((tt / 9) * LH + (tt / 3) % 3) * LWP + tt % 3) * FCKP;
+        a[(i + 1) & 1][0] = *(const f32x4*)(lds + abase + toff); a[(i + 1) & 1][1] = *(const f32x4*)(lds + abase + toff + 4);
+        b[(i + 1) & 1][0] = *(const f32x4*)(wlane + tt * 512);   b[(i + 1) & 1][1] = *(const f32x4*)(wlane + tt * 512 + 256);
+      }
+      if (i < 6 || wave < 3) {                             // only wave 3 lacks a 7th tap (wave-uniform)
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i & 1][kp >> 2][kp & 3], b[i & 1][kp >> 2][kp & 3], acc, 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- fixed-order sum of the four waves' tiles through LDS; wave w finishes accumulator registers 4w..4w+3
+  __syncthreads();
+  float* red = lds;                                        // [wave][16][64] floats = 16 KiB (the tile buffer is free now)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) red[(wave * 16 + j) * 64 + lane] = acc[j];
+  __syncthreads();
+  float v[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const float* rp = red + ((wave * 4 + jj)) * 64 + lane;
+    v[jj] = ((rp[0] + rp[16 * 64]) + rp[32 * 64]) + rp[48 * 64];
+  }
+  const int co = ntile * 32 + li;
+  const bool covalid = co < c.Cout;
+  const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
+  const int ocs = c.ocs0;
+  const size_t out_sample = (size_t)c.Do * c.Ho * c.Wo;
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
+                                                                (int)(out_sample * ocs * 4), 0x00020000);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    // accumulator register j = 4*wave + jj holds M row (j&3) + 8*(j>>2) + 4*lhalf = jj + 8*wave + 4*lhalf
+    const int iv = jj + 8 * wave + 4 * lhalf;
+    const int od = od0 + (iv >> 4), oh = oh0 + ((iv >> 2) & 3), ow = ow0 + (iv & 3);
+    const bool ok = covalid && od < c.Do && oh < c.Ho && ow < c.Wo;
+    const int off = ok ? (((od * c.Ho + oh) * c.Wo + ow) * ocs + co) * 4 : (int)0x80000000;
+    float o = v[jj] + bv;
+    if (c.accumulate) o += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rd, off, 0, 0);
+    if (ok) { s1 += o; s2 = fmaf(o, o, s2); }
+  }
+  if (c.stats_part != nullptr) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    __syncthreads();
+    if (lhalf == 0) { red[(wave * 32 + li) * 2] = s1; red[(wave * 32 + li) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 32 && (ntile * 32 + tid) < c.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += red[(w * 32 + tid) * 2]; t2 += red[(w * 32 + tid) * 2 + 1]; }
+      float* sp = c.stats_part + ((size_t)((size_t)nb * P.nsb + sb) * c.Cout + ntile * 32 + tid) * 2;
+      sp[0] = t1; sp[1] = t2;
+    }
+  }
+}
+
+// ================================================================================================
 // Runtime-geometry forward kernel on the FAST design (any kernel size 1..3, stride 1..2, pad, strided output placement):
 // LDS image [voxel][20], ds_read_b128 operands, float4 weights, buffer loads/stores.  The tap loop is a runtime loop
 // (unrolled by two with ping-pong fragments); the only vector-ALU work inside it is one address add per M tile and tap
@@ -1293,7 +1402,7 @@ static int pick_cfg(const mt_conv3d_t* p) {
 }
 
 // which kernel family serves a problem, and with which tile shape
-enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2, CONV_FAST_STRIDED = 3 };
+enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2, CONV_FAST_STRIDED = 3, CONV_TAPSPLIT = 4 };
 struct ConvPlan { int kind; int cfg; };
 static bool conv_is_fast(const mt_conv3d_t* p);
 static bool conv_rt_ok(const mt_conv3d_t* p);
@@ -1304,7 +1413,16 @@ static ConvPlan conv_plan(const mt_conv3d_t* p) {
   if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
   if (use_rt < 0) { const char* e = getenv("MT_CONV_RT"); use_rt = e ? atoi(e) : 1; }
   ConvPlan pl; pl.kind = CONV_GENERIC; pl.cfg = pick_cfg(p);
-  if (conv_is_fast(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0) { pl.kind = CONV_FAST; return pl; }
+  if (conv_is_fast(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0) {
+    pl.kind = CONV_FAST;
+    // low-resolution stages: fewer than two workgroups per CU -> split the taps over the waves instead
+    static int use_ts = -1;
+    if (use_ts < 0) { const char* e = getenv("MT_CONV_TAPSPLIT"); use_ts = e ? atoi(e) : 1; }
+    int TD, TH, TW; cfg_tile(kCfgs[pl.cfg], &TD, &TH, &TW);
+    const long wgs = (long)p->N * mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW) * mt_cdiv(p->Cout, 32);
+    if (use_ts && wgs < 512 && p->csplit >= p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 < 2147483648.0) pl.kind = CONV_TAPSPLIT;
+    return pl;
+  }
   if (use_rt && conv_fast_strided_ok(p)) { pl.kind = CONV_FAST_STRIDED; pl.cfg = 0; return pl; }
   if (use_rt && conv_rt_ok(p)) {
     const int i = pick_rt_cfg(p);
@@ -1320,6 +1438,7 @@ extern "C" int mt_conv3d_stats_blocks(const mt_conv3d_t* p) {
   const ConvPlan pl = conv_plan(p);
   if (pl.cfg < 0) return -1;
   if (pl.kind == CONV_FAST_STRIDED) return mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 8);
+  if (pl.kind == CONV_TAPSPLIT) return mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 4);
   int TD, TH, TW; cfg_tile(kCfgs[pl.cfg], &TD, &TH, &TW);
   return mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW);
 }
@@ -1428,6 +1547,28 @@ static int launch_fast_strided(const mt_conv3d_t* p, hipStream_t st) {
   return p->SD == 2 ? launch_fast_strided_t<2>(p, st) : launch_fast_strided_t<1>(p, st);
 }
 
+static int launch_tapsplit(const mt_conv3d_t* p, hipStream_t st) {
+  ConvKParams P;
+  P.c = *p;
+  if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
+  P.tilesD = mt_cdiv(p->Do, 2); P.tilesH = mt_cdiv(p->Ho, 4); P.tilesW = mt_cdiv(p->Wo, 4);
+  P.nsb = P.tilesD * P.tilesH * P.tilesW;
+  P.ntaps = 27; P.dbg = 0; P.stagger = 0;
+  P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
+  MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
+  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
+  const size_t red = (size_t)4 * 16 * 64 * sizeof(float);
+  if (conv_fast_vec(p) == 2) {
+    size_t l = stage_lds_bytes<4, 6, 6, 2>(); if (l < red) l = red;
+    hipLaunchKernelGGL((conv_tapsplit_kernel<2>), grid, dim3(256), l, st, P);
+  } else {
+    size_t l = stage_lds_bytes<4, 6, 6, 1>(); if (l < red) l = red;
+    hipLaunchKernelGGL((conv_tapsplit_kernel<1>), grid, dim3(256), l, st, P);
+  }
+  MT_CHECK_LAUNCH("conv3d_tapsplit");
+  return MT_OK;
+}
+
 static size_t rt_lds(const ConvCfg& g, const mt_conv3d_t* p) {
   int TD = g.TD, TH = (32 / g.MW) * g.RH, TW = g.MW;
   const size_t LD = (TD - 1) * p->SD + p->KD, LH = (TH - 1) * p->SH + p->KH, LW = (TW - 1) * p->SW + p->KW;
@@ -1522,6 +1663,8 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   const bool fast = conv_is_fast(p);
   if (pl.kind == CONV_FAST)
     snprintf(buf, n, "conv_fast_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
+  else if (pl.kind == CONV_TAPSPLIT)
+    snprintf(buf, n, "conv_tapsplit_kernel<%d>", conv_fast_vec(p));
   else if (pl.kind == CONV_FAST_STRIDED)
     snprintf(buf, n, "conv_fast_strided_kernel<%d, %d, %d, %d>", p->SD, p->SH, p->SW, conv_fast_vec(p));
   else if (pl.kind == CONV_RT)
@@ -1545,6 +1688,7 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
              (p->Do - 1) * p->osD + p->ooD < p->OD && (p->Ho - 1) * p->osH + p->ooH < p->OH && (p->Wo - 1) * p->osW + p->ooW < p->OW),
              "conv3d: bad strided output placement");
   if (pl.kind == CONV_FAST_STRIDED) return launch_fast_strided(p, st);
+  if (pl.kind == CONV_TAPSPLIT) return launch_tapsplit(p, st);
   if (pl.kind == CONV_RT) {
     const int vec = conv_fast_vec(p);
     switch (i) {

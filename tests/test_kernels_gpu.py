@@ -82,6 +82,8 @@ def ref_inputs(srcs_cpu, lazy):
     (1, 320, 320, (3, 6, 6), (3, 3, 3), (1, 2, 2)),      # bottleneck
     (1, 30, 2, (4, 8, 16), (1, 1, 1), (1, 1, 1)),        # 1x1x1 via the conv kernel
     (1, 17, 33, (3, 5, 7), (3, 3, 3), (1, 1, 1)),        # odd everything
+    (2, 16, 64, (24, 48, 64), (3, 3, 3), (1, 1, 1)),     # >= 512 workgroups: the full-tile kernel (smaller grids take the tap-split kernel)
+    (2, 20, 40, (23, 45, 70), (3, 3, 3), (1, 1, 1)),     # same, ragged
 ])
 def test_conv_fwd(dev, N, Cin, Cout, shape, k, stride):
     g = torch.Generator().manual_seed(1)
@@ -93,6 +95,13 @@ def test_conv_fwd(dev, N, Cin, Cout, shape, k, stride):
     ref = F.conv3d(x, w, b, stride=stride, padding=pad)
     got = to_ncdhw(out.cpu())
     assert got.shape == ref.shape
+    if k == (3, 3, 3) and stride == (1, 1, 1):
+        ops = _ops()
+        geom = ops.ConvGeom(shape, k, stride, pad)
+        name = ops.conv_kernel_name(ops.fill_conv([ops.Act(torch.empty((N,) + shape + (Cin,), device=dev))], geom, Cout,
+                                                  out0=ops.Act(out)))
+        big = N * np.prod([-(-s // t) for s, t in zip(shape, (2, 4, 32))]) * -(-Cout // 32) >= 512
+        assert name.startswith('conv_fast_kernel' if big else 'conv_tapsplit_kernel'), name
     assert relerr(got, ref) < 1e-5
     # per-block statistics partials sum to per-(n,c) sums
     s = part.cpu().double().sum(1)
