@@ -1052,6 +1052,108 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
 }
 
 // ================================================================================================
+// Stem kernels: the first convolution of the network has ONE input channel (CT), so padding Cin to a 16-channel chunk would
+// spend 16x the necessary MFMAs.  Here the 27 TAPS are the contraction dimension: A[voxel][k = tap] is gathered from a scalar
+// LDS image of the haloed tile, B[k = tap][cout] comes from the packed weights (channel 0 of the single chunk); one M tile of 32
+// voxels costs 14 MFMAs instead of 216.  Both kernels are bound by the 32-channel output / gradient stream (HBM).
+template <int TD, int TH, int TW>
+__device__ __forceinline__ void stem_stage(float* __restrict__ xs, const mt_conv3d_t& c, int nb, int od0, int oh0, int ow0, int tid) {
+  constexpr int LD = TD + 2, LH = TH + 2, LW = TW + 2;
+  const mt_src_t& S = c.src[0];
+  const bool aff = S.scale != nullptr;
+  const float sc = aff ? S.scale[(size_t)nb * S.C] : 1.f, sh = aff ? S.shift[(size_t)nb * S.C] : 0.f;
+  const float slope = aff ? S.slope : 1.f;
+  for (int e = tid; e < LD * LH * LW; e += 256) {
+    const int lw = e % LW, lh = (e / LW) % LH, ld = e / (LW * LH);
+    const int ud = od0 - 1 + ld, uh = oh0 - 1 + lh, uw = ow0 - 1 + lw;
+    float x = 0.f;
+    if ((unsigned)ud < (unsigned)c.Di && (unsigned)uh < (unsigned)c.Hi && (unsigned)uw < (unsigned)c.Wi) {
+      x = S.ptr[((size_t)((size_t)((size_t)nb * c.Di + ud) * c.Hi + uh) * c.Wi + uw) * S.cs];
+      x = mt_lrelu(fmaf(x, sc, sh), slope);
+    }
+    xs[e] = x;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(const ConvKParams P) {
+  constexpr int TD = 2, TH = 4, TW = 32, LH = TH + 2, LW = TW + 2, NJ = 14;      // 14 MFMAs x k=2 cover 27 taps (+1 zero)
+  __shared__ float xs[(TD + 2) * LH * LW];
+  __shared__ float red[4 * 32 * 2];
+  const mt_conv3d_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = blockIdx.y;
+  const int tw = tile % P.tilesW; tile /= P.tilesW;
+  const int th = tile % P.tilesH; tile /= P.tilesH;
+  const int td = tile % P.tilesD;
+  const int nb = tile / P.tilesD;
+  const int sb = (td * P.tilesH + th) * P.tilesW + tw;
+  const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+  stem_stage<TD, TH, TW>(xs, c, nb, od0, oh0, ow0, tid);
+  // B fragments: W[tap = 2j + lhalf][cout = li] = channel 0 of the chunk = element 0 of lane li's first float4 of the tap
+  const float* wq = c.wpack + (size_t)ntile * P.nchunks * (27 * 512) + li * 4;
+  float b[NJ];
+  int koff[NJ];
+  // this wave's two M tiles: plane dm = wave/2, rows (wave%2)*2 + {0,1}
+  const int mbase = (((wave >> 1)) * LH + (wave & 1) * 2) * LW + li;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int k = 2 * j + lhalf;
+    const bool kv = k < 27;
+    b[j] = kv ? wq[(kv ? k : 0) * 512] : 0.f;
+    const int kk = kv ? k : 0;
+    koff[j] = mbase + ((kk / 9) * LH + (kk / 3) % 3) * LW + kk % 3;
+  }
+  __syncthreads();
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[koff[j] + m * LW], b[j], acc[m], 0, 0, 0);
+  }
+  const int co = ntile * 32 + li;
+  const bool covalid = co < c.Cout;
+  const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
+  const int ocs = c.ocs0;
+  const size_t out_sample = (size_t)c.Do * c.Ho * c.Wo;
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
+                                                                (int)(out_sample * ocs * 4), 0x00020000);
+  float s1 = 0.f, s2 = 0.f;
+  const int od = od0 + (wave >> 1);
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int oh = oh0 + (wave & 1) * 2 + m;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int ow = ow0 + (q & 3) + 8 * (q >> 2) + 4 * lhalf;
+      const bool ok = covalid && od < c.Do && oh < c.Ho && ow < c.Wo;
+      const int off = ok ? (((od * c.Ho + oh) * c.Wo + ow) * ocs + co) * 4 : (int)0x80000000;
+      float v = acc[m][q] + bv;
+      if (c.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, 0);
+      if (ok) { s1 += v; s2 = fmaf(v, v, s2); }
+    }
+  }
+  if (c.stats_part != nullptr) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lhalf == 0) { red[(wave * 32 + li) * 2] = s1; red[(wave * 32 + li) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 32 && (ntile * 32 + tid) < c.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += red[(w * 32 + tid) * 2]; t2 += red[(w * 32 + tid) * 2 + 1]; }
+      float* sp = c.stats_part + ((size_t)((size_t)nb * P.nsb + sb) * c.Cout + ntile * 32 + tid) * 2;
+      sp[0] = t1; sp[1] = t2;
+    }
+  }
+}
+
+// ================================================================================================
 // Runtime-geometry forward kernel on the FAST design (any kernel size 1..3, stride 1..2, pad, strided output placement):
 // LDS image [voxel][20], ds_read_b128 operands, float4 weights, buffer loads/stores.  The tap loop is a runtime loop
 // (unrolled by two with ping-pong fragments); the only vector-ALU work inside it is one address add per M tile and tap
@@ -1402,7 +1504,7 @@ static int pick_cfg(const mt_conv3d_t* p) {
 }
 
 // which kernel family serves a problem, and with which tile shape
-enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2, CONV_FAST_STRIDED = 3, CONV_TAPSPLIT = 4 };
+enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2, CONV_FAST_STRIDED = 3, CONV_TAPSPLIT = 4, CONV_STEM = 5 };
 struct ConvPlan { int kind; int cfg; };
 static bool conv_is_fast(const mt_conv3d_t* p);
 static bool conv_rt_ok(const mt_conv3d_t* p);
@@ -1413,6 +1515,12 @@ static ConvPlan conv_plan(const mt_conv3d_t* p) {
   if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
   if (use_rt < 0) { const char* e = getenv("MT_CONV_RT"); use_rt = e ? atoi(e) : 1; }
   ConvPlan pl; pl.kind = CONV_GENERIC; pl.cfg = pick_cfg(p);
+  if (conv_is_fast(p) && use_v2 && p->osD <= 0 && p->nsrc == 1 && p->Cin == 1 && p->csplit >= p->Cout &&
+      (double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 < 2147483648.0) {
+    static int use_stem = -1;
+    if (use_stem < 0) { const char* e = getenv("MT_CONV_STEM"); use_stem = e ? atoi(e) : 1; }
+    if (use_stem) { pl.kind = CONV_STEM; pl.cfg = 0; return pl; }
+  }
   if (conv_is_fast(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0) {
     pl.kind = CONV_FAST;
     // low-resolution stages: fewer than two workgroups per CU -> split the taps over the waves instead
@@ -1569,6 +1677,20 @@ static int launch_tapsplit(const mt_conv3d_t* p, hipStream_t st) {
   return MT_OK;
 }
 
+static int launch_stem(const mt_conv3d_t* p, hipStream_t st) {
+  ConvKParams P;
+  P.c = *p;
+  P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0;
+  P.tilesD = mt_cdiv(p->Do, 2); P.tilesH = mt_cdiv(p->Ho, 4); P.tilesW = mt_cdiv(p->Wo, 32);
+  P.nsb = P.tilesD * P.tilesH * P.tilesW;
+  P.ntaps = 27; P.dbg = 0; P.stagger = 0;
+  P.nchunks = mt_build_chunks(1, 0, FCK, P.chunk);
+  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
+  hipLaunchKernelGGL(conv_stem_kernel, grid, dim3(256), 0, st, P);
+  MT_CHECK_LAUNCH("conv3d_stem");
+  return MT_OK;
+}
+
 static size_t rt_lds(const ConvCfg& g, const mt_conv3d_t* p) {
   int TD = g.TD, TH = (32 / g.MW) * g.RH, TW = g.MW;
   const size_t LD = (TD - 1) * p->SD + p->KD, LH = (TH - 1) * p->SH + p->KH, LW = (TW - 1) * p->SW + p->KW;
@@ -1665,6 +1787,8 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
     snprintf(buf, n, "conv_fast_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
   else if (pl.kind == CONV_TAPSPLIT)
     snprintf(buf, n, "conv_tapsplit_kernel<%d>", conv_fast_vec(p));
+  else if (pl.kind == CONV_STEM)
+    snprintf(buf, n, "conv_stem_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
     snprintf(buf, n, "conv_fast_strided_kernel<%d, %d, %d, %d>", p->SD, p->SH, p->SW, conv_fast_vec(p));
   else if (pl.kind == CONV_RT)
@@ -1689,6 +1813,7 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
              "conv3d: bad strided output placement");
   if (pl.kind == CONV_FAST_STRIDED) return launch_fast_strided(p, st);
   if (pl.kind == CONV_TAPSPLIT) return launch_tapsplit(p, st);
+  if (pl.kind == CONV_STEM) return launch_stem(p, st);
   if (pl.kind == CONV_RT) {
     const int vec = conv_fast_vec(p);
     switch (i) {

@@ -76,7 +76,8 @@ def ref_inputs(srcs_cpu, lazy):
 @pytest.mark.parametrize("N,Cin,Cout,shape,k,stride", [
     (1, 30, 30, (4, 8, 32), (3, 3, 3), (1, 1, 1)),
     (2, 30, 30, (5, 9, 37), (3, 3, 3), (1, 1, 1)),      # ragged tiles
-    (1, 1, 30, (4, 8, 32), (3, 3, 3), (1, 1, 1)),        # stem
+    (1, 1, 30, (4, 8, 32), (3, 3, 3), (1, 1, 1)),        # stem (taps-as-K kernel)
+    (2, 1, 40, (5, 9, 37), (3, 3, 3), (1, 1, 1)),        # stem, ragged tiles, two cout tiles
     (1, 30, 60, (6, 12, 34), (3, 3, 3), (2, 2, 2)),      # strided
     (1, 60, 47, (3, 6, 12), (1, 3, 3), (1, 1, 1)),       # anisotropic kernel, Cout not multiple of 32
     (1, 320, 320, (3, 6, 6), (3, 3, 3), (1, 2, 2)),      # bottleneck
@@ -101,7 +102,7 @@ def test_conv_fwd(dev, N, Cin, Cout, shape, k, stride):
         name = ops.conv_kernel_name(ops.fill_conv([ops.Act(torch.empty((N,) + shape + (Cin,), device=dev))], geom, Cout,
                                                   out0=ops.Act(out)))
         big = N * np.prod([-(-s // t) for s, t in zip(shape, (2, 4, 32))]) * -(-Cout // 32) >= 512
-        assert name.startswith('conv_fast_kernel' if big else 'conv_tapsplit_kernel'), name
+        assert name.startswith('conv_stem_kernel' if Cin == 1 else ('conv_fast_kernel' if big else 'conv_tapsplit_kernel')), name
     assert relerr(got, ref) < 1e-5
     # per-block statistics partials sum to per-(n,c) sums
     s = part.cpu().double().sum(1)
