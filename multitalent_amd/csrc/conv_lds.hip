@@ -2565,6 +2565,74 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
   bwdw_wg_reduce_store<NT>(acc, lds, P.part + ((size_t)((size_t)(chi * P.ncot + cot) * P.nsg + sg) * NT) * 512, wave, lane);
 }
 
+// Stem backward-weight (Cin = 1): dW[tap][cout] = sum over voxels of x[voxel + tap] * dY[voxel][cout] as a GEMM with
+// M = taps (27 of 32 rows), N = cout, K = voxels: per MFMA one scalar LDS read (lane = tap, voxel parity) and one coalesced
+// dY load (lane = cout, voxel parity).  dY is streamed exactly once; persistent workgroups, fixed-order reduction.
+__global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P) {
+  constexpr int TD = 2, TH = 4, TW = 32, LH = TH + 2, LW = TW + 2;
+  __shared__ float xs[(TD + 2) * LH * LW];
+  __shared__ float red[3 * 16 * 64];
+  const mt_conv3d_t& c = P.c;
+  const mt_src_t& Y = P.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  const int sg = blockIdx.x, cot = blockIdx.y;
+  const int co = cot * 32 + li;
+  const int tap = li < 27 ? li : 26;
+  const int dm = wave >> 1, r0 = (wave & 1) * 2;
+  const int xlane = ((dm + tap / 9) * LH + r0 + (tap / 3) % 3) * LW + tap % 3 + lhalf;
+  const int ylane = (co < c.Cout) ? (lhalf * Y.cs + co) * 4 : (int)0x80000000;
+  const size_t ysample = (size_t)c.Do * c.Ho * c.Wo * Y.cs;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  for (int tile = sg; tile < P.ntiles_total; tile += P.nsg) {
+    int r = tile;
+    const int tw = r % P.tilesW; r /= P.tilesW;
+    const int th = r % P.tilesH; r /= P.tilesH;
+    const int td = r % P.tilesD;
+    const int nb = r / P.tilesD;
+    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+    __syncthreads();
+    stem_stage<TD, TH, TW>(xs, c, nb, od0, oh0, ow0, tid);
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(Y.ptr + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
+    const int od = od0 + dm;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int oh = oh0 + r0 + m;
+      const bool rowok = od < c.Do && oh < c.Ho;                         // wave-uniform
+      const int rowoff = rowok ? ((od * c.Ho + oh) * c.Wo + ow0) * Y.cs * 4 : 0;
+      float b[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const bool ok = rowok && (ow0 + 2 * v + lhalf < c.Wo);
+        b[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ok ? ylane : (int)0x80000000, rowoff + v * 2 * Y.cs * 4, 0));
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[xlane + m * LW + 2 * v], b[v], acc, 0, 0, 0);
+    }
+  }
+  // fixed-order reduction of the four waves, then one partial per workgroup: [cot][sg][tap][ci slot 0][cout]
+  __syncthreads();
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[((wave - 1) * 16 + q) * 64 + lane] = acc[q];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* pp = P.part + ((size_t)((size_t)cot * P.nsg + sg) * 27) * 512;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float t = ((acc[q] + red[q * 64 + lane]) + red[(16 + q) * 64 + lane]) + red[(32 + q) * 64 + lane];
+      const int row = (q & 3) + 8 * (q >> 2) + 4 * lhalf;      // tap
+      if (row < 27) pp[(size_t)row * 512 + li] = t;
+    }
+  }
+}
+
 // compile-time geometries of the fast backward-weight kernel: (K, S) with pad (K-1)/2 for K=3/1 and 0 for K=2
 struct BwGeo { int KD, KH, KW, SD, SH, SW; };
 static const BwGeo kBwGeos[] = {
@@ -2589,6 +2657,17 @@ static int bwdw_fast_geo(const mt_conv3d_t* p, const mt_src_t* y) {
   return -1;
 }
 static bool bwdw_is_fast(const mt_conv3d_t* p, const mt_src_t* y) { return bwdw_fast_geo(p, y) >= 0; }
+#define BW_STEM_WGS 512
+static bool bwdw_is_stem(const mt_conv3d_t* p, const mt_src_t* y) {
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_CONV_STEM"); use = e ? atoi(e) : 1; }
+  if (!use || p->nsrc != 1 || p->Cin != 1 || p->src[0].C != 1) return false;
+  if (!(p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 1 && p->PH == 1 && p->PW == 1)) return false;
+  if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
+  if (y != nullptr && y->scale != nullptr) return false;                 // lazily activated dY takes the general kernel
+  if ((double)p->Do * p->Ho * p->Wo * (y ? y->cs : p->Cout) * 4.0 >= 2147483648.0) return false;
+  return true;
+}
 static bool bwdw_use_march(const mt_conv3d_t* p) {
   static int use = -1;
   if (use < 0) { const char* e = getenv("MT_BWDW_MARCH"); use = e ? atoi(e) : 1; }
@@ -2717,6 +2796,10 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
       if (fast > generic) generic = fast;
     }
   }
+  if (bwdw_is_stem(p, nullptr)) {
+    const size_t stem = (size_t)mt_cdiv(p->Cout, 32) * BW_STEM_WGS * 27 * 512 * sizeof(float);
+    if (stem > generic) generic = stem;
+  }
   return generic;
 }
 
@@ -2734,6 +2817,29 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
   P.y = *ysrc;
   static int use_fast = -1;
   if (use_fast < 0) { const char* e = getenv("MT_BWDW_FAST"); use_fast = e ? atoi(e) : 1; }
+  if (use_fast && bwdw_is_stem(p, ysrc)) {
+    P.TD = 2; P.TH = 4; P.TW = 32;
+    P.tilesD = mt_cdiv(p->Do, 2); P.tilesH = mt_cdiv(p->Ho, 4); P.tilesW = mt_cdiv(p->Wo, 32);
+    P.ntiles_total = P.tilesD * P.tilesH * P.tilesW * p->N;
+    P.ntaps = 27; P.ncot = mt_cdiv(p->Cout, 32);
+    P.nchunks = mt_build_chunks(1, 0, BW_CK, P.chunk);
+    P.nsg = P.ntiles_total < BW_STEM_WGS ? P.ntiles_total : BW_STEM_WGS;
+    const size_t need = (size_t)P.ncot * P.nsg * 27 * 512 * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need) { mt_set_error("bwd_weight: workspace %zu < %zu", workspace_bytes, need); return MT_EWORKSPACE; }
+    P.part = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_bwdw_stem_kernel, dim3(P.nsg, P.ncot, 1), dim3(256), 0, st, P);
+    MT_CHECK_LAUNCH("conv_bwdw_stem");
+    BwdWReduceParams R;
+    R.part = P.part; R.dw = dw; R.Cin = p->Cin; R.Cout = p->Cout; R.KD = 3; R.KH = 3; R.KW = 3;
+    R.nchunks = 1; R.ncot = P.ncot; R.nsg = P.nsg; R.ntaps = 27; R.accumulate = accumulate;
+    R.s_ci = s_ci; R.s_co = s_co; R.s_kd = s_kd; R.s_kh = s_kh; R.s_kw = s_kw;
+    R.chunk[0] = P.chunk[0];
+    const long total = (long)P.ncot * 27 * 512;
+    hipLaunchKernelGGL(bwdw_reduce_kernel, dim3(mt_cdiv(total, 256)), dim3(256), 0, st, R);
+    MT_CHECK_LAUNCH("bwdw_reduce");
+    return MT_OK;
+  }
   const int geo = use_fast ? bwdw_fast_geo(p, ysrc) : -1;
   if (geo >= 0) {
     bwdw_fast_plan(p, &P);

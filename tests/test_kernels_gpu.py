@@ -236,6 +236,9 @@ def test_conv_bwd_data(dev, Cin, Cout, shape, k, stride):
     (60, 47, (3, 6, 12), (1, 1, 1), (1, 1, 1)),
     (17, 33, (3, 5, 7), (3, 3, 3), (1, 1, 1)),
     (40, 24, (5, 7, 9), (1, 3, 3), (1, 2, 2)),
+    (1, 32, (4, 8, 32), (3, 3, 3), (1, 1, 1)),       # stem: taps-as-M kernel
+    (1, 40, (5, 9, 37), (3, 3, 3), (1, 1, 1)),       # stem, ragged tiles, two cout tiles
+    (32, 32, (6, 8, 32), (3, 3, 3), (1, 1, 1)),      # marching kernel, several planes per column
 ])
 def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
     ops = _ops()
