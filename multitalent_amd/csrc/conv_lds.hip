@@ -1528,7 +1528,7 @@ static ConvPlan conv_plan(const mt_conv3d_t* p) {
     if (use_ts < 0) { const char* e = getenv("MT_CONV_TAPSPLIT"); use_ts = e ? atoi(e) : 1; }
     int TD, TH, TW; cfg_tile(kCfgs[pl.cfg], &TD, &TH, &TW);
     const long wgs = (long)p->N * mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW) * mt_cdiv(p->Cout, 32);
-    if (use_ts && wgs < 512 && p->csplit >= p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 < 2147483648.0) pl.kind = CONV_TAPSPLIT;
+    if (use_ts && wgs < 300 && p->csplit >= p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 < 2147483648.0) pl.kind = CONV_TAPSPLIT;
     return pl;
   }
   if (use_rt && conv_fast_strided_ok(p)) { pl.kind = CONV_FAST_STRIDED; pl.cfg = 0; return pl; }
