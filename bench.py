@@ -150,12 +150,56 @@ def cpu_baseline(workload):
             "sample": "1 training iteration (fwd+loss+bwd+clip+SGD), batch 1, patch 48x192x192, fp32, torch CPU oracle, %.1f s" % dt}
 
 
+def bench_infer(args, dev, rank, world, ddp):
+    """BASELINE.json configs[4]: predict_MultiTalent-style sliding-window inference of ONE synthetic CT volume, tiles sharded
+    over the ranks (strong scaling), Gaussian weighting, step 0.5, optional 8-fold mirroring; a 'step' is one whole volume.
+    Metric: volumes per minute, volume already resident in host memory, result left on the device."""
+    from multitalent_amd.inference.sliding_window import predict_3D
+    torch.manual_seed(1234)
+    net = build_network('task100').to(dev)
+    net.eval()
+    net.inference_apply_nonlin = nn.Sigmoid()
+    vol = np.random.RandomState(7).randn(1, *args.volume).astype(np.float32)
+    shard = (rank, world) if world > 1 else None
+    run = lambda: predict_3D(net, vol, bool(args.mirror), (0, 1, 2), True, 0.5, PATCH, None, True, 'constant', None, True,
+                             False, True, tile_shard=shard, return_device_tensors=True)
+    for _ in range(max(1, min(args.warmup, 1))):
+        run()
+    torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if ddp:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "sliding-window vols/min", "value": round(60.0 * args.steps / dt, 3), "unit": "volumes/min",
+            "n_gpus": world, "steps": args.steps, "warmup": 1, "ms_per_step": round(dt / args.steps * 1e3, 1),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "predict_MultiTalent sliding window, Generic_UNet nc=47 sigmoid", "volume": list(args.volume),
+                       "patch": list(PATCH), "step_size": 0.5, "gaussian": True, "mirror_tta": bool(args.mirror),
+                       "parallelism": "tile-shard%d" % world}}), flush=True)
+    if ddp:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default=None, choices=[None, 'task009', 'task100'])
+    ap.add_argument('--workload', default=None, choices=[None, 'task009', 'task100', 'infer'])
+    ap.add_argument('--volume', type=int, nargs=3, default=[512, 512, 512], help='--workload infer: synthetic CT volume')
+    ap.add_argument('--mirror', type=int, default=1, help='--workload infer: 8-fold mirror TTA (reference default)')
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -173,6 +217,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', init_method='env://')
     workload = args.workload or 'task009'      # same per-GPU workload at every N (weak scaling on BASELINE configs[1])
+    if workload == 'infer':
+        return bench_infer(args, dev, rank, world, ddp)
     B = args.batch or (2 if workload == 'task009' else 4)
 
     from multitalent_amd.training.hot_loop import FusedTrainStep
