@@ -6,32 +6,53 @@
 
 // acc[c][d][h][w] (+)= weight * nonlin(logits[fd][fh][fw][c]);  logits are of the FLIPPED input, so the
 // un-flip (neural_network.py:531-586 `torch.flip(pred, axes)`) is the same index reflection.
+// One workgroup per (d, h) row: the source row (W voxels x cs channels, contiguous) is read coalesced into LDS with an odd
+// channel pitch, each thread then owns one voxel (all C channels from LDS: softmax needs them together) and the C output
+// planes are written coalesced along w.  NDHWC logits -> NCDHW accumulator is a transpose; doing it through LDS keeps both
+// sides of it at full line width.
 __global__ __launch_bounds__(256) void flip_accumulate_kernel(const float* __restrict__ logits, int cs, int D, int H, int W, int C,
                                                               int fD, int fH, int fW, int nonlin, float weight,
                                                               float* __restrict__ acc, int first) {
+  extern __shared__ float row[];                 // [256 voxels][C | 1]
+  const int CP = C | 1;
   const long V = (long)D * H * W;
-  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
-    const int w = (int)(v % W), h = (int)((v / W) % H), d = (int)(v / ((long)W * H));
-    const int sd = fD ? D - 1 - d : d, shh = fH ? H - 1 - h : h, sw = fW ? W - 1 - w : w;
-    const float* src = logits + ((size_t)((size_t)sd * H + shh) * W + sw) * cs;
-    if (nonlin == 2) {
-      float mx = -3.0e38f;
-      for (int c = 0; c < C; ++c) mx = fmaxf(mx, src[c]);
-      float se = 0.f;
-      for (int c = 0; c < C; ++c) se += expf(src[c] - mx);
-      const float inv = 1.f / se;
-      for (int c = 0; c < C; ++c) {
-        const float p = expf(src[c] - mx) * inv * weight;
-        float* a = acc + (size_t)c * V + v;
-        *a = first ? p : *a + p;
-      }
-    } else {
-      for (int c = 0; c < C; ++c) {
-        float x = src[c];
-        if (nonlin == 1) x = 1.f / (1.f + expf(-x));
-        x *= weight;
-        float* a = acc + (size_t)c * V + v;
-        *a = first ? x : *a + x;
+  const int d = blockIdx.x / H, h = blockIdx.x % H;
+  const int sd = fD ? D - 1 - d : d, shh = fH ? H - 1 - h : h;
+  const float* srow = logits + ((size_t)sd * H + shh) * (size_t)W * cs;
+  for (int w0 = 0; w0 < W; w0 += 256) {
+    const int nw = (W - w0 < 256) ? (W - w0) : 256;
+    // source voxels of output columns [w0, w0+nw): sw = fW ? W-1-w : w  -> a contiguous run either way
+    const int s0 = fW ? W - w0 - nw : w0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nw * C; e += 256) {
+      const int sv = e / C, c = e - sv * C;
+      row[sv * CP + c] = srow[(size_t)(s0 + sv) * cs + c];
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < nw) {
+      const int sv = fW ? nw - 1 - t : t;
+      const float* src = row + sv * CP;
+      const long v = ((long)d * H + h) * W + w0 + t;
+      if (nonlin == 2) {
+        float mx = -3.0e38f;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, src[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(src[c] - mx);
+        const float inv = 1.f / se;
+        for (int c = 0; c < C; ++c) {
+          const float p = expf(src[c] - mx) * inv * weight;
+          float* a = acc + (size_t)c * V + v;
+          *a = first ? p : *a + p;
+        }
+      } else {
+        for (int c = 0; c < C; ++c) {
+          float x = src[c];
+          if (nonlin == 1) x = 1.f / (1.f + expf(-x));
+          x *= weight;
+          float* a = acc + (size_t)c * V + v;
+          *a = first ? x : *a + x;
+        }
       }
     }
   }
@@ -39,10 +60,14 @@ __global__ __launch_bounds__(256) void flip_accumulate_kernel(const float* __res
 extern "C" int mt_flip_accumulate(const float* logits, int cs, int D, int H, int W, int C, int flipD, int flipH, int flipW,
                                   int nonlin, float weight, float* acc, int first, mt_stream_t stream) {
   MT_REQUIRE(logits && acc && D > 0 && H > 0 && W > 0 && C > 0, "flip_accumulate: bad args");
-  const long V = (long)D * H * W;
-  int blocks = mt_cdiv(V, 256); if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(flip_accumulate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, cs, D, H, W, C, flipD, flipH,
-                     flipW, nonlin, weight, acc, first);
+  const size_t ldsb = (size_t)256 * (C | 1) * sizeof(float);
+  MT_REQUIRE(ldsb <= 160 * 1024, "flip_accumulate: too many classes (%d)", C);
+  if (ldsb > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)flip_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) { mt_set_error("flip_accumulate: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
+  }
+  hipLaunchKernelGGL(flip_accumulate_kernel, dim3((unsigned)(D * H)), dim3(256), ldsb, (hipStream_t)stream, logits, cs, D, H, W, C,
+                     flipD, flipH, flipW, nonlin, weight, acc, first);
   MT_CHECK_LAUNCH("flip_accumulate");
   return MT_OK;
 }
