@@ -207,6 +207,15 @@ int mt_tile_accumulate(const float* acc, const float* gauss, int C, int D, int H
 /* probs = agg/nb; seg = argmax_c or per-channel >0.5 in regions_class_order (neural_network.py:405-417) */
 int mt_normalize_threshold(float* agg, const float* nb, int C, long V, const int32_t* class_order,
                            int use_regions, int32_t* seg, mt_stream_t stream);
+/* ---- device-side target preparation ----------------------------------------
+ * Deep-supervision label pyramid: DownsampleSegForDSTransform2 / downsample_seg_for_ds_transform2 (downsampling.py:70-104,
+ * order 0 = nearest through batchgenerators' resize_segmentation -> skimage.transform.resize(order 0, mode "edge") ->
+ * scipy.ndimage.zoom(order 0, grid_mode=True): source index = floor((o + 0.5) * in / out), clamped) and, when
+ * remove_minus_one != 0, RemoveLabelTransform(-1, 0) (data_augmentation_moreDA.py:117).  src/dst: [NC, D, H, W] float32
+ * label maps (the reference's target layout [B,1,D,H,W] with NC = B). */
+int mt_downsample_seg_nearest(const float* src, int NC, int Di, int Hi, int Wi, float* dst, int Do, int Ho, int Wo,
+                              int remove_minus_one, mt_stream_t stream);
+
 /* NCDHW <-> NDHWC transposes used at the module boundary */
 int mt_ncdhw_to_ndhwc(const float* in, float* out, int N, int C, long V, int ocs, mt_stream_t stream);
 int mt_ndhwc_to_ncdhw(const float* in, int ics, float* out, int N, int C, long V, mt_stream_t stream);

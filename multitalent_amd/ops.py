@@ -369,3 +369,15 @@ def ndhwc_to_ncdhw(a, out=None):
         out = torch.empty((N, Cn, D, H, W), dtype=torch.float32, device=a.buf.device)
     _lib.check(_lib.load().mt_ndhwc_to_ncdhw(C.c_void_p(a.data_ptr()), a.cs, _ptr(out), N, Cn, a.V, _stream()), 'ndhwc_to_ncdhw')
     return out
+
+
+def downsample_seg_nearest(seg, out_spatial, remove_minus_one=False, out=None):
+    """seg: [B, C, D, H, W] float32 label maps (contiguous) -> [B, C, *out_spatial]; see mt_downsample_seg_nearest."""
+    _check_dev(seg)
+    assert seg.dim() == 5 and seg.dtype == torch.float32 and seg.is_contiguous()
+    B, Cn, D, H, W = seg.shape
+    if out is None:
+        out = torch.empty((B, Cn) + tuple(int(i) for i in out_spatial), dtype=torch.float32, device=seg.device)
+    _lib.check(_lib.load().mt_downsample_seg_nearest(_ptr(seg), B * Cn, D, H, W, _ptr(out), *[int(i) for i in out_spatial],
+                                                    int(remove_minus_one), _stream()), 'downsample_seg_nearest')
+    return out

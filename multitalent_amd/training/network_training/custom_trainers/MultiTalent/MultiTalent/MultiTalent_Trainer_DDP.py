@@ -50,7 +50,7 @@ class MultiTalent_trainer_ddp(nnUNetTrainerV2_DDP):
 
     def loss_args(self, data_dict):
         valid_regions = [p['valid_regions'] for p in data_dict['properties']]     # reference :329
-        return (self._to_device(data_dict['target']), valid_regions)
+        return (self.prepare_target(data_dict['target']), valid_regions)
 
     def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False):
         data_dict = next(data_generator)

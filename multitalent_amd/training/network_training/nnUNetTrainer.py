@@ -305,8 +305,18 @@ class nnUNetTrainerV2(nnUNetTrainer):
             a = torch.from_numpy(a).float()
         return a.cuda(non_blocking=True) if not a.is_cuda else a
 
+    def prepare_target(self, target):
+        """The reference's augmenter delivers the deep-supervision pyramid as a list (DownsampleSegForDSTransform2 in CPU
+        workers).  A single full-resolution label map [B,1,D,H,W] is also accepted: the pyramid is then built on the device
+        (RemoveLabelTransform(-1, 0) included)."""
+        target = self._to_device(target)
+        if torch.is_tensor(target):
+            from ..data_augmentation.downsampling import downsample_seg_for_ds_transform2
+            target = downsample_seg_for_ds_transform2(target, self.deep_supervision_scales, 0, None, remove_minus_one=True)
+        return target
+
     def loss_args(self, data_dict):
-        return (self._to_device(data_dict['target']),)
+        return (self.prepare_target(data_dict['target']),)
 
     def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False):
         """nnUNetTrainerV2.py:225-274: fwd, loss, bwd, clip 12, step — one call into the fused hot loop."""

@@ -358,3 +358,21 @@ def test_layout_transposes(dev):
     assert torch.equal(nd.cpu(), to_ndhwc(x))
     back = ops.ndhwc_to_ncdhw(ops.Act(nd))
     assert torch.equal(back.cpu(), x)
+
+
+def test_ds_label_pyramid_on_device(dev):
+    """mt_downsample_seg_nearest == oracle restatement of DownsampleSegForDSTransform2(order 0) + RemoveLabelTransform(-1, 0),
+    bit-exact (labels are copied, never interpolated)."""
+    from oracle import reference_ops as R
+    from multitalent_amd.training.data_augmentation.downsampling import downsample_seg_for_ds_transform2
+    rng = np.random.RandomState(5)
+    for shape, scales in [((48, 192, 192), [(1, 1, 1), (0.5, 0.5, 0.5), (0.25, 0.25, 0.25), (0.125, 0.125, 0.125), (0.0625, 0.0625, 0.0625)]),
+                          ((48, 96, 80), [(1, 1, 1), (1, 0.5, 0.5), (0.5, 0.25, 0.25)]),
+                          ((37, 45, 51), [(0.5, 0.5, 0.5), (0.25, 0.5, 0.125)])]:
+        seg = rng.randint(-1, 48, size=(2, 1) + shape).astype(np.float32)
+        ref = R.downsample_seg_for_ds_transform2(R.remove_label(seg), scales, 0)
+        got = downsample_seg_for_ds_transform2(torch.from_numpy(seg).to(dev), scales, 0, None, remove_minus_one=True)
+        assert len(got) == len(ref)
+        for g, r in zip(got, ref):
+            assert tuple(g.shape) == r.shape
+            assert np.array_equal(g.cpu().numpy(), r)

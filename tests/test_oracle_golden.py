@@ -231,3 +231,29 @@ def test_c_oracle_multitalent_loss_statistics():
         dc = (2 * tp / np.maximum(2 * tp + fp + fn, 1e-7)).sum()
         total += z['weights'][i] * (ce - dc)
     assert abs(total - z['bd1/loss'][0]) < 1e-4 * abs(z['bd1/loss'][0])
+
+
+def test_ds_label_pyramid_matches_scipy_zoom_order0():
+    """downsample_seg_for_ds_transform2 (downsampling.py:86-104): the oracle's index arithmetic for batchgenerators'
+    resize_segmentation(order 0) -> skimage.resize -> scipy.ndimage.zoom(order 0, grid_mode=True) against scipy itself
+    (skimage is not in the image: parity with it is unpinned, the delegate routine is pinned here)."""
+    from scipy import ndimage
+    from oracle import reference_ops as R
+    rng = np.random.RandomState(3)
+    for shape, scales in [((48, 192, 192), [(1, 1, 1), (0.5, 0.5, 0.5), (0.25, 0.25, 0.25), (0.125, 0.125, 0.125), (0.0625, 0.0625, 0.0625)]),
+                          ((48, 96, 80), [(1, 0.5, 0.5), (0.5, 0.25, 0.25)]),
+                          ((37, 45, 51), [(0.5, 0.5, 0.5), (0.25, 0.5, 0.125)])]:
+        seg = rng.randint(-1, 48, size=(2, 1) + shape).astype(np.float32)
+        got = R.downsample_seg_for_ds_transform2(seg, scales, 0)
+        for s, g in zip(scales, got):
+            if all(i == 1 for i in s):
+                assert g is seg
+                continue
+            new = np.round(np.array(shape, dtype=float) * np.array(s)).astype(int)
+            assert g.shape == (2, 1) + tuple(new)
+            for b in range(2):
+                ref = ndimage.zoom(seg[b, 0].astype(float), [n / i for n, i in zip(new, shape)], order=0, mode='nearest',
+                                   grid_mode=True)
+                assert ref.shape == tuple(new)
+                assert np.array_equal(g[b, 0], ref.astype(np.float32))
+    assert np.array_equal(R.remove_label(np.array([-1., 0., 3.])), np.array([0., 0., 3.]))
