@@ -2166,7 +2166,7 @@ __global__ void bwdw_reduce_kernel(const BwdWReduceParams P) {
 // Deterministic in-workgroup reduction of the four waves' accumulator tiles through LDS (waves 2,3 -> 0,1, then 1 -> 0) and
 // ONE partial per workgroup in global memory: [chunk][cot][sg][tap][16 ci][32 co].  Needs 2 * NT * 512 floats of LDS.
 #define BW_RED_LDS(NT_) ((size_t)2 * (NT_) * 512 * sizeof(float))
-template <int NT>
+template <int NT, bool NPERM = false>
 __device__ __forceinline__ void bwdw_wg_reduce_store(f32x4 (&acc)[NT][2], float* __restrict__ lds, float* __restrict__ pp,
                                                      int wave, int lane) {
   const int li = lane & 15, lk = lane >> 4;
@@ -2209,7 +2209,7 @@ __device__ __forceinline__ void bwdw_wg_reduce_store(f32x4 (&acc)[NT][2], float*
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          pp[(size_t)t * 512 + (lk * 4 + j) * 32 + h * 16 + li] = acc[t][h][j] + b[((t * 2 + h) * 4 + j) * 64];
+          pp[(size_t)t * 512 + (lk * 4 + j) * 32 + (NPERM ? 2 * li + h : h * 16 + li)] = acc[t][h][j] + b[((t * 2 + h) * 4 + j) * 64];
   }
 }
 
@@ -2355,19 +2355,19 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
 // per column instead of once per output plane (the tile kernel above re-stages all three planes of every tile); one barrier per
 // plane.  While the 432 MFMAs of plane d issue, plane d+2 of X and the Y fragments of plane d+1 are in flight.
 // Voxel pitch 16 (SW = 1) / 24 (SW = 2) dwords makes the four k-groups of an A-fragment ds_read_b32 land on disjoint banks.
-template <int KH, int KW, int SH, int SW, int TH, int TW, int VEC>
+template <int KH, int KW, int SH, int SW, int TH, int TW, int VEC, int YV>
 __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P) {
   constexpr int KD = 3, NT = KD * KH * KW;
   constexpr int PH = (KH == 3) ? 1 : 0, PW = (KW == 3) ? 1 : 0;
   constexpr int LH = (TH - 1) * SH + KH, LW = (TW - 1) * SW + KW, TV = TH * TW;
-  constexpr int KS = TV / 16, SPR = TW / 4;
+  constexpr int KS = TV / 16, SPR = TW / 4;      // k-steps (4 voxels each) per wave and per tile row
   constexpr int PITCH = (SW == 1) ? 16 : 24;
   // staging geometry: 64 lanes = VPS voxels x LPV channel groups; NI steps cover a row, RPW rows per wave.  Rows are padded to
   // LWP = NI*VPS voxels in LDS so that every lane of every step may store unconditionally.
   constexpr int LPV = FCK / VEC, VPS = 64 / LPV, NI = (LW + VPS - 1) / VPS, RPW = (LH + 3) / 4, LWP = NI * VPS;
   constexpr int LHP = RPW * 4;                 // rows padded likewise: every wave stores RPW rows unconditionally
   constexpr int PLANE = LHP * LWP * PITCH;
-  static_assert(TV == 128, "tile must hold 128 voxels");
+  static_assert(TV % 64 == 0 && (KS % SPR == 0 || SPR % KS == 0), "tile must split evenly over 4 waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2386,25 +2386,26 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[t][h][j] = 0.f;
 
-  const int row0 = (wave * KS) / SPR;
-  const int xlane = ((row0 * SH * LWP) + lk * SW) * PITCH + li;
-  const int co = cot * 32 + li;
+  const int row0 = (wave * KS) / SPR, col0 = 4 * ((wave * KS) % SPR);
+  const int xlane = ((row0 * SH * LWP) + (col0 + lk) * SW) * PITCH + li;
+  // N permutation: column li of the MFMA for half h is output channel 2*li + h, so a lane's two B operands are ADJACENT in
+  // memory (one 8-byte load) — bwdw_wg_reduce_store<NT, true> undoes it when the partial is written
+  const int co0 = cot * 32 + 2 * li;
   const bool yaff = Y.scale != nullptr;
   const size_t ysample = (size_t)c.Do * c.Ho * c.Wo * Y.cs;
   const size_t xsample = (size_t)c.Di * c.Hi * c.Wi * S.cs;
-  const int xplane_bytes = c.Hi * c.Wi * S.cs * 4, yplane_bytes = c.Ho * c.Wo * Y.cs * 4;
+  const int xplane_bytes = __builtin_amdgcn_readfirstlane(c.Hi * c.Wi * S.cs * 4);
+  const int yplane_bytes = __builtin_amdgcn_readfirstlane(c.Ho * c.Wo * Y.cs * 4);
 
   // staging lane constants
   const int cl = (lane % LPV) * VEC, vl = lane / LPV;
   const bool xaff = S.scale != nullptr;
   const float xslope = xaff ? S.slope : 1.f;
-  bool cval[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) cval[e] = (cl + e) < cc.ck;
   const int swlane = vl * PITCH + cl + wave * (LWP * PITCH);      // this lane's LDS store offset inside a plane (row r: + 4r rows)
+  const int yoob1 = (co0 + 1 < c.Cout) ? 0 : (int)0x80000000;      // second channel of the pair exists?
 
   float xv[RPW][NI][VEC];      // the X plane in flight
-  float ycur[KS][2], ynxt[KS][2];
+  float ycur[KS][2];           // dY fragments of the current plane; refilled in place for the next plane
 
   for (int unit = sg; unit < P.nunits; unit += P.nsg) {
     int r = unit;
@@ -2417,20 +2418,19 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
     const int d0 = seg * P.dseg;
     const int d1 = (d0 + P.dseg < c.Do) ? d0 + P.dseg : c.Do;
 
-    // ---- per-unit constants: every per-plane load below is (constant VGPR offset, scalar plane/row offset)
+    // ---- per-unit constants: every per-plane load below is (constant VGPR offset, scalar plane/row offset).  Validity is
+    // carried as data (masks / out-of-range offsets), never as control flow: uniform conditions would otherwise become dozens
+    // of scalar branches around single loads and stores
     __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * xsample), 0, (int)(xsample * 4), 0x00020000);
     __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Y.ptr + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
-    // validity is carried as data (masks / out-of-range offsets), never as control flow: uniform conditions would otherwise
-    // become dozens of scalar branches around single loads and stores
     int xvo[NI];
-    unsigned mval[NI][VEC];
+    unsigned mval[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int lw = vl + i * VPS, uw = uw0 + lw;
       const bool ok = (lw < LW) && ((unsigned)uw < (unsigned)c.Wi);
-      xvo[i] = (ok && cval[0]) ? (uw * S.cs + cc.c0 + cl) * 4 : (int)0x80000000;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) mval[i][e] = (ok && cval[e]) ? 0xffffffffu : 0u;
+      xvo[i] = ok ? (uw * S.cs + cc.c0 + cl) * 4 : (int)0x80000000;
+      mval[i] = ok ? 0xffffffffu : 0u;
     }
     int rowm[RPW], rowoff[RPW];
 #pragma unroll
@@ -2443,23 +2443,22 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
     float sc[VEC], sh[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      sc[e] = 1.f; sh[e] = 0.f;
-      if (xaff && cval[e]) { sc[e] = S.scale[(size_t)nb * S.C + cc.c0 + cl + e]; sh[e] = S.shift[(size_t)nb * S.C + cc.c0 + cl + e]; }
+      const bool cv = (cl + e) < cc.ck;
+      sc[e] = cv ? 1.f : 0.f; sh[e] = 0.f;                    // channel slots beyond the chunk stage as zeros
+      if (xaff && cv) { sc[e] = S.scale[(size_t)nb * S.C + cc.c0 + cl + e]; sh[e] = S.shift[(size_t)nb * S.C + cc.c0 + cl + e]; }
     }
-    int yvo[KS][2];
+    int yvo[KS];
 #pragma unroll
     for (int s2 = 0; s2 < KS; ++s2) {
       const int ks = wave * KS + s2;
       const int oh = oh0 + ks / SPR, ow = ow0 + 4 * (ks % SPR) + lk;
-      const bool vok = (oh < c.Ho) && (ow < c.Wo);
-      const int base = ((oh * c.Wo + ow) * Y.cs + co) * 4;
-      yvo[s2][0] = (vok && co < c.Cout) ? base : (int)0x80000000;
-      yvo[s2][1] = (vok && co + 16 < c.Cout) ? base + 64 : (int)0x80000000;
+      const bool vok = (oh < c.Ho) && (ow < c.Wo) && (co0 < c.Cout);
+      yvo[s2] = vok ? ((oh * c.Wo + ow) * Y.cs + co0) * 4 : (int)0x80000000;
     }
     float ysc0 = 1.f, ysh0 = 0.f, ysc1 = 1.f, ysh1 = 0.f;
     if (yaff) {
-      if (co < c.Cout) { ysc0 = Y.scale[(size_t)nb * Y.C + co]; ysh0 = Y.shift[(size_t)nb * Y.C + co]; }
-      if (co + 16 < c.Cout) { ysc1 = Y.scale[(size_t)nb * Y.C + co + 16]; ysh1 = Y.shift[(size_t)nb * Y.C + co + 16]; }
+      if (co0 < c.Cout) { ysc0 = Y.scale[(size_t)nb * Y.C + co0]; ysh0 = Y.shift[(size_t)nb * Y.C + co0]; }
+      if (co0 + 1 < c.Cout) { ysc1 = Y.scale[(size_t)nb * Y.C + co0 + 1]; ysh1 = Y.shift[(size_t)nb * Y.C + co0 + 1]; }
     }
 
     auto load_x = [&](int ud) {            // issue only
@@ -2499,7 +2498,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
           for (int e = 0; e < VEC; ++e) {
             const float t = fmaf(xv[q][i][e], scq[e], shq[e]);
             const float a = mt_lrelu(t, xslope);
-            x[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & mval[i][e]);
+            x[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & mval[i]);
           }
           float* d = lp + (4 * q * LWP + i * VPS) * PITCH;
           if constexpr (VEC == 2) { float2 t; t.x = x[0]; t.y = x[1]; *(float2*)d = t; }
@@ -2507,39 +2506,41 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
         }
       }
     };
-    auto load_y = [&](int od) {
-      const int poff = od * yplane_bytes;
-#pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) {
-        ynxt[s2][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yvo[s2][0], poff, 0));
-        ynxt[s2][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yvo[s2][1], poff, 0));
+    auto load_y1 = [&](int s2, int poff, int oob) {      // the two dY operands of one k-step (oob masks a finished segment)
+      if constexpr (YV == 2) {
+        const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(yrs, yvo[s2] | oob, poff, 0));
+        ycur[s2][0] = t.x; ycur[s2][1] = t.y;
+      } else {
+        ycur[s2][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yvo[s2] | oob, poff, 0));
+        ycur[s2][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, yvo[s2] | oob | yoob1, poff + 4, 0));
       }
     };
-    auto rotate_y = [&]() {
+    auto activate_y = [&]() {          // lazy InstanceNorm+LeakyReLU of the dY fragments, in place; invalid lanes stay zero
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) {
-        if (yaff) {
-          ycur[s2][0] = (yvo[s2][0] >= 0) ? mt_lrelu(fmaf(ynxt[s2][0], ysc0, ysh0), Y.slope) : 0.f;
-          ycur[s2][1] = (yvo[s2][1] >= 0) ? mt_lrelu(fmaf(ynxt[s2][1], ysc1, ysh1), Y.slope) : 0.f;
-        } else { ycur[s2][0] = ynxt[s2][0]; ycur[s2][1] = ynxt[s2][1]; }
+        ycur[s2][0] = (yvo[s2] >= 0) ? mt_lrelu(fmaf(ycur[s2][0], ysc0, ysh0), Y.slope) : 0.f;
+        ycur[s2][1] = (yvo[s2] >= 0 && yoob1 == 0) ? mt_lrelu(fmaf(ycur[s2][1], ysc1, ysh1), Y.slope) : 0.f;
       }
     };
 
-    // ---- prologue: planes d0-1 and d0 into the ring, plane d0+1 and the Y fragments of plane d0 in flight
+    // ---- prologue: planes d0-1 and d0 into the ring, plane d0+1 and the dY fragments of plane d0 in flight
     __syncthreads();       // the previous unit's A reads are done
-    if (!(BW_ABL & 1)) { load_x(d0 - 1); store_x(d0 - 1, (d0 + 3) & 3); load_x(d0); store_x(d0, d0 & 3); load_x(d0 + 1); }
-    if (!(BW_ABL & 2)) load_y(d0);
+    load_x(d0 - 1); store_x(d0 - 1, (d0 + 3) & 3); load_x(d0); store_x(d0, d0 & 3); load_x(d0 + 1);
+    {
+      const int p0 = __builtin_amdgcn_readfirstlane(d0 * yplane_bytes);
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) load_y1(s2, p0, 0);
+    }
 
     for (int d = d0; d < d1; ++d) {
       // slot (d+1)&3 last held plane d-3, read no later than step d-2: every wave has passed the barrier of step d-1 since
-      if (!(BW_ABL & 1)) store_x(d + 1, (d + 1) & 3);
-      if (!(BW_ABL & 2)) rotate_y();
+      store_x(d + 1, (d + 1) & 3);
+      if (yaff) activate_y();
       __syncthreads();
-      if (d + 1 < d1) {
-        if (!(BW_ABL & 1)) load_x(d + 2);
-        if (!(BW_ABL & 2)) load_y(d + 1);
-      }
-      if (BW_ABL & 8) continue;
+      const bool more = d + 1 < d1;
+      if (more) load_x(d + 2);
+      const int ynext = __builtin_amdgcn_readfirstlane(more ? (d + 1) * yplane_bytes : 0);
+      const int yoob = __builtin_amdgcn_readfirstlane(more ? 0 : (int)0x80000000);
       int xb[3];
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd) xb[kd] = ((d + 3 + kd) & 3) * PLANE + xlane;      // plane d-1+kd
@@ -2551,7 +2552,9 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
       for (int s2 = 0; s2 < KS; ++s2) {
         float (&ac)[NT] = (s2 & 1) ? a1 : a0;
         float (&an)[NT] = (s2 & 1) ? a0 : a1;
-        const int svox = ((s2 + 1) / SPR) * SH * LWP + 4 * ((s2 + 1) % SPR) * SW;
+        // voxel offset of k-step s2+1 relative to this wave's first k-step (rows advance every SPR k-steps)
+        const int ksn = s2 + 1;
+        const int svox = (ksn / SPR) * SH * LWP + 4 * (ksn % SPR) * SW;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           if (s2 + 1 < KS) an[t] = lds[xb[t / (KH * KW)] + (svox + ((t / KW) % KH) * LWP + (t % KW)) * PITCH];
@@ -2559,10 +2562,12 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
           acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][1], acc[t][1], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
+        load_y1(s2, ynext, yoob);          // this k-step's operands are consumed: fetch the next plane's in place
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
-  bwdw_wg_reduce_store<NT>(acc, lds, P.part + ((size_t)((size_t)(chi * P.ncot + cot) * P.nsg + sg) * NT) * 512, wave, lane);
+  bwdw_wg_reduce_store<NT, true>(acc, lds, P.part + ((size_t)((size_t)(chi * P.ncot + cot) * P.nsg + sg) * NT) * 512, wave, lane);
 }
 
 // Stem backward-weight (Cin = 1): dW[tap][cout] = sum over voxels of x[voxel + tap] * dY[voxel][cout] as a GEMM with
@@ -2690,7 +2695,12 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   if (nsg < 1) nsg = 1;
   P->nsg = nsg;
   P->nunits = 0; P->nseg = 1; P->dseg = p->Do;
-  if (bwdw_use_march(p)) bwdw_march_plan(p, P);
+  if (bwdw_use_march(p)) {
+    static int tall = -1;
+    if (tall < 0) { const char* e = getenv("MT_BWDW_TALL"); tall = e ? atoi(e) : 1; }
+    if (tall && wide && p->Ho >= 8) { P->TH = 8; P->tilesH = mt_cdiv(p->Ho, 8); P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N; }
+    bwdw_march_plan(p, P);
+  }
 }
 
 // marching plan: columns x D segments; the segment count balances the units over the workgroups of a (chunk, cout tile) pair
@@ -2709,27 +2719,32 @@ static void bwdw_march_plan(const mt_conv3d_t* p, BwdWParams* P) {
   P->nsg = P->nsg_cap < P->nunits ? P->nsg_cap : P->nunits;
 }
 template <int KH, int KW, int SH, int SW>
-static int launch_bwdw_march(const BwdWParams& P, int vec, hipStream_t st) {
+static int launch_bwdw_march(const BwdWParams& P, int vec, int yv, hipStream_t st) {
   constexpr int PITCH = (SW == 1) ? 16 : 24;
-  constexpr int LHa = 3 * SH + KH, LWa = 31 * SW + KW, LHb = 7 * SH + KH, LWb = 15 * SW + KW;
   const int vps = vec == 2 ? 8 : 4;                                 // voxels per staging step; rows are padded to a multiple
-  const int lwa = mt_cdiv(LWa, vps) * vps, lwb = mt_cdiv(LWb, vps) * vps;
-  const int lha = mt_cdiv(LHa, 4) * 4, lhb = mt_cdiv(LHb, 4) * 4;
-  size_t ldsb = (size_t)4 * (P.TW == 32 ? lha * lwa : lhb * lwb) * PITCH * sizeof(float);
+  const int LH = (P.TH - 1) * SH + KH, LW = (P.TW - 1) * SW + KW;
+  size_t ldsb = (size_t)4 * (mt_cdiv(LH, 4) * 4) * (mt_cdiv(LW, vps) * vps) * PITCH * sizeof(float);
   if (ldsb < BW_RED_LDS(3 * KH * KW)) ldsb = BW_RED_LDS(3 * KH * KW);
   MT_REQUIRE(ldsb <= 160 * 1024, "bwd_weight: LDS ring too large (%zu)", ldsb);
   dim3 grid(P.nsg, P.ncot, P.nchunks);
-#define MT_BW_LAUNCH(TH_, TW_, VEC_)                                                                          \
+#define MT_BW_LAUNCH(TH_, TW_, VEC_, YV_)                                                                     \
   do {                                                                                                        \
-    auto kfn = conv_bwdw_march_kernel<KH, KW, SH, SW, TH_, TW_, VEC_>;                                        \
+    auto kfn = conv_bwdw_march_kernel<KH, KW, SH, SW, TH_, TW_, VEC_, YV_>;                                   \
     if (ldsb > 64 * 1024) {                                                                                   \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
       if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; } \
     }                                                                                                         \
     hipLaunchKernelGGL(kfn, grid, dim3(256), ldsb, st, P);                                                    \
   } while (0)
-  if (P.TW == 32) { if (vec == 2) MT_BW_LAUNCH(4, 32, 2); else MT_BW_LAUNCH(4, 32, 1); }
-  else            { if (vec == 2) MT_BW_LAUNCH(8, 16, 2); else MT_BW_LAUNCH(8, 16, 1); }
+#define MT_BW_LAUNCH_T(TH_, TW_)                                                                              \
+  do {                                                                                                        \
+    if (vec == 2) { if (yv == 2) MT_BW_LAUNCH(TH_, TW_, 2, 2); else MT_BW_LAUNCH(TH_, TW_, 2, 1); }           \
+    else          { if (yv == 2) MT_BW_LAUNCH(TH_, TW_, 1, 2); else MT_BW_LAUNCH(TH_, TW_, 1, 1); }           \
+  } while (0)
+  if (P.TW == 32 && P.TH == 8) MT_BW_LAUNCH_T(8, 32);
+  else if (P.TW == 32)         MT_BW_LAUNCH_T(4, 32);
+  else                         MT_BW_LAUNCH_T(8, 16);
+#undef MT_BW_LAUNCH_T
 #undef MT_BW_LAUNCH
   MT_CHECK_LAUNCH("conv_bwdw_march");
   return MT_OK;
@@ -2851,7 +2866,11 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     hipStream_t st = (hipStream_t)stream;
     int rc = MT_EINVAL;
     switch (geo) {
-      case 0: rc = bwdw_use_march(p) ? launch_bwdw_march<3, 3, 1, 1>(P, vec, st) : launch_bwdw_fast<3, 3, 3, 1, 1, 1>(P, vec, st); break;
+      case 0: {
+        const int yv = ((ysrc->cs & 1) || (p->Cout & 1) || (((uintptr_t)ysrc->ptr) & 7)) ? 1 : 2;
+        rc = bwdw_use_march(p) ? launch_bwdw_march<3, 3, 1, 1>(P, vec, yv, st) : launch_bwdw_fast<3, 3, 3, 1, 1, 1>(P, vec, st);
+        break;
+      }
       case 1: rc = launch_bwdw_fast<3, 3, 3, 2, 2, 2>(P, vec, st); break;
       case 2: rc = launch_bwdw_fast<3, 3, 3, 1, 2, 2>(P, vec, st); break;
       case 3: rc = launch_bwdw_fast<2, 2, 2, 2, 2, 2>(P, vec, st); break;
