@@ -24,6 +24,17 @@ from ...dataset_conversion.Task100_MultiTalent import (MultiTalent_region_output
 from ...ops import Act
 
 _ws_cache = {}
+_const_cache = {}
+
+
+def _const(values, dev):
+    """Small constant vector on the device, uploaded once (a per-step torch.tensor(list, device=...) is a blocking copy)."""
+    key = (tuple(float(v) for v in values), str(dev))
+    t = _const_cache.get(key)
+    if t is None:
+        t = torch.tensor(key[0], dtype=torch.float32, device=dev)
+        _const_cache[key] = t
+    return t
 
 
 def _workspace(dev, nbytes):
@@ -107,6 +118,7 @@ class MultiTalentLoss(nn.Module):
             lut[self.region_idx[name]] = m
         self._lut_host = np.array(lut, dtype=np.uint64).view(np.int64)
         self._lut = {}
+        self._valid_cache = {}
 
     def _masks(self, valid_regions, dev):
         if dev not in self._lut:
@@ -117,7 +129,13 @@ class MultiTalentLoss(nn.Module):
             for r in names:
                 m |= (1 << self.region_idx[r])
             v.append(m)
-        valid = torch.from_numpy(np.array(v, dtype=np.uint64).view(np.int64)).to(dev)
+        key = (tuple(v), str(dev))                    # the per-sample masks repeat (one per dataset): upload each combination once
+        valid = self._valid_cache.get(key)
+        if valid is None:
+            if len(self._valid_cache) > 4096:
+                self._valid_cache.clear()
+            valid = torch.from_numpy(np.array(v, dtype=np.uint64).view(np.int64)).to(dev)
+            self._valid_cache[key] = valid
         return valid, self._lut[dev]
 
     def forward(self, output, target, valid_regions):
@@ -132,18 +150,16 @@ class MultiTalentLoss(nn.Module):
         stats_all = torch.stack(stats_all, 0)                                  # [L, B, C, 4]
         dice_stats = stats_all[..., 1:]
         if self.batch_dice:
-            # sum over RANKS only (same local sample index), one collective for all levels (distributed.py:60-73)
             dice_stats = distributed_utils.sum_over_ranks(dice_stats)
-        for i in range(len(output)):
-            w = self.ds_loss_weights[i]
-            ce_loss = stats_all[i, :, :, 0].sum() / nvox[i]                    # mean over voxels, summed over (b, region)
-            tp, fp, fn = dice_stats[i, :, :, 0], dice_stats[i, :, :, 1], dice_stats[i, :, :, 2]
-            dc = (2 * tp / torch.clamp(2 * tp + fp + fn, min=1e-7)).sum()
-            l = w * (ce_loss - dc)
-            total_loss = l if total_loss is None else total_loss + l
-            total_ce = w * ce_loss if total_ce is None else total_ce + w * ce_loss
-            total_dc = w * dc if total_dc is None else total_dc + w * dc
-        return total_loss, total_ce, total_dc
+        # all levels at once ([L]-vectors): the per-level Python loop of the reference costs ~40 tiny launches per level
+        w = _const(self.ds_loss_weights[:len(output)], dev)
+        inv_nvox = _const([1.0 / n for n in nvox], dev)
+        ce = stats_all[..., 0].sum((1, 2)) * inv_nvox                          # BCE: mean over voxels, summed over (b, region)
+        tp, fp, fn = dice_stats[..., 0], dice_stats[..., 1], dice_stats[..., 2]
+        dc = (2 * tp / torch.clamp(2 * tp + fp + fn, min=1e-7)).sum((1, 2))
+        total_ce = (w * ce).sum()
+        total_dc = (w * dc).sum()
+        return total_ce - total_dc, total_ce, total_dc
 
 
 class DC_and_CE_DS_loss(nn.Module):
@@ -179,8 +195,37 @@ class DC_and_CE_DS_loss(nn.Module):
         return ce - dc.mean()
 
     def forward(self, output, target):
-        l = self.ds_loss_weights[0] * self.level_loss(output[0], target[0])
-        for i in range(1, len(output)):
-            if self.ds_loss_weights[i] != 0:
+        active = [i for i in range(len(output)) if i == 0 or self.ds_loss_weights[i] != 0]     # deep_supervision.py:37-42
+        if len({tuple(output[i].shape[:2]) for i in active}) != 1:
+            l = self.ds_loss_weights[0] * self.level_loss(output[0], target[0])
+            for i in active[1:]:
                 l = l + self.ds_loss_weights[i] * self.level_loss(output[i], target[i])
-        return l
+            return l
+        # same (B, C) at every level: combine all levels with [L]-vector math (the per-level loop is ~40 tiny launches each)
+        dev = output[0].device
+        stats, bv = [], []
+        for i in active:
+            t = _target_flat(target[i])
+            stats.append(_SoftmaxStats.apply(output[i], t))
+            bv.append(t.shape[0] * t.shape[1])
+        st = torch.stack(stats, 0)                                             # [L, B, C, 4]
+        w = _const([self.ds_loss_weights[i] for i in active], dev)
+        inv_bv = _const([1.0 / n for n in bv], dev)
+        ce = st[:, :, 0, 0].sum(1) * inv_bv                                    # CrossEntropyLoss mean over all voxels
+        tp, fp, fn = st[..., 1], st[..., 2], st[..., 3]
+        if not self.do_bg:
+            tp, fp, fn = tp[:, :, 1:], fp[:, :, 1:], fn[:, :, 1:]
+        if self.ddp:
+            nominator = 2 * tp
+            denominator = 2 * tp + fp + fn
+            if self.batch_dice:
+                nd = distributed_utils.sum_over_ranks(torch.stack((nominator, denominator), 0))
+                nominator, denominator = nd[0], nd[1]
+            dice_loss = (-(nominator + self.smooth) / (denominator + self.smooth)).mean((1, 2))
+            return (w * (ce + dice_loss)).sum()
+        if self.batch_dice:
+            tp, fp, fn = tp.sum(1), fp.sum(1), fn.sum(1)
+            dc = ((2 * tp + self.smooth) / (2 * tp + fp + fn + self.smooth + 1e-8)).mean(1)
+        else:
+            dc = ((2 * tp + self.smooth) / (2 * tp + fp + fn + self.smooth + 1e-8)).mean((1, 2))
+        return (w * (ce - dc)).sum()
