@@ -98,6 +98,15 @@ int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats,
 int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream);
 int mt_conv3d_stats_blocks(const mt_conv3d_t* p); /* spatial blocks per sample (size of stats_part dim 1) */
 int mt_conv3d_ck(const mt_conv3d_t* p);           /* channel chunk the kernel will use (pack weights with it) */
+/* Batched packing: all layers of one optimizer step in one launch.  mt_pack_desc_fill writes one opaque descriptor
+ * (mt_pack_desc_size() bytes, same arguments as mt_pack_conv_weights) into HOST memory; the caller uploads the table once and
+ * calls mt_pack_batched(table_on_device, n) every step — the descriptors stay valid while the weight and destination buffers
+ * do. */
+size_t mt_pack_desc_size(void);
+int mt_pack_desc_fill(void* desc, const float* w, float* dst, int C0, int C1, int Cout, int KD, int KH, int KW, long s_ci,
+                      long s_co, long s_kd, long s_kh, long s_kw, int flip, int ck, int layout, const int32_t* tapmap);
+int mt_pack_batched(const void* descs_device, int n, mt_stream_t stream);
+
 /* Backward-data of a strided 3x3x3 convolution (pad 1, stride (2,2,2) or (1,2,2)) in one launch — replaces autograd's
  * conv_transpose for the strided stage convs (generic_UNet.py:263-278 `first_stride`, generic_modular_UNet.py:69-77).
  * p carries the FORWARD geometry: Di/Hi/Wi = X dims, Do/Ho/Wo = Y dims, K, S, P, Cin, Cout; src[0] = dY (C = Cout, may be lazy);

@@ -61,6 +61,9 @@ SIGNATURES = {
     'mt_conv3d_fwd': (_i, [_P(mt_conv3d_t), _vp]),
     'mt_conv3d_stats_blocks': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_ck': (_i, [_P(mt_conv3d_t)]),
+    'mt_pack_desc_size': (_sz, []),
+    'mt_pack_desc_fill': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _i, _vp]),
+    'mt_pack_batched': (_i, [_vp, _i, _vp]),
     'mt_conv3d_bwd_data_strided': (_i, [_P(mt_conv3d_t), _vp]),
     'mt_conv3d_bwd_data_strided_supported': (_i, [_P(mt_conv3d_t)]),
     'mt_downsample_seg_nearest': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),

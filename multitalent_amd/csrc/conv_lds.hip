@@ -16,6 +16,7 @@
 //  * epilogue adds bias, writes NDHWC (optionally into two destinations = split of a concat
 //    gradient, optionally accumulating) and emits per-block (sum, sumsq) partials for InstanceNorm.
 #include "mt_common.h"
+#include <cstring>
 #include <stdlib.h>
 
 struct ConvChunk { short src, c0, ck, cglob; };
@@ -1902,9 +1903,9 @@ struct PackParams {
   long s_ci, s_co, s_kd, s_kh, s_kw;
   ConvChunk chunk[MT_MAX_CHUNKS];
 };
-__global__ void pack_weights_kernel(const PackParams P) {
+__device__ __forceinline__ void pack_weights_body(const PackParams& P, long first, long stride) {
   const long total = (long)P.ntiles * P.nchunks * P.KD * P.KH * P.KW * P.nkp * 64;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first; i < total; i += stride) {
     long r = i;
     int l, kp;
     if (P.layout == 1) {      // [.. tap][kp/4][lane][4]: one float4 per lane carries 4 consecutive channel pairs
@@ -1936,25 +1937,56 @@ __global__ void pack_weights_kernel(const PackParams P) {
     P.dst[i] = v;
   }
 }
+__global__ void pack_weights_kernel(const PackParams P) {
+  pack_weights_body(P, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+// every layer's packing of one optimizer step in ONE launch: blockIdx.y selects the descriptor (table in device memory)
+__global__ void pack_weights_batched_kernel(const PackParams* __restrict__ tab) {
+  pack_weights_body(tab[blockIdx.y], (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
 
-extern "C" int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats, int C0, int C1, int Cout,
-                                    int KD, int KH, int KW, long s_ci, long s_co, long s_kd, long s_kh, long s_kw,
-                                    int flip, int ck, int layout, const int32_t* tapmap, mt_stream_t stream) {
+static int pack_fill(PackParams& P, size_t* packed_floats, const float* w, float* dst, int C0, int C1, int Cout, int KD, int KH,
+                     int KW, long s_ci, long s_co, long s_kd, long s_kh, long s_kw, int flip, int ck, int layout,
+                     const int32_t* tapmap) {
   MT_REQUIRE(ck >= 2 && (ck % 2) == 0, "pack: ck must be even (got %d)", ck);
   MT_REQUIRE(layout == 0 || (layout == 1 && (ck % 8) == 0), "pack: layout 1 needs ck %% 8 == 0");
-  PackParams P;
+  std::memset((void*)&P, 0, sizeof(P));
   P.nchunks = mt_build_chunks(C0, C1, ck, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "pack: too many chunks");
   P.ntiles = mt_cdiv(Cout, 32);
   P.nkp = ck / 2;
-  const size_t total = (size_t)P.ntiles * P.nchunks * KD * KH * KW * P.nkp * 64;
-  if (packed_floats) *packed_floats = total;
-  if (dst == nullptr) return MT_OK;
-  MT_REQUIRE(w != nullptr, "pack: null weights");
+  if (packed_floats) *packed_floats = (size_t)P.ntiles * P.nchunks * KD * KH * KW * P.nkp * 64;
   P.w = w; P.dst = dst; P.Cout = Cout; P.KD = KD; P.KH = KH; P.KW = KW; P.flip = flip; P.layout = layout;
   P.has_tm = tapmap != nullptr;
   for (int d = 0; d < 3; ++d) { P.tb[d] = tapmap ? tapmap[2 * d] : 0; P.ts[d] = tapmap ? tapmap[2 * d + 1] : 1; }
   P.s_ci = s_ci; P.s_co = s_co; P.s_kd = s_kd; P.s_kh = s_kh; P.s_kw = s_kw;
+  return MT_OK;
+}
+extern "C" size_t mt_pack_desc_size(void) { return sizeof(PackParams); }
+extern "C" int mt_pack_desc_fill(void* desc, const float* w, float* dst, int C0, int C1, int Cout, int KD, int KH, int KW,
+                                 long s_ci, long s_co, long s_kd, long s_kh, long s_kw, int flip, int ck, int layout,
+                                 const int32_t* tapmap) {
+  MT_REQUIRE(desc != nullptr && w != nullptr && dst != nullptr, "pack_desc_fill: null pointers");
+  return pack_fill(*(PackParams*)desc, nullptr, w, dst, C0, C1, Cout, KD, KH, KW, s_ci, s_co, s_kd, s_kh, s_kw, flip, ck, layout, tapmap);
+}
+extern "C" int mt_pack_batched(const void* descs_device, int n, mt_stream_t stream) {
+  MT_REQUIRE(descs_device != nullptr && n > 0, "pack_batched: empty table");
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(48, (unsigned)n, 1), dim3(256), 0, (hipStream_t)stream,
+                     (const PackParams*)descs_device);
+  MT_CHECK_LAUNCH("pack_weights_batched");
+  return MT_OK;
+}
+
+extern "C" int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats, int C0, int C1, int Cout,
+                                    int KD, int KH, int KW, long s_ci, long s_co, long s_kd, long s_kh, long s_kw,
+                                    int flip, int ck, int layout, const int32_t* tapmap, mt_stream_t stream) {
+  PackParams P;
+  size_t total = 0;
+  int rc = pack_fill(P, &total, w, dst, C0, C1, Cout, KD, KH, KW, s_ci, s_co, s_kd, s_kh, s_kw, flip, ck, layout, tapmap);
+  if (rc != MT_OK) return rc;
+  if (packed_floats) *packed_floats = total;
+  if (dst == nullptr) return MT_OK;
+  MT_REQUIRE(w != nullptr, "pack: null weights");
   int blocks = mt_cdiv((long)total, 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
   MT_CHECK_LAUNCH("pack_weights");
@@ -2155,8 +2187,18 @@ __global__ void bwdw_reduce_kernel(const BwdWReduceParams P) {
     const int co = cot * 32 + col;
     if (cil >= cc.ck || co >= P.Cout) continue;
     const float* pp = P.part + ((size_t)(chi * P.ncot + cot) * P.nsg * P.ntaps + tap) * 512 + cil * 32 + col;
-    double s = 0.0;
-    for (int g = 0; g < P.nsg; ++g) s += (double)pp[(size_t)g * P.ntaps * 512];
+    // four independent chains keep several loads in flight (the order is fixed, so the result stays deterministic)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const size_t gs = (size_t)P.ntaps * 512;
+    int g = 0;
+    for (; g + 4 <= P.nsg; g += 4) {
+      s0 += (double)pp[(size_t)g * gs];
+      s1 += (double)pp[(size_t)(g + 1) * gs];
+      s2 += (double)pp[(size_t)(g + 2) * gs];
+      s3 += (double)pp[(size_t)(g + 3) * gs];
+    }
+    for (; g < P.nsg; ++g) s0 += (double)pp[(size_t)g * gs];
+    const double s = (s0 + s1) + (s2 + s3);
     const int kw = tap % P.KW, kh = (tap / P.KW) % P.KH, kd = tap / (P.KW * P.KH);
     const long o = (long)(cc.cglob + cil) * P.s_ci + (long)co * P.s_co + kd * P.s_kd + kh * P.s_kh + kw * P.s_kw;
     if (P.accumulate) P.dw[o] += (float)s; else P.dw[o] = (float)s;

@@ -355,6 +355,7 @@ class Engine:
         self._ws = None
         self._planned = None
         self._packed_version = None
+        self._pack_programs = {}
         self.flat = None
         self.flat_grad = None
         self._views = {}
@@ -419,6 +420,7 @@ class Engine:
         self._buffers.clear()
         self._planned = None
         self._packed_version = None
+        self._pack_programs = {}
         self.params_version += 1
 
     def grad_of(self, p):
@@ -448,13 +450,27 @@ class Engine:
         self.x.grad = None
         self._planned = key
         self._packed_version = None
+        self._pack_programs = {}
 
     def _pack(self, need_grad):
         ver = (self.params_version, self.flat._version, need_grad)
         if self._packed_version == ver:
             return
-        for op in self.ops:
-            op.pack(self, need_grad)
+        key = (self.params_version, need_grad)
+        prog = self._pack_programs.get(key)
+        if prog is None:            # record the ops' packing calls once; afterwards every step is one batched launch
+            rec = []
+            ops._pack_recorder = rec
+            try:
+                for op in self.ops:
+                    op.pack(self, need_grad)
+            finally:
+                ops._pack_recorder = None
+            prog = ops.PackProgram(rec, self.device) if rec else None
+            self._pack_programs = {k: v for k, v in self._pack_programs.items() if k[0] == key[0]}   # drop older parameter versions
+            self._pack_programs[key] = prog
+        if prog is not None:
+            prog.run()
         self._packed_version = ver
 
     # ---- execution --------------------------------------------------------------------------------

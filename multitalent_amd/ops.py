@@ -172,6 +172,30 @@ def conv_stats_blocks(p):
     return _lib.load().mt_conv3d_stats_blocks(C.byref(p))
 
 
+_pack_recorder = None      # list while an Engine records its per-step packing program (see Engine._pack)
+
+
+class PackProgram:
+    """All weight packings of one optimizer step as ONE launch (mt_pack_batched): the descriptors are recorded once from the
+    ordinary pack_conv_weights calls and live in a device table; valid while the weight and destination buffers are."""
+
+    def __init__(self, records, device):
+        lib = _lib.load()
+        sz = lib.mt_pack_desc_size()
+        self.n = len(records)
+        host = (C.c_uint8 * (sz * self.n))()
+        self.keep = []
+        for i, (w, out, args, tm) in enumerate(records):
+            tmc = (C.c_int32 * 6)(*[int(t) for t in tm]) if tm is not None else None
+            _lib.check(lib.mt_pack_desc_fill(C.cast(C.byref(host, i * sz), C.c_void_p), _ptr(w), _ptr(out), *args,
+                                             C.cast(tmc, C.c_void_p) if tmc is not None else None), 'pack_desc_fill')
+            self.keep.append((w, out))
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+
+    def run(self):
+        _lib.check(_lib.load().mt_pack_batched(_ptr(self.table), self.n, _stream()), 'pack_batched')
+
+
 def pack_conv_weights(w, C0, C1, Cout, kernel, strides, flip, ck, out=None, layout=1, tapmap=None):
     """strides = (s_ci, s_co, s_kd, s_kh, s_kw) element strides of `w` for W_eff[tap][ci][co].
     layout 1 = every MFMA kernel (mt_conv3d_fwd with ck = mt_conv3d_ck, mt_pointwise_fwd with ck = POINTWISE_CK)."""
@@ -184,6 +208,9 @@ def pack_conv_weights(w, C0, C1, Cout, kernel, strides, flip, ck, out=None, layo
     if out is None:
         out = torch.empty(n.value, dtype=torch.float32, device=w.device)
     assert out.numel() >= n.value
+    if _pack_recorder is not None:
+        _pack_recorder.append((w, out, (C0, C1, Cout, kd, kh, kw) + tuple(int(s) for s in strides) + (int(flip), ck, layout), tapmap))
+        return out
     _lib.check(lib.mt_pack_conv_weights(_ptr(w), _ptr(out), C.byref(n), C0, C1, Cout, kd, kh, kw, *strides, int(flip), ck, layout,
                                         C.cast(tm, C.c_void_p) if tm is not None else None, _stream()), 'pack')
     return out
