@@ -1,0 +1,146 @@
+"""Parity at BASELINE.json's FULL sizes (N = 2, 48x192x192 patches) through size-independent properties — the CPU oracle
+would need minutes per layer there, these identities need none:
+
+  * adjoint identity  <conv(x; w), g> = <x, bwd_data(g; w)> = <w, bwd_weight(x, g)>  ties the forward kernel to BOTH backward
+    kernels of the same layer (any indexing, padding, parity-class or tap-split mistake breaks it);
+  * linearity  conv(x1 + 2 x2) = conv(x1) + 2 conv(x2);
+  * determinism: every kernel uses fixed-order reductions, so a repeated training step is bit-identical;
+  * InstanceNorm statistics from the conv epilogue: the lazily normalised activation has mean beta and variance gamma^2.
+Tolerances: 1e-4 relative for the fp64 inner products of fp32 tensors with ~1e8 terms (observed <= 2e-6)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from multitalent_amd import ops
+    return ops
+
+
+def dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def conv_fwd(ops, x, w, stride, pad, stats=False):
+    """x: NDHWC device tensor; w: [Cout, Cin, k...] device tensor."""
+    N, Cin, Cout, k = x.shape[0], x.shape[4], w.shape[0], tuple(w.shape[2:])
+    geom = ops.ConvGeom(tuple(x.shape[1:4]), k, stride, pad)
+    out = torch.empty((N,) + geom.out + (Cout,), device=x.device)
+    p = ops.fill_conv([ops.Act(x)], geom, Cout, out0=ops.Act(out))
+    wp = ops.pack_conv_weights(w, Cin, 0, Cout, k, ops.conv_weight_strides(w), False, ops.conv_ck(p))
+    p.wpack = wp.data_ptr()
+    part = None
+    if stats:
+        part = torch.zeros((N, ops.conv_stats_blocks(p), Cout, 2), device=x.device)
+        p.stats_part = part.data_ptr()
+    name = ops.conv_kernel_name(p)
+    ops.conv3d_fwd(p)
+    return out, geom, name, part
+
+
+def conv_bwd_data(ops, g, w, geom, in_shape):
+    """the engine's choices: one-launch strided kernel when supported, else flipped-weight stride-1 conv."""
+    N, Cout, Cin, k = g.shape[0], w.shape[0], w.shape[1], tuple(w.shape[2:])
+    dx = torch.full((N,) + tuple(in_shape) + (Cin,), float('nan'), device=g.device)
+    if geom.s != (1, 1, 1):
+        p = ops.fill_conv([ops.Act(g)], geom, Cout, out0=ops.Act(dx))
+        p.Cin = Cin
+        assert ops.conv3d_bwd_data_strided_supported(p)
+        wp = ops.pack_conv_weights(w, Cout, 0, Cin, k, ops.conv_weight_strides(w, as_bwd_data=True), False, 16)
+        p.wpack = wp.data_ptr()
+        ops.conv3d_bwd_data_strided(p)
+        return dx
+    geomT = ops.ConvGeom(geom.out, k, (1, 1, 1), tuple(kk - 1 - pp for kk, pp in zip(k, geom.p)), out_spatial=in_shape)
+    p = ops.fill_conv([ops.Act(g)], geomT, Cin, out0=ops.Act(dx))
+    wp = ops.pack_conv_weights(w, Cout, 0, Cin, k, ops.conv_weight_strides(w, as_bwd_data=True), True, ops.conv_ck(p))
+    p.wpack = wp.data_ptr()
+    ops.conv3d_fwd(p)
+    return dx
+
+
+def conv_bwd_weight(ops, x, g, w_shape, geom):
+    p = ops.fill_conv([ops.Act(x)], geom, w_shape[0])
+    ws = torch.empty(max(ops.conv3d_bwd_weight_workspace(p) // 4, 1), device=x.device)
+    dw = torch.full(w_shape, float('nan'), device=x.device)
+    ops.conv3d_bwd_weight(p, ops.Act(g), dw, ops.conv_weight_strides(dw), False, ws)
+    return dw
+
+
+@pytest.mark.parametrize("Cin,Cout,shape,stride,kernel", [
+    (30, 30, (48, 192, 192), (1, 1, 1), 'conv_fast_kernel'),         # the dominant layer of the benchmark
+    (60, 30, (48, 192, 192), (1, 1, 1), 'conv_fast_kernel'),         # decoder stage 0, two chunks per source
+    (1, 30, (48, 192, 192), (1, 1, 1), 'conv_stem_kernel'),          # stem
+    (30, 60, (48, 192, 192), (2, 2, 2), 'conv_fast_strided_kernel'), # first strided stage
+    (240, 320, (6, 24, 24), (2, 2, 2), 'conv_fast_strided_kernel'),
+    (320, 320, (3, 12, 12), (1, 1, 1), 'conv_tapsplit_kernel'),      # low-resolution stage
+    (320, 320, (3, 12, 12), (1, 2, 2), 'conv_fast_strided_kernel'),  # bottleneck
+])
+def test_adjoint_identity_and_linearity_at_full_size(dev, Cin, Cout, shape, stride, kernel):
+    ops = _ops()
+    gen = torch.Generator(device='cpu').manual_seed(11)
+    N, k, pad = 2, (3, 3, 3), (1, 1, 1)
+    x = torch.randn((N,) + shape + (Cin,), generator=gen).to(dev)
+    x2 = torch.randn((N,) + shape + (Cin,), generator=gen).to(dev)
+    w = (torch.randn((Cout, Cin) + k, generator=gen) / np.sqrt(Cin * 27)).to(dev)
+    y, geom, name, _ = conv_fwd(ops, x, w, stride, pad)
+    assert name.startswith(kernel), name
+    g = torch.randn(y.shape, generator=gen).to(dev)
+    dx = conv_bwd_data(ops, g, w, geom, shape)
+    dw = conv_bwd_weight(ops, x, g, tuple(w.shape), geom)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx).all() and torch.isfinite(dw).all()
+    a, b, c = dot(y, g), dot(x, dx), dot(w, dw)
+    scale = float(y.double().norm() * g.double().norm())
+    assert abs(a - b) < 1e-4 * scale * 1e-2 + 1e-4 * abs(a), (a, b)
+    assert abs(a - c) < 1e-4 * scale * 1e-2 + 1e-4 * abs(a), (a, c)
+    # linearity
+    y2, _, _, _ = conv_fwd(ops, x2, w, stride, pad)
+    y12, _, _, _ = conv_fwd(ops, x + 2 * x2, w, stride, pad)
+    err = float((y12 - (y + 2 * y2)).abs().max() / y12.abs().max())
+    assert err < 2e-5, err
+
+
+def test_instance_norm_statistics_from_conv_epilogue_at_full_size(dev):
+    """conv epilogue partials -> finalize: the lazily normalised output has per-(n, c) mean beta and variance gamma^2."""
+    ops = _ops()
+    gen = torch.Generator(device='cpu').manual_seed(12)
+    N, C, shape = 2, 30, (48, 192, 192)
+    x = torch.randn((N,) + shape + (C,), generator=gen).to(dev)
+    w = (torch.randn((C, C, 3, 3, 3), generator=gen) / np.sqrt(C * 27)).to(dev)
+    y, geom, _, part = conv_fwd(ops, x, w, (1, 1, 1), (1, 1, 1), stats=True)
+    gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+    beta = torch.randn(C, generator=gen).to(dev)
+    st = torch.empty((4, N, C), device=dev)
+    V = int(np.prod(shape))
+    ops.inorm_finalize(part, N, part.shape[1], C, V, gamma, beta, 1e-5, st[0], st[1], st[2], st[3])
+    a = y.double() * st[2].double()[:, None, None, None, :] + st[3].double()[:, None, None, None, :]
+    m = a.mean((1, 2, 3))
+    v = a.var((1, 2, 3), unbiased=False)
+    assert float((m - beta.double()[None]).abs().max()) < 1e-4
+    assert float((v / (gamma.double()[None] ** 2) - 1).abs().max()) < 1e-3
+
+
+def test_training_step_is_bit_reproducible_at_full_size(dev):
+    """Every reduction (InstanceNorm partials, backward-weight partials, loss statistics, gradient norm) has a fixed order:
+    the same step from the same state gives bit-identical parameters."""
+    import copy
+    import bench
+    from multitalent_amd.training.hot_loop import FusedTrainStep
+    results = []
+    for _ in range(2):
+        torch.manual_seed(1234)
+        net = bench.build_network('task009')
+        net.train()
+        step = FusedTrainStep(net, bench.make_loss('task009', False), lr=1e-2, ddp=False)
+        x, largs = bench.make_batch('task009', 2, dev, 0)
+        for _ in range(2):
+            loss = step(x, *largs)
+        torch.cuda.synchronize()
+        results.append((float(loss[0] if isinstance(loss, tuple) else loss),
+                        torch.cat([p.detach().flatten() for p in net.parameters()]).clone()))
+        del step, net
+        torch.cuda.empty_cache()
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])
