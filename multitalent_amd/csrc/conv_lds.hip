@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
 // The staging pass uses 8-byte buffer loads (2 channels) with hardware bounds checking and ds_write_b64.
 #define FCK 16
 #define FCKP 20
+__device__ __constant__ float kWinoG[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
 #ifndef CF_ABL
 #define CF_ABL 0   // compile-time timing ablations of conv_fast_kernel: 1 skip staging, 4 skip epilogue, 8 skip MFMA
 #endif
@@ -1468,6 +1469,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   }
 }
 
+#include "conv_wino.inc"
+
 // ------------------------------------------------------------------------------------------------
 // host side of mt_conv3d_fwd
 struct ConvCfg { int MW, RH, TD, CK; };
@@ -1505,12 +1508,13 @@ static int pick_cfg(const mt_conv3d_t* p) {
 }
 
 // which kernel family serves a problem, and with which tile shape
-enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2, CONV_FAST_STRIDED = 3, CONV_TAPSPLIT = 4, CONV_STEM = 5 };
+enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2, CONV_FAST_STRIDED = 3, CONV_TAPSPLIT = 4, CONV_STEM = 5, CONV_WINO = 6 };
 struct ConvPlan { int kind; int cfg; };
 static bool conv_is_fast(const mt_conv3d_t* p);
 static bool conv_rt_ok(const mt_conv3d_t* p);
 static int pick_rt_cfg(const mt_conv3d_t* p);
 static bool conv_fast_strided_ok(const mt_conv3d_t* p);
+static bool conv_wino_ok(const mt_conv3d_t* p);
 static ConvPlan conv_plan(const mt_conv3d_t* p) {
   static int use_v2 = -1, use_rt = -1;
   if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
@@ -1522,6 +1526,7 @@ static ConvPlan conv_plan(const mt_conv3d_t* p) {
     if (use_stem < 0) { const char* e = getenv("MT_CONV_STEM"); use_stem = e ? atoi(e) : 1; }
     if (use_stem) { pl.kind = CONV_STEM; pl.cfg = 0; return pl; }
   }
+  if (conv_is_fast(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0 && conv_wino_ok(p)) { pl.kind = CONV_WINO; return pl; }
   if (conv_is_fast(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0) {
     pl.kind = CONV_FAST;
     // low-resolution stages: fewer than two workgroups per CU -> split the taps over the waves instead
@@ -1541,13 +1546,18 @@ static ConvPlan conv_plan(const mt_conv3d_t* p) {
 }
 extern "C" int mt_conv3d_ck(const mt_conv3d_t* p) {
   const ConvPlan pl = conv_plan(p);
+  if (pl.kind == CONV_WINO) return WCK;
   return pl.cfg < 0 ? -1 : kCfgs[pl.cfg].CK;
+}
+extern "C" int mt_conv3d_pack_layout(const mt_conv3d_t* p) {      // layout argument of mt_pack_conv_weights for this problem
+  return conv_plan(p).kind == CONV_WINO ? 2 : 1;
 }
 extern "C" int mt_conv3d_stats_blocks(const mt_conv3d_t* p) {
   const ConvPlan pl = conv_plan(p);
   if (pl.cfg < 0) return -1;
   if (pl.kind == CONV_FAST_STRIDED) return mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 8);
   if (pl.kind == CONV_TAPSPLIT) return mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 4);
+  if (pl.kind == CONV_WINO) return mt_cdiv(p->Do, 4) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 16);
   int TD, TH, TW; cfg_tile(kCfgs[pl.cfg], &TD, &TH, &TW);
   return mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW);
 }
@@ -1692,6 +1702,39 @@ static int launch_stem(const mt_conv3d_t* p, hipStream_t st) {
   return MT_OK;
 }
 
+// Winograd eligibility: FAST geometry, 8-byte channel pairs in every source, one destination, enough workgroups to fill
+// the chip with 4x4x16 tiles and enough input channels to amortise the transforms
+static bool conv_wino_ok(const mt_conv3d_t* p) {
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_CONV_WINO"); use = e ? atoi(e) : 0; }
+  if (!use) return false;
+  if (p->csplit < p->Cout || p->Cin < 16 || conv_fast_vec(p) != 2) return false;
+  if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return false;
+  const long wgs = (long)p->N * mt_cdiv(p->Do, 4) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 16) * mt_cdiv(p->Cout, 32);
+  return wgs >= 256 || use == 2;          // MT_CONV_WINO=2 forces it (tests on small shapes)
+}
+static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
+  ConvKParams P;
+  P.c = *p;
+  if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
+  P.tilesD = mt_cdiv(p->Do, 4); P.tilesH = mt_cdiv(p->Ho, 4); P.tilesW = mt_cdiv(p->Wo, 16);
+  P.nsb = P.tilesD * P.tilesH * P.tilesW;
+  P.ntaps = 27; P.dbg = 0; P.stagger = 0;
+  P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, WCK, P.chunk);
+  MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks for the Winograd kernel (Cin=%d)", p->Cin);
+  const size_t ldsb = (size_t)(W_RAWF + W_VF) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
+  hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), ldsb, st, P);
+  MT_CHECK_LAUNCH("conv3d_wino");
+  return MT_OK;
+}
+
 static size_t rt_lds(const ConvCfg& g, const mt_conv3d_t* p) {
   int TD = g.TD, TH = (32 / g.MW) * g.RH, TW = g.MW;
   const size_t LD = (TD - 1) * p->SD + p->KD, LH = (TH - 1) * p->SH + p->KH, LW = (TW - 1) * p->SW + p->KW;
@@ -1790,6 +1833,8 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
     snprintf(buf, n, "conv_tapsplit_kernel<%d>", conv_fast_vec(p));
   else if (pl.kind == CONV_STEM)
     snprintf(buf, n, "conv_stem_kernel");
+  else if (pl.kind == CONV_WINO)
+    snprintf(buf, n, "conv_wino_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
     snprintf(buf, n, "conv_fast_strided_kernel<%d, %d, %d, %d>", p->SD, p->SH, p->SW, conv_fast_vec(p));
   else if (pl.kind == CONV_RT)
@@ -1815,6 +1860,7 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   if (pl.kind == CONV_FAST_STRIDED) return launch_fast_strided(p, st);
   if (pl.kind == CONV_TAPSPLIT) return launch_tapsplit(p, st);
   if (pl.kind == CONV_STEM) return launch_stem(p, st);
+  if (pl.kind == CONV_WINO) return launch_wino(p, st);
   if (pl.kind == CONV_RT) {
     const int vec = conv_fast_vec(p);
     switch (i) {
@@ -1904,6 +1950,34 @@ struct PackParams {
   ConvChunk chunk[MT_MAX_CHUNKS];
 };
 __device__ __forceinline__ void pack_weights_body(const PackParams& P, long first, long stride) {
+  if (P.layout == 2) {     // Winograd F(2x2x2, 3x3x3): U = G g G^T (3D) in B-fragment order [ntile][chunk of 8][xi 64][lane][4]
+    const long total = (long)P.ntiles * P.nchunks * 64 * 256;
+    for (long i = first; i < total; i += stride) {
+      long r = i;
+      const int e = (int)(r % 4); r /= 4;
+      const int l = (int)(r % 64); r /= 64;
+      const int xi = (int)(r % 64); r /= 64;
+      const int ch = (int)(r % P.nchunks); r /= P.nchunks;
+      const int nt = (int)r;
+      const ConvChunk cc = P.chunk[ch];
+      const int cin_local = 4 * (l >> 5) + e, co = nt * 32 + (l & 31);
+      float v = 0.f;
+      if (cin_local < cc.ck && co < P.Cout) {
+        const int ci = cc.cglob + cin_local;
+        const int a = xi >> 4, b = (xi >> 2) & 3, c3 = xi & 3;
+        const float* wp = P.w + ci * P.s_ci + co * P.s_co;
+        for (int kd = 0; kd < 3; ++kd)
+          for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) {
+              const float g = kWinoG[a][kd] * kWinoG[b][kh] * kWinoG[c3][kw];
+              const int zd = P.flip ? 2 - kd : kd, zh = P.flip ? 2 - kh : kh, zw = P.flip ? 2 - kw : kw;
+              if (g != 0.f) v = fmaf(g, wp[zd * P.s_kd + zh * P.s_kh + zw * P.s_kw], v);
+            }
+      }
+      P.dst[i] = v;
+    }
+    return;
+  }
   const long total = (long)P.ntiles * P.nchunks * P.KD * P.KH * P.KW * P.nkp * 64;
   for (long i = first; i < total; i += stride) {
     long r = i;
@@ -1949,13 +2023,14 @@ static int pack_fill(PackParams& P, size_t* packed_floats, const float* w, float
                      int KW, long s_ci, long s_co, long s_kd, long s_kh, long s_kw, int flip, int ck, int layout,
                      const int32_t* tapmap) {
   MT_REQUIRE(ck >= 2 && (ck % 2) == 0, "pack: ck must be even (got %d)", ck);
-  MT_REQUIRE(layout == 0 || (layout == 1 && (ck % 8) == 0), "pack: layout 1 needs ck %% 8 == 0");
+  MT_REQUIRE(layout == 0 || (layout == 1 && (ck % 8) == 0) || (layout == 2 && ck == 8 && KD == 3 && KH == 3 && KW == 3 && tapmap == nullptr),
+             "pack: layout 1 needs ck %% 8 == 0; layout 2 (Winograd) needs ck == 8 and a 3x3x3 kernel");
   std::memset((void*)&P, 0, sizeof(P));
   P.nchunks = mt_build_chunks(C0, C1, ck, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "pack: too many chunks");
   P.ntiles = mt_cdiv(Cout, 32);
   P.nkp = ck / 2;
-  if (packed_floats) *packed_floats = (size_t)P.ntiles * P.nchunks * KD * KH * KW * P.nkp * 64;
+  if (packed_floats) *packed_floats = layout == 2 ? (size_t)P.ntiles * P.nchunks * 64 * 256 : (size_t)P.ntiles * P.nchunks * KD * KH * KW * P.nkp * 64;
   P.w = w; P.dst = dst; P.Cout = Cout; P.KD = KD; P.KH = KH; P.KW = KW; P.flip = flip; P.layout = layout;
   P.has_tm = tapmap != nullptr;
   for (int d = 0; d < 3; ++d) { P.tb[d] = tapmap ? tapmap[2 * d] : 0; P.ts[d] = tapmap ? tapmap[2 * d + 1] : 1; }

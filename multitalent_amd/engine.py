@@ -108,7 +108,8 @@ class ConvNormOp(_Op):
             return
         p = self._fwd_params(eng)
         self.ck_f = ops.conv_ck(p)
-        self.wf = ops.pack_conv_weights(w, C0, C1, Cout, self.kernel, _strides(w), False, self.ck_f, out=self.wf)
+        self.wf = ops.pack_conv_weights(w, C0, C1, Cout, self.kernel, _strides(w), False, self.ck_f, out=self.wf,
+                                        layout=ops.conv_pack_layout(p))
         if need_bwd and any(s.grad is not None for s in self.srcs):
             if self._use_strided_bwd(eng):
                 self.wb = ops.pack_conv_weights(w, Cout, 0, C0, self.kernel, _strides(w, as_bwd_data=True), False, 16, out=self.wb)
@@ -123,8 +124,13 @@ class ConvNormOp(_Op):
                                                        ops.conv_ck(pb), out=self.wb[i], tapmap=tapmap)
                 return
             pb = self._bwd_data_params(eng, None)
+            pb.ocs0 = C0                      # the kernel choice (and with it the packed layout) must match the launch in backward()
+            if C1:
+                pb.csplit = C0
+                pb.ocs1 = C1
             self.ck_b = ops.conv_ck(pb)
-            self.wb = ops.pack_conv_weights(w, Cout, 0, C0 + C1, self.kernel, _strides(w, as_bwd_data=True), True, self.ck_b, out=self.wb)
+            self.wb = ops.pack_conv_weights(w, Cout, 0, C0 + C1, self.kernel, _strides(w, as_bwd_data=True), True, self.ck_b, out=self.wb,
+                                            layout=ops.conv_pack_layout(pb))
 
     def _strided_bwd_params(self, g):
         """mt_conv3d_bwd_data_strided takes the FORWARD geometry with src[0] = dY and out0 = dX."""

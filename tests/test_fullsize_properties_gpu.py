@@ -29,7 +29,7 @@ def conv_fwd(ops, x, w, stride, pad, stats=False):
     geom = ops.ConvGeom(tuple(x.shape[1:4]), k, stride, pad)
     out = torch.empty((N,) + geom.out + (Cout,), device=x.device)
     p = ops.fill_conv([ops.Act(x)], geom, Cout, out0=ops.Act(out))
-    wp = ops.pack_conv_weights(w, Cin, 0, Cout, k, ops.conv_weight_strides(w), False, ops.conv_ck(p))
+    wp = ops.pack_conv_weights(w, Cin, 0, Cout, k, ops.conv_weight_strides(w), False, ops.conv_ck(p), layout=ops.conv_pack_layout(p))
     p.wpack = wp.data_ptr()
     part = None
     if stats:
@@ -54,7 +54,7 @@ def conv_bwd_data(ops, g, w, geom, in_shape):
         return dx
     geomT = ops.ConvGeom(geom.out, k, (1, 1, 1), tuple(kk - 1 - pp for kk, pp in zip(k, geom.p)), out_spatial=in_shape)
     p = ops.fill_conv([ops.Act(g)], geomT, Cin, out0=ops.Act(dx))
-    wp = ops.pack_conv_weights(w, Cout, 0, Cin, k, ops.conv_weight_strides(w, as_bwd_data=True), True, ops.conv_ck(p))
+    wp = ops.pack_conv_weights(w, Cout, 0, Cin, k, ops.conv_weight_strides(w, as_bwd_data=True), True, ops.conv_ck(p), layout=ops.conv_pack_layout(p))
     p.wpack = wp.data_ptr()
     ops.conv3d_fwd(p)
     return dx

@@ -48,7 +48,7 @@ def run_conv(dev, srcs_cpu, w, b, stride, pad, lazy=None, stats=False):
     wd = w.to(dev).contiguous()
     C0 = acts[0].C
     C1 = acts[1].C if len(acts) > 1 else 0
-    wp = ops.pack_conv_weights(wd, C0, C1, Cout, w.shape[2:], ops.conv_weight_strides(wd), False, ck)
+    wp = ops.pack_conv_weights(wd, C0, C1, Cout, w.shape[2:], ops.conv_weight_strides(wd), False, ck, layout=ops.conv_pack_layout(p))
     p.wpack = wp.data_ptr()
     part = None
     if stats:
@@ -223,7 +223,7 @@ def test_conv_bwd_data(dev, Cin, Cout, shape, k, stride):
     p = ops.fill_conv([dyb], geom, Cin, out0=ops.Act(dx))
     ck = ops.conv_ck(p)
     wd = w.to(dev).contiguous()
-    wp = ops.pack_conv_weights(wd, Cout, 0, Cin, k, ops.conv_weight_strides(wd, as_bwd_data=True), True, ck)
+    wp = ops.pack_conv_weights(wd, Cout, 0, Cin, k, ops.conv_weight_strides(wd, as_bwd_data=True), True, ck, layout=ops.conv_pack_layout(p))
     p.wpack = wp.data_ptr()
     ops.conv3d_fwd(p)
     torch.cuda.synchronize()

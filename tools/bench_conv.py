@@ -24,7 +24,7 @@ flops = 2.0 * N * geom.out[0] * geom.out[1] * geom.out[2] * Cin * Cout * a.k[0] 
 if a.mode == 'fwd':
     p = ops.fill_conv([xa], geom, Cout, bias=b, out0=ops.Act(out))
     ck = ops.conv_ck(p)
-    wp = ops.pack_conv_weights(w, Cin, 0, Cout, a.k, ops.conv_weight_strides(w), False, ck)
+    wp = ops.pack_conv_weights(w, Cin, 0, Cout, a.k, ops.conv_weight_strides(w), False, ck, layout=ops.conv_pack_layout(p))
     p.wpack = wp.data_ptr()
     part = torch.zeros((N, ops.conv_stats_blocks(p), Cout, 2), device=dev)
     p.stats_part = part.data_ptr()
