@@ -1706,9 +1706,11 @@ static int launch_stem(const mt_conv3d_t* p, hipStream_t st) {
 // the chip with 4x4x16 tiles and enough input channels to amortise the transforms
 static bool conv_wino_ok(const mt_conv3d_t* p) {
   static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_CONV_WINO"); use = e ? atoi(e) : 0; }
+  if (use < 0) { const char* e = getenv("MT_CONV_WINO"); use = e ? atoi(e) : 1; }
   if (!use) return false;
-  if (p->csplit < p->Cout || p->Cin < 16 || conv_fast_vec(p) != 2) return false;
+  if (p->Cin < 16 || conv_fast_vec(p) != 2) return false;
+  if (p->csplit < p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs1 * 4.0 >= 2147483648.0) return false;
+  if (mt_cdiv(p->src[0].C, WCK) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, WCK) : 0) > MT_MAX_CHUNKS) return false;
   if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return false;
   const long wgs = (long)p->N * mt_cdiv(p->Do, 4) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 16) * mt_cdiv(p->Cout, 32);
   return wgs >= 256 || use == 2;          // MT_CONV_WINO=2 forces it (tests on small shapes)
@@ -1951,30 +1953,66 @@ struct PackParams {
 };
 __device__ __forceinline__ void pack_weights_body(const PackParams& P, long first, long stride) {
   if (P.layout == 2) {     // Winograd F(2x2x2, 3x3x3): U = G g G^T (3D) in B-fragment order [ntile][chunk of 8][xi 64][lane][4]
-    const long total = (long)P.ntiles * P.nchunks * 64 * 256;
+    // one work item per (cin, cout) pair: the 27 weights are read once and transformed separably into the 64 xi values
+    const long total = (long)P.ntiles * P.nchunks * 256;
     for (long i = first; i < total; i += stride) {
       long r = i;
       const int e = (int)(r % 4); r /= 4;
       const int l = (int)(r % 64); r /= 64;
-      const int xi = (int)(r % 64); r /= 64;
       const int ch = (int)(r % P.nchunks); r /= P.nchunks;
       const int nt = (int)r;
       const ConvChunk cc = P.chunk[ch];
       const int cin_local = 4 * (l >> 5) + e, co = nt * 32 + (l & 31);
-      float v = 0.f;
+      float u[4][4][4];
       if (cin_local < cc.ck && co < P.Cout) {
-        const int ci = cc.cglob + cin_local;
-        const int a = xi >> 4, b = (xi >> 2) & 3, c3 = xi & 3;
-        const float* wp = P.w + ci * P.s_ci + co * P.s_co;
+        const float* wp = P.w + (cc.cglob + cin_local) * P.s_ci + co * P.s_co;
+        float g[3][3][3];
+#pragma unroll
         for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
           for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-              const float g = kWinoG[a][kd] * kWinoG[b][kh] * kWinoG[c3][kw];
               const int zd = P.flip ? 2 - kd : kd, zh = P.flip ? 2 - kh : kh, zw = P.flip ? 2 - kw : kw;
-              if (g != 0.f) v = fmaf(g, wp[zd * P.s_kd + zh * P.s_kh + zw * P.s_kw], v);
+              g[kd][kh][kw] = wp[zd * P.s_kd + zh * P.s_kh + zw * P.s_kw];
             }
+        float t1[3][3][4], t2[3][4][4];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const float g0 = g[kd][kh][0], g1 = g[kd][kh][1], g2 = g[kd][kh][2];
+            t1[kd][kh][0] = g0; t1[kd][kh][1] = 0.5f * (g0 + g1 + g2); t1[kd][kh][2] = 0.5f * (g0 - g1 + g2); t1[kd][kh][3] = g2;
+          }
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float g0 = t1[kd][0][k], g1 = t1[kd][1][k], g2 = t1[kd][2][k];
+            t2[kd][0][k] = g0; t2[kd][1][k] = 0.5f * (g0 + g1 + g2); t2[kd][2][k] = 0.5f * (g0 - g1 + g2); t2[kd][3][k] = g2;
+          }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float g0 = t2[0][b][k], g1 = t2[1][b][k], g2 = t2[2][b][k];
+            u[0][b][k] = g0; u[1][b][k] = 0.5f * (g0 + g1 + g2); u[2][b][k] = 0.5f * (g0 - g1 + g2); u[3][b][k] = g2;
+          }
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[a][b][k] = 0.f;
       }
-      P.dst[i] = v;
+      float* dp = P.dst + ((size_t)(nt * P.nchunks + ch) * 64) * 256 + l * 4 + e;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dp[((a * 4 + b) * 4 + k) * 256] = u[a][b][k];
     }
     return;
   }

@@ -102,7 +102,7 @@ def test_conv_fwd(dev, N, Cin, Cout, shape, k, stride):
         name = ops.conv_kernel_name(ops.fill_conv([ops.Act(torch.empty((N,) + shape + (Cin,), device=dev))], geom, Cout,
                                                   out0=ops.Act(out)))
         big = N * np.prod([-(-s // t) for s, t in zip(shape, (2, 4, 32))]) * -(-Cout // 32) >= 300
-        assert name.startswith('conv_stem_kernel' if Cin == 1 else ('conv_fast_kernel' if big else 'conv_tapsplit_kernel')), name
+        assert name.startswith(('conv_stem_kernel',) if Cin == 1 else (('conv_fast_kernel', 'conv_wino_kernel') if big else ('conv_tapsplit_kernel',))), name
     assert relerr(got, ref) < 1e-5
     # per-block statistics partials sum to per-(n,c) sums
     s = part.cpu().double().sum(1)

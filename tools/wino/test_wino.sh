@@ -1,4 +1,3 @@
-export MT_CONV_WINO=1
 python - <<'PY'
 import torch, numpy as np, torch.nn.functional as F
 import sys; sys.path.insert(0,'.')
