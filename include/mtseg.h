@@ -115,6 +115,9 @@ int mt_pack_batched(const void* descs_device, int n, mt_stream_t stream);
  * into the accumulator of the parity class (x mod stride) it reaches: no work on inserted zeros. */
 int mt_conv3d_bwd_data_strided(const mt_conv3d_t* p, mt_stream_t stream);
 int mt_conv3d_bwd_data_strided_supported(const mt_conv3d_t* p);   /* 1 when the geometry is handled, else 0 */
+/* Runtime options (tests, A/B measurements): "conv_wino" = 0 direct kernels only, 1 Winograd where the grid fills the chip
+ * (default, also MT_CONV_WINO), 2 Winograd wherever the geometry is eligible. */
+int mt_set_option(const char* name, int value);
 int mt_conv3d_pack_layout(const mt_conv3d_t* p);   /* `layout` for mt_pack_conv_weights: 1, or 2 when the Winograd kernel serves p */
 int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n); /* device kernel that will run (profiler name) */
 

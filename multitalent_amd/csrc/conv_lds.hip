@@ -1704,9 +1704,15 @@ static int launch_stem(const mt_conv3d_t* p, hipStream_t st) {
 
 // Winograd eligibility: FAST geometry, 8-byte channel pairs in every source, one destination, enough workgroups to fill
 // the chip with 4x4x16 tiles and enough input channels to amortise the transforms
+static int g_wino_mode = -1;       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
+extern "C" int mt_set_option(const char* name, int value) {
+  if (name != nullptr && strcmp(name, "conv_wino") == 0) { g_wino_mode = value; return MT_OK; }
+  mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
+  return MT_EINVAL;
+}
 static bool conv_wino_ok(const mt_conv3d_t* p) {
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_CONV_WINO"); use = e ? atoi(e) : 1; }
+  if (g_wino_mode < 0) { const char* e = getenv("MT_CONV_WINO"); g_wino_mode = e ? atoi(e) : 1; }
+  const int use = g_wino_mode;
   if (!use) return false;
   if (p->Cin < 16 || conv_fast_vec(p) != 2) return false;
   if (p->csplit < p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs1 * 4.0 >= 2147483648.0) return false;

@@ -162,6 +162,10 @@ def conv_ck(p):
     return ck
 
 
+def set_option(name, value):
+    _lib.check(_lib.load().mt_set_option(name.encode(), int(value)), 'set_option')
+
+
 def conv_pack_layout(p):
     return _lib.load().mt_conv3d_pack_layout(C.byref(p))
 

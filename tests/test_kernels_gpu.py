@@ -376,3 +376,58 @@ def test_ds_label_pyramid_on_device(dev):
         for g, r in zip(got, ref):
             assert tuple(g.shape) == r.shape
             assert np.array_equal(g.cpu().numpy(), r)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,shape,two_src", [
+    (2, 32, 32, (8, 16, 64), False),
+    (2, 30, 30, (9, 18, 70), False),        # ragged tiles, channel tail (chunks 8,8,8,6), Cout not a multiple of 32
+    (1, 64, 40, (12, 20, 33), False),
+    (1, 30, 30, (5, 7, 19), True),          # concat input: chunks never straddle the two sources
+    (1, 16, 70, (4, 4, 16), False),         # exactly one tile, three cout tiles
+])
+def test_conv_winograd(dev, N, Cin, Cout, shape, two_src):
+    """conv_wino_kernel (3D Winograd F(2x2x2,3x3x3)) forced on small shapes: forward with lazy inputs + statistics, and the
+    flipped-weight backward-data form with two destinations; vs F.conv3d / autograd (tolerance 1e-5: +-1 and 1/2 transforms)."""
+    ops = _ops()
+    ops.set_option('conv_wino', 2)
+    try:
+        g = torch.Generator().manual_seed(21)
+        srcs = [torch.randn((N, Cin) + shape, generator=g)]
+        lazy = [(torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)]
+        if two_src:
+            srcs.append(torch.randn((N, Cin) + shape, generator=g))
+            lazy.append(None)
+        Ct = Cin * len(srcs)
+        w = torch.randn((Cout, Ct, 3, 3, 3), generator=g) / np.sqrt(Ct * 27)
+        b = torch.randn(Cout, generator=g)
+        out, part = run_conv(dev, srcs, w, b, (1, 1, 1), (1, 1, 1), lazy=lazy, stats=True)
+        xin = ref_inputs(srcs, lazy)
+        ref = F.conv3d(xin, w, b, padding=1)
+        assert relerr(to_ncdhw(out.cpu()), ref) < 1e-5
+        s = part.cpu().double().sum(1)
+        assert np.allclose(s[..., 0].numpy(), ref.double().sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3 * np.sqrt(ref[0, 0].numel()))
+        assert np.allclose(s[..., 1].numpy(), (ref.double() ** 2).sum((2, 3, 4)).numpy(), rtol=1e-4)
+        # backward-data through the same kernel (flipped, transposed weights), accumulate into two destinations
+        x = xin.clone().requires_grad_(True)
+        y = F.conv3d(x, w, None, padding=1)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        C0 = Ct // 2 if Ct % 4 == 0 else Ct
+        base0 = torch.randn((N,) + shape + (C0,), generator=g)
+        base1 = torch.randn((N,) + shape + (max(Ct - C0, 1),), generator=g)
+        d0, d1 = base0.to(dev), base1.to(dev)
+        geomT = ops.ConvGeom(shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+        dyd = to_ndhwc(dy).to(dev)            # keep alive: the parameter struct only holds raw pointers
+        p = ops.fill_conv([ops.Act(dyd)], geomT, Ct, out0=ops.Act(d0), out1=ops.Act(d1) if C0 < Ct else None,
+                          csplit=C0, accumulate=True)
+        assert ops.conv_kernel_name(p).startswith('conv_wino_kernel') == (Cout % 2 == 0)
+        wd = w.to(dev).contiguous()
+        wp = ops.pack_conv_weights(wd, Cout, 0, Ct, (3, 3, 3), ops.conv_weight_strides(wd, as_bwd_data=True), True, ops.conv_ck(p),
+                                   layout=ops.conv_pack_layout(p))
+        p.wpack = wp.data_ptr()
+        ops.conv3d_fwd(p)
+        torch.cuda.synchronize()
+        got = torch.cat([d0.cpu() - base0] + ([d1.cpu() - base1] if C0 < Ct else []), -1)
+        assert relerr(to_ncdhw(got), x.grad) < 1e-5
+    finally:
+        ops.set_option('conv_wino', 1)
