@@ -1704,9 +1704,11 @@ static int launch_stem(const mt_conv3d_t* p, hipStream_t st) {
 
 // Winograd eligibility: FAST geometry, 8-byte channel pairs in every source, one destination, enough workgroups to fill
 // the chip with 4x4x16 tiles and enough input channels to amortise the transforms
+static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
 static int g_wino_mode = -1;       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
 extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "conv_wino") == 0) { g_wino_mode = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "bwdw_wino") == 0) { g_bwdw_wino = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
 }
@@ -2799,6 +2801,8 @@ __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P)
   }
 }
 
+#include "bwdw_wino.inc"
+
 // compile-time geometries of the fast backward-weight kernel: (K, S) with pad (K-1)/2 for K=3/1 and 0 for K=2
 struct BwGeo { int KD, KH, KW, SD, SH, SW; };
 static const BwGeo kBwGeos[] = {
@@ -2840,6 +2844,11 @@ static bool bwdw_use_march(const mt_conv3d_t* p) {
   return use && p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 1 && p->Do >= 3;
 }
 static void bwdw_march_plan(const mt_conv3d_t* p, BwdWParams* P);
+static int conv_fast_vec(const mt_conv3d_t* p);
+static bool bwdw_use_wino(const mt_conv3d_t* p) {
+  if (g_bwdw_wino < 0) { const char* e = getenv("MT_BWDW_WINO"); g_bwdw_wino = e ? atoi(e) : 1; }
+  return g_bwdw_wino && bwdw_use_march(p) && p->Wo > 16 && p->Ho >= 2 && conv_fast_vec(p) == 2;
+}
 // plan for the fast kernel: tile 1 x TH x TW with (TH,TW) = (4,32) or (8,16)
 static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   const bool wide = p->Wo > 16;
@@ -2859,7 +2868,8 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   if (bwdw_use_march(p)) {
     static int tall = -1;
     if (tall < 0) { const char* e = getenv("MT_BWDW_TALL"); tall = e ? atoi(e) : 1; }
-    if (tall && wide && p->Ho >= 8) { P->TH = 8; P->tilesH = mt_cdiv(p->Ho, 8); P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N; }
+    if (bwdw_use_wino(p)) { P->TH = 4; P->TW = 32; P->tilesH = mt_cdiv(p->Ho, 4); P->tilesW = mt_cdiv(p->Wo, 32); P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N; }
+    else if (tall && wide && p->Ho >= 8) { P->TH = 8; P->tilesH = mt_cdiv(p->Ho, 8); P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N; }
     bwdw_march_plan(p, P);
   }
 }
@@ -3028,6 +3038,19 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     int rc = MT_EINVAL;
     switch (geo) {
       case 0: {
+        if (bwdw_use_wino(p)) {
+          const size_t ldsb = (size_t)BWW_LDS_FLOATS * sizeof(float);
+          static bool attr = false;
+          if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv_bwdw_wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
+            attr = true;
+          }
+          hipLaunchKernelGGL(conv_bwdw_wino_kernel<2>, dim3(P.nsg, P.ncot, P.nchunks), dim3(256), ldsb, st, P);
+          MT_CHECK_LAUNCH("conv_bwdw_wino");
+          rc = MT_OK;
+          break;
+        }
         const int yv = ((ysrc->cs & 1) || (p->Cout & 1) || (((uintptr_t)ysrc->ptr) & 7)) ? 1 : 2;
         rc = bwdw_use_march(p) ? launch_bwdw_march<3, 3, 1, 1>(P, vec, yv, st) : launch_bwdw_fast<3, 3, 3, 1, 1, 1>(P, vec, st);
         break;

@@ -239,6 +239,9 @@ def test_conv_bwd_data(dev, Cin, Cout, shape, k, stride):
     (1, 32, (4, 8, 32), (3, 3, 3), (1, 1, 1)),       # stem: taps-as-M kernel
     (1, 40, (5, 9, 37), (3, 3, 3), (1, 1, 1)),       # stem, ragged tiles, two cout tiles
     (32, 32, (6, 8, 32), (3, 3, 3), (1, 1, 1)),      # marching kernel, several planes per column
+    (24, 40, (5, 9, 37), (3, 3, 3), (1, 1, 1)),      # Winograd backward-weight: ragged tiles in H and W, two cout tiles
+    (16, 70, (4, 6, 40), (3, 3, 3), (1, 1, 1)),      # ... three cout tiles, one cin chunk
+    (30, 30, (3, 5, 20), (3, 3, 3), (1, 1, 1)),      # ... odd H (half tile), channel tails
 ])
 def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
     ops = _ops()
@@ -259,6 +262,17 @@ def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
     ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
     torch.cuda.synchronize()
     assert relerr(dw.cpu(), w.grad) < 2e-5
+    if k == (3, 3, 3) and stride == (1, 1, 1) and Cin > 1 and shape[2] > 16 and shape[0] >= 3:
+        # these shapes take the Winograd kernel by default: the direct marching kernel must agree too
+        ops.set_option('bwdw_wino', 0)
+        try:
+            dw2 = torch.full(w.shape, float('nan'), device=dev)
+            ws2 = torch.empty(max(ops.conv3d_bwd_weight_workspace(p) // 4, 1), device=dev)
+            ops.conv3d_bwd_weight(p, ya, dw2, ops.conv_weight_strides(dw2), False, ws2)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_option('bwdw_wino', 1)
+        assert relerr(dw2.cpu(), w.grad) < 2e-5
 
 
 @pytest.mark.parametrize("Cin,Cout,base,so", [
