@@ -1705,15 +1705,20 @@ static int launch_stem(const mt_conv3d_t* p, hipStream_t st) {
 // Winograd eligibility: FAST geometry, 8-byte channel pairs in every source, one destination, enough workgroups to fill
 // the chip with 4x4x16 tiles and enough input channels to amortise the transforms
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
+static int g_wino_waves = 8;       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
 static int g_wino_mode = -1;       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
 extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "conv_wino") == 0) { g_wino_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_wino") == 0) { g_bwdw_wino = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "wino_waves") == 0) { g_wino_waves = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
 }
 static bool conv_wino_ok(const mt_conv3d_t* p) {
-  if (g_wino_mode < 0) { const char* e = getenv("MT_CONV_WINO"); g_wino_mode = e ? atoi(e) : 1; }
+  if (g_wino_mode < 0) {
+    const char* e = getenv("MT_CONV_WINO"); g_wino_mode = e ? atoi(e) : 1;
+    const char* w = getenv("MT_WINO_WAVES"); if (w) g_wino_waves = atoi(w);
+  }
   const int use = g_wino_mode;
   if (!use) return false;
   if (p->Cin < 16 || conv_fast_vec(p) != 2) return false;
@@ -1740,6 +1745,18 @@ static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
+  if (g_wino_waves == 8) {
+    const size_t l8 = (size_t)(2 * W_RAWF + W_VF) * sizeof(float);
+    static bool attr8 = false;
+    if (!attr8) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv_wino8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l8);
+      if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", l8, hipGetErrorString(e)); return MT_EHIP; }
+      attr8 = true;
+    }
+    hipLaunchKernelGGL(conv_wino8_kernel, grid, dim3(512), l8, st, P);
+    MT_CHECK_LAUNCH("conv3d_wino8");
+    return MT_OK;
+  }
   hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), ldsb, st, P);
   MT_CHECK_LAUNCH("conv3d_wino");
   return MT_OK;
@@ -1844,7 +1861,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   else if (pl.kind == CONV_STEM)
     snprintf(buf, n, "conv_stem_kernel");
   else if (pl.kind == CONV_WINO)
-    snprintf(buf, n, "conv_wino_kernel");
+    snprintf(buf, n, g_wino_waves == 8 ? "conv_wino8_kernel" : "conv_wino_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
     snprintf(buf, n, "conv_fast_strided_kernel<%d, %d, %d, %d>", p->SD, p->SH, p->SW, conv_fast_vec(p));
   else if (pl.kind == CONV_RT)

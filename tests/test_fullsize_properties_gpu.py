@@ -85,7 +85,7 @@ def test_adjoint_identity_and_linearity_at_full_size(dev, Cin, Cout, shape, stri
     x2 = torch.randn((N,) + shape + (Cin,), generator=gen).to(dev)
     w = (torch.randn((Cout, Cin) + k, generator=gen) / np.sqrt(Cin * 27)).to(dev)
     y, geom, name, _ = conv_fwd(ops, x, w, stride, pad)
-    assert name.startswith(kernel) or (kernel == 'conv_fast_kernel' and name.startswith('conv_wino_kernel')), name
+    assert name.startswith(kernel) or (kernel == 'conv_fast_kernel' and name.startswith('conv_wino')), name
     g = torch.randn(y.shape, generator=gen).to(dev)
     dx = conv_bwd_data(ops, g, w, geom, shape)
     dw = conv_bwd_weight(ops, x, g, tuple(w.shape), geom)

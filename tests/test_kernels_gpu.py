@@ -102,7 +102,7 @@ def test_conv_fwd(dev, N, Cin, Cout, shape, k, stride):
         name = ops.conv_kernel_name(ops.fill_conv([ops.Act(torch.empty((N,) + shape + (Cin,), device=dev))], geom, Cout,
                                                   out0=ops.Act(out)))
         big = N * np.prod([-(-s // t) for s, t in zip(shape, (2, 4, 32))]) * -(-Cout // 32) >= 300
-        assert name.startswith(('conv_stem_kernel',) if Cin == 1 else (('conv_fast_kernel', 'conv_wino_kernel') if big else ('conv_tapsplit_kernel',))), name
+        assert name.startswith(('conv_stem_kernel',) if Cin == 1 else (('conv_fast_kernel', 'conv_wino') if big else ('conv_tapsplit_kernel',))), name
     assert relerr(got, ref) < 1e-5
     # per-block statistics partials sum to per-(n,c) sums
     s = part.cpu().double().sum(1)
@@ -434,7 +434,7 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src):
         dyd = to_ndhwc(dy).to(dev)            # keep alive: the parameter struct only holds raw pointers
         p = ops.fill_conv([ops.Act(dyd)], geomT, Ct, out0=ops.Act(d0), out1=ops.Act(d1) if C0 < Ct else None,
                           csplit=C0, accumulate=True)
-        assert ops.conv_kernel_name(p).startswith('conv_wino_kernel') == (Cout % 2 == 0)
+        assert ops.conv_kernel_name(p).startswith('conv_wino') == (Cout % 2 == 0)
         wd = w.to(dev).contiguous()
         wp = ops.pack_conv_weights(wd, Cout, 0, Ct, (3, 3, 3), ops.conv_weight_strides(wd, as_bwd_data=True), True, ops.conv_ck(p),
                                    layout=ops.conv_pack_layout(p))
