@@ -399,11 +399,13 @@ def test_ds_label_pyramid_on_device(dev):
     (1, 30, 30, (5, 7, 19), True),          # concat input: chunks never straddle the two sources
     (1, 16, 70, (4, 4, 16), False),         # exactly one tile, three cout tiles
 ])
-def test_conv_winograd(dev, N, Cin, Cout, shape, two_src):
+@pytest.mark.parametrize("waves", [8, 4])
+def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
     """conv_wino_kernel (3D Winograd F(2x2x2,3x3x3)) forced on small shapes: forward with lazy inputs + statistics, and the
     flipped-weight backward-data form with two destinations; vs F.conv3d / autograd (tolerance 1e-5: +-1 and 1/2 transforms)."""
     ops = _ops()
     ops.set_option('conv_wino', 2)
+    ops.set_option('wino_waves', waves)      # 8: wave-specialised two-waves-per-SIMD kernel (default), 4: the four-wave kernel
     try:
         g = torch.Generator().manual_seed(21)
         srcs = [torch.randn((N, Cin) + shape, generator=g)]
@@ -445,3 +447,4 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src):
         assert relerr(to_ncdhw(got), x.grad) < 1e-5
     finally:
         ops.set_option('conv_wino', 1)
+        ops.set_option('wino_waves', 8)
