@@ -29,9 +29,18 @@ KERNELS = [[3, 3, 3]] * 6
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
 
 
+RESENC_POOLS = [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]]     # SURVEY §8a N6 (resenc_bs4 plan)
+RESENC_KERNELS = [[1, 3, 3]] + [[3, 3, 3]] * 5
+RESENC_BLOCKS = [1, 2, 3, 4, 4, 4]
+
+
 def build_network(workload):
     from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
     from multitalent_amd.network_architecture.initialization import InitWeights_He
+    if workload == 'resenc':        # BASELINE configs[3] architecture (FabiansUNet, MultiTalent_meets_resenc.py:72-104), here in fp32
+        from multitalent_amd.network_architecture.generic_modular_residual_UNet import FabiansUNet, get_default_network_config
+        return FabiansUNet(1, 30, RESENC_BLOCKS, 2, RESENC_POOLS, RESENC_KERNELS, get_default_network_config(3, None, norm_type="in"),
+                           47, [1] * (len(RESENC_POOLS) - 1), True, False, 320, InitWeights_He(1e-2))
     nc = 2 if workload == 'task009' else 47
     return Generic_UNet(1, 30, nc, len(POOLS), 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
                         nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True},
@@ -41,7 +50,7 @@ def build_network(workload):
 def make_batch(workload, B, dev, rank):
     from multitalent_amd.synthetic import ds_scales, synthetic_ct, synthetic_targets
     from multitalent_amd.dataset_conversion.Task100_MultiTalent import MultiTalent_regions, MultiTalent_valid_regions
-    scales = ds_scales(POOLS)
+    scales = ds_scales(RESENC_POOLS, skip_first=True) if workload == 'resenc' else ds_scales(POOLS)
     x = synthetic_ct(B, PATCH, 1234 + rank, dev)
     if workload == 'task009':
         t = synthetic_targets(B, PATCH, scales, [[1]] * B, 1234 + rank, dev)
@@ -56,7 +65,7 @@ def make_batch(workload, B, dev, rank):
 def make_loss(workload, ddp):
     from multitalent_amd.training.ds_weights import ds_loss_weights
     from multitalent_amd.training.loss_functions.fused_losses import DC_and_CE_DS_loss, MultiTalentLoss
-    w = ds_loss_weights(len(POOLS))
+    w = ds_loss_weights(len(RESENC_POOLS) - 1 if workload == 'resenc' else len(POOLS))
     if workload == 'task009':
         return DC_and_CE_DS_loss(w, batch_dice=False, ddp=ddp)
     return MultiTalentLoss(w, batch_dice=True)
@@ -203,7 +212,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default=None, choices=[None, 'task009', 'task100', 'infer'])
+    ap.add_argument('--workload', default=None, choices=[None, 'task009', 'task100', 'resenc', 'infer'])
     ap.add_argument('--volume', type=int, nargs=3, default=[512, 512, 512], help='--workload infer: synthetic CT volume')
     ap.add_argument('--mirror', type=int, default=1, help='--workload infer: 8-fold mirror TTA (reference default)')
     ap.add_argument('--batch', type=int, default=None)
@@ -225,7 +234,7 @@ def main():
     workload = args.workload or 'task009'      # same per-GPU workload at every N (weak scaling on BASELINE configs[1])
     if workload == 'infer':
         return bench_infer(args, dev, rank, world, ddp)
-    B = args.batch or (2 if workload == 'task009' else 4)
+    B = args.batch or {'task009': 2, 'task100': 4, 'resenc': 2}[workload]
 
     from multitalent_amd.training.hot_loop import FusedTrainStep
     torch.manual_seed(1234)           # identical initial weights on all ranks (DDP broadcast semantics)
@@ -263,8 +272,9 @@ def main():
             "metric": "CT patches/s (48x192x192) train fwd+bwd", "value": round(value, 3), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("Task009_Spleen Generic_UNet nc=2 softmax Dice+CE" if workload == 'task009'
-                                    else "Task100_MultiTalent Generic_UNet nc=47 MultiTalent BCE+Dice loss"),
+            "config": {"workload": {"task009": "Task009_Spleen Generic_UNet nc=2 softmax Dice+CE",
+                                    "task100": "Task100_MultiTalent Generic_UNet nc=47 MultiTalent BCE+Dice loss",
+                                    "resenc": "Task100_MultiTalent FabiansUNet (residual encoder) nc=47 MultiTalent BCE+Dice loss, fp32"}[workload],
                        "patch": list(PATCH), "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "step": "fwd+loss+bwd+clip12+SGD-nesterov",
                        "final_loss": round(float(loss), 5)},

@@ -6,6 +6,7 @@
 // Reference: nn.InstanceNorm3d(eps=1e-5, affine=True) + nn.LeakyReLU(1e-2, inplace) inside
 // ConvDropoutNormNonlin (generic_UNet.py:63-64,69-70; nnUNetTrainerV2.py:152-155), biased variance.
 #include "mt_common.h"
+#include <initializer_list>
 
 // ---- finalize: partial (sum,sumsq) -> mean, rstd, scale, shift ---------------------------------
 __global__ __launch_bounds__(64) void inorm_finalize_kernel(const float* __restrict__ part, int nsb, int C, double count,
@@ -74,11 +75,14 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const ApplyParams P) {
     }
   }
 }
+struct ApplyParams;
+static int launch_apply_fast(const ApplyParams& P, int N, mt_stream_t stream, const float* res_or_y);
 extern "C" int mt_inorm_lrelu_apply(const float* y, int ycs, const float* scale, const float* shift, float slope,
                                     const float* res, int rcs, const float* rscale, const float* rshift, float rslope,
                                     float* out, int ocs, int N, long V, int C, mt_stream_t stream) {
   MT_REQUIRE(y && out && N > 0 && V > 0 && C > 0, "inorm_lrelu_apply: bad args");
   ApplyParams P{y, ycs, scale, shift, slope, res, rcs, rscale, rshift, rslope, out, ocs, V, C};
+  if (ycs == C && ocs == C && (res == nullptr || rcs == C)) return launch_apply_fast(P, N, stream, res != nullptr ? res : y);
   hipLaunchKernelGGL(inorm_apply_kernel, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P);
   MT_CHECK_LAUNCH("inorm_lrelu_apply");
   return MT_OK;
@@ -371,11 +375,94 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const LBwdParams P) {
     }
   }
 }
+
+// ---- dense fast paths of the two element-wise kernels above (every operand contiguous, cs == C, C % VEC == 0): one thread
+// moves VEC consecutive channels of a voxel per iteration with 16/8-byte accesses; the per-(n, c) scale/shift come from a
+// small table read through the cache.  HBM-bound: apply = 2-3 streams, lrelu_bwd = 3-5 streams.
+template <int VEC>
+__global__ __launch_bounds__(256) void inorm_apply_fast_kernel(const ApplyParams P, long per_sample) {
+  typedef typename VecT<VEC>::T V;
+  const int n = blockIdx.y;
+  const size_t base = (size_t)n * per_sample;                    // elements
+  const bool has_res = P.res != nullptr;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC; i < per_sample; i += (long)gridDim.x * 256 * VEC) {
+    const int c = (int)(i % P.C);
+    float y[VEC], r[VEC], o[VEC];
+    *(V*)y = *(const V*)(P.y + base + i);
+    if (has_res) *(V*)r = *(const V*)(P.res + base + i);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float sc = P.scale ? P.scale[(size_t)n * P.C + c + e] : 1.f, sh = P.scale ? P.shift[(size_t)n * P.C + c + e] : 0.f;
+      float t = fmaf(y[e], sc, sh);
+      if (has_res) {
+        const float rsc = P.rscale ? P.rscale[(size_t)n * P.C + c + e] : 1.f, rsh = P.rscale ? P.rshift[(size_t)n * P.C + c + e] : 0.f;
+        t += mt_lrelu(fmaf(r[e], rsc, rsh), P.rslope);
+      }
+      o[e] = mt_lrelu(t, P.slope);
+    }
+    *(V*)(P.out + base + i) = *(V*)o;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void lrelu_bwd_fast_kernel(const LBwdParams P, long per_sample) {
+  typedef typename VecT<VEC>::T V;
+  const int n = blockIdx.y;
+  const size_t base = (size_t)n * per_sample;
+  const bool has2 = P.y2 != nullptr;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC; i < per_sample; i += (long)gridDim.x * 256 * VEC) {
+    const int c = (int)(i % P.C);
+    float y[VEC], y2[VEC], g[VEC];
+    *(V*)y = *(const V*)(P.y + base + i);
+    *(V*)g = *(const V*)(P.g + base + i);
+    if (has2) *(V*)y2 = *(const V*)(P.y2 + base + i);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float sc = P.scale ? P.scale[(size_t)n * P.C + c + e] : 1.f, sh = P.scale ? P.shift[(size_t)n * P.C + c + e] : 0.f;
+      float t = fmaf(y[e], sc, sh);
+      if (has2) {
+        const float sc2 = P.scale2 ? P.scale2[(size_t)n * P.C + c + e] : 1.f, sh2 = P.scale2 ? P.shift2[(size_t)n * P.C + c + e] : 0.f;
+        t += mt_lrelu(fmaf(y2[e], sc2, sh2), P.slope2);
+      }
+      g[e] = t > 0.f ? g[e] : g[e] * P.slope;
+    }
+    *(V*)(P.g + base + i) = *(V*)g;
+    if (P.gcopy) *(V*)(P.gcopy + base + i) = *(V*)g;
+  }
+}
+static int dense_vec(int C, std::initializer_list<const void*> ptrs) {
+  int v = (C % 4 == 0) ? 4 : ((C % 2 == 0) ? 2 : 1);
+  for (const void* q : ptrs)
+    if (q != nullptr) { while (v > 1 && (((uintptr_t)q) & (v * 4 - 1))) v >>= 1; }
+  return v;
+}
+
+static int launch_apply_fast(const ApplyParams& P, int N, mt_stream_t stream, const float* res_or_y) {
+  const long per = P.V * P.C;
+  const int vec = dense_vec(P.C, {P.y, P.out, res_or_y});
+  int blocks = (int)((per / vec + 255) / 256); if (blocks > 8192) blocks = 8192;
+  if (vec == 4) hipLaunchKernelGGL(inorm_apply_fast_kernel<4>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
+  else if (vec == 2) hipLaunchKernelGGL(inorm_apply_fast_kernel<2>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
+  else hipLaunchKernelGGL(inorm_apply_fast_kernel<1>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
+  MT_CHECK_LAUNCH("inorm_apply_fast");
+  return MT_OK;
+}
+
 extern "C" int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale, const float* shift, float slope,
                             const float* y2, int y2cs, const float* scale2, const float* shift2, float slope2,
                             float* gcopy, int gcopycs, int N, long V, int C, mt_stream_t stream) {
   MT_REQUIRE(g && y && N > 0 && V > 0 && C > 0, "lrelu_bwd: bad args");
   LBwdParams P{g, gcs, y, ycs, scale, shift, slope, y2, y2cs, scale2, shift2, slope2, gcopy, gcopycs, V, C};
+  if (gcs == C && ycs == C && (y2 == nullptr || y2cs == C) && (gcopy == nullptr || gcopycs == C) && V * C < (1L << 40)) {
+    const long per = V * C;
+    const int vec = dense_vec(C, {g, y, y2, gcopy});
+    int blocks = (int)((per / vec + 255) / 256); if (blocks > 8192) blocks = 8192;
+    if (vec == 4) hipLaunchKernelGGL(lrelu_bwd_fast_kernel<4>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
+    else if (vec == 2) hipLaunchKernelGGL(lrelu_bwd_fast_kernel<2>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
+    else hipLaunchKernelGGL(lrelu_bwd_fast_kernel<1>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
+    MT_CHECK_LAUNCH("lrelu_bwd_fast");
+    return MT_OK;
+  }
   hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P);
   MT_CHECK_LAUNCH("lrelu_bwd");
   return MT_OK;
