@@ -1325,17 +1325,25 @@ __global__ __launch_bounds__(256) void conv_rt_kernel(const ConvKParams P) {
     if (tap < ntaps) fast_frag_mfma<MT>(f0, acc);
   }
 
-  // ---- epilogue (single destination; strided placement)
+  // ---- epilogue (strided placement; one or two destinations: each lane stores through the descriptor of its channel, the other
+  // store of a split launch carries the hardware-masked offset)
   const int co = ntile * 32 + li;
   const bool covalid = co < c.Cout;
   const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
   const int osD = c.osD > 0 ? c.osD : 1, osH = c.osH > 0 ? c.osH : 1, osW = c.osW > 0 ? c.osW : 1;
   const int OD = c.osD > 0 ? c.OD : c.Do, OH = c.osD > 0 ? c.OH : c.Ho, OW = c.osD > 0 ? c.OW : c.Wo;
   const int ooD = c.osD > 0 ? c.ooD : 0, ooH = c.osD > 0 ? c.ooH : 0, ooW = c.osD > 0 ? c.ooW : 0;
-  const int ocs = c.ocs0;
+  const bool split = c.csplit < c.Cout;
+  const bool use1 = split && co >= c.csplit;
+  const int ocs = use1 ? c.ocs1 : c.ocs0;
+  const int cofs = use1 ? co - c.csplit : co;
   const size_t out_sample = (size_t)OD * OH * OW;
-  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
-                                                                (int)(out_sample * ocs * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * c.ocs0), 0,
+                                                                (int)(out_sample * c.ocs0 * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rd1 = rd;
+  if (split) rd1 = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out1 + (size_t)nb * out_sample * c.ocs1), 0,
+                                                     (int)(out_sample * c.ocs1 * 4), 0x00020000);
+  const int m0 = use1 ? (int)0x80000000 : 0, m1 = use1 ? 0 : (int)0x80000000;
   const int lane_col = 4 * lhalf;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1350,10 +1358,14 @@ __global__ __launch_bounds__(256) void conv_rt_kernel(const ConvKParams P) {
       const int oh = oh0 + rh * MH + r, ow = ow0 + colj + lane_col;
       const bool ok = covalid && (od < c.Do) && (oh < c.Ho) && (ow < c.Wo);
       const int vox = ((od * osD + ooD) * OH + (oh * osH + ooH)) * OW + (ow * osW + ooW);
-      const int off = ok ? (vox * ocs + co) * 4 : (int)0x80000000;
+      const int off = ok ? (vox * ocs + cofs) * 4 : (int)0x80000000;
       float v = acc[m][j] + bv;
-      if (c.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, 0);
+      if (c.accumulate) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off | m0, 0, 0));
+        if (split) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd1, off | m1, 0, 0));
+      }
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off | m0, 0, 0);
+      if (split) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd1, off | m1, 0, 0);
       if (ok) { s1 += v; s2 = fmaf(v, v, s2); }
     }
   }
@@ -1770,7 +1782,7 @@ static size_t rt_lds(const ConvCfg& g, const mt_conv3d_t* p) {
 }
 static bool conv_rt_ok(const mt_conv3d_t* p) {
   if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
-  if (p->csplit < p->Cout) return false;
+  if (p->csplit < p->Cout && (p->osD > 0 || (double)p->Do * p->Ho * p->Wo * p->ocs1 * 4.0 >= 2147483648.0)) return false;
   for (int i = 0; i < p->nsrc; ++i)
     if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 4.0 >= 2147483648.0) return false;
   const double od = p->osD > 0 ? (double)p->OD * p->OH * p->OW : (double)p->Do * p->Ho * p->Wo;
