@@ -1430,30 +1430,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     __syncthreads();
     mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
     __syncthreads();
-    // offsets outer (A fragment fetched once per offset), taps of that offset inner
+    // all 27 taps unrolled in natural order; tap t reads the A fragment at its compile-time offset (jd, jh, jw) and accumulates
+    // into the tile of its parity class.  Weight fragments are prefetched 3 taps ahead through a register ring, A fragments
+    // one tap ahead (same software pipeline as fast_chunk — the plain loop nest left every L2 round trip exposed).
+    {
+      constexpr int NB = 4;
+      f32x4 b[NB][2];
+      f32x4 a[2][2];
 #pragma unroll
-    for (int jd = 0; jd < LD - TD + 1; ++jd)
+      for (int t = 0; t < 3; ++t) {
+        b[t][0] = *(const f32x4*)(wlane + t * 512);
+        b[t][1] = *(const f32x4*)(wlane + t * 512 + 256);
+      }
+      {
+        constexpr int o0 = ((bd_off<SD>(0) * LH + bd_off<SH>(0)) * LWP + bd_off<SW>(0)) * FCKP;
+        a[0][0] = *(const f32x4*)(lds + abase + o0);
+        a[0][1] = *(const f32x4*)(lds + abase + o0 + 4);
+      }
 #pragma unroll
-      for (int jh = 0; jh < LH - TH + 1; ++jh)
-#pragma unroll
-        for (int jw = 0; jw < LW - TW + 1; ++jw) {
-          const float* ap = lds + abase + ((jd * LH + jh) * LWP + jw) * FCKP;
-          const f32x4 a0 = *(const f32x4*)(ap);
-          const f32x4 a1 = *(const f32x4*)(ap + 4);
-#pragma unroll
-          for (int tap = 0; tap < 27; ++tap) {
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            if (bd_off<SD>(kd) == jd && bd_off<SH>(kh) == jh && bd_off<SW>(kw) == jw) {
-              const int q = (bd_par<SD>(kd) * SH + bd_par<SH>(kh)) * SW + bd_par<SW>(kw);
-              const f32x4 b0 = *(const f32x4*)(wlane + tap * 512);
-              const f32x4 b1 = *(const f32x4*)(wlane + tap * 512 + 256);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[q], 0, 0, 0);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[q], 0, 0, 0);
-            }
-          }
+      for (int t = 0; t < 27; ++t) {
+        if (t + 3 < 27) {
+          b[(t + 3) % NB][0] = *(const f32x4*)(wlane + (t + 3) * 512);
+          b[(t + 3) % NB][1] = *(const f32x4*)(wlane + (t + 3) * 512 + 256);
         }
+        if (t + 1 < 27) {
+          const int t1 = t + 1;
+          const int o1 = ((bd_off<SD>(t1 / 9) * LH + bd_off<SH>((t1 / 3) % 3)) * LWP + bd_off<SW>(t1 % 3)) * FCKP;
+          a[t1 & 1][0] = *(const f32x4*)(lds + abase + o1);
+          a[t1 & 1][1] = *(const f32x4*)(lds + abase + o1 + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = (bd_par<SD>(t / 9) * SH + bd_par<SH>((t / 3) % 3)) * SW + bd_par<SW>(t % 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1][0][e], b[t % NB][0][e], acc[q], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1][1][e], b[t % NB][1][e], acc[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
 
   // ---- epilogue: class (pd,ph,pw) of dY position m lands at dX[S*m + par]
