@@ -1,0 +1,84 @@
+"""Device-side patch feed: pinned, double-buffered host-to-device transfer of the batches produced by the
+reference's CPU pipeline (`DataLoader3D.generate_train_batch`, dataset_loading.py:224-380 -> `{'data','seg'/'target',
+'properties','keys'}`), with the deep-supervision label pyramid built on the device.
+
+The reference hands `maybe_to_torch(...)`/`to_cuda(...)` a pageable numpy batch every iteration and ships FIVE label maps per
+sample (`DownsampleSegForDSTransform2` runs in the CPU workers).  Here the generator may deliver only the full-resolution label
+map: the batch is copied into one of two pinned staging buffers, uploaded on a side HIP stream while the previous iteration
+computes, and `mt_downsample_seg_nearest` builds the pyramid.  One 48x192x192 fp32 patch is 7 MB (data) + 7 MB (labels):
+0.3 ms per patch over PCIe Gen5 — hidden behind a 20 ms/patch training step."""
+import numpy as np
+import torch
+
+from ..data_augmentation.downsampling import downsample_seg_for_ds_transform2
+
+
+class DeviceBatchFeeder:
+    """Wraps any iterator of reference-style batch dicts; yields dicts whose 'data' / 'target' live on the HIP device.
+
+    `target` in the incoming dict may be a list (already a pyramid: passed through level by level) or one array
+    [B,1,D,H,W] (then `ds_scales` is applied on the device, with RemoveLabelTransform(-1, 0))."""
+
+    def __init__(self, generator, ds_scales=None, device=None, depth=2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeviceBatchFeeder needs a HIP device (no CPU fallback)")
+        self.gen = iter(generator)
+        self.ds_scales = ds_scales
+        self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.depth = max(int(depth), 1)
+        self._pinned = [dict() for _ in range(self.depth)]      # per slot: name -> pinned staging tensor
+        self._queue = []                                          # in-flight (batch, event)
+        self._slot = 0
+        self._exhausted = False
+
+    def _stage(self, slot, name, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float32) if isinstance(arr, np.ndarray) else arr
+        t = torch.from_numpy(a) if isinstance(a, np.ndarray) else a.detach().float().contiguous()
+        if t.is_cuda:
+            return t
+        buf = self._pinned[slot].get(name)
+        if buf is None or buf.shape != t.shape:
+            buf = torch.empty(t.shape, dtype=torch.float32).pin_memory()
+            self._pinned[slot][name] = buf
+        buf.copy_(t)
+        return buf.to(self.device, non_blocking=True)
+
+    def _issue(self):
+        try:
+            b = next(self.gen)
+        except StopIteration:
+            self._exhausted = True
+            return
+        slot = self._slot
+        self._slot = (self._slot + 1) % self.depth
+        tgt_key = 'target' if 'target' in b else 'seg'
+        with torch.cuda.stream(self.stream):
+            out = dict(b)
+            out['data'] = self._stage(slot, 'data', b['data'])
+            tgt = b[tgt_key]
+            if isinstance(tgt, (list, tuple)):
+                out['target'] = [self._stage(slot, 'target%d' % i, t) for i, t in enumerate(tgt)]
+            else:
+                full = self._stage(slot, 'target', tgt)
+                scales = self.ds_scales if self.ds_scales is not None else [[1, 1, 1]]
+                out['target'] = downsample_seg_for_ds_transform2(full, scales, 0, None, remove_minus_one=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._queue.append((out, ev))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        while len(self._queue) < self.depth and not self._exhausted:
+            self._issue()
+        if not self._queue:
+            raise StopIteration
+        out, ev = self._queue.pop(0)
+        torch.cuda.current_stream(self.device).wait_event(ev)       # no host sync: the compute stream waits for the upload
+        for t in [out['data']] + list(out['target']):
+            t.record_stream(torch.cuda.current_stream(self.device))
+        if not self._exhausted:
+            self._issue()
+        return out

@@ -87,3 +87,30 @@ def test_single_gpu_trainer_softmax(dev, tmp_path):
     assert l[-1] < l[0]
     tr.maybe_update_lr(500)
     assert abs(tr.train_step.lr - 1e-2 * (1 - 500 / 1000) ** 0.9) < 1e-12
+
+
+def test_device_batch_feeder_matches_cpu_pipeline(dev):
+    """DeviceBatchFeeder: pinned double-buffered upload + on-device label pyramid == the reference's CPU result
+    (oracle restatement of DownsampleSegForDSTransform2 + RemoveLabelTransform), order preserved, pyramids passed through."""
+    import numpy as np
+    from oracle import reference_ops as R
+    from multitalent_amd.training.dataloading.device_feed import DeviceBatchFeeder
+    rng = np.random.RandomState(9)
+    scales = [[1, 1, 1], [0.5, 0.5, 0.5], [0.25, 0.25, 0.25]]
+    shape = (16, 32, 48)
+    batches = [{'data': rng.randn(2, 1, *shape).astype(np.float32),
+                'target': rng.randint(-1, 48, size=(2, 1) + shape).astype(np.float32),
+                'properties': [{'valid_regions': ['03_liver']}] * 2, 'keys': ['a', 'b']} for _ in range(5)]
+    got = list(DeviceBatchFeeder(iter(batches), ds_scales=scales))
+    assert len(got) == 5
+    for b, g in zip(batches, got):
+        assert g['data'].is_cuda and np.array_equal(g['data'].cpu().numpy(), b['data'])
+        ref = R.downsample_seg_for_ds_transform2(R.remove_label(b['target']), scales, 0)
+        assert len(g['target']) == 3
+        for t, r in zip(g['target'], ref):
+            assert np.array_equal(t.cpu().numpy(), r)
+        assert g['properties'] is b['properties'] and g['keys'] == b['keys']
+    # an already-built pyramid is uploaded level by level, untouched
+    pyr = [{'data': batches[0]['data'], 'target': [np.ones((2, 1, 4, 4, 4), np.float32), np.zeros((2, 1, 2, 2, 2), np.float32)]}]
+    g = next(DeviceBatchFeeder(iter(pyr)))
+    assert [tuple(t.shape) for t in g['target']] == [(2, 1, 4, 4, 4), (2, 1, 2, 2, 2)] and float(g['target'][0].sum()) == 128.0
