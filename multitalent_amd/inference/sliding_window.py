@@ -137,14 +137,22 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
         tiles = tiles[rank * per:(rank + 1) * per]           # contiguous run keeps the per-voxel order of the reference
     was_training = net.training
     with torch.no_grad():
-        for (xs, ys, zs) in tiles:
-            tile = vol[None, :, xs:xs + patch_size[0], ys:ys + patch_size[1], zs:zs + patch_size[2]]
-            for i, c in enumerate(combos):
-                inp = torch.flip(tile, tuple(a + 2 for a in c)) if len(c) else tile
-                logits = eng.forward(inp.contiguous(), need_grad=False, all_heads=False)[0]     # [1, D, H, W, C]
-                flips = (0 in c, 1 in c, 2 in c)
-                ops.flip_accumulate(Act(logits), flips, nonlin, 1.0 / num_results, acc, i == 0)
-            ops.tile_accumulate(acc, mult, num_classes, patch_size, agg, nb, shp[1:], (xs, ys, zs))
+        # all mirrored versions of a tile — and several consecutive tiles — go through the network as ONE batch (per-sample
+        # results do not depend on the batch, and the aggregate is still updated tile by tile in the reference's x -> y -> z
+        # order with the reference's mirror order inside a tile): up to 8x larger grids on the low-resolution stages
+        group = max(1, 8 // len(combos))
+        for g0 in range(0, len(tiles), group):
+            chunk = tiles[g0:g0 + group]
+            inp = []
+            for (xs, ys, zs) in chunk:
+                tile = vol[None, :, xs:xs + patch_size[0], ys:ys + patch_size[1], zs:zs + patch_size[2]]
+                inp += [torch.flip(tile, tuple(a + 2 for a in c)) if len(c) else tile for c in combos]
+            logits = eng.forward(torch.cat(inp, 0).contiguous(), need_grad=False, all_heads=False)[0]   # [B, D, H, W, C]
+            for t, (xs, ys, zs) in enumerate(chunk):
+                for i, c in enumerate(combos):
+                    k = t * len(combos) + i
+                    ops.flip_accumulate(Act(logits[k:k + 1]), (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
+                ops.tile_accumulate(acc, mult, num_classes, patch_size, agg, nb, shp[1:], (xs, ys, zs))
     if tile_shard is not None and tile_shard[1] > 1:
         import torch.distributed as dist
         dist.all_reduce(agg)
