@@ -1156,6 +1156,106 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvKParams P) {
 }
 
 // ================================================================================================
+// Non-overlapping convolution (kernel == stride in every dim, pad 0): the backward-data of ConvTranspose3d(k = s)
+// (generic_UNet.py:335-336) — every output voxel reads its own kD*kH*kW block, nothing is shared between outputs, so there is
+// no halo to stage: A fragments come straight from global memory (32-byte per-lane vectors, lazy activation in registers) as in
+// the pointwise kernel, one accumulator tile per wave of 32 output voxels x 32 channels.
+template <int VEC>
+__global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
+  const mt_conv3d_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  const long V = (long)c.Do * c.Ho * c.Wo;
+  const int nsb = (int)((V + 127) / 128);
+  const int bx = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const int nb = bx / nsb, sb = bx % nsb;
+  const int ntile = blockIdx.y;
+  const long m0 = (long)sb * 128 + wave * 32;
+  const mt_src_t& S = c.src[0];
+  const long mv = m0 + li;
+  const bool vok = mv < V;
+  const int ow = (int)(mv % c.Wo), oh = (int)((mv / c.Wo) % c.Ho), od = (int)(mv / ((long)c.Wo * c.Ho));
+  const size_t in_sample = (size_t)c.Di * c.Hi * c.Wi * S.cs;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0, (int)(in_sample * 4), 0x00020000);
+  const int abase = vok ? ((((od * c.SD) * c.Hi + oh * c.SH) * c.Wi + ow * c.SW) * S.cs + 8 * lhalf) * 4 : (int)0x80000000;
+  const bool aff = S.scale != nullptr;
+  const float slope = aff ? S.slope : 1.f;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(aff ? S.scale + (size_t)nb * S.C : S.ptr), 0, aff ? S.C * 4 : 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)(aff ? S.shift + (size_t)nb * S.C : S.ptr), 0, aff ? S.C * 4 : 0, 0x00020000);
+  const int ntaps = P.ntaps, total = P.nchunks * ntaps;
+
+  auto load_a = [&](int it, float (&x)[8]) {           // it = chunk * ntaps + tap
+    const int ch = it / ntaps, tap = it - ch * ntaps;
+    const int kw = tap % c.KW, kh = (tap / c.KW) % c.KH, kd = tap / (c.KW * c.KH);
+    const int so = __builtin_amdgcn_readfirstlane((((kd * c.Hi + kh) * c.Wi + kw) * S.cs + ch * FCK) * 4);
+    if constexpr (VEC == 4) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, abase + g * 16, so, 0));
+        x[4 * g] = t[0]; x[4 * g + 1] = t[1]; x[4 * g + 2] = t[2]; x[4 * g + 3] = t[3];
+      }
+    } else if constexpr (VEC == 2) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra, abase + g * 8, so, 0));
+        x[2 * g] = t.x; x[2 * g + 1] = t.y;
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) x[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, abase + g * 4, so, 0));
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  float xa[8], xn[8], sc[8], sh[8];
+  load_a(0, xa);
+  for (int it = 0; it < total; ++it) {
+    const int ch = it / ntaps, tap = it - ch * ntaps;
+    if (it + 1 < total) load_a(it + 1, xn);
+    const int cb = ch * FCK + 8 * lhalf;
+    if (tap == 0) {                                      // per-chunk lazy-activation constants (0 for channels beyond Cin)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool cv = cb + e < c.Cin;
+        sc[e] = aff ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cv ? (cb + e) * 4 : (int)0x80000000, 0, 0)) : (cv ? 1.f : 0.f);
+        sh[e] = aff ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, cv ? (cb + e) * 4 : (int)0x80000000, 0, 0)) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = fmaf(xa[e], sc[e], sh[e]);
+      xa[e] = vok ? mt_lrelu(t, slope) : 0.f;
+    }
+    const float* wq = c.wpack + ((size_t)(ntile * P.nchunks + ch) * ntaps + tap) * 512 + lane * 4;
+    const f32x4 b0 = *(const f32x4*)(wq);
+    const f32x4 b1 = *(const f32x4*)(wq + 256);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], b0[e], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[4 + e], b1[e], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xa[e] = xn[e];
+  }
+
+  const int co = ntile * 32 + li;
+  const bool covalid = co < c.Cout;
+  const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
+  const size_t out_sample = (size_t)V * c.ocs0;
+  __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample), 0, (int)(out_sample * 4), 0x00020000);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const long v = m0 + (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+    const int off = (covalid && v < V) ? (int)((v * c.ocs0 + co) * 4) : (int)0x80000000;
+    float val = acc[j] + bv;
+    if (c.accumulate) val += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro, off, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, off, 0, 0);
+  }
+}
+
+// ================================================================================================
 // Runtime-geometry forward kernel on the FAST design (any kernel size 1..3, stride 1..2, pad, strided output placement):
 // LDS image [voxel][20], ds_read_b128 operands, float4 weights, buffer loads/stores.  The tap loop is a runtime loop
 // (unrolled by two with ping-pong fragments); the only vector-ALU work inside it is one address add per M tile and tap
@@ -1541,6 +1641,8 @@ static bool conv_rt_ok(const mt_conv3d_t* p);
 static int pick_rt_cfg(const mt_conv3d_t* p);
 static bool conv_fast_strided_ok(const mt_conv3d_t* p);
 static bool conv_wino_ok(const mt_conv3d_t* p);
+static bool conv_gather_ok(const mt_conv3d_t* p);
+static int launch_gather(const mt_conv3d_t* p, hipStream_t st);
 static ConvPlan conv_plan(const mt_conv3d_t* p) {
   static int use_v2 = -1, use_rt = -1;
   if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
@@ -1788,6 +1890,37 @@ static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
   return MT_OK;
 }
 
+// kernel == stride, pad 0, one plain destination, no statistics: every output owns its input block (conv_gather_kernel)
+static bool conv_gather_ok(const mt_conv3d_t* p) {
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_CONV_GATHER"); use = e ? atoi(e) : 1; }
+  if (!use || p->nsrc != 1 || p->csplit < p->Cout || p->osD > 0 || p->stats_part != nullptr) return false;
+  if (!(p->KD == p->SD && p->KH == p->SH && p->KW == p->SW && p->PD == 0 && p->PH == 0 && p->PW == 0)) return false;
+  if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
+  if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return false;
+  return true;
+}
+static int launch_gather(const mt_conv3d_t* p, hipStream_t st) {
+  ConvKParams P;
+  P.c = *p;
+  P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0;
+  P.ntaps = p->KD * p->KH * p->KW; P.dbg = 0; P.stagger = 0;
+  P.nchunks = mt_build_chunks(p->src[0].C, 0, FCK, P.chunk);
+  MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
+  const long V = (long)p->Do * p->Ho * p->Wo;
+  P.tilesD = P.tilesH = P.tilesW = 1; P.nsb = (int)((V + 127) / 128);
+  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
+  const mt_src_t& S = p->src[0];
+  int vec = 1;
+  if ((S.cs % 4) == 0 && (((uintptr_t)S.ptr) & 15) == 0) vec = 4;
+  else if ((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0) vec = 2;
+  if (vec == 4) hipLaunchKernelGGL(conv_gather_kernel<4>, grid, dim3(256), 0, st, P);
+  else if (vec == 2) hipLaunchKernelGGL(conv_gather_kernel<2>, grid, dim3(256), 0, st, P);
+  else hipLaunchKernelGGL(conv_gather_kernel<1>, grid, dim3(256), 0, st, P);
+  MT_CHECK_LAUNCH("conv3d_gather");
+  return MT_OK;
+}
+
 static size_t rt_lds(const ConvCfg& g, const mt_conv3d_t* p) {
   int TD = g.TD, TH = (32 / g.MW) * g.RH, TW = g.MW;
   const size_t LD = (TD - 1) * p->SD + p->KD, LH = (TH - 1) * p->SH + p->KH, LW = (TW - 1) * p->SW + p->KW;
@@ -1890,6 +2023,8 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
     snprintf(buf, n, g_wino_waves == 8 ? "conv_wino8_kernel" : "conv_wino_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
     snprintf(buf, n, "conv_fast_strided_kernel<%d, %d, %d, %d>", p->SD, p->SH, p->SW, conv_fast_vec(p));
+  else if (pl.kind == CONV_RT && conv_gather_ok(p))
+    snprintf(buf, n, "conv_gather_kernel");
   else if (pl.kind == CONV_RT)
     snprintf(buf, n, "conv_rt_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
   else
@@ -1914,6 +2049,7 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   if (pl.kind == CONV_TAPSPLIT) return launch_tapsplit(p, st);
   if (pl.kind == CONV_STEM) return launch_stem(p, st);
   if (pl.kind == CONV_WINO) return launch_wino(p, st);
+  if (pl.kind == CONV_RT && conv_gather_ok(p)) return launch_gather(p, st);
   if (pl.kind == CONV_RT) {
     const int vec = conv_fast_vec(p);
     switch (i) {

@@ -448,3 +448,33 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
     finally:
         ops.set_option('conv_wino', 1)
         ops.set_option('wino_waves', 8)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,shape,k", [
+    (2, 30, 60, (6, 12, 34), (2, 2, 2)),
+    (1, 64, 33, (5, 9, 21), (2, 2, 2)),          # odd sizes: the last input plane/row/column is unused
+    (2, 60, 30, (4, 8, 16), (1, 2, 2)),
+    (1, 17, 40, (4, 6, 10), (2, 2, 2)),          # odd channel stride: scalar loads
+])
+def test_conv_kernel_equals_stride_gather(dev, N, Cin, Cout, shape, k):
+    """kernel == stride, pad 0 (the backward-data form of ConvTranspose3d(k = s)): conv_gather_kernel, lazy input, accumulate."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn((N, Cin) + shape, generator=g)
+    sc, sh = torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g)
+    w = torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))
+    xin = ref_inputs([x], [(sc, sh, 0.01)])
+    ref = F.conv3d(xin, w, None, stride=k, padding=0)
+    xb = to_ndhwc(x).to(dev)
+    act = ops.Act(xb, scale=sc.to(dev).contiguous(), shift=sh.to(dev).contiguous(), slope=0.01)
+    geom = ops.ConvGeom(shape, k, k, (0, 0, 0))
+    base = torch.randn((N,) + geom.out + (Cout,), generator=g)
+    out = base.to(dev)
+    p = ops.fill_conv([act], geom, Cout, out0=ops.Act(out), accumulate=True)
+    assert ops.conv_kernel_name(p) == 'conv_gather_kernel'
+    wd = w.to(dev).contiguous()
+    wp = ops.pack_conv_weights(wd, Cin, 0, Cout, k, ops.conv_weight_strides(wd), False, ops.conv_ck(p), layout=ops.conv_pack_layout(p))
+    p.wpack = wp.data_ptr()
+    ops.conv3d_fwd(p)
+    torch.cuda.synchronize()
+    assert relerr(to_ncdhw(out.cpu() - base), ref) < 1e-5
