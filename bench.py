@@ -27,6 +27,7 @@ PATCH = (48, 192, 192)
 POOLS = [[2, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2]]
 KERNELS = [[3, 3, 3]] * 6
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 RESENC_POOLS = [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]]     # SURVEY §8a N6 (resenc_bs4 plan)
@@ -102,7 +103,9 @@ def measure_roofline(step, x, largs, nrep=3):
         # algorithmic work: 2 * |out| * Cin * k^3; a zero-inserted input (backward-data of a strided conv) only carries
         # 1/prod(dil) non-structural-zero taps
         flops = 2.0 * p.N * p.Do * p.Ho * p.Wo * p.Cin * p.Cout * p.KD * p.KH * p.KW / (p.dilD * p.dilH * p.dilW)
-        rec.setdefault(ops.conv_kernel_name(p), []).append((e0, e1, flops))
+        # algorithmic bytes: the input read once, the output written once (read+written when accumulating), fp32
+        nbytes = 4.0 * p.N * (p.Di * p.Hi * p.Wi * p.Cin + p.Do * p.Ho * p.Wo * p.Cout * (2 if p.accumulate else 1))
+        rec.setdefault(ops.conv_kernel_name(p), []).append((e0, e1, flops, nbytes))
 
     ops.conv3d_fwd = timed
     try:
@@ -111,15 +114,21 @@ def measure_roofline(step, x, largs, nrep=3):
         torch.cuda.synchronize()
     finally:
         ops.conv3d_fwd = orig
-    groups = {k: (sum(a.elapsed_time(b) for a, b, _ in v), sum(f for _, _, f in v), len(v)) for k, v in rec.items()}
+    groups = {k: (sum(a.elapsed_time(b) for a, b, _, _ in v), sum(f for _, _, f, _ in v), len(v), sum(nb for _, _, _, nb in v))
+              for k, v in rec.items()}
     name = max(groups, key=lambda k: groups[k][0])
-    ms, fl, n = groups[name]
+    ms, fl, n, nby = groups[name]
     ach = fl / (ms * 1e-3) / 1e12
     all_ms = sum(g[0] for g in groups.values()); all_fl = sum(g[1] for g in groups.values())
     out = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": n // nrep,
             "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
             "all_conv_fwd_launches": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / nrep, 3)}}
+    if name.startswith('conv_bf16'):
+        # bf16 matrix inputs: 27 MFMAs per 16-channel chunk instead of 216 — the kernel is bound by moving the fp32 activations
+        gbs = nby / (ms * 1e-3) / 1e9
+        out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "algorithmic_mbytes_per_launch": round(nby / n / 1e6, 1), "algorithmic_tflops": round(ach, 1)})
     if name.startswith('conv_wino'):
         # `achieved` counts the ALGORITHMIC FLOPs of the direct convolution; the Winograd F(2x2x2,3x3x3) kernel executes
         # 64/216 of them on the matrix cores (plus the transforms on the vector ALU), so frac may exceed what a direct kernel can
@@ -216,6 +225,8 @@ def main():
     ap.add_argument('--volume', type=int, nargs=3, default=[512, 512, 512], help='--workload infer: synthetic CT volume')
     ap.add_argument('--mirror', type=int, default=1, help='--workload infer: 8-fold mirror TTA (reference default)')
     ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                    help='bf16 = mixed precision (BASELINE configs[3]): bf16 matrix inputs, fp32 accumulation/storage; the headline metric is fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -240,6 +251,7 @@ def main():
     torch.manual_seed(1234)           # identical initial weights on all ranks (DDP broadcast semantics)
     net = build_network(workload)
     net.train()
+    net.engine().set_precision(args.precision)
     step = FusedTrainStep(net, make_loss(workload, ddp), lr=1e-2, ddp=ddp)
     x, largs = make_batch(workload, B, dev, rank)
 
@@ -271,12 +283,15 @@ def main():
         line = {
             "metric": "CT patches/s (48x192x192) train fwd+bwd", "value": round(value, 3), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == 'fp32' else "bf16", "data": "synthetic",
             "config": {"workload": {"task009": "Task009_Spleen Generic_UNet nc=2 softmax Dice+CE",
                                     "task100": "Task100_MultiTalent Generic_UNet nc=47 MultiTalent BCE+Dice loss",
                                     "resenc": "Task100_MultiTalent FabiansUNet (residual encoder) nc=47 MultiTalent BCE+Dice loss, fp32"}[workload],
                        "patch": list(PATCH), "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "step": "fwd+loss+bwd+clip12+SGD-nesterov",
+                       "precision": "fp32" if args.precision == 'fp32' else
+                       "bf16 matrix inputs + fp32 accumulation in the 3x3x3 stride-1 convs (fwd, bwd-data); fp32 storage, norm, loss, dW, optimizer",
                        "final_loss": round(float(loss), 5)},
             "algorithmic_tflop_per_step": round(fl / 1e12, 3),
             "step_frac_of_mfma_roofline": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),

@@ -74,7 +74,8 @@ typedef struct {
    * (OD,OH,OW).  Used by the backward-data of a strided conv, which is computed as one exact stride-1 convolution per
    * parity class of the input position instead of a convolution over a zero-inserted gradient. */
   int32_t OD, OH, OW, osD, osH, osW, ooD, ooH, ooW;
-  int32_t _pad2;
+  int32_t mma;                /* matrix input type of the convolution: 0 fp32 (exact), 1 bf16 inputs with fp32 accumulation
+                                 (mixed precision, the reference's autocast mode); packed weights must match (mt_conv3d_pack_layout) */
 } mt_conv3d_t;
 
 const char* mt_last_error(void);

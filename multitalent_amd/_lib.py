@@ -35,7 +35,7 @@ class mt_conv3d_t(C.Structure):
                 ('stats_part', C.c_void_p),
                 ('OD', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
                 ('osD', C.c_int32), ('osH', C.c_int32), ('osW', C.c_int32),
-                ('ooD', C.c_int32), ('ooH', C.c_int32), ('ooW', C.c_int32), ('_pad2', C.c_int32)]
+                ('ooD', C.c_int32), ('ooH', C.c_int32), ('ooW', C.c_int32), ('mma', C.c_int32)]
 
 
 class mt_pointwise_t(C.Structure):

@@ -864,6 +864,8 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
   }
 }
 
+#include "conv_bf16.inc"
+
 // ================================================================================================
 // Forward 3x3x3 convolution with stride (2,2,2) or (1,2,2), pad 1 (the first conv of every encoder stage,
 // generic_UNet.py:263-278) on the FAST design with compile-time taps.  Tile = 2 x 4 x 8 outputs x 64 output channels:
@@ -1604,6 +1606,8 @@ static const ConvCfg kCfgs[] = {
   {32, 4, 2, 16}, {16, 2, 2, 16}, {8, 2, 2, 16}, {32, 4, 2, 8}, {16, 2, 2, 8}, {8, 2, 2, 8}, {32, 4, 4, 16},
 };
 
+static const ConvCfg kBfCfgs[] = { {32, 4, 4, 16}, {32, 4, 2, 16}, {16, 4, 2, 16} };    // tiles of conv_bf16_kernel: 4x4x32, 2x4x32, 2x8x16
+
 static void cfg_tile(const ConvCfg& g, int* TD, int* TH, int* TW) {
   *TD = g.TD; *TH = (32 / g.MW) * g.RH; *TW = g.MW;
 }
@@ -1634,7 +1638,7 @@ static int pick_cfg(const mt_conv3d_t* p) {
 }
 
 // which kernel family serves a problem, and with which tile shape
-enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2, CONV_FAST_STRIDED = 3, CONV_TAPSPLIT = 4, CONV_STEM = 5, CONV_WINO = 6 };
+enum ConvKind { CONV_FAST = 0, CONV_RT = 1, CONV_GENERIC = 2, CONV_FAST_STRIDED = 3, CONV_TAPSPLIT = 4, CONV_STEM = 5, CONV_WINO = 6, CONV_BF16 = 7 };
 struct ConvPlan { int kind; int cfg; };
 static bool conv_is_fast(const mt_conv3d_t* p);
 static bool conv_rt_ok(const mt_conv3d_t* p);
@@ -1643,11 +1647,16 @@ static bool conv_fast_strided_ok(const mt_conv3d_t* p);
 static bool conv_wino_ok(const mt_conv3d_t* p);
 static bool conv_gather_ok(const mt_conv3d_t* p);
 static int launch_gather(const mt_conv3d_t* p, hipStream_t st);
+static int conv_bf16_cfg(const mt_conv3d_t* p);
 static ConvPlan conv_plan(const mt_conv3d_t* p) {
   static int use_v2 = -1, use_rt = -1;
   if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
   if (use_rt < 0) { const char* e = getenv("MT_CONV_RT"); use_rt = e ? atoi(e) : 1; }
   ConvPlan pl; pl.kind = CONV_GENERIC; pl.cfg = pick_cfg(p);
+  if (p->mma == 1) {                      // bf16 matrix inputs where the bf16 kernel serves the problem; fp32 kernels elsewhere
+    const int bc = conv_bf16_cfg(p);
+    if (bc >= 0) { pl.kind = CONV_BF16; pl.cfg = bc; return pl; }
+  }
   if (conv_is_fast(p) && use_v2 && p->osD <= 0 && p->nsrc == 1 && p->Cin == 1 && p->csplit >= p->Cout &&
       (double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 < 2147483648.0) {
     static int use_stem = -1;
@@ -1675,10 +1684,12 @@ static ConvPlan conv_plan(const mt_conv3d_t* p) {
 extern "C" int mt_conv3d_ck(const mt_conv3d_t* p) {
   const ConvPlan pl = conv_plan(p);
   if (pl.kind == CONV_WINO) return WCK;
+  if (pl.kind == CONV_BF16) return FCK;
   return pl.cfg < 0 ? -1 : kCfgs[pl.cfg].CK;
 }
 extern "C" int mt_conv3d_pack_layout(const mt_conv3d_t* p) {      // layout argument of mt_pack_conv_weights for this problem
-  return conv_plan(p).kind == CONV_WINO ? 2 : 1;
+  const int k = conv_plan(p).kind;
+  return k == CONV_WINO ? 2 : k == CONV_BF16 ? 3 : 1;
 }
 extern "C" int mt_conv3d_stats_blocks(const mt_conv3d_t* p) {
   const ConvPlan pl = conv_plan(p);
@@ -1686,6 +1697,7 @@ extern "C" int mt_conv3d_stats_blocks(const mt_conv3d_t* p) {
   if (pl.kind == CONV_FAST_STRIDED) return mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 8);
   if (pl.kind == CONV_TAPSPLIT) return mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 4);
   if (pl.kind == CONV_WINO) return mt_cdiv(p->Do, 4) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 16);
+  if (pl.kind == CONV_BF16) { int TD, TH, TW; cfg_tile(kBfCfgs[pl.cfg], &TD, &TH, &TW); return mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW); }
   int TD, TH, TW; cfg_tile(kCfgs[pl.cfg], &TD, &TH, &TW);
   return mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW);
 }
@@ -1832,6 +1844,67 @@ static int launch_stem(const mt_conv3d_t* p, hipStream_t st) {
 
 // Winograd eligibility: FAST geometry, 8-byte channel pairs in every source, one destination, enough workgroups to fill
 // the chip with 4x4x16 tiles and enough input channels to amortise the transforms
+// ---- bf16 matrix inputs (conv_bf16.inc)
+static int g_bf16_mode = -1;       // -1: read MT_CONV_BF16 (default 1); 0 never; 1 where the grid fills the chip; 2 wherever eligible
+static int conv_bf16_cfg(const mt_conv3d_t* p) {
+  if (g_bf16_mode < 0) { const char* e = getenv("MT_CONV_BF16"); g_bf16_mode = e ? atoi(e) : 1; }
+  const int use = g_bf16_mode;
+  if (!use || !conv_is_fast(p) || p->osD > 0 || p->Cin < 16 || conv_fast_vec(p) != 2) return -1;
+  if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return -1;            // 31-bit store offsets per sample
+  if (p->csplit < p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs1 * 4.0 >= 2147483648.0) return -1;
+  if (mt_cdiv(p->src[0].C, FCK) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, FCK) : 0) > MT_MAX_CHUNKS) return -1;
+  static int force = -2;
+  if (force == -2) { const char* e = getenv("MT_BF16_CFG"); force = e ? atoi(e) : -1; }
+  int best = -1; double bestcost = 1e300;
+  for (int i = 0; i < (int)(sizeof(kBfCfgs) / sizeof(kBfCfgs[0])); ++i) {
+    int TD, TH, TW; cfg_tile(kBfCfgs[i], &TD, &TH, &TW);
+    const double vol = (double)mt_cdiv(p->Do, TD) * TD * mt_cdiv(p->Ho, TH) * TH * mt_cdiv(p->Wo, TW) * TW;
+    const double halo = (double)(TD + 2) * (TH + 2) * (TW + 2) / ((double)TD * TH * TW);
+    const double cost = vol * (0.5 + 0.5 * halo / 2.0);
+    if (i == force) { best = i; break; }
+    if (cost < bestcost - 1e-9) { bestcost = cost; best = i; }
+  }
+  if (best < 0) return -1;
+  int TD, TH, TW; cfg_tile(kBfCfgs[best], &TD, &TH, &TW);
+  const long wgs = (long)p->N * mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW);
+  if (wgs < 128 && use != 2) return -1;          // low-resolution stages stay on the fp32 latency-oriented kernels
+  return best;
+}
+static int conv_bf16_vec(const mt_conv3d_t*) { return 2; }    // 16-byte staging loads measured slower (0.409 vs 0.372 ms on 32->32)
+template <int MW, int RH, int TD, int VEC, int NT, int NW>
+static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
+  ConvKParams P;
+  P.c = *p;
+  if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
+  constexpr int TH = (32 / MW) * RH, TW = MW;
+  P.tilesD = mt_cdiv(p->Do, TD); P.tilesH = mt_cdiv(p->Ho, TH); P.tilesW = mt_cdiv(p->Wo, TW);
+  P.nsb = P.tilesD * P.tilesH * P.tilesW;
+  P.ntaps = 27; P.dbg = 0; P.stagger = 0;
+  P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
+  MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
+  const size_t ldsb = bstage_lds_bytes<TD + 2, TH + 2, TW + 2, VEC, NW>();
+  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(mt_cdiv(p->Cout, 32), NT), 1);
+  auto kfn = conv_bf16_kernel<MW, RH, TD, VEC, NT, NW>;
+  if (ldsb > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
+  }
+  hipLaunchKernelGGL(kfn, grid, dim3(64 * NW), ldsb, st, P);
+  MT_CHECK_LAUNCH("conv3d_bf16");
+  return MT_OK;
+}
+static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
+  // NT = 2 (64 output channels per workgroup) measured slower: 0.197 vs 0.179 ms on 64->64 @ 24x96x96; 8 waves: no gain
+#define MT_BF_CASE(I_, MW_, RH_, TD_, NW_)                                                   \
+  if (cfg == I_) return launch_bf16_t<MW_, RH_, TD_, 2, 1, NW_>(p, st);
+  MT_BF_CASE(0, 32, 4, 4, 4)
+  MT_BF_CASE(1, 32, 4, 2, 4)
+  MT_BF_CASE(2, 16, 4, 2, 4)
+#undef MT_BF_CASE
+  mt_set_error("conv3d bf16: bad tile configuration %d", cfg);
+  return MT_EINVAL;
+}
+
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
 static int g_wino_waves = 8;       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
 static int g_wino_mode = -1;       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
@@ -1839,6 +1912,7 @@ extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "conv_wino") == 0) { g_wino_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_wino") == 0) { g_bwdw_wino = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "wino_waves") == 0) { g_wino_waves = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "conv_bf16") == 0) { g_bf16_mode = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
 }
@@ -2011,6 +2085,10 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   const ConvPlan pl = conv_plan(p);
   const int i = pl.cfg;
   if (i < 0) return MT_EINVAL;
+  if (pl.kind == CONV_BF16) {
+    snprintf(buf, n, "conv_bf16_kernel<%d, %d, %d, %d, 1, 4>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, conv_bf16_vec(p));
+    return MT_OK;
+  }
   const ConvCfg& g = kCfgs[i];
   const bool fast = conv_is_fast(p);
   if (pl.kind == CONV_FAST)
@@ -2038,6 +2116,7 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   const ConvPlan pl = conv_plan(p);
   const int i = pl.cfg;
   MT_REQUIRE(i >= 0, "conv3d: no tile configuration fits LDS");
+  if (pl.kind == CONV_BF16) return launch_bf16(p, i, (hipStream_t)stream);
   const ConvCfg& g = kCfgs[i];
   hipStream_t st = (hipStream_t)stream;
   const bool fast = conv_is_fast(p);
@@ -2203,6 +2282,33 @@ __device__ __forceinline__ void pack_weights_body(const PackParams& P, long firs
     }
     return;
   }
+  if (P.layout == 3) {     // bf16 B fragments of v_mfma_f32_32x32x16_bf16: [ntile][chunk of 16][tap][lane][4 dwords = 8 channels]
+    const long total3 = (long)P.ntiles * P.nchunks * P.KD * P.KH * P.KW * 256;
+    for (long i = first; i < total3; i += stride) {
+      long r = i;
+      const int e = (int)(r % 4); r /= 4;
+      const int l = (int)(r % 64); r /= 64;
+      const int kw = (int)(r % P.KW); r /= P.KW;
+      const int kh = (int)(r % P.KH); r /= P.KH;
+      const int kd = (int)(r % P.KD); r /= P.KD;
+      const int ch = (int)(r % P.nchunks); r /= P.nchunks;
+      const int nt = (int)r;
+      const ConvChunk cc = P.chunk[ch];
+      const int co = nt * 32 + (l & 31);
+      int zd = P.flip ? P.KD - 1 - kd : kd, zh = P.flip ? P.KH - 1 - kh : kh, zw = P.flip ? P.KW - 1 - kw : kw;
+      if (P.has_tm) { zd = P.tb[0] + P.ts[0] * kd; zh = P.tb[1] + P.ts[1] * kh; zw = P.tb[2] + P.ts[2] * kw; }
+      float v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cin_local = (l >> 5) * 8 + 2 * e + h;
+        v[h] = 0.f;
+        if (cin_local < cc.ck && co < P.Cout)
+          v[h] = P.w[(cc.cglob + cin_local) * P.s_ci + co * P.s_co + zd * P.s_kd + zh * P.s_kh + zw * P.s_kw];
+      }
+      ((unsigned*)P.dst)[i] = mt_pack_bf16(v[0], v[1]);
+    }
+    return;
+  }
   const long total = (long)P.ntiles * P.nchunks * P.KD * P.KH * P.KW * P.nkp * 64;
   for (long i = first; i < total; i += stride) {
     long r = i;
@@ -2248,14 +2354,17 @@ static int pack_fill(PackParams& P, size_t* packed_floats, const float* w, float
                      int KW, long s_ci, long s_co, long s_kd, long s_kh, long s_kw, int flip, int ck, int layout,
                      const int32_t* tapmap) {
   MT_REQUIRE(ck >= 2 && (ck % 2) == 0, "pack: ck must be even (got %d)", ck);
-  MT_REQUIRE(layout == 0 || (layout == 1 && (ck % 8) == 0) || (layout == 2 && ck == 8 && KD == 3 && KH == 3 && KW == 3 && tapmap == nullptr),
-             "pack: layout 1 needs ck %% 8 == 0; layout 2 (Winograd) needs ck == 8 and a 3x3x3 kernel");
+  MT_REQUIRE(layout == 0 || (layout == 1 && (ck % 8) == 0) || (layout == 2 && ck == 8 && KD == 3 && KH == 3 && KW == 3 && tapmap == nullptr) ||
+             (layout == 3 && ck == 16),
+             "pack: layout 1 needs ck %% 8 == 0; layout 2 (Winograd) needs ck == 8 and a 3x3x3 kernel; layout 3 (bf16) needs ck == 16");
   std::memset((void*)&P, 0, sizeof(P));
   P.nchunks = mt_build_chunks(C0, C1, ck, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "pack: too many chunks");
   P.ntiles = mt_cdiv(Cout, 32);
   P.nkp = ck / 2;
-  if (packed_floats) *packed_floats = layout == 2 ? (size_t)P.ntiles * P.nchunks * 64 * 256 : (size_t)P.ntiles * P.nchunks * KD * KH * KW * P.nkp * 64;
+  if (packed_floats) *packed_floats = layout == 2 ? (size_t)P.ntiles * P.nchunks * 64 * 256
+                                    : layout == 3 ? (size_t)P.ntiles * P.nchunks * KD * KH * KW * 256
+                                                  : (size_t)P.ntiles * P.nchunks * KD * KH * KW * P.nkp * 64;
   P.w = w; P.dst = dst; P.Cout = Cout; P.KD = KD; P.KH = KH; P.KW = KW; P.flip = flip; P.layout = layout;
   P.has_tm = tapmap != nullptr;
   for (int d = 0; d < 3; ++d) { P.tb[d] = tapmap ? tapmap[2 * d] : 0; P.ts[d] = tapmap ? tapmap[2 * d + 1] : 1; }

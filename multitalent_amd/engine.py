@@ -368,6 +368,18 @@ class Engine:
         self.params_version = 0
         self.grad_ready_hook = None         # callable(lo, hi) on flat_grad element ranges, in completion order
         self.dummy = None
+        self.mma = 0                        # matrix input type of the convolutions: 0 fp32, 1 bf16 (mixed precision)
+
+    def set_precision(self, precision):
+        """'fp32' (exact, default) or 'bf16': mixed precision — the reference's autocast mode (nnUNetTrainerV2.py:236-249) on
+        gfx950 terms: bf16 matrix inputs with fp32 accumulation for the 3x3x3 stride-1 convolutions (forward and backward-data),
+        fp32 activations, master weights, normalisation, loss, weight gradients and optimizer; no loss scaling is needed."""
+        mma = {'fp32': 0, 'bf16': 1, 0: 0, 1: 1, False: 0, True: 1}[precision]
+        if mma != self.mma:
+            self.mma = mma
+            self._planned = None            # packed layouts and statistics tilings depend on the kernel choice
+            self._packed_version = None
+            self._pack_programs = {}
 
     # ---- memory -----------------------------------------------------------------------------------
     def buffer(self, name, shape):
@@ -464,6 +476,7 @@ class Engine:
             return
         key = (self.params_version, need_grad)
         prog = self._pack_programs.get(key)
+        ops.set_mma(self.mma)
         if prog is None:            # record the ops' packing calls once; afterwards every step is one batched launch
             rec = []
             ops._pack_recorder = rec
@@ -485,6 +498,7 @@ class Engine:
         if not x.is_cuda:
             raise RuntimeError("multitalent_amd: the network runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
         self.attach(x.device)
+        ops.set_mma(self.mma)
         N, Cin = x.shape[0], x.shape[1]
         spatial = tuple(x.shape[2:])
         self._plan(N, spatial, need_grad)
@@ -509,6 +523,7 @@ class Engine:
     def backward(self, dlogits):
         """dlogits: list (module output order) of NDHWC gradient tensors or None.  Fills flat_grad."""
         self.flat_grad.zero_()
+        ops.set_mma(self.mma)
         for op in self.ops:
             op.out.grad_init = False
         for h, g in zip(self.heads, dlogits):

@@ -92,11 +92,22 @@ class ConvGeom:
         self.out = _triple(out_spatial)
 
 
+# matrix input type given to every mt_conv3d_t built by fill_conv: 0 = fp32, 1 = bf16 inputs / fp32 accumulation.  The engine
+# sets it on entry of pack / forward / backward (Engine.mma), so several engines with different modes can coexist.
+_MMA = 0
+
+
+def set_mma(mode):
+    global _MMA
+    _MMA = int(mode)
+
+
 def fill_conv(srcs, geom, Cout, wpack=None, bias=None, out0=None, out1=None, csplit=None, accumulate=False,
-              stats_part=None, place=None):
+              stats_part=None, place=None, mma=None):
     """Build an mt_conv3d_t.  srcs: list of 1-2 Act; out0/out1: Act-like destination slices.
     place = (stored_spatial, out_stride, out_offset): logical output o is written at o*stride + offset."""
     p = mt_conv3d_t()
+    p.mma = _MMA if mma is None else int(mma)
     p.nsrc = len(srcs)
     for i, a in enumerate(srcs):
         p.src[i] = a.src()

@@ -270,6 +270,9 @@ class nnUNetTrainerV2(nnUNetTrainer):
         self.setup_DA_params()
         self.ds_loss_weights = ds_loss_weights(len(self.net_num_pool_op_kernel_sizes))    # nnUNetTrainerV2.py:78-90
         self.initialize_network()
+        # fp16=True is the reference's mixed-precision switch (autocast + GradScaler, nnUNetTrainerV2.py:236-249); here it
+        # selects bf16 matrix inputs with fp32 accumulation (Engine.set_precision) — no loss scaling needed
+        self.network.engine().set_precision('bf16' if self.fp16 else 'fp32')
         self.initialize_optimizer_and_scheduler()
         self.was_initialized = True
 

@@ -450,6 +450,73 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
         ops.set_option('wino_waves', 8)
 
 
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,shape,two_src", [
+    (2, 32, 32, (8, 16, 64), False),
+    (2, 30, 30, (9, 18, 70), False),        # ragged tiles, channel tail (chunks 16 + 14), Cout not a multiple of 32
+    (1, 64, 40, (12, 20, 33), False),
+    (1, 30, 30, (5, 7, 19), True),          # concat input: chunks never straddle the two sources
+    (1, 16, 70, (4, 4, 16), False),
+])
+def test_conv_bf16_mixed_precision(dev, N, Cin, Cout, shape, two_src):
+    """conv_bf16_kernel (mt_conv3d_t.mma = 1: bf16 matrix inputs, fp32 accumulation), forced on small shapes.  Tight check
+    against the SAME arithmetic restated on the CPU (inputs rounded to bf16 after the fp32 InstanceNorm+LeakyReLU, weights
+    rounded to bf16, fp32 products/sums): 1e-4; loose check against the exact fp32 convolution: 2e-2 of the largest output
+    (bf16 has 8 mantissa bits).  Forward with lazy inputs + statistics, and the flipped-weight backward-data form with two
+    destinations."""
+    ops = _ops()
+    ops.set_option('conv_bf16', 2)
+    ops.set_mma(1)
+    try:
+        g = torch.Generator().manual_seed(23)
+        srcs = [torch.randn((N, Cin) + shape, generator=g)]
+        lazy = [(torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)]
+        if two_src:
+            srcs.append(torch.randn((N, Cin) + shape, generator=g))
+            lazy.append(None)
+        Ct = Cin * len(srcs)
+        w = torch.randn((Cout, Ct, 3, 3, 3), generator=g) / np.sqrt(Ct * 27)
+        b = torch.randn(Cout, generator=g)
+        out, part = run_conv(dev, srcs, w, b, (1, 1, 1), (1, 1, 1), lazy=lazy, stats=True)
+        xin = ref_inputs(srcs, lazy)
+        ref_same = F.conv3d(_bf16_round(xin).double(), _bf16_round(w).double(), b.double(), padding=1)
+        ref_exact = F.conv3d(xin, w, b, padding=1)
+        got = to_ncdhw(out.cpu())
+        assert relerr(got, ref_same) < 1e-4
+        assert relerr(got, ref_exact) < 2e-2
+        s = part.cpu().double().sum(1)
+        assert np.allclose(s[..., 0].numpy(), ref_same.sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3 * np.sqrt(ref_same[0, 0].numel()))
+        assert np.allclose(s[..., 1].numpy(), (ref_same ** 2).sum((2, 3, 4)).numpy(), rtol=1e-4)
+        # backward-data through the same kernel (flipped, transposed weights), accumulate into two destinations
+        dy = torch.randn(ref_exact.shape, generator=g)
+        x = torch.zeros_like(xin, dtype=torch.float64).requires_grad_(True)
+        F.conv3d(x, _bf16_round(w).double(), None, padding=1).backward(_bf16_round(dy).double())
+        C0 = Ct // 2 if Ct % 4 == 0 else Ct
+        base0 = torch.randn((N,) + shape + (C0,), generator=g)
+        base1 = torch.randn((N,) + shape + (max(Ct - C0, 1),), generator=g)
+        d0, d1 = base0.to(dev), base1.to(dev)
+        geomT = ops.ConvGeom(shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+        dyd = to_ndhwc(dy).to(dev)            # keep alive: the parameter struct only holds raw pointers
+        p = ops.fill_conv([ops.Act(dyd)], geomT, Ct, out0=ops.Act(d0), out1=ops.Act(d1) if C0 < Ct else None,
+                          csplit=C0, accumulate=True)
+        assert ops.conv_kernel_name(p).startswith('conv_bf16') == (Cout % 2 == 0 and Cout >= 16)
+        wd = w.to(dev).contiguous()
+        wp = ops.pack_conv_weights(wd, Cout, 0, Ct, (3, 3, 3), ops.conv_weight_strides(wd, as_bwd_data=True), True, ops.conv_ck(p),
+                                   layout=ops.conv_pack_layout(p))
+        p.wpack = wp.data_ptr()
+        ops.conv3d_fwd(p)
+        torch.cuda.synchronize()
+        gotb = torch.cat([d0.cpu() - base0] + ([d1.cpu() - base1] if C0 < Ct else []), -1)
+        tol = 1e-4 if ops.conv_kernel_name(p).startswith('conv_bf16') else 2e-2      # odd Cout: exact fp32 kernel on unrounded data
+        assert relerr(to_ncdhw(gotb), x.grad) < tol
+    finally:
+        ops.set_option('conv_bf16', 1)
+        ops.set_mma(0)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,shape,k", [
     (2, 30, 60, (6, 12, 34), (2, 2, 2)),
     (1, 64, 33, (5, 9, 21), (2, 2, 2)),          # odd sizes: the last input plane/row/column is unused

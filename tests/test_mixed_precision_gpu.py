@@ -1,0 +1,87 @@
+"""bf16 mixed precision (the reference's fp16=True / autocast mode, nnUNetTrainerV2.py:236-249; BASELINE configs[3]) at engine
+level: the same network and batch in fp32 and bf16 mode.  The reference itself gives no tolerance for its AMP path; the bound
+used here is what 8 mantissa bits allow through a U-Net of this depth: logits within 3e-2 of the largest logit, loss within
+1e-2, gradient direction cos > 0.995, and training curves that stay within 2e-2 of the fp32 ones over three steps."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(dev, base=16):
+    from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
+    pools = [[2, 2, 2], [2, 2, 2]]
+    kernels = [[3, 3, 3]] * 3
+    torch.manual_seed(5)
+    net = Generic_UNet(1, base, 3, len(pools), 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                       {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True}, True, False,
+                       lambda x: x, None, pools, kernels, False, True, True)
+    return net.to(dev)
+
+
+def _batch(dev):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((2, 1, 16, 32, 48), generator=g).to(dev)
+    t0 = torch.randint(0, 3, (2, 1, 16, 32, 48), generator=g).float()
+    tg = [t0.to(dev), t0[:, :, ::2, ::2, ::2].contiguous().to(dev), t0[:, :, ::4, ::4, ::4].contiguous().to(dev)]
+    return x, tg
+
+
+def test_bf16_mode_uses_the_bf16_kernel_and_tracks_fp32(dev):
+    from multitalent_amd import ops
+    from multitalent_amd.engine import ConvNormOp
+    from multitalent_amd.training.hot_loop import FusedTrainStep
+    from multitalent_amd.training.loss_functions.fused_losses import DC_and_CE_DS_loss
+    ops.set_option('conv_bf16', 2)              # also on the small grids of this test
+    try:
+        x, tg = _batch(dev)
+        w = np.array([4 / 7, 2 / 7, 1 / 7])
+        res = {}
+        for mode in ('fp32', 'bf16'):
+            net = _net(dev)
+            net.train()
+            eng = net.engine()
+            eng.set_precision(mode)
+            out = net(x)
+            loss = DC_and_CE_DS_loss(w, batch_dice=False)(out, tg)
+            loss.backward()
+            ops.set_mma(eng.mma)
+            names = [ops.conv_kernel_name(op._fwd_params(eng)) for op in eng.ops if isinstance(op, ConvNormOp) and not op.pointwise]
+            ops.set_mma(0)
+            grads = torch.cat([eng.grad_of(p).reshape(-1) for p in net.parameters()]).cpu().double()
+            step = FusedTrainStep(net, DC_and_CE_DS_loss(w, batch_dice=False), lr=1e-2)
+            losses = [float(step(x, tg)) for _ in range(3)]
+            res[mode] = ([o.detach().cpu() for o in out], float(loss.detach()), grads, losses, names)
+        assert not any(n.startswith('conv_bf16') for n in res['fp32'][4])
+        assert sum(n.startswith('conv_bf16') for n in res['bf16'][4]) >= 5, res['bf16'][4]      # every Cin >= 16 3x3x3 stride-1 conv
+        for a, b in zip(res['bf16'][0], res['fp32'][0]):
+            assert float((a - b).abs().max()) < 3e-2 * float(b.abs().max())
+        assert abs(res['bf16'][1] - res['fp32'][1]) < 1e-2
+        ga, gb = res['bf16'][2], res['fp32'][2]
+        assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.995
+        for la, lb in zip(res['bf16'][3], res['fp32'][3]):
+            assert np.isfinite(la) and abs(la - lb) < 2e-2, (res['bf16'][3], res['fp32'][3])
+        assert res['bf16'][3][-1] < res['bf16'][3][0]                   # it trains
+    finally:
+        ops.set_option('conv_bf16', 1)
+        ops.set_mma(0)
+
+
+def test_trainer_fp16_flag_selects_bf16(dev, tmp_path):
+    """fp16=True in the reference's trainer constructor (nnUNetTrainerV2.py:45-46) turns mixed precision on."""
+    from multitalent_amd import plans as P
+    from multitalent_amd.training.model_restore import find_trainer_class
+    sp = {'batch_size': 2, 'patch_size': np.array([16, 32, 32]), 'pool_op_kernel_sizes': [[2, 2, 2], [2, 2, 2], [1, 2, 2]],
+          'conv_kernel_sizes': [[3, 3, 3]] * 4, 'do_dummy_2D_data_aug': False}
+    plans = P.make_plans(sp, base_num_features=16, num_classes=1, stage=0)
+    for fp16 in (False, True):
+        tr = find_trainer_class('nnUNetTrainerV2')(plans, 0, output_folder=str(tmp_path / ('o%d' % fp16)), batch_dice=False, stage=0,
+                                                   fp16=fp16)
+        tr.initialize(True)
+        assert tr.network.engine().mma == (1 if fp16 else 0)
+        gen = tr._default_generator()
+        tr.network.train()
+        l = [float(tr.run_iteration(gen, True)) for _ in range(3)]
+        assert np.isfinite(l).all() and l[-1] < l[0]

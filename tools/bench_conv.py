@@ -9,8 +9,9 @@ ap.add_argument('--cin', type=int, default=30); ap.add_argument('--cout', type=i
 ap.add_argument('--shape', type=int, nargs=3, default=[48, 192, 192]); ap.add_argument('--n', type=int, default=2)
 ap.add_argument('--k', type=int, nargs=3, default=[3, 3, 3]); ap.add_argument('--stride', type=int, nargs=3, default=[1, 1, 1])
 ap.add_argument('--reps', type=int, default=5); ap.add_argument('--mode', default='fwd', choices=['fwd', 'bwdw'])
-ap.add_argument('--lazy', type=int, default=1)
+ap.add_argument('--lazy', type=int, default=1); ap.add_argument('--mma', type=int, default=0)
 a = ap.parse_args()
+ops.set_mma(a.mma)
 dev = torch.device('cuda:0')
 N, Cin, Cout = a.n, a.cin, a.cout
 x = torch.randn((N,) + tuple(a.shape) + (Cin,), device=dev)
@@ -56,6 +57,18 @@ else:
     ya = ops.Act(dy)
     run = lambda: ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
 run(); torch.cuda.synchronize()
+if a.mode == 'fwd':
+    print('kernel:', ops.conv_kernel_name(p))
+if a.mode == 'fwd' and a.mma:          # error against the fp32 kernel on the same inputs
+    p0 = ops.fill_conv([xa], geom, Cout, bias=b, out0=ops.Act(torch.empty_like(out)), mma=0)
+    o0 = torch.empty_like(out); p0.out0 = o0.data_ptr()
+    wp0 = ops.pack_conv_weights(w, Cin, 0, Cout, a.k, ops.conv_weight_strides(w), False, ops.conv_ck(p0), layout=ops.conv_pack_layout(p0))
+    p0.wpack = wp0.data_ptr()
+    part0 = torch.zeros((N, ops.conv_stats_blocks(p0), Cout, 2), device=dev); p0.stats_part = part0.data_ptr()
+    ops.conv3d_fwd(p0); torch.cuda.synchronize()
+    print('bf16 vs fp32: max abs err %.4g, rms err %.4g, rms ref %.4g; stats sum rel err %.3g' % (
+        (out - o0).abs().max().item(), (out - o0).pow(2).mean().sqrt().item(), o0.pow(2).mean().sqrt().item(),
+        ((part.sum(1) - part0.sum(1)).abs().max() / part0.sum(1).abs().max()).item()))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.reps):
