@@ -287,11 +287,11 @@ def main():
             "dtype": "f32" if args.precision == 'fp32' else "bf16", "data": "synthetic",
             "config": {"workload": {"task009": "Task009_Spleen Generic_UNet nc=2 softmax Dice+CE",
                                     "task100": "Task100_MultiTalent Generic_UNet nc=47 MultiTalent BCE+Dice loss",
-                                    "resenc": "Task100_MultiTalent FabiansUNet (residual encoder) nc=47 MultiTalent BCE+Dice loss, fp32"}[workload],
+                                    "resenc": "Task100_MultiTalent FabiansUNet (residual encoder) nc=47 MultiTalent BCE+Dice loss"}[workload],
                        "patch": list(PATCH), "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "step": "fwd+loss+bwd+clip12+SGD-nesterov",
                        "precision": "fp32" if args.precision == 'fp32' else
-                       "bf16 matrix inputs + fp32 accumulation in the 3x3x3 stride-1 convs (fwd, bwd-data); fp32 storage, norm, loss, dW, optimizer",
+                       "bf16 matrix inputs + fp32 accumulation in the 3x3x3 stride-1 convs (fwd, bwd-data, bwd-weight); fp32 storage, norm, loss, optimizer, other layers",
                        "final_loss": round(float(loss), 5)},
             "algorithmic_tflop_per_step": round(fl / 1e12, 3),
             "step_frac_of_mfma_roofline": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),

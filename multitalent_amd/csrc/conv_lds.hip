@@ -1905,6 +1905,7 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
   return MT_EINVAL;
 }
 
+static int g_bwdw_bf16 = -1;       // -1: read MT_BWDW_BF16 (default 1): bf16 Winograd backward-weight kernel when mt_conv3d_t.mma == 1
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
 static int g_wino_waves = 8;       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
 static int g_wino_mode = -1;       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
@@ -1913,6 +1914,7 @@ extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "bwdw_wino") == 0) { g_bwdw_wino = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "wino_waves") == 0) { g_wino_waves = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "conv_bf16") == 0) { g_bf16_mode = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "bwdw_bf16") == 0) { g_bwdw_bf16 = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
 }
@@ -3090,6 +3092,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P)
 }
 
 #include "bwdw_wino.inc"
+#include "bwdw_bf16.inc"
 
 // compile-time geometries of the fast backward-weight kernel: (K, S) with pad (K-1)/2 for K=3/1 and 0 for K=2
 struct BwGeo { int KD, KH, KW, SD, SH, SW; };
@@ -3137,6 +3140,10 @@ static bool bwdw_use_wino(const mt_conv3d_t* p) {
   if (g_bwdw_wino < 0) { const char* e = getenv("MT_BWDW_WINO"); g_bwdw_wino = e ? atoi(e) : 1; }
   return g_bwdw_wino && bwdw_use_march(p) && p->Wo > 16 && p->Ho >= 2 && conv_fast_vec(p) == 2;
 }
+static bool bwdw_use_bf16(const mt_conv3d_t* p) {
+  if (g_bwdw_bf16 < 0) { const char* e = getenv("MT_BWDW_BF16"); g_bwdw_bf16 = e ? atoi(e) : 1; }
+  return g_bwdw_bf16 && p->mma == 1 && bwdw_use_wino(p);
+}
 // plan for the fast kernel: tile 1 x TH x TW with (TH,TW) = (4,32) or (8,16)
 static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   const bool wide = p->Wo > 16;
@@ -3148,6 +3155,7 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   P->ncot = mt_cdiv(p->Cout, 32);
   int pairs = P->nchunks * P->ncot; if (pairs < 1) pairs = 1;
   int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
+  if (bwdw_use_march(p) && bwdw_use_bf16(p)) nsg = (512 + pairs - 1) / pairs;      // 64 KiB ring: two workgroups per CU
   P->nsg_cap = nsg;
   if (nsg > P->ntiles_total) nsg = P->ntiles_total;
   if (nsg < 1) nsg = 1;
@@ -3326,6 +3334,12 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     int rc = MT_EINVAL;
     switch (geo) {
       case 0: {
+        if (bwdw_use_bf16(p)) {
+          hipLaunchKernelGGL(conv_bwdw_wino_bf16_kernel, dim3(P.nsg, P.ncot, P.nchunks), dim3(256), BWB_LDS_BYTES, st, P);
+          MT_CHECK_LAUNCH("conv_bwdw_wino_bf16");
+          rc = MT_OK;
+          break;
+        }
         if (bwdw_use_wino(p)) {
           const size_t ldsb = (size_t)BWW_LDS_FLOATS * sizeof(float);
           static bool attr = false;

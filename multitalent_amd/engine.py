@@ -372,8 +372,8 @@ class Engine:
 
     def set_precision(self, precision):
         """'fp32' (exact, default) or 'bf16': mixed precision — the reference's autocast mode (nnUNetTrainerV2.py:236-249) on
-        gfx950 terms: bf16 matrix inputs with fp32 accumulation for the 3x3x3 stride-1 convolutions (forward and backward-data),
-        fp32 activations, master weights, normalisation, loss, weight gradients and optimizer; no loss scaling is needed."""
+        gfx950 terms: bf16 matrix inputs with fp32 accumulation for the 3x3x3 stride-1 convolutions (forward, backward-data and
+        backward-weight), fp32 activations, master weights, gradients, normalisation, loss and optimizer; no loss scaling needed."""
         mma = {'fp32': 0, 'bf16': 1, 0: 0, 1: 1, False: 0, True: 1}[precision]
         if mma != self.mma:
             self.mma = mma

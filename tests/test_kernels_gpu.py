@@ -275,6 +275,41 @@ def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
         assert relerr(dw2.cpu(), w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,shape,lazy", [
+    (32, 32, (6, 8, 32), False),
+    (24, 40, (5, 9, 37), True),       # ragged tiles in H and W, two cout tiles, lazily activated input
+    (16, 70, (4, 6, 40), False),      # three cout tiles, one cin chunk
+    (30, 30, (3, 5, 20), True),       # odd H (half tile), channel tails
+])
+def test_conv_bwd_weight_bf16_mixed_precision(dev, Cin, Cout, shape, lazy):
+    """conv_bwdw_wino_bf16_kernel (mt_conv3d_t.mma = 1): Winograd-domain operands rounded to bf16, fp32 accumulation and output
+    transform.  Against the exact fp32 weight gradient of autograd: 1e-2 of the largest entry (observed ~3e-3; the rounding of
+    B^T X B and A dY A^T is not restated on the CPU); the accumulating form (dW += ...) is checked on top."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(14)
+    N = 2
+    x = torch.randn((N, Cin) + shape, generator=g)
+    lz = [(torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)] if lazy else None
+    xin = ref_inputs([x], lz)
+    w = (torch.randn((Cout, Cin, 3, 3, 3), generator=g) / np.sqrt(Cin * 27)).requires_grad_(True)
+    y = F.conv3d(xin, w, None, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xb = to_ndhwc(x).to(dev)
+    xa = ops.Act(xb, scale=lz[0][0].to(dev).contiguous(), shift=lz[0][1].to(dev).contiguous(), slope=0.01) if lazy else ops.Act(xb)
+    ya = ops.Act(to_ndhwc(dy).to(dev))
+    geom = ops.ConvGeom(shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    p = ops.fill_conv([xa], geom, Cout, mma=1)
+    ws = torch.empty(max(ops.conv3d_bwd_weight_workspace(p) // 4, 1), device=dev)
+    base = torch.randn(w.shape, generator=g)
+    dw = base.to(dev)
+    ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), True, ws)
+    torch.cuda.synchronize()
+    got = dw.cpu() - base
+    err = relerr(got, w.grad)
+    assert 1e-5 < err < 1e-2, err          # > 1e-5: the bf16 kernel really ran (the fp32 kernels reach 2e-5 only on other shapes)
+
+
 @pytest.mark.parametrize("Cin,Cout,base,so", [
     (60, 30, (4, 6, 10), (2, 2, 2)),
     (320, 320, (3, 6, 6), (1, 2, 2)),

@@ -56,6 +56,14 @@ else:
     dw = torch.empty_like(w)
     ya = ops.Act(dy)
     run = lambda: ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
+    if a.mma:
+        p0 = ops.fill_conv([xa], geom, Cout, mma=0)
+        ws0 = torch.empty(ops.conv3d_bwd_weight_workspace(p0) // 4 + 16, device=dev)
+        dw0 = torch.empty_like(w)
+        ops.conv3d_bwd_weight(p0, ya, dw0, ops.conv_weight_strides(dw0), False, ws0)
+        run(); torch.cuda.synchronize()
+        print('bf16 vs fp32 dW: max abs err %.4g, rms err %.4g, rms ref %.4g' % ((dw - dw0).abs().max().item(),
+              (dw - dw0).pow(2).mean().sqrt().item(), dw0.pow(2).mean().sqrt().item()))
 run(); torch.cuda.synchronize()
 if a.mode == 'fwd':
     print('kernel:', ops.conv_kernel_name(p))
