@@ -182,6 +182,7 @@ def bench_infer(args, dev, rank, world, ddp):
     torch.manual_seed(1234)
     net = build_network('task100').to(dev)
     net.eval()
+    net.engine().set_precision(args.precision)
     net.inference_apply_nonlin = nn.Sigmoid()
     vol = np.random.RandomState(7).randn(1, *args.volume).astype(np.float32)
     shard = (rank, world) if world > 1 else None
@@ -207,7 +208,7 @@ def bench_infer(args, dev, rank, world, ddp):
         print(json.dumps({
             "metric": "sliding-window vols/min", "value": round(60.0 * args.steps / dt, 3), "unit": "volumes/min",
             "n_gpus": world, "steps": args.steps, "warmup": 1, "ms_per_step": round(dt / args.steps * 1e3, 1),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.precision == 'fp32' else "bf16", "data": "synthetic",
             "config": {"workload": "predict_MultiTalent sliding window, Generic_UNet nc=47 sigmoid", "volume": list(args.volume),
                        "patch": list(PATCH), "step_size": 0.5, "gaussian": True, "mirror_tta": bool(args.mirror),
                        "parallelism": "tile-shard%d" % world}}), flush=True)
