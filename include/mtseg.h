@@ -90,7 +90,8 @@ int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_floats,
                          int C0, int C1, int Cout, int KD, int KH, int KW,
                          long s_ci, long s_co, long s_kd, long s_kh, long s_kw, int flip, int ck,
                          int layout /* 1: all MFMA kernels ([kp/4][lane][4], pair (kp, ck/2+kp)); mt_pointwise_fwd takes ck = 16;
-                                       0: legacy [kp][lane], pair (2kp,2kp+1) */,
+                                       0: legacy [kp][lane], pair (2kp,2kp+1); 2: Winograd F(2x2x2,3x3x3) U = G g G^T (ck = 8);
+                                       3: bf16 B fragments of v_mfma_f32_32x32x16_bf16, [tap][lane][8 bf16] (ck = 16), RNE */,
                          const int32_t* tapmap /* NULL, or {tbD,tsD,tbH,tsH,tbW,tsW}: packed tap j of dim d takes source
                                                   tap tb + ts*j (overrides flip) — sub-kernels of the parity classes */,
                          mt_stream_t stream);
@@ -117,9 +118,11 @@ int mt_pack_batched(const void* descs_device, int n, mt_stream_t stream);
 int mt_conv3d_bwd_data_strided(const mt_conv3d_t* p, mt_stream_t stream);
 int mt_conv3d_bwd_data_strided_supported(const mt_conv3d_t* p);   /* 1 when the geometry is handled, else 0 */
 /* Runtime options (tests, A/B measurements): "conv_wino" = 0 direct kernels only, 1 Winograd where the grid fills the chip
- * (default, also MT_CONV_WINO), 2 Winograd wherever the geometry is eligible. */
+ * (default, also MT_CONV_WINO), 2 Winograd wherever the geometry is eligible; "wino_waves" 8 | 4; "bwdw_wino" 0 | 1;
+ * "conv_bf16" (problems with mma == 1) = 0 never, 1 where the grid fills the chip (default), 2 wherever eligible;
+ * "bwdw_bf16" 0 | 1. */
 int mt_set_option(const char* name, int value);
-int mt_conv3d_pack_layout(const mt_conv3d_t* p);   /* `layout` for mt_pack_conv_weights: 1, or 2 when the Winograd kernel serves p */
+int mt_conv3d_pack_layout(const mt_conv3d_t* p);   /* `layout` for mt_pack_conv_weights: 1; 2 when the Winograd kernel serves p; 3 (bf16) when p->mma == 1 and the bf16 kernel does */
 int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n); /* device kernel that will run (profiler name) */
 
 /* ---- backward-weight -------------------------------------------------------------------------
