@@ -44,6 +44,14 @@ class MultiTalent_trainer_ddp(nnUNetTrainerV2_DDP):
         super().initialize(training, force_load_plans)
         self.regions_class_order = list(range(self.num_classes))              # reference :127
 
+    def _sampling_probabilities(self, keys):
+        """p(case) ~ 1/sqrt(cases of its dataset) (reference :629-647); the per-dataset totals are logged like the reference."""
+        from .....dataloading.dataset_loading import sqrt_sampling_probabilities
+        p, per_dataset = sqrt_sampling_probabilities(keys)
+        self.dataset_prob = per_dataset
+        self.print_to_log_file('probabilities per dataset:', per_dataset)
+        return p
+
     def compute_loss(self, output, target, valid_regions):
         """Signature of the reference's compute_loss (:544-623); fused statistics kernels + [B,47] glue."""
         return self.train_step.loss_fn(output, target, valid_regions)
@@ -84,6 +92,7 @@ class MultiTalent_trainer_ddp(nnUNetTrainerV2_DDP):
         if not self.was_initialized:
             self.initialize(True)
         self.maybe_update_lr(self.epoch)
+        self.maybe_setup_data_generators()
         if self.tr_gen is None:
             self.tr_gen = self._default_generator()
         if self.val_gen is None:

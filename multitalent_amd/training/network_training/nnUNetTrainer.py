@@ -339,11 +339,94 @@ class nnUNetTrainerV2(nnUNetTrainer):
         from ...synthetic import SyntheticBatchGenerator
         return SyntheticBatchGenerator(self)
 
+    # ---- real data: preprocessed cases on disk ---------------------------------------------
+    @property
+    def folder_with_preprocessed_data(self):
+        """<dataset_directory>/<data_identifier>_stage<stage> (nnUNetTrainer.py:389-391 / :181-182)."""
+        if self.dataset_directory is None or self.plans is None:
+            return None
+        return os.path.join(self.dataset_directory, self.plans['data_identifier'] + "_stage%d" % self.stage)
+
+    def load_dataset(self):
+        from ..dataloading.dataset_loading import load_dataset
+        self.dataset = load_dataset(self.folder_with_preprocessed_data)              # nnUNetTrainer.py:411-412
+
+    def do_split(self):
+        """nnUNetTrainerV2.py:276-340: splits_final.pkl (created as a seeded 5-fold split when missing), fold 'all', or a seeded
+        80:20 split for folds beyond the file."""
+        import pickle
+        from collections import OrderedDict
+        if self.fold == "all":
+            tr_keys = val_keys = list(self.dataset.keys())
+        else:
+            splits_file = os.path.join(self.dataset_directory, "splits_final.pkl")
+            if not os.path.isfile(splits_file):
+                from sklearn.model_selection import KFold
+                self.print_to_log_file("Creating new 5-fold cross-validation split...")
+                splits = []
+                all_keys_sorted = np.sort(list(self.dataset.keys()))
+                for train_idx, test_idx in KFold(n_splits=5, shuffle=True, random_state=12345).split(all_keys_sorted):
+                    splits.append(OrderedDict())
+                    splits[-1]['train'] = np.array(all_keys_sorted)[train_idx]
+                    splits[-1]['val'] = np.array(all_keys_sorted)[test_idx]
+                with open(splits_file, 'wb') as f:
+                    pickle.dump(splits, f)
+            else:
+                with open(splits_file, 'rb') as f:
+                    splits = pickle.load(f)
+            if self.fold < len(splits):
+                tr_keys, val_keys = splits[self.fold]['train'], splits[self.fold]['val']
+            else:
+                rnd = np.random.RandomState(seed=12345 + self.fold)
+                keys = np.sort(list(self.dataset.keys()))
+                idx_tr = rnd.choice(len(keys), int(len(keys) * 0.8), replace=False)
+                tr_keys = [keys[i] for i in idx_tr]
+                val_keys = [keys[i] for i in range(len(keys)) if i not in idx_tr]
+        tr_keys, val_keys = sorted(tr_keys), sorted(val_keys)
+        self.dataset_tr = OrderedDict((i, self.dataset[i]) for i in tr_keys)
+        self.dataset_val = OrderedDict((i, self.dataset[i]) for i in val_keys)
+
+    oversample_foreground_percent = 0.33                                            # nnUNetTrainer.py:131
+    pad_all_sides = None
+
+    def _sampling_probabilities(self, keys):
+        return None
+
+    def get_basic_generators(self):
+        """nnUNetTrainer.py:394-409 (MultiTalent: …_Trainer_DDP.py:625-661).  The loader draws network-sized patches: the
+        oversized `basic_generator_patch_size` only exists for the CPU SpatialTransform, which is not part of this path."""
+        from ..dataloading.dataset_loading import DataLoader3D
+        self.load_dataset()
+        self.do_split()
+        ps = tuple(int(i) for i in self.patch_size)
+        mk = lambda ds: DataLoader3D(ds, ps, ps, self.batch_size, False, oversample_foreground_percent=self.oversample_foreground_percent,
+                                     pad_mode="constant", pad_sides=self.pad_all_sides, memmap_mode='r',
+                                     sampling_probabilities=self._sampling_probabilities(list(ds.keys())))
+        return mk(self.dataset_tr), mk(self.dataset_val)
+
+    def maybe_setup_data_generators(self):
+        """real cases when <dataset_directory>/<data_identifier>_stage<k> exists and no generator was attached."""
+        f = self.folder_with_preprocessed_data
+        if self.tr_gen is None and f is not None and os.path.isdir(f):
+            self.setup_data_generators()
+
+    def setup_data_generators(self):
+        """tr_gen / val_gen from the preprocessed cases under dataset_directory (unpacked to .npy first, like
+        nnUNetTrainerV2.initialize :113-121); the batches carry ONE label map, the device builds the pyramid."""
+        from ..dataloading.dataset_loading import SegToTargetGenerator, unpack_dataset
+        if self.unpack_data and self.local_rank == 0:
+            unpack_dataset(self.folder_with_preprocessed_data)
+        if self.ddp and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
+        dl_tr, dl_val = self.get_basic_generators()
+        self.tr_gen, self.val_gen = SegToTargetGenerator(dl_tr), SegToTargetGenerator(dl_val)
+
     def run_training(self):
         """epoch loop of network_trainer.py:411-470 without plotting / early stopping bookkeeping."""
         if not self.was_initialized:
             self.initialize(True)
         self.maybe_update_lr(self.epoch)
+        self.maybe_setup_data_generators()
         if self.tr_gen is None:
             self.tr_gen = self._default_generator()
         if self.val_gen is None:

@@ -114,3 +114,34 @@ def test_device_batch_feeder_matches_cpu_pipeline(dev):
     pyr = [{'data': batches[0]['data'], 'target': [np.ones((2, 1, 4, 4, 4), np.float32), np.zeros((2, 1, 2, 2, 2), np.float32)]}]
     g = next(DeviceBatchFeeder(iter(pyr)))
     assert [tuple(t.shape) for t in g['target']] == [(2, 1, 4, 4, 4), (2, 1, 2, 2, 2)] and float(g['target'][0].sum()) == 128.0
+
+
+def test_training_from_preprocessed_cases_on_disk(dev, pg, tmp_path):
+    """SURVEY §8f rank 2 end to end: <dataset_directory>/<data_identifier>_stage1/*.npz|pkl -> unpack -> split -> sqrt-balanced
+    DataLoader3D -> one label map per batch -> device-side pyramid -> fused MultiTalent loss/step, through run_training()."""
+    from multitalent_amd import plans as P
+    from multitalent_amd.training.model_restore import find_trainer_class
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'loader.npz'))
+    sp = {'batch_size': 2, 'patch_size': np.array([16, 32, 32]), 'pool_op_kernel_sizes': [[2, 2, 2], [2, 2, 2]],
+          'conv_kernel_sizes': [[3, 3, 3]] * 3, 'do_dummy_2D_data_aug': False}
+    plans = P.make_plans(sp, base_num_features=8, num_classes=47, stage=1)
+    folder = tmp_path / (plans['data_identifier'] + '_stage1')
+    folder.mkdir()
+    for k in z.files:
+        if k.startswith('case/'):
+            arr = z[k]
+            np.savez_compressed(str(folder / (k[5:] + '.npz')), data=arr)
+            props = {'class_locations': {c: np.argwhere(arr[-1] == c) for c in (1, 2, 4)},
+                     'valid_regions': ('03_liver', '03_cancer') if k[5:].startswith('BTCV') else ('07_pancreas',)}
+            with open(str(folder / (k[5:] + '.pkl')), 'wb') as f:
+                pickle.dump(props, f)
+    tr = find_trainer_class('MultiTalent_trainer_ddp')(plans, 'all', 0, output_folder=str(tmp_path / 'out'),
+                                                        dataset_directory=str(tmp_path), stage=1)
+    tr.initialize(True)
+    tr.max_num_epochs, tr.num_batches_per_epoch, tr.num_val_batches_per_epoch, tr.save_every = 2, 3, 1, 100
+    np.random.seed(0)
+    tr.run_training()
+    assert tr.tr_gen is not None and type(tr.tr_gen).__name__ == 'SegToTargetGenerator'
+    assert any(f.endswith('.npy') for f in os.listdir(str(folder)))                    # unpacked for memory-mapped reads
+    assert len(tr.all_tr_losses) == 2 and np.isfinite(tr.all_tr_losses).all() and np.isfinite(tr.all_val_losses).all()
+    assert os.path.isfile(str(tmp_path / 'out' / 'model_final_checkpoint.model'))
