@@ -74,6 +74,36 @@ class FusedTrainStep:
         self.sumsq = None
         self.ws = None
         self.reducer = GradAllReducer(self.eng) if ddp else None
+        self.head_params, self.head_opt = None, None
+
+    def set_head_optimizer(self, params, lr=3e-3, weight_decay=3e-5):
+        """Heads-only phase of the fine-tuning trainers (reference nnUNetTrainerV2_warmup.py:119-132): AdamW(amsgrad) on `params`
+        (a few 1x1x1 conv tensors: torch glue, not a hot path) instead of the fused SGD over the flat buffer; forward, loss,
+        backward and the clip norm over ALL parameters stay the same launches.  None switches back to SGD.  `self.lr` remains
+        the knob the trainers' schedules turn."""
+        if params is None:
+            self.head_params, self.head_opt = None, None
+            return
+        self.head_params = list(params)
+        self.head_opt = torch.optim.AdamW(self.head_params, lr, weight_decay=weight_decay, amsgrad=True)
+
+    def reset_momentum(self):
+        """a fresh optimizer instance in the reference = momentum buffers start from the next gradient."""
+        if self.buf is not None:
+            self.buf.zero_()
+        self.first = True
+
+    def _head_step(self):
+        eng = self.eng
+        # torch.nn.utils.clip_grad_norm_(network.parameters(), 12): coefficient from the norm of the WHOLE flat gradient
+        coef = torch.clamp(self.max_norm / (self.sumsq.sqrt() + 1e-6), max=1.0)
+        for p in self.head_params:
+            p.grad = eng.grad_of(p) * coef
+        for g in self.head_opt.param_groups:
+            g['lr'] = self.lr
+        self.head_opt.step()
+        for p in self.head_params:
+            p.grad = None
 
     def _state(self, dev):
         if self.buf is None or self.buf.device != dev or self.buf.numel() != self.eng.flat.numel():
@@ -109,8 +139,11 @@ class FusedTrainStep:
             self.reducer.finish()
         self._state(eng.flat.device)
         ops.sumsq(eng.flat_grad, self.sumsq, self.ws)
-        ops.sgd_nesterov(eng.flat, eng.flat_grad, self.buf, self.lr, self.wd, self.mom, self.first, self.sumsq, self.max_norm)
-        self.first = False
+        if self.head_opt is not None:
+            self._head_step()
+        else:
+            ops.sgd_nesterov(eng.flat, eng.flat_grad, self.buf, self.lr, self.wd, self.mom, self.first, self.sumsq, self.max_norm)
+            self.first = False
         eng.mark_params_dirty()
         if isinstance(res, (tuple, list)):
             return tuple(r.detach() for r in res)

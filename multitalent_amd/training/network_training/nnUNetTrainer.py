@@ -119,6 +119,8 @@ class nnUNetTrainer(object):
     # ---- checkpoints (network_trainer.py:256-362, nnUNetTrainer.py:726-734) --------------------------------
     def _optimizer_state_dict(self):
         """torch.optim.SGD-format state built from the flat momentum buffer of the fused step."""
+        if self.train_step is not None and getattr(self.train_step, 'head_opt', None) is not None:
+            return self.train_step.head_opt.state_dict()          # heads-only phase of the fine-tuning trainers: AdamW state
         params = list(self.network.parameters())
         st = {}
         if self.train_step is not None and self.train_step.buf is not None and not self.train_step.first:
@@ -134,6 +136,10 @@ class nnUNetTrainer(object):
     def restore_optimizer_state(self, osd):
         """Momentum buffers of a torch.optim.SGD state_dict -> the flat momentum buffer of the fused step."""
         if not torch.cuda.is_available() or not osd.get('state'):
+            return
+        if getattr(self.train_step, 'head_opt', None) is not None:
+            if any('exp_avg' in s for s in osd['state'].values()):
+                self.train_step.head_opt.load_state_dict(osd)
             return
         eng = self.network.engine()
         eng.attach(torch.device('cuda', torch.cuda.current_device()))
