@@ -124,6 +124,23 @@ def measure_roofline(step, x, largs, nrep=3):
             "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": n // nrep,
             "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
             "all_conv_fwd_launches": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / nrep, 3)}}
+    # HBM bytes per launch of the dominant kernel from the PMC counters: rocprofv3 --pmc cannot run inside this process, so the
+    # table is produced by tools/profile_pmc_bench.sh (separate FETCH_SIZE / WRITE_SIZE passes over THIS command, averaged over
+    # the kernel's launches of a step) and committed as profiles/r01_pmc_per_kernel.json; gfx950 correction per
+    # MI355X_MICROARCH.md §HBM: FETCH_SIZE tallies 128-B requests at 64 B -> x2 (upper bound), WRITE_SIZE as counted
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_per_kernel.json')) as f:
+            pmc = json.load(f)
+        for prec in pmc.values():
+            if name in prec:
+                e = prec[name]
+                out["traffic"] = int((2 * e['fetch_kb_per_launch'] + e['write_kb_per_launch']) * 1024)
+                out["traffic_as_counted"] = int((e['fetch_kb_per_launch'] + e['write_kb_per_launch']) * 1024)
+                out["traffic_unit"] = "bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_pmc_per_kernel.json)"
+                out["algorithmic_bytes_per_launch"] = int(nby / n)
+                break
+    except (OSError, ValueError, KeyError):
+        pass
     if name.startswith('conv_bf16'):
         # bf16 matrix inputs: 27 MFMAs per 16-channel chunk instead of 216 — the kernel is bound by moving the fp32 activations
         gbs = nby / (ms * 1e-3) / 1e9

@@ -486,7 +486,8 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
 
 
 def _bf16_round(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+    from oracle.reference_ops import bf16_round
+    return bf16_round(x)
 
 
 @pytest.mark.parametrize("N,Cin,Cout,shape,two_src", [
@@ -517,7 +518,8 @@ def test_conv_bf16_mixed_precision(dev, N, Cin, Cout, shape, two_src):
         b = torch.randn(Cout, generator=g)
         out, part = run_conv(dev, srcs, w, b, (1, 1, 1), (1, 1, 1), lazy=lazy, stats=True)
         xin = ref_inputs(srcs, lazy)
-        ref_same = F.conv3d(_bf16_round(xin).double(), _bf16_round(w).double(), b.double(), padding=1)
+        from oracle.reference_ops import conv3d_mixed_precision
+        ref_same = conv3d_mixed_precision(xin, w, b)
         ref_exact = F.conv3d(xin, w, b, padding=1)
         got = to_ncdhw(out.cpu())
         assert relerr(got, ref_same) < 1e-4
