@@ -132,8 +132,8 @@ def measure_roofline(step, x, largs, nrep=3):
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_per_kernel.json')) as f:
             pmc = json.load(f)
         for prec in pmc.values():
-            if name in prec:
-                e = prec[name]
+            e = next((v for k, v in prec.items() if k.replace('void ', '').split('(')[0] == name), None)   # rocprofv3 prints "void name<...>(Params)"
+            if e is not None:
                 out["traffic"] = int((2 * e['fetch_kb_per_launch'] + e['write_kb_per_launch']) * 1024)
                 out["traffic_as_counted"] = int((e['fetch_kb_per_launch'] + e['write_kb_per_launch']) * 1024)
                 out["traffic_unit"] = "bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_pmc_per_kernel.json)"

@@ -144,3 +144,40 @@ def test_training_step_is_bit_reproducible_at_full_size(dev):
         torch.cuda.empty_cache()
     assert results[0][0] == results[1][0]
     assert torch.equal(results[0][1], results[1][1])
+
+
+@pytest.mark.parametrize("Cin,Cout", [(30, 30), (60, 30)])
+def test_adjoint_identity_at_full_size_mixed_precision(dev, Cin, Cout):
+    """The same identity with bf16 matrix inputs (mt_conv3d_t.mma = 1) at N = 2 x 48x192x192: the three kernels round DIFFERENT
+    operands (forward: x and w; backward-data: g and w; backward-weight: the Winograd images of x and g), so the inner products
+    agree to the bf16 rounding of ~1e8 random terms — 1e-3 of |y||g| (observed ~1e-5; a wrong tap, halo or k-order is O(1))."""
+    ops = _ops()
+    ops.set_mma(1)
+    try:
+        gen = torch.Generator(device='cpu').manual_seed(12)
+        N, shape, k, pad, stride = 2, (48, 192, 192), (3, 3, 3), (1, 1, 1), (1, 1, 1)
+        x = torch.randn((N,) + shape + (Cin,), generator=gen).to(dev)
+        w = (torch.randn((Cout, Cin) + k, generator=gen) / np.sqrt(Cin * 27)).to(dev)
+        y, geom, name, part = conv_fwd(ops, x, w, stride, pad, stats=True)
+        assert name.startswith('conv_bf16_kernel'), name
+        g = torch.randn(y.shape, generator=gen).to(dev)
+        dx = conv_bwd_data(ops, g, w, geom, shape)
+        dw = conv_bwd_weight(ops, x, g, tuple(w.shape), geom)
+        torch.cuda.synchronize()
+        assert torch.isfinite(dx).all() and torch.isfinite(dw).all()
+        a, b, c = dot(y, g), dot(x, dx), dot(w, dw)
+        scale = float(y.double().norm() * g.double().norm())
+        assert abs(a - b) < 1e-3 * scale and abs(a - c) < 1e-3 * scale, (a, b, c, scale)
+        # the epilogue statistics describe the stored fp32 output exactly (they are taken after the fp32 accumulation)
+        s = part.double().sum(1)
+        assert torch.allclose(s[..., 0], y.double().sum((1, 2, 3)), rtol=1e-4, atol=1e-2 * float(np.sqrt(np.prod(shape))))
+        assert torch.allclose(s[..., 1], (y.double() ** 2).sum((1, 2, 3)), rtol=1e-4)
+        # against the exact fp32 kernels on the same inputs
+        ops.set_mma(0)
+        y0, _, name0, _ = conv_fwd(ops, x, w, stride, pad)
+        assert not name0.startswith('conv_bf16')
+        assert float((y - y0).abs().max() / y0.abs().max()) < 2e-2
+        dw0 = conv_bwd_weight(ops, x, g, tuple(w.shape), geom)
+        assert float((dw - dw0).abs().max() / dw0.abs().max()) < 1e-2
+    finally:
+        ops.set_mma(0)
