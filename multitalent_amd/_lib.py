@@ -69,6 +69,7 @@ SIGNATURES = {
     'mt_downsample_seg_nearest': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     'mt_set_option': (_i, [C.c_char_p, _i]),
     'mt_conv3d_pack_layout': (_i, [_P(mt_conv3d_t)]),
+    'mt_conv3d_bwd_data_strided_pack_layout': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_kernel_name': (_i, [_P(mt_conv3d_t), C.c_char_p, _sz]),
     'mt_conv3d_bwd_weight_workspace': (_sz, [_P(mt_conv3d_t)]),
     'mt_conv3d_bwd_weight': (_i, [_P(mt_conv3d_t), _P(mt_src_t), _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp]),

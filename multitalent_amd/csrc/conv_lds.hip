@@ -871,10 +871,13 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
 // generic_UNet.py:263-278) on the FAST design with compile-time taps.  Tile = 2 x 4 x 8 outputs x 64 output channels:
 // the haloed input tile ((TD-1)*SD+3) x 9 x 17 voxels x 16 channels stays under 64 KiB so two workgroups share a CU; the four
 // waves are 2 M tiles (one output plane each) x 2 N tiles, so every staged voxel feeds 64 output channels.
-template <int SD, int SH, int SW, int VEC>
+// BF = true (mixed precision, mt_conv3d_t.mma == 1): bf16 LDS image and v_mfma_f32_32x32x16_bf16 through mt_stage_bf16 / bf16_chunk.
+template <int SD, int SH, int SW, int VEC, bool BF = false>
 __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParams P) {
   constexpr int TD = 2, TH = 4, TW = 8;
-  constexpr int LD = (TD - 1) * SD + 3, LH = (TH - 1) * SH + 3, LW = (TW - 1) * SW + 3, LWP = stage_lwp<LD, LH, LW, VEC>();
+  constexpr int LD = (TD - 1) * SD + 3, LH = (TH - 1) * SH + 3, LW = (TW - 1) * SW + 3;
+  constexpr int LWP = BF ? bstage_lwp<LD, LH, LW, VEC, 4>() : stage_lwp<LD, LH, LW, VEC>();
+  constexpr int PITCH = BF ? BFP : FCKP;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -893,18 +896,26 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
 
   int abase[1];
-  abase[0] = ((dm * SD * LH + (li >> 3) * SH) * LWP + (li & 7) * SW) * FCKP + lhalf * 8;
-  f32x16 acc[1];
+  abase[0] = ((dm * SD * LH + (li >> 3) * SH) * LWP + (li & 7) * SW) * PITCH + lhalf * (BF ? 4 : 8);
+  f32x16 accb[1][1];
+  f32x16 (&acc)[1] = accb[0];
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[0][j] = 0.f;
 
   for (int ch = 0; ch < P.nchunks; ++ch) {
     const ConvChunk cc = P.chunk[ch];
-    const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
     __syncthreads();
-    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
-    __syncthreads();
-    fast_chunk<1, LH, LWP>(lds, abase, wlane, acc);
+    if constexpr (BF) {
+      const unsigned* wlane = (const unsigned*)c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 256) + lane * 4;
+      mt_stage_bf16<LD, LH, LW, VEC, 4>((unsigned*)lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
+      __syncthreads();
+      bf16_chunk<1, 1, LH, LWP>((const unsigned*)lds, abase, wlane, 0, accb);
+    } else {
+      const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
+      mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
+      __syncthreads();
+      fast_chunk<1, LH, LWP>(lds, abase, wlane, acc);
+    }
   }
 
   const int co = ntile_raw * 32 + li;
@@ -1498,11 +1509,13 @@ __global__ __launch_bounds__(256) void conv_rt_kernel(const ConvKParams P) {
 template <int S> __host__ __device__ constexpr int bd_par(int k) { return S == 2 ? (k == 1 ? 0 : 1) : 0; }
 template <int S> __host__ __device__ constexpr int bd_off(int k) { return S == 2 ? (k == 0 ? 1 : 0) : 2 - k; }
 
-template <int SD, int SH, int SW, int VEC>
+// BF = true (mixed precision): bf16 LDS image (mt_stage_bf16) and one v_mfma_f32_32x32x16_bf16 per tap.
+template <int SD, int SH, int SW, int VEC, bool BF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_bwdd_strided_kernel(const ConvKParams P) {
   constexpr int TD = 2, TH = 4, TW = 16;                       // dY positions per workgroup: 4 waves x 32
   constexpr int LD = TD + (SD == 2 ? 1 : 2), LH = TH + (SH == 2 ? 1 : 2), LW = TW + (SW == 2 ? 1 : 2);
-  constexpr int NC = SD * SH * SW, LWP = stage_lwp<LD, LH, LW, VEC>();
+  constexpr int NC = SD * SH * SW, LWP = BF ? bstage_lwp<LD, LH, LW, VEC, 4>() : stage_lwp<LD, LH, LW, VEC>();
+  constexpr int PITCH = BF ? BFP : FCKP;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1518,7 +1531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 
   // this wave's M tile: dm = wave/2, rows (wave%2)*2 + {0,1}, 16 columns
   const int dm = wave >> 1, rbase = (wave & 1) * 2;
-  const int abase = ((dm * LH + rbase + (li >> 4)) * LWP + (li & 15)) * FCKP + lhalf * 8;
+  const int abase = ((dm * LH + rbase + (li >> 4)) * LWP + (li & 15)) * PITCH + lhalf * (BF ? 4 : 8);
 
   f32x16 acc[NC];
 #pragma unroll
@@ -1530,6 +1543,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const ConvChunk cc = P.chunk[ch];
     const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
     __syncthreads();
+    if constexpr (BF) {
+      mt_stage_bf16<LD, LH, LW, VEC, 4>((unsigned*)lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
+      __syncthreads();
+      const unsigned* ldsu = (const unsigned*)lds;
+      const unsigned* wl = (const unsigned*)c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 256) + lane * 4;
+      constexpr int BPF = 5, NB = BPF + 1;
+      bf16x8 b[NB], a[2];
+#pragma unroll
+      for (int t = 0; t < BPF; ++t) b[t] = *(const bf16x8*)(wl + t * 256);
+      {
+        constexpr int o0 = ((bd_off<SD>(0) * LH + bd_off<SH>(0)) * LWP + bd_off<SW>(0)) * PITCH;
+        a[0] = *(const bf16x8*)(ldsu + abase + o0);
+      }
+#pragma unroll
+      for (int t = 0; t < 27; ++t) {
+        if (t + BPF < 27) b[(t + BPF) % NB] = *(const bf16x8*)(wl + (t + BPF) * 256);
+        if (t + 1 < 27) {
+          const int t1 = t + 1;
+          const int o1 = ((bd_off<SD>(t1 / 9) * LH + bd_off<SH>((t1 / 3) % 3)) * LWP + bd_off<SW>(t1 % 3)) * PITCH;
+          a[t1 & 1] = *(const bf16x8*)(ldsu + abase + o1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int q = (bd_par<SD>(t / 9) * SH + bd_par<SH>((t / 3) % 3)) * SW + bd_par<SW>(t % 3);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1], b[t % NB], acc[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      continue;
+    }
     mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
     __syncthreads();
     // all 27 taps unrolled in natural order; tap t reads the A fragment at its compile-time offset (jd, jh, jw) and accumulates
@@ -1648,6 +1689,7 @@ static bool conv_wino_ok(const mt_conv3d_t* p);
 static bool conv_gather_ok(const mt_conv3d_t* p);
 static int launch_gather(const mt_conv3d_t* p, hipStream_t st);
 static int conv_bf16_cfg(const mt_conv3d_t* p);
+static bool strided_use_bf16(const mt_conv3d_t* p);
 static ConvPlan conv_plan(const mt_conv3d_t* p) {
   static int use_v2 = -1, use_rt = -1;
   if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
@@ -1689,6 +1731,7 @@ extern "C" int mt_conv3d_ck(const mt_conv3d_t* p) {
 }
 extern "C" int mt_conv3d_pack_layout(const mt_conv3d_t* p) {      // layout argument of mt_pack_conv_weights for this problem
   const int k = conv_plan(p).kind;
+  if (k == CONV_FAST_STRIDED && strided_use_bf16(p)) return 3;
   return k == CONV_WINO ? 2 : k == CONV_BF16 ? 3 : 1;
 }
 extern "C" int mt_conv3d_stats_blocks(const mt_conv3d_t* p) {
@@ -1788,7 +1831,9 @@ static int launch_fast_strided_t(const mt_conv3d_t* p, hipStream_t st) {
   P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 64), 1);
-  if (conv_fast_vec(p) == 2) {
+  if (strided_use_bf16(p)) {
+    hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
+  } else if (conv_fast_vec(p) == 2) {
     hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 2>()), st, P);
   } else {
     constexpr size_t l1 = stage_lds_bytes<LD, LH, LW, 1>();
@@ -1869,6 +1914,12 @@ static int conv_bf16_cfg(const mt_conv3d_t* p) {
   const long wgs = (long)p->N * mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW);
   if (wgs < 128 && use != 2) return -1;          // low-resolution stages stay on the fp32 latency-oriented kernels
   return best;
+}
+static bool strided_use_bf16(const mt_conv3d_t* p) {      // forward strided stage convs in mixed precision
+  if (g_bf16_mode < 0) { const char* e = getenv("MT_CONV_BF16"); g_bf16_mode = e ? atoi(e) : 1; }
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_STRIDED_BF16"); use = e ? atoi(e) : 1; }
+  return use && g_bf16_mode && p->mma == 1 && p->Cin >= 16 && conv_fast_vec(p) == 2;
 }
 static int conv_bf16_vec(const mt_conv3d_t*) { return 2; }    // 16-byte staging loads measured slower (0.409 vs 0.372 ms on 32->32)
 template <int MW, int RH, int TD, int VEC, int NT, int NW>
@@ -2102,7 +2153,8 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   else if (pl.kind == CONV_WINO)
     snprintf(buf, n, g_wino_waves == 8 ? "conv_wino8_kernel" : "conv_wino_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
-    snprintf(buf, n, "conv_fast_strided_kernel<%d, %d, %d, %d>", p->SD, p->SH, p->SW, conv_fast_vec(p));
+    snprintf(buf, n, strided_use_bf16(p) ? "conv_fast_strided_kernel<%d, %d, %d, %d, true>" : "conv_fast_strided_kernel<%d, %d, %d, %d, false>",
+             p->SD, p->SH, p->SW, conv_fast_vec(p));
   else if (pl.kind == CONV_RT && conv_gather_ok(p))
     snprintf(buf, n, "conv_gather_kernel");
   else if (pl.kind == CONV_RT)
@@ -2165,6 +2217,14 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // mt_conv3d_bwd_data_strided: see include/mtseg.h.  p carries the FORWARD geometry (Di.. = X dims, Do.. = Y dims, K = 3,
 // S in {(2,2,2), (1,2,2)}, P = 1); src[0] = dY (C = Cout of the conv), out0 = dX (Cin channels).
+static bool bwdd_strided_use_bf16(const mt_conv3d_t* p) {          // p = FORWARD geometry, src[0] = dY
+  if (g_bf16_mode < 0) { const char* e = getenv("MT_CONV_BF16"); g_bf16_mode = e ? atoi(e) : 1; }
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_STRIDED_BF16"); use = e ? atoi(e) : 1; }
+  const mt_src_t& s0 = p->src[0];
+  return use && g_bf16_mode && p->mma == 1 && p->Cout >= 16 && !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7));
+}
+extern "C" int mt_conv3d_bwd_data_strided_pack_layout(const mt_conv3d_t* p) { return (p != nullptr && bwdd_strided_use_bf16(p)) ? 3 : 1; }
 template <int SD, int SH, int SW>
 static int launch_bwdd_strided(const mt_conv3d_t* p, hipStream_t st) {
   constexpr int TD = 2, TH = 4, TW = 16;
@@ -2185,7 +2245,8 @@ static int launch_bwdd_strided(const mt_conv3d_t* p, hipStream_t st) {
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cin, 32), 1);
   const mt_src_t& s0 = p->src[0];
   const bool v2 = !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7));
-  if (v2) hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 2>()), st, P);
+  if (bwdd_strided_use_bf16(p)) hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
+  else if (v2) hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 2>()), st, P);
   else    hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 1>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 1>()), st, P);
   MT_CHECK_LAUNCH("conv_bwdd_strided");
   return MT_OK;

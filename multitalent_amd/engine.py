@@ -112,7 +112,8 @@ class ConvNormOp(_Op):
                                         layout=ops.conv_pack_layout(p))
         if need_bwd and any(s.grad is not None for s in self.srcs):
             if self._use_strided_bwd(eng):
-                self.wb = ops.pack_conv_weights(w, Cout, 0, C0, self.kernel, _strides(w, as_bwd_data=True), False, 16, out=self.wb)
+                self.wb = ops.pack_conv_weights(w, Cout, 0, C0, self.kernel, _strides(w, as_bwd_data=True), False, 16, out=self.wb,
+                                                layout=ops.conv_bwd_data_strided_pack_layout(self._strided_bwd_params(None)))
                 return
             if self._use_parity_classes():
                 cls = self._parity_classes()

@@ -181,6 +181,10 @@ def conv_pack_layout(p):
     return _lib.load().mt_conv3d_pack_layout(C.byref(p))
 
 
+def conv_bwd_data_strided_pack_layout(p):
+    return _lib.load().mt_conv3d_bwd_data_strided_pack_layout(C.byref(p))
+
+
 def conv_kernel_name(p):
     buf = C.create_string_buffer(128)
     _lib.check(_lib.load().mt_conv3d_kernel_name(C.byref(p), buf, 128), 'conv3d_kernel_name')
