@@ -1911,8 +1911,8 @@ static int conv_bf16_cfg(const mt_conv3d_t* p) {
   }
   if (best < 0) return -1;
   int TD, TH, TW; cfg_tile(kBfCfgs[best], &TD, &TH, &TW);
-  const long wgs = (long)p->N * mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW);
-  if (wgs < 128 && use != 2) return -1;          // low-resolution stages stay on the fp32 latency-oriented kernels
+  const long wgs = (long)p->N * mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW) * mt_cdiv(p->Cout, 32);
+  if (wgs < 256 && use != 2) return -1;          // low-resolution stages stay on the fp32 latency-oriented kernels
   return best;
 }
 static bool strided_use_bf16(const mt_conv3d_t* p) {      // forward strided stage convs in mixed precision
@@ -2345,30 +2345,40 @@ __device__ __forceinline__ void pack_weights_body(const PackParams& P, long firs
     }
     return;
   }
-  if (P.layout == 3) {     // bf16 B fragments of v_mfma_f32_32x32x16_bf16: [ntile][chunk of 16][tap][lane][4 dwords = 8 channels]
-    const long total3 = (long)P.ntiles * P.nchunks * P.KD * P.KH * P.KW * 256;
-    for (long i = first; i < total3; i += stride) {
+  if (P.layout == 1 || P.layout == 3) {
+    // One work item per (lane slot, channel group) of a fragment, looping over the taps: the K taps of a (cin, cout) pair are
+    // contiguous in the torch weight (one 108-byte run, read once), and for a fixed tap consecutive work items write consecutive
+    // dwords.  (The previous one-item-per-element mapping fetched 837 MB for 117 MB of weights: profiles/r01_pmc_per_kernel.json.)
+    //   layout 1: [ntile][chunk][tap][kp/4][lane][4]: lane half h owns channels h*nkp .. h*nkp+nkp-1, float4 = 4 consecutive
+    //   layout 3: [ntile][chunk][tap][lane][4 dwords]: lane half h owns channels 8h .. 8h+7 as bf16 pairs (RNE)
+    const int K3 = P.KD * P.KH * P.KW;
+    const int nq = P.layout == 1 ? P.nkp / 4 : 1;
+    const int per_tap = nq * 256;
+    const long items = (long)P.ntiles * P.nchunks * per_tap;
+    for (long i = first; i < items; i += stride) {
       long r = i;
       const int e = (int)(r % 4); r /= 4;
       const int l = (int)(r % 64); r /= 64;
-      const int kw = (int)(r % P.KW); r /= P.KW;
-      const int kh = (int)(r % P.KH); r /= P.KH;
-      const int kd = (int)(r % P.KD); r /= P.KD;
+      const int q = (int)(r % nq); r /= nq;
       const int ch = (int)(r % P.nchunks); r /= P.nchunks;
       const int nt = (int)r;
       const ConvChunk cc = P.chunk[ch];
       const int co = nt * 32 + (l & 31);
-      int zd = P.flip ? P.KD - 1 - kd : kd, zh = P.flip ? P.KH - 1 - kh : kh, zw = P.flip ? P.KW - 1 - kw : kw;
-      if (P.has_tm) { zd = P.tb[0] + P.ts[0] * kd; zh = P.tb[1] + P.ts[1] * kh; zw = P.tb[2] + P.ts[2] * kw; }
-      float v[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int cin_local = (l >> 5) * 8 + 2 * e + h;
-        v[h] = 0.f;
-        if (cin_local < cc.ck && co < P.Cout)
-          v[h] = P.w[(cc.cglob + cin_local) * P.s_ci + co * P.s_co + zd * P.s_kd + zh * P.s_kh + zw * P.s_kw];
-      }
-      ((unsigned*)P.dst)[i] = mt_pack_bf16(v[0], v[1]);
+      const int c0 = P.layout == 1 ? (l >> 5) * P.nkp + q * 4 + e : (l >> 5) * 8 + 2 * e;
+      const bool v0 = c0 < cc.ck && co < P.Cout, v1 = P.layout == 3 && (c0 + 1) < cc.ck && co < P.Cout;
+      const float* w0 = P.w + (long)(cc.cglob + c0) * P.s_ci + (long)co * P.s_co;
+      float* dp = P.dst + ((size_t)(nt * P.nchunks + ch) * K3) * per_tap + (q * 64 + l) * 4 + e;
+      int tap = 0;
+      for (int kd = 0; kd < P.KD; ++kd)
+        for (int kh = 0; kh < P.KH; ++kh)
+          for (int kw = 0; kw < P.KW; ++kw, ++tap) {
+            int zd = P.flip ? P.KD - 1 - kd : kd, zh = P.flip ? P.KH - 1 - kh : kh, zw = P.flip ? P.KW - 1 - kw : kw;
+            if (P.has_tm) { zd = P.tb[0] + P.ts[0] * kd; zh = P.tb[1] + P.ts[1] * kh; zw = P.tb[2] + P.ts[2] * kw; }
+            const long o = zd * P.s_kd + zh * P.s_kh + zw * P.s_kw;
+            const float a0 = v0 ? w0[o] : 0.f;
+            if (P.layout == 1) dp[(size_t)tap * per_tap] = a0;
+            else ((unsigned*)dp)[(size_t)tap * per_tap] = mt_pack_bf16(a0, v1 ? w0[o + P.s_ci] : 0.f);
+          }
     }
     return;
   }
