@@ -225,6 +225,15 @@ int mt_tile_accumulate(const float* acc, const float* gauss, int C, int D, int H
 /* probs = agg/nb; seg = argmax_c or per-channel >0.5 in regions_class_order (neural_network.py:405-417) */
 int mt_normalize_threshold(float* agg, const float* nb, int C, long V, const int32_t* class_order,
                            int use_regions, int32_t* seg, mt_stream_t stream);
+/* Export post-processing: save_segmentation_nifti_from_softmax (segmentation_export.py:27-160) without the
+ * resampled 47-channel intermediate — probabilities [C, D, H, W] are interpolated at the OD x OH x OW grid of the original
+ * spacing (order 1, skimage/scipy half-pixel rule, edge clamp; sep_axis in 0..2 = the anisotropic axis sampled nearest as in
+ * resample_data_or_seg's separate-z branch, preprocessing.py:134-187; -1 = trilinear), classified per voxel (use_regions: last
+ * channel i in order with p_i > 0.5 gives class_order[i], else 0; otherwise argmax) and written as uint8 into the uncropped
+ * volume out[FD, FH, FW] at offset (bD, bH, bW), clipped to the volume (crop_bbox re-insertion).  The caller zero-fills out. */
+int mt_resample_classify(const float* probs, int C, int D, int H, int W, int OD, int OH, int OW, int sep_axis,
+                         const int32_t* class_order, int use_regions, uint8_t* out, long FD, long FH, long FW,
+                         int bD, int bH, int bW, mt_stream_t stream);
 /* ---- device-side target preparation ----------------------------------------
  * Deep-supervision label pyramid: DownsampleSegForDSTransform2 / downsample_seg_for_ds_transform2 (downsampling.py:70-104,
  * order 0 = nearest through batchgenerators' resize_segmentation -> skimage.transform.resize(order 0, mode "edge") ->

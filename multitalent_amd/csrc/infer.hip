@@ -123,3 +123,74 @@ extern "C" int mt_normalize_threshold(float* agg, const float* nb, int C, long V
   MT_CHECK_LAUNCH("normalize_threshold");
   return MT_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Export post-processing on the device: the probabilities of a volume are resampled back to the original
+// voxel grid and turned into a label map in ONE pass — save_segmentation_nifti_from_softmax (segmentation_export.py:27-160) =
+// resample_data_or_seg(is_seg=False, order 1[, separate z with order_z 0]) (preprocessing.py:109-197) -> per-region threshold
+// in regions_class_order or argmax -> re-insertion into the uncropped volume.  The 47-channel resampled volume (25 GB at 512^3)
+// never exists: each output voxel interpolates every channel from the low-resolution probabilities and keeps only its label.
+// Coordinate rule of skimage.transform.resize(order=1, mode='edge', anti_aliasing=False) = scipy.ndimage.zoom(order=1,
+// mode='nearest', grid_mode=True): x = (o + 0.5) * in/out - 0.5, clamped to [0, in-1]; the separate-z branch samples the
+// anisotropic axis at floor(x + 0.5) (map_coordinates order 0, mode 'nearest', preprocessing.py:166-174).
+struct ResampleParams {
+  const float* probs; const int32_t* order; uint8_t* out;
+  int C, D, H, W, OD, OH, OW, sep_axis, use_regions;
+  long FD, FH, FW;          // dims of the uncropped output volume
+  int bD, bH, bW;           // insertion offset (crop_bbox lower corner)
+  int cD, cH, cW;           // voxels actually written per dim (clipped to the volume)
+};
+__device__ __forceinline__ void mt_axis_coord(int o, int I, int O, bool nearest, int& i0, int& i1, float& f) {
+  const double x = ((double)o + 0.5) * ((double)I / (double)O) - 0.5;
+  if (nearest) {
+    int i = (int)floor(x + 0.5); i = i < 0 ? 0 : (i > I - 1 ? I - 1 : i);
+    i0 = i1 = i; f = 0.f;
+    return;
+  }
+  const double xc = x < 0.0 ? 0.0 : (x > (double)(I - 1) ? (double)(I - 1) : x);
+  const int a = (int)floor(xc);
+  i0 = a; i1 = a + 1 > I - 1 ? I - 1 : a + 1; f = (float)(xc - (double)a);
+}
+__global__ __launch_bounds__(256) void resample_classify_kernel(const ResampleParams P) {
+  const long total = (long)P.cD * P.cH * P.cW;
+  const size_t V = (size_t)P.D * P.H * P.W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ow = (int)(i % P.cW), oh = (int)((i / P.cW) % P.cH), od = (int)(i / ((long)P.cW * P.cH));
+    int d0, d1, h0, h1, w0, w1; float fd, fh, fw;
+    mt_axis_coord(od, P.D, P.OD, P.sep_axis == 0, d0, d1, fd);
+    mt_axis_coord(oh, P.H, P.OH, P.sep_axis == 1, h0, h1, fh);
+    mt_axis_coord(ow, P.W, P.OW, P.sep_axis == 2, w0, w1, fw);
+    const size_t o00 = ((size_t)d0 * P.H + h0) * P.W, o01 = ((size_t)d0 * P.H + h1) * P.W;
+    const size_t o10 = ((size_t)d1 * P.H + h0) * P.W, o11 = ((size_t)d1 * P.H + h1) * P.W;
+    int s = 0; float best = -3.0e38f;
+    for (int c = 0; c < P.C; ++c) {
+      const float* p = P.probs + (size_t)c * V;
+      const float a00 = p[o00 + w0] + fw * (p[o00 + w1] - p[o00 + w0]);
+      const float a01 = p[o01 + w0] + fw * (p[o01 + w1] - p[o01 + w0]);
+      const float a10 = p[o10 + w0] + fw * (p[o10 + w1] - p[o10 + w0]);
+      const float a11 = p[o11 + w0] + fw * (p[o11 + w1] - p[o11 + w0]);
+      const float a0 = a00 + fh * (a01 - a00), a1 = a10 + fh * (a11 - a10);
+      const float v = a0 + fd * (a1 - a0);
+      if (P.use_regions) { if (v > 0.5f) s = P.order[c]; }
+      else if (v > best) { best = v; s = c; }
+    }
+    P.out[((size_t)(P.bD + od) * P.FH + (P.bH + oh)) * P.FW + (P.bW + ow)] = (uint8_t)s;
+  }
+}
+extern "C" int mt_resample_classify(const float* probs, int C, int D, int H, int W, int OD, int OH, int OW, int sep_axis,
+                                    const int32_t* class_order, int use_regions, uint8_t* out, long FD, long FH, long FW,
+                                    int bD, int bH, int bW, mt_stream_t stream) {
+  MT_REQUIRE(probs && out && C > 0 && D > 0 && H > 0 && W > 0 && OD > 0 && OH > 0 && OW > 0, "resample_classify: bad sizes");
+  MT_REQUIRE(sep_axis >= -1 && sep_axis <= 2 && (!use_regions || class_order), "resample_classify: bad mode");
+  MT_REQUIRE(bD >= 0 && bH >= 0 && bW >= 0 && bD < FD && bH < FH && bW < FW, "resample_classify: insertion offset outside the volume");
+  ResampleParams P;
+  P.probs = probs; P.order = class_order; P.out = out; P.C = C; P.D = D; P.H = H; P.W = W; P.OD = OD; P.OH = OH; P.OW = OW;
+  P.sep_axis = sep_axis; P.use_regions = use_regions; P.FD = FD; P.FH = FH; P.FW = FW; P.bD = bD; P.bH = bH; P.bW = bW;
+  P.cD = (int)((bD + (long)OD <= FD) ? OD : FD - bD); P.cH = (int)((bH + (long)OH <= FH) ? OH : FH - bH);
+  P.cW = (int)((bW + (long)OW <= FW) ? OW : FW - bW);
+  const long total = (long)P.cD * P.cH * P.cW;
+  int blocks = mt_cdiv(total, 256); if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(resample_classify_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+  MT_CHECK_LAUNCH("resample_classify");
+  return MT_OK;
+}
