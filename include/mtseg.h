@@ -225,6 +225,21 @@ int mt_tile_accumulate(const float* acc, const float* gauss, int C, int D, int H
 /* probs = agg/nb; seg = argmax_c or per-channel >0.5 in regions_class_order (neural_network.py:405-417) */
 int mt_normalize_threshold(float* agg, const float* nb, int C, long V, const int32_t* class_order,
                            int use_regions, int32_t* seg, mt_stream_t stream);
+/* Spatial augmentation (second half): batchgenerators' SpatialTransform as configured by
+ * data_augmentation_moreDA.py:66-80 (rotation + scaling, order_data 3, order_seg 1, constant borders) = per sample
+ * scipy.ndimage.map_coordinates over the affine field  x = M (o - (O-1)/2) + centre.
+ * mt_spline_prefilter3: in-place cubic B-spline prefilter of vol[NC, D, H, W] (pole sqrt(3)-2, gain 6, scipy's exact mirror
+ * boundary initialisation = what map_coordinates(order=3, mode='constant') filters with).
+ * mt_affine_sample: dst[N, C, OD, OH, OW] from src[N, C, D, H, W]; mats = N x 12 floats (row-major 3x3 M, then the centre);
+ * mode 0 nearest, 1 linear, 3 cubic (src must be prefiltered), 11 = segmentation rule for order 1 (label c where the linear
+ * interpolation of (seg == c) is >= 0.5, larger labels override, else 0).  A coordinate outside [0, n-1] on any axis gives cval
+ * (mode 11: 0); stencil taps off the array read the mirrored element (scipy 'constant' mode). */
+int mt_spline_prefilter3(float* vol, int NC, int D, int H, int W, int axes /* bit 0 W, 1 H, 2 D; 7 = 3D, 3 = per slice */,
+                         mt_stream_t stream);
+int mt_affine_sample(const float* src, int N, int C, int D, int H, int W, float* dst, int OD, int OH, int OW,
+                     const float* mats, int mode, float cval,
+                     int planar /* 1: nnU-Net's "dummy 2D" augmentation — every D slice is an independent 2D image, OD == D */,
+                     mt_stream_t stream);
 /* Export post-processing: save_segmentation_nifti_from_softmax (segmentation_export.py:27-160) without the
  * resampled 47-channel intermediate — probabilities [C, D, H, W] are interpolated at the OD x OH x OW grid of the original
  * spacing (order 1, skimage/scipy half-pixel rule, edge clamp; sep_axis in 0..2 = the anisotropic axis sampled nearest as in

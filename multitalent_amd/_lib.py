@@ -90,6 +90,8 @@ SIGNATURES = {
     'mt_sumsq_workspace': (_sz, [_l]),
     'mt_sgd_nesterov': (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp, _f, _vp]),
     'mt_flip_accumulate': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),
+    'mt_spline_prefilter3': (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    'mt_affine_sample': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _f, _i, _vp]),
     'mt_resample_classify': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _l, _l, _l, _i, _i, _i, _vp]),
     'mt_tile_accumulate': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _l, _l, _l, _i, _i, _i, _vp]),
     'mt_normalize_threshold': (_i, [_vp, _vp, _i, _l, _vp, _i, _vp, _vp]),

@@ -405,10 +405,31 @@ class nnUNetTrainerV2(nnUNetTrainer):
         self.load_dataset()
         self.do_split()
         ps = tuple(int(i) for i in self.patch_size)
-        mk = lambda ds: DataLoader3D(ds, ps, ps, self.batch_size, False, oversample_foreground_percent=self.oversample_foreground_percent,
-                                     pad_mode="constant", pad_sides=self.pad_all_sides, memmap_mode='r',
-                                     sampling_probabilities=self._sampling_probabilities(list(ds.keys())))
-        return mk(self.dataset_tr), mk(self.dataset_val)
+        bps = tuple(int(i) for i in self.basic_generator_patch_size) if self.device_augmentation else ps
+        mk = lambda ds, p: DataLoader3D(ds, p, ps, self.batch_size, False, oversample_foreground_percent=self.oversample_foreground_percent,
+                                        pad_mode="constant", pad_sides=self.pad_all_sides, memmap_mode='r',
+                                        sampling_probabilities=self._sampling_probabilities(list(ds.keys())))
+        return mk(self.dataset_tr, bps), mk(self.dataset_val, ps)
+
+    device_augmentation = True      # rotation/scaling/intensity/mirror augmentation of the training batches on the device
+
+    def setup_augmentation_params(self):
+        """nnUNetTrainerV2.setup_DA_params (:352-389): +-30 degree rotations (+-180 in-plane for the dummy-2D mode of anisotropic
+        patches), scale (0.7, 1.4), no elastic deformation; the loader patch is computed BEFORE the scale override, i.e. with
+        the default (0.85, 1.25) — a quirk of the reference that is kept."""
+        from ..data_augmentation.color import default_3d_augmentation_params
+        from ..data_augmentation.spatial import get_patch_size
+        p = default_3d_augmentation_params()
+        ps = [int(i) for i in self.patch_size]
+        if getattr(self, 'do_dummy_2D_aug', False):
+            p['dummy_2D'] = True
+            p['rotation_x'] = (-np.pi, np.pi)                      # default_2D_augmentation_params['rotation_x']
+            self.basic_generator_patch_size = np.array([ps[0]] + list(get_patch_size(ps[1:], p['rotation_x'], p['rotation_y'],
+                                                                                     p['rotation_z'], (0.85, 1.25))))
+        else:
+            self.basic_generator_patch_size = get_patch_size(ps, p['rotation_x'], p['rotation_y'], p['rotation_z'], (0.85, 1.25))
+        self.data_aug_params.update(p)
+        return p
 
     def maybe_setup_data_generators(self):
         """real cases when <dataset_directory>/<data_identifier>_stage<k> exists and no generator was attached."""
@@ -424,8 +445,15 @@ class nnUNetTrainerV2(nnUNetTrainer):
             unpack_dataset(self.folder_with_preprocessed_data)
         if self.ddp and dist.is_initialized() and dist.get_world_size() > 1:
             dist.barrier()
+        params = self.setup_augmentation_params() if self.device_augmentation else None
         dl_tr, dl_val = self.get_basic_generators()
-        self.tr_gen, self.val_gen = SegToTargetGenerator(dl_tr), SegToTargetGenerator(dl_val)
+        self.val_gen = SegToTargetGenerator(dl_val)
+        if self.device_augmentation and torch.cuda.is_available():
+            from ..data_augmentation.color import MoreDADeviceAugmenter
+            self.tr_gen = MoreDADeviceAugmenter(dl_tr, tuple(int(i) for i in self.patch_size), params,
+                                                torch.device('cuda', torch.cuda.current_device()))
+        else:
+            self.tr_gen = SegToTargetGenerator(dl_tr, tuple(int(i) for i in self.patch_size))
 
     def run_training(self):
         """epoch loop of network_trainer.py:411-470 without plotting / early stopping bookkeeping."""

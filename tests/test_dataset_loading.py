@@ -91,6 +91,7 @@ def test_trainer_generators_split_and_sqrt_sampling(tmp_path):
     tr.load_plans_file(); tr.process_plans(tr.plans)
     assert tr.folder_with_preprocessed_data == str(folder)
     np.random.seed(0)
+    tr.device_augmentation = False
     dl_tr, dl_val = tr.get_basic_generators()
     assert os.path.isfile(os.path.join(str(tmp_path), 'splits_final.pkl'))
     with open(os.path.join(str(tmp_path), 'splits_final.pkl'), 'rb') as f:
@@ -109,7 +110,9 @@ def test_trainer_generators_split_and_sqrt_sampling(tmp_path):
     own_group = not dist.is_initialized()
     mt = find_trainer_class('MultiTalent_trainer_ddp')(plans, 'all', 0, output_folder=None, dataset_directory=str(tmp_path), stage=1)
     mt.load_plans_file(); mt.process_plans(mt.plans)
-    dl_tr, _ = mt.get_basic_generators()
+    mt.setup_augmentation_params()
+    dl_tr, dl_val = mt.get_basic_generators()
+    assert tuple(dl_tr.patch_size) == tuple(int(i) for i in mt.basic_generator_patch_size) and tuple(dl_val.patch_size) == (12, 24, 24)
     from multitalent_amd.training.dataloading.dataset_loading import sqrt_sampling_probabilities
     assert np.array_equal(dl_tr.sampling_probabilities, sqrt_sampling_probabilities(list(mt.dataset_tr.keys()))[0])
     assert abs(sum(mt.dataset_prob.values()) - 1) < 1e-12 and set(mt.dataset_prob) == {'BTCV', 'KiTS', 'LiTS'}

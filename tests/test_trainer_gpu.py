@@ -141,7 +141,10 @@ def test_training_from_preprocessed_cases_on_disk(dev, pg, tmp_path):
     tr.max_num_epochs, tr.num_batches_per_epoch, tr.num_val_batches_per_epoch, tr.save_every = 2, 3, 1, 100
     np.random.seed(0)
     tr.run_training()
-    assert tr.tr_gen is not None and type(tr.tr_gen).__name__ == 'SegToTargetGenerator'
+    assert type(tr.tr_gen).__name__ == 'MoreDADeviceAugmenter' and type(tr.val_gen).__name__ == 'SegToTargetGenerator'
+    assert tuple(tr.basic_generator_patch_size) == (35, 51, 42)          # loader patch of the 16x32x32 network patch (+-30 deg, /0.85)
+    b = next(tr.tr_gen)
+    assert b['data'].is_cuda and tuple(b['data'].shape) == (2, 1, 16, 32, 32) and tuple(b['target'].shape) == (2, 1, 16, 32, 32)
     assert any(f.endswith('.npy') for f in os.listdir(str(folder)))                    # unpacked for memory-mapped reads
     assert len(tr.all_tr_losses) == 2 and np.isfinite(tr.all_tr_losses).all() and np.isfinite(tr.all_val_losses).all()
     assert os.path.isfile(str(tmp_path / 'out' / 'model_final_checkpoint.model'))
