@@ -1889,12 +1889,21 @@ static int launch_stem(const mt_conv3d_t* p, hipStream_t st) {
 
 // Winograd eligibility: FAST geometry, 8-byte channel pairs in every source, one destination, enough workgroups to fill
 // the chip with 4x4x16 tiles and enough input channels to amortise the transforms
+// 1x3x3, stride 1, pad (0,1,1): the first stage of the residual encoder (generic_modular_residual_UNet.py:28-118, plan kernels)
+static bool conv_is_133(const mt_conv3d_t* p) {
+  if (!conv_slopes_ok(p)) return false;
+  if (!(p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 0 && p->PH == 1 &&
+        p->PW == 1 && p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
+  for (int i = 0; i < p->nsrc; ++i)
+    if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 4.0 >= 2147483648.0) return false;
+  return true;
+}
 // ---- bf16 matrix inputs (conv_bf16.inc)
 static int g_bf16_mode = -1;       // -1: read MT_CONV_BF16 (default 1); 0 never; 1 where the grid fills the chip; 2 wherever eligible
 static int conv_bf16_cfg(const mt_conv3d_t* p) {
   if (g_bf16_mode < 0) { const char* e = getenv("MT_CONV_BF16"); g_bf16_mode = e ? atoi(e) : 1; }
   const int use = g_bf16_mode;
-  if (!use || !conv_is_fast(p) || p->osD > 0 || p->Cin < 16 || conv_fast_vec(p) != 2) return -1;
+  if (!use || !(conv_is_fast(p) || conv_is_133(p)) || p->osD > 0 || p->Cin < 16 || conv_fast_vec(p) != 2) return -1;
   if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return -1;            // 31-bit store offsets per sample
   if (p->csplit < p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs1 * 4.0 >= 2147483648.0) return -1;
   if (mt_cdiv(p->src[0].C, FCK) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, FCK) : 0) > MT_MAX_CHUNKS) return -1;
@@ -1922,7 +1931,7 @@ static bool strided_use_bf16(const mt_conv3d_t* p) {      // forward strided sta
   return use && g_bf16_mode && p->mma == 1 && p->Cin >= 16 && conv_fast_vec(p) == 2;
 }
 static int conv_bf16_vec(const mt_conv3d_t*) { return 2; }    // 16-byte staging loads measured slower (0.409 vs 0.372 ms on 32->32)
-template <int MW, int RH, int TD, int VEC, int NT, int NW>
+template <int MW, int RH, int TD, int VEC, int NT, int NW, int KD = 3>
 static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   ConvKParams P;
   P.c = *p;
@@ -1930,12 +1939,12 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   constexpr int TH = (32 / MW) * RH, TW = MW;
   P.tilesD = mt_cdiv(p->Do, TD); P.tilesH = mt_cdiv(p->Ho, TH); P.tilesW = mt_cdiv(p->Wo, TW);
   P.nsb = P.tilesD * P.tilesH * P.tilesW;
-  P.ntaps = 27; P.dbg = 0; P.stagger = 0;
+  P.ntaps = KD * 9; P.dbg = 0; P.stagger = 0;
   P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
-  const size_t ldsb = bstage_lds_bytes<TD + 2, TH + 2, TW + 2, VEC, NW>();
+  const size_t ldsb = bstage_lds_bytes<TD + KD - 1, TH + 2, TW + 2, VEC, NW>();
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(mt_cdiv(p->Cout, 32), NT), 1);
-  auto kfn = conv_bf16_kernel<MW, RH, TD, VEC, NT, NW>;
+  auto kfn = conv_bf16_kernel<MW, RH, TD, VEC, NT, NW, KD>;
   if (ldsb > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
@@ -1947,7 +1956,7 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
 static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
   // NT = 2 (64 output channels per workgroup) measured slower: 0.197 vs 0.179 ms on 64->64 @ 24x96x96; 8 waves: no gain
 #define MT_BF_CASE(I_, MW_, RH_, TD_, NW_)                                                   \
-  if (cfg == I_) return launch_bf16_t<MW_, RH_, TD_, 2, 1, NW_>(p, st);
+  if (cfg == I_) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 2, 1, NW_, 1>(p, st) : launch_bf16_t<MW_, RH_, TD_, 2, 1, NW_>(p, st);
   MT_BF_CASE(0, 32, 4, 4, 4)
   MT_BF_CASE(1, 32, 4, 2, 4)
   MT_BF_CASE(2, 16, 4, 2, 4)
@@ -2139,7 +2148,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   const int i = pl.cfg;
   if (i < 0) return MT_EINVAL;
   if (pl.kind == CONV_BF16) {
-    snprintf(buf, n, "conv_bf16_kernel<%d, %d, %d, %d, 1, 4>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, conv_bf16_vec(p));
+    snprintf(buf, n, "conv_bf16_kernel<%d, %d, %d, %d, 1, 4, %d>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, conv_bf16_vec(p), p->KD);
     return MT_OK;
   }
   const ConvCfg& g = kCfgs[i];
@@ -3175,6 +3184,8 @@ static const BwGeo kBwGeos[] = {
   {1, 2, 2, 1, 2, 2},   // 4: ConvTranspose3d(k = s = (1,2,2))
   {1, 1, 1, 1, 1, 1},   // 5: 1x1x1 heads
   {1, 3, 3, 1, 1, 1},   // 6: residual-encoder stage 0
+  {1, 1, 1, 2, 2, 2},   // 7: strided 1x1x1 skip convs of the residual blocks (conv_blocks.py:159-165)
+  {1, 1, 1, 1, 2, 2},   // 8: ... of the anisotropic stages
 };
 static int bwdw_fast_geo(const mt_conv3d_t* p, const mt_src_t* y) {
   if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return -1;
@@ -3215,6 +3226,11 @@ static bool bwdw_use_bf16(const mt_conv3d_t* p) {
   if (g_bwdw_bf16 < 0) { const char* e = getenv("MT_BWDW_BF16"); g_bwdw_bf16 = e ? atoi(e) : 1; }
   return g_bwdw_bf16 && p->mma == 1 && bwdw_use_wino(p);
 }
+static bool bwdw_use_bf16_133(const mt_conv3d_t* p) {       // 1x3x3 stride-1 backward-weight on the bf16 Winograd marching kernel
+  if (g_bwdw_bf16 < 0) { const char* e = getenv("MT_BWDW_BF16"); g_bwdw_bf16 = e ? atoi(e) : 1; }
+  return g_bwdw_bf16 && p->mma == 1 && p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 &&
+         p->PD == 0 && p->PH == 1 && p->PW == 1 && p->Wo > 16 && p->Ho >= 2 && p->Do >= 1 && conv_fast_vec(p) == 2;
+}
 // plan for the fast kernel: tile 1 x TH x TW with (TH,TW) = (4,32) or (8,16)
 static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   const bool wide = p->Wo > 16;
@@ -3226,12 +3242,17 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   P->ncot = mt_cdiv(p->Cout, 32);
   int pairs = P->nchunks * P->ncot; if (pairs < 1) pairs = 1;
   int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
-  if (bwdw_use_march(p) && bwdw_use_bf16(p)) nsg = (512 + pairs - 1) / pairs;      // 64 KiB ring: two workgroups per CU
+  if ((bwdw_use_march(p) && bwdw_use_bf16(p)) || bwdw_use_bf16_133(p)) nsg = (512 + pairs - 1) / pairs;      // 64 KiB ring: two workgroups per CU
   P->nsg_cap = nsg;
   if (nsg > P->ntiles_total) nsg = P->ntiles_total;
   if (nsg < 1) nsg = 1;
   P->nsg = nsg;
   P->nunits = 0; P->nseg = 1; P->dseg = p->Do;
+  if (bwdw_use_bf16_133(p)) {
+    P->TH = 4; P->TW = 32; P->tilesH = mt_cdiv(p->Ho, 4); P->tilesW = mt_cdiv(p->Wo, 32);
+    P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N;
+    bwdw_march_plan(p, P);
+  }
   if (bwdw_use_march(p)) {
     static int tall = -1;
     if (tall < 0) { const char* e = getenv("MT_BWDW_TALL"); tall = e ? atoi(e) : 1; }
@@ -3406,7 +3427,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     switch (geo) {
       case 0: {
         if (bwdw_use_bf16(p)) {
-          hipLaunchKernelGGL(conv_bwdw_wino_bf16_kernel, dim3(P.nsg, P.ncot, P.nchunks), dim3(256), BWB_LDS_BYTES, st, P);
+          hipLaunchKernelGGL(conv_bwdw_wino_bf16_kernel<3>, dim3(P.nsg, P.ncot, P.nchunks), dim3(256), BWB_LDS_BYTES, st, P);
           MT_CHECK_LAUNCH("conv_bwdw_wino_bf16");
           rc = MT_OK;
           break;
@@ -3433,7 +3454,17 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
       case 3: rc = launch_bwdw_fast<2, 2, 2, 2, 2, 2>(P, vec, st); break;
       case 4: rc = launch_bwdw_fast<1, 2, 2, 1, 2, 2>(P, vec, st); break;
       case 5: rc = launch_bwdw_fast<1, 1, 1, 1, 1, 1>(P, vec, st); break;
-      case 6: rc = launch_bwdw_fast<1, 3, 3, 1, 1, 1>(P, vec, st); break;
+      case 7: rc = launch_bwdw_fast<1, 1, 1, 2, 2, 2>(P, vec, st); break;
+      case 8: rc = launch_bwdw_fast<1, 1, 1, 1, 2, 2>(P, vec, st); break;
+      case 6:
+        if (bwdw_use_bf16_133(p)) {
+          hipLaunchKernelGGL(conv_bwdw_wino_bf16_kernel<1>, dim3(P.nsg, P.ncot, P.nchunks), dim3(256), BWB_LDS_BYTES, st, P);
+          MT_CHECK_LAUNCH("conv_bwdw_wino_bf16<1>");
+          rc = MT_OK;
+          break;
+        }
+        rc = launch_bwdw_fast<1, 3, 3, 1, 1, 1>(P, vec, st);
+        break;
     }
     if (rc != MT_OK) return rc;
     BwdWReduceParams R;

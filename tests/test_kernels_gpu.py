@@ -261,6 +261,8 @@ def test_conv_bwd_data(dev, Cin, Cout, shape, k, stride):
     (24, 40, (5, 9, 37), (3, 3, 3), (1, 1, 1)),      # Winograd backward-weight: ragged tiles in H and W, two cout tiles
     (16, 70, (4, 6, 40), (3, 3, 3), (1, 1, 1)),      # ... three cout tiles, one cin chunk
     (30, 30, (3, 5, 20), (3, 3, 3), (1, 1, 1)),      # ... odd H (half tile), channel tails
+    (30, 60, (6, 12, 34), (1, 1, 1), (2, 2, 2)),     # strided 1x1x1 skip conv of a residual block
+    (60, 120, (5, 9, 12), (1, 1, 1), (1, 2, 2)),
 ])
 def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
     ops = _ops()
@@ -292,6 +294,44 @@ def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
         finally:
             ops.set_option('bwdw_wino', 1)
         assert relerr(dw2.cpu(), w.grad) < 2e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,shape", [(2, 30, 30, (5, 18, 70)), (1, 32, 64, (3, 8, 32))])
+def test_conv_bf16_1x3x3(dev, N, Cin, Cout, shape):
+    """the 1x3x3 form of conv_bf16_kernel (first stage of the residual encoder): forward with lazy input + statistics and the
+    flipped-weight backward-data, against the same arithmetic on the CPU (operands rounded to bf16): 1e-4."""
+    ops = _ops()
+    ops.set_option('conv_bf16', 2)
+    ops.set_mma(1)
+    try:
+        g = torch.Generator().manual_seed(29)
+        srcs = [torch.randn((N, Cin) + shape, generator=g)]
+        lazy = [(torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)]
+        w = torch.randn((Cout, Cin, 1, 3, 3), generator=g) / np.sqrt(Cin * 9)
+        b = torch.randn(Cout, generator=g)
+        out, part = run_conv(dev, srcs, w, b, (1, 1, 1), (0, 1, 1), lazy=lazy, stats=True)
+        xin = ref_inputs(srcs, lazy)
+        ref = F.conv3d(_bf16_round(xin).double(), _bf16_round(w).double(), b.double(), padding=(0, 1, 1))
+        assert relerr(to_ncdhw(out.cpu()), ref) < 1e-4
+        assert np.allclose(part.cpu().double().sum(1)[..., 1].numpy(), (ref ** 2).sum((2, 3, 4)).numpy(), rtol=1e-4)
+        dy = torch.randn(ref.shape, generator=g)
+        x = torch.zeros_like(xin, dtype=torch.float64).requires_grad_(True)
+        F.conv3d(x, _bf16_round(w).double(), None, padding=(0, 1, 1)).backward(_bf16_round(dy).double())
+        dx = torch.full((N,) + shape + (Cin,), float('nan'), device=dev)
+        dyd = to_ndhwc(dy).to(dev)
+        geomT = ops.ConvGeom(shape, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        p = ops.fill_conv([ops.Act(dyd)], geomT, Cin, out0=ops.Act(dx))
+        assert ops.conv_kernel_name(p).startswith('conv_bf16')
+        wd = w.to(dev).contiguous()
+        wp = ops.pack_conv_weights(wd, Cout, 0, Cin, (1, 3, 3), ops.conv_weight_strides(wd, as_bwd_data=True), True, ops.conv_ck(p),
+                                   layout=ops.conv_pack_layout(p))
+        p.wpack = wp.data_ptr()
+        ops.conv3d_fwd(p)
+        torch.cuda.synchronize()
+        assert relerr(to_ncdhw(dx.cpu()), x.grad) < 1e-4
+    finally:
+        ops.set_option('conv_bf16', 1)
+        ops.set_mma(0)
 
 
 @pytest.mark.parametrize("Cin,Cout,shape,lazy", [
@@ -327,6 +367,28 @@ def test_conv_bwd_weight_bf16_mixed_precision(dev, Cin, Cout, shape, lazy):
     got = dw.cpu() - base
     err = relerr(got, w.grad)
     assert 1e-5 < err < 1e-2, err          # > 1e-5: the bf16 kernel really ran (the fp32 kernels reach 2e-5 only on other shapes)
+
+
+@pytest.mark.parametrize("Cin,Cout,shape", [(30, 30, (5, 9, 37)), (32, 64, (3, 8, 40)), (16, 30, (1, 6, 20))])
+def test_conv_bwd_weight_bf16_1x3x3(dev, Cin, Cout, shape):
+    """conv_bwdw_wino_bf16_kernel<1>: 1x3x3 weight gradient (residual encoder stage 0) vs autograd, 1e-2 of the largest entry."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(15)
+    N = 2
+    x = torch.randn((N, Cin) + shape, generator=g)
+    w = (torch.randn((Cout, Cin, 1, 3, 3), generator=g) / np.sqrt(Cin * 9)).requires_grad_(True)
+    y = F.conv3d(x, w, None, padding=(0, 1, 1))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xa, ya = ops.Act(to_ndhwc(x).to(dev)), ops.Act(to_ndhwc(dy).to(dev))
+    geom = ops.ConvGeom(shape, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    p = ops.fill_conv([xa], geom, Cout, mma=1)
+    ws = torch.empty(max(ops.conv3d_bwd_weight_workspace(p) // 4, 1), device=dev)
+    dw = torch.full(w.shape, float('nan'), device=dev)
+    ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
+    torch.cuda.synchronize()
+    err = relerr(dw.cpu(), w.grad)
+    assert 1e-5 < err < 1e-2, err
 
 
 @pytest.mark.parametrize("Cin,Cout,base,so", [
