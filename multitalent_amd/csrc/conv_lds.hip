@@ -702,10 +702,10 @@ __device__ __forceinline__ void fast_frag_mfma(const FastFrag<MT>& f, f32x16 (&a
 #ifndef CF_BPF
 #define CF_BPF 3
 #endif
-template <int MT, int LH, int LW>
+template <int MT, int LH, int LW, int KD = 3>
 __device__ __forceinline__ void fast_chunk(const float* __restrict__ lds, const int (&abase)[MT], const float* __restrict__ wlane,
                                            f32x16 (&acc)[MT]) {
-  constexpr int NB = CF_BPF + 1;
+  constexpr int NB = CF_BPF + 1, NTAP = KD * 9;       // KD = 1: the 1x3x3 convolutions of the residual encoder's first stage
   f32x4 b[NB][2];
   f32x4 a[2][MT][2];
 #pragma unroll
@@ -719,12 +719,12 @@ __device__ __forceinline__ void fast_chunk(const float* __restrict__ lds, const 
     a[0][m][1] = *(const f32x4*)(lds + abase[m] + 4);
   }
 #pragma unroll
-  for (int t = 0; t < 27; ++t) {
-    if (t + CF_BPF < 27 && !(CF_ABL & 64)) {
+  for (int t = 0; t < NTAP; ++t) {
+    if (t + CF_BPF < NTAP && !(CF_ABL & 64)) {
       b[(t + CF_BPF) % NB][0] = *(const f32x4*)(wlane + (t + CF_BPF) * 512);
       b[(t + CF_BPF) % NB][1] = *(const f32x4*)(wlane + (t + CF_BPF) * 512 + 256);
     }
-    if (t + 1 < 27 && !(CF_ABL & 32)) {
+    if (t + 1 < NTAP && !(CF_ABL & 32)) {
       const int t1 = t + 1;
       const int toff = (((t1 / 9) * LH + (t1 / 3) % 3) * LW + t1 % 3) * FCKP;
 #pragma unroll
@@ -743,10 +743,10 @@ __device__ __forceinline__ void fast_chunk(const float* __restrict__ lds, const 
   }
 }
 
-template <int MW, int RH, int TD, int VEC>
+template <int MW, int RH, int TD, int VEC, int KD = 3>
 __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
   constexpr int MH = 32 / MW, TH = MH * RH, TW = MW, NMT = TD * RH, MT = NMT / 4;
-  constexpr int LD = TD + 2, LH = TH + 2, LW = TW + 2, LWP = stage_lwp<LD, LH, LW, VEC>();
+  constexpr int LD = TD + KD - 1, LH = TH + 2, LW = TW + 2, LWP = stage_lwp<LD, LH, LW, VEC>();
   static_assert(NMT % 4 == 0, "M tiles must split over 4 waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
@@ -778,11 +778,11 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
 
   for (int ch = 0; ch < P.nchunks; ++ch) {
     const ConvChunk cc = P.chunk[ch];
-    const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
+    const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (KD * 9 * 512) + lane * 4;
     if (!(CF_ABL & 16)) __syncthreads();
-    if (!(CF_ABL & 1)) mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+    if (!(CF_ABL & 1)) mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 - (KD - 1) / 2, oh0 - 1, ow0 - 1, lane, wave);
     if (!(CF_ABL & 16)) __syncthreads();
-    if (!(CF_ABL & 8)) fast_chunk<MT, LH, LWP>(lds, abase, wlane, acc);
+    if (!(CF_ABL & 8)) fast_chunk<MT, LH, LWP, KD>(lds, abase, wlane, acc);
   }
 
   // ---- epilogue: bias, store, statistics.  Stores go through a buffer descriptor: per-lane byte offset (column part)
@@ -1688,6 +1688,7 @@ static bool conv_fast_strided_ok(const mt_conv3d_t* p);
 static bool conv_wino_ok(const mt_conv3d_t* p);
 static bool conv_gather_ok(const mt_conv3d_t* p);
 static int launch_gather(const mt_conv3d_t* p, hipStream_t st);
+static bool conv_is_133(const mt_conv3d_t* p);
 static int conv_bf16_cfg(const mt_conv3d_t* p);
 static bool strided_use_bf16(const mt_conv3d_t* p);
 static ConvPlan conv_plan(const mt_conv3d_t* p) {
@@ -1715,6 +1716,11 @@ static ConvPlan conv_plan(const mt_conv3d_t* p) {
     const long wgs = (long)p->N * mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW) * mt_cdiv(p->Cout, 32);
     if (use_ts && wgs < 300 && p->csplit >= p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 < 2147483648.0) pl.kind = CONV_TAPSPLIT;
     return pl;
+  }
+  if (conv_is_133(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0 && p->Cin >= 8) {      // compile-time taps instead of conv_rt
+    static int use133 = -1;
+    if (use133 < 0) { const char* e = getenv("MT_CONV_FAST133"); use133 = e ? atoi(e) : 1; }
+    if (use133) { pl.kind = CONV_FAST; return pl; }
   }
   if (use_rt && conv_fast_strided_ok(p)) { pl.kind = CONV_FAST_STRIDED; pl.cfg = 0; return pl; }
   if (use_rt && conv_rt_ok(p)) {
@@ -1785,7 +1791,7 @@ static int conv_fast_vec(const mt_conv3d_t* p) {
   return 2;
 }
 
-template <int MW, int RH, int TD, int VEC>
+template <int MW, int RH, int TD, int VEC, int KD = 3>
 static int launch_fast2(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
   ConvKParams P;
   P.c = *p;
@@ -1793,13 +1799,13 @@ static int launch_fast2(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) 
   int TDv, TH, TW; TDv = g.TD; TH = (32 / g.MW) * g.RH; TW = g.MW;
   P.tilesD = mt_cdiv(p->Do, TDv); P.tilesH = mt_cdiv(p->Ho, TH); P.tilesW = mt_cdiv(p->Wo, TW);
   P.nsb = P.tilesD * P.tilesH * P.tilesW;
-  P.ntaps = 27; P.dbg = 0; P.stagger = 0;
+  P.ntaps = KD * 9; P.dbg = 0; P.stagger = 0;
   P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
   constexpr int TH_ = (32 / MW) * RH;
-  const size_t ldsb = stage_lds_bytes<TD + 2, TH_ + 2, MW + 2, VEC>();
+  const size_t ldsb = stage_lds_bytes<TD + KD - 1, TH_ + 2, MW + 2, VEC>();
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
-  auto kfn = conv_fast_kernel<MW, RH, TD, VEC>;
+  auto kfn = conv_fast_kernel<MW, RH, TD, VEC, KD>;
   if (ldsb > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
@@ -2154,7 +2160,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   const ConvCfg& g = kCfgs[i];
   const bool fast = conv_is_fast(p);
   if (pl.kind == CONV_FAST)
-    snprintf(buf, n, "conv_fast_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
+    snprintf(buf, n, "conv_fast_kernel<%d, %d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p), p->KD);
   else if (pl.kind == CONV_TAPSPLIT)
     snprintf(buf, n, "conv_tapsplit_kernel<%d>", conv_fast_vec(p));
   else if (pl.kind == CONV_STEM)
@@ -2203,6 +2209,13 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   }
   if (pl.kind == CONV_FAST) {
     const int vec = conv_fast_vec(p);
+    if (p->KD == 1) {
+      switch (i) {
+        case 0: return vec == 2 ? launch_fast2<32, 4, 2, 2, 1>(p, g, st) : launch_fast2<32, 4, 2, 1, 1>(p, g, st);
+        case 1: return vec == 2 ? launch_fast2<16, 2, 2, 2, 1>(p, g, st) : launch_fast2<16, 2, 2, 1, 1>(p, g, st);
+        default: return vec == 2 ? launch_fast2<8, 2, 2, 2, 1>(p, g, st) : launch_fast2<8, 2, 2, 1, 1>(p, g, st);
+      }
+    }
     switch (i) {
       case 0: return vec == 2 ? launch_fast2<32, 4, 2, 2>(p, g, st) : launch_fast2<32, 4, 2, 1>(p, g, st);
       case 1: return vec == 2 ? launch_fast2<16, 2, 2, 2>(p, g, st) : launch_fast2<16, 2, 2, 1>(p, g, st);
