@@ -1,0 +1,27 @@
+"""One case end to end on the device (SURVEY §3.2 call stack, predict_MultiTalent.py:222-266 + preprocessing.py:226-311 +
+segmentation_export.py:27-160): cropped CT -> resample to the plan spacing + clip/z-score -> sliding window (Gaussian weighting,
+optional mirroring) -> probabilities resampled to the original grid, thresholded per region and re-inserted into the uncropped
+volume.  The volume never leaves HBM between the stages; reading / cropping the image and writing the NIfTI stay with the
+caller (SimpleITK)."""
+import numpy as np
+
+from ..preprocessing.device_preprocessing import resample_and_normalize_ct
+from .segmentation_export import resample_and_classify
+from .sliding_window import predict_3D
+
+
+def predict_case_on_device(network, cropped_data, properties, target_spacing, intensityproperties, patch_size,
+                           regions_class_order=None, do_mirroring=True, mirror_axes=(0, 1, 2), step_size=0.5,
+                           transpose_forward=(0, 1, 2), force_separate_z=None, tile_shard=None, verbose=False):
+    """cropped_data: [C, X, Y, Z] (numpy or device tensor) already transposed by `transpose_forward`; properties: the case's
+    dict (`original_spacing`, `size_after_cropping`, `original_size_of_raw_data`, `crop_bbox`).  Returns the uint8 label volume
+    (device tensor, shape `original_size_of_raw_data`) and the properties with the resampling entries filled in."""
+    spacing = np.array(properties['original_spacing'])[list(transpose_forward)]
+    x = resample_and_normalize_ct(cropped_data, spacing, target_spacing, intensityproperties, force_separate_z)
+    properties = dict(properties)
+    properties['size_after_resampling'] = tuple(int(i) for i in x.shape[1:])
+    properties['spacing_after_resampling'] = np.array(target_spacing)
+    _, probs = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
+                          'constant', None, True, verbose, True, tile_shard=tile_shard, return_device_tensors=True)
+    seg = resample_and_classify(probs, properties, regions_class_order, 1, force_separate_z, 0)
+    return seg, properties

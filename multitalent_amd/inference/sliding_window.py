@@ -102,8 +102,23 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
     num_classes = net.num_classes
     nonlin = _nonlin_code(net)
 
-    data, slicer = pad_nd_image(np.asarray(x, dtype=np.float32), patch_size, pad_border_mode, pad_kwargs)
-    shp = data.shape
+    if torch.is_tensor(x) and x.is_cuda:
+        # device-resident input (e.g. from preprocessing.device_preprocessing): pad_nd_image's constant padding with F.pad
+        if pad_border_mode != 'constant':
+            raise NotImplementedError("device-resident volumes are padded with pad_border_mode='constant' only")
+        old = [int(i) for i in x.shape[1:]]
+        diff = [max(p, o) - o for p, o in zip(patch_size, old)]
+        below = [d // 2 for d in diff]
+        above = [d // 2 + d % 2 for d in diff]
+        data = x.float()
+        if any(diff):
+            data = torch.nn.functional.pad(data, (below[2], above[2], below[1], above[1], below[0], above[0]), mode='constant',
+                                           value=float(pad_kwargs.get('constant_values', 0)))
+        slicer = [slice(None)] + [slice(b, b + o) for b, o in zip(below, old)]
+        dev = x.device
+    else:
+        data, slicer = pad_nd_image(np.asarray(x, dtype=np.float32), patch_size, pad_border_mode, pad_kwargs)
+    shp = tuple(data.shape)
     steps = compute_steps_for_sliding_window(patch_size, shp[1:], step_size)
     num_tiles = len(steps[0]) * len(steps[1]) * len(steps[2])
     if verbose:
@@ -118,7 +133,7 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
         gaussian = torch.ones(patch_size, dtype=torch.float32, device=dev)
     mult = gaussian if (use_gaussian and num_tiles > 1) else None          # neural_network.py:384-386
 
-    vol = torch.from_numpy(np.ascontiguousarray(data)).to(dev)                # [C, X, Y, Z]
+    vol = data.contiguous() if torch.is_tensor(data) else torch.from_numpy(np.ascontiguousarray(data)).to(dev)   # [C, X, Y, Z]
     V = int(np.prod(shp[1:]))
     agg = torch.zeros((num_classes,) + tuple(shp[1:]), dtype=torch.float32, device=dev)
     nb = torch.zeros(tuple(shp[1:]), dtype=torch.float32, device=dev)

@@ -78,3 +78,35 @@ def test_device_export_rejects_unsupported_modes(dev):
         resample_and_classify(probs, props, order, 3, force, 0)
     with pytest.raises(NotImplementedError):
         save_segmentation_nifti_from_softmax(probs, 'x.nii.gz', props, 1, order, resampled_npz_fname='x.npz', verbose=False)
+
+
+@pytest.mark.gpu
+def test_case_end_to_end_on_device(dev):
+    """predict_case_on_device = resample_and_normalize_ct -> predict_3D -> resample_and_classify without leaving the device; the
+    device-resident input path of predict_3D equals its numpy path (same padding, same tiles)."""
+    import torch
+    from torch import nn
+    from multitalent_amd.inference.predict import predict_case_on_device
+    from multitalent_amd.inference.sliding_window import predict_3D
+    from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
+    from multitalent_amd.preprocessing.device_preprocessing import resample_and_normalize_ct
+    torch.manual_seed(3)
+    net = Generic_UNet(1, 8, 5, 2, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                       {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x, None,
+                       [[2, 2, 2], [2, 2, 2]], [[3, 3, 3]] * 3, False, True, True).to(dev)
+    net.eval(); net.do_ds = False
+    net.inference_apply_nonlin = nn.Sigmoid()
+    rs = np.random.RandomState(0)
+    ct = (rs.randn(1, 14, 40, 36) * 300).astype(np.float32)
+    props = {'original_spacing': np.array([3.0, 0.9, 0.9]), 'size_after_cropping': np.array([14, 40, 36]),
+             'original_size_of_raw_data': np.array([16, 44, 36]), 'crop_bbox': [[1, 15], [2, 42], [0, 36]]}
+    ip = {0: {'mean': 63.44, 'sd': 175.48, 'percentile_00_5': -927.0, 'percentile_99_5': 275.0}}
+    order = [1, 2, 3, 4, 5]
+    seg, p2 = predict_case_on_device(net, ct, props, (2.0, 1.2, 1.2), ip, (16, 32, 32), order, do_mirroring=True)
+    assert seg.dtype == torch.uint8 and tuple(seg.shape) == (16, 44, 36) and p2['size_after_resampling'] == (21, 30, 27)
+    assert int(seg[0].max()) == 0 and int(seg[-1].max()) == 0 and int(seg[:, :2].max()) == 0          # outside the crop box
+    x = resample_and_normalize_ct(ct, props['original_spacing'], (2.0, 1.2, 1.2), ip)
+    a = predict_3D(net, x, True, (0, 1, 2), True, 0.5, (16, 32, 32), order, True, 'constant', None, True, False, True, return_device_tensors=True)
+    b = predict_3D(net, x.cpu().numpy(), True, (0, 1, 2), True, 0.5, (16, 32, 32), order, True, 'constant', None, True, False, True,
+                   return_device_tensors=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
