@@ -219,6 +219,11 @@ int mt_sgd_nesterov(float* p, const float* g, float* buf, long n, float lr, floa
 int mt_flip_accumulate(const float* logits, int cs, int D, int H, int W, int C, int flipD, int flipH,
                        int flipW, int nonlin /*0 none,1 sigmoid,2 softmax*/, float weight, float* acc,
                        int first, mt_stream_t stream);
+/* Fused form of (1x1x1 head -> mt_flip_accumulate) for inference: p describes the head (src = its lazily activated input of N
+ * samples, Cin, Cout <= 64, wpack layout 1 ck 16, bias; Db,Hb,Wb = tile size); sample `sample` is evaluated, passed through the
+ * nonlinearity, un-flipped and accumulated into acc[Cout][D][H][W] like mt_flip_accumulate — the logits are never stored. */
+int mt_head_flip_accumulate(const mt_pointwise_t* p, int sample, int flipD, int flipH, int flipW, int nonlin, float weight,
+                            float* acc, int first, mt_stream_t stream);
 /* agg[c, tile] += acc * gauss ; nb[tile] += gauss   (neural_network.py:388-394) */
 int mt_tile_accumulate(const float* acc, const float* gauss, int C, int D, int H, int W, float* agg,
                        float* nb, long aX, long aY, long aZ, int x0, int y0, int z0, mt_stream_t stream);

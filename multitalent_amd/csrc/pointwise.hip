@@ -165,6 +165,176 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Inference: segmentation head + nonlinearity + un-flip + accumulation in ONE kernel (neural_network.py:502-591 does
+// pred = nonlin(net(flip(x))); result += flip^-1(pred) / num_results per mirror combination).  The 1x1x1 head is computed with the
+// MFMA operand roles SWAPPED (weights as the row operand), so a lane owns a VOXEL and its registers are output channels: the
+// channel-major accumulator acc[C][D][H][W] is then written with 32 consecutive voxels per channel row — 128-byte aligned runs —
+// instead of 47-channel NDHWC rows of 188 bytes, and the logits never exist in HBM (the separate head wrote 2.7 GB per batch of
+// eight tiles at 0.9 TB/s and flip_accumulate read them back).  The register contents of both operands are exactly those of
+// pw_fast_kernel; only their order in the MFMA changes.
+struct HeadAccParams {
+  mt_pointwise_t c;
+  int nchunks, nsb, sample, fD, fH, fW, nonlin, first;
+  long V;
+  float weight;
+  float* acc;
+};
+template <int VEC>
+__global__ __launch_bounds__(256) void head_flip_accumulate_kernel(const HeadAccParams P) {
+  const mt_pointwise_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  const int sb = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const int nb = P.sample;
+  const long m0 = (long)sb * 128 + wave * 32;
+  const mt_src_t& S = c.src;
+  const long bv = m0 + li;
+  const bool vok = bv < P.V;
+  const size_t in_sample = (size_t)P.V * S.cs;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0, (int)(in_sample * 4), 0x00020000);
+  const int aoff = vok ? (int)((bv * S.cs + 8 * lhalf) * 4) : (int)0x80000000;
+  const bool aff = S.scale != nullptr;
+  const float slope = S.slope;
+  const bool lrelu_ok = (slope >= 0.f) && (slope <= 1.f);
+  __shared__ __attribute__((aligned(16))) float ssc[PW_MAXC], ssh[PW_MAXC];
+  if (aff) {
+    for (int i = tid; i < P.nchunks * PW_CK; i += 256) {
+      ssc[i] = i < S.C ? S.scale[(size_t)nb * S.C + i] : 0.f;
+      ssh[i] = i < S.C ? S.shift[(size_t)nb * S.C + i] : 0.f;
+    }
+    __syncthreads();
+  }
+  auto load_a = [&](int ch, float (&x)[8]) {
+    const int o = aoff + ch * (PW_CK * 4);
+    if constexpr (VEC == 2) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra, o + g * 8, 0, 0));
+        x[2 * g] = t.x; x[2 * g + 1] = t.y;
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) x[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, o + g * 4, 0, 0));
+    }
+  };
+  auto finish_a = [&](int ch, float (&x)[8]) {
+    const int cb = ch * PW_CK + 8 * lhalf;
+    if (aff) {
+      const f32x4 sc0 = *(const f32x4*)(ssc + cb), sc1 = *(const f32x4*)(ssc + cb + 4);
+      const f32x4 sh0 = *(const f32x4*)(ssh + cb), sh1 = *(const f32x4*)(ssh + cb + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = fmaf(x[e], e < 4 ? sc0[e & 3] : sc1[e & 3], e < 4 ? sh0[e & 3] : sh1[e & 3]);
+        x[e] = lrelu_ok ? fmaxf(t, t * slope) : mt_lrelu(t, slope);
+      }
+    }
+    if (cb + 8 > c.Cin || !vok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = (vok && cb + e < c.Cin) ? x[e] : 0.f;
+    }
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[n][j] = 0.f;
+  const bool two = c.Cout > 32;                      // block-uniform
+  float xa[8], xn[8];
+  load_a(0, xa);
+  for (int ch = 0; ch < P.nchunks; ++ch) {
+    if (ch + 1 < P.nchunks) load_a(ch + 1, xn);
+    finish_a(ch, xa);
+    const float* wq = c.wpack + (size_t)ch * 512 + lane * 4;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      if (n == 1 && !two) break;
+      const float* wn = wq + (size_t)n * P.nchunks * 512;
+      const f32x4 b0 = *(const f32x4*)(wn), b1 = *(const f32x4*)(wn + 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[e], xa[e], acc[n], 0, 0, 0);      // rows = channels
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[e], xa[4 + e], acc[n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xa[e] = xn[e];
+  }
+  // ---- epilogue: this lane's voxel, channels n*32 + (j&3) + 8*(j>>2) + 4*lhalf
+  if (c.bias != nullptr) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int cj = n * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+        acc[n][j] += cj < c.Cout ? c.bias[cj] : 0.f;
+      }
+  }
+  if (P.nonlin == 2) {                                // softmax over ALL channels of the voxel: own registers + the partner lane's
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (n * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhalf < c.Cout) mx = fmaxf(mx, acc[n][j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float se = 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const bool cv = n * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhalf < c.Cout;
+        acc[n][j] = cv ? expf(acc[n][j] - mx) : 0.f;
+        se += acc[n][j];
+      }
+    se += __shfl_xor(se, 32, 64);
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[n][j] *= inv;
+  } else if (P.nonlin == 1) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[n][j] = 1.f / (1.f + expf(-acc[n][j]));
+  }
+  if (!vok) return;
+  const int w = (int)(bv % c.Wb), h = (int)((bv / c.Wb) % c.Hb), d = (int)(bv / ((long)c.Wb * c.Hb));
+  const long dv = ((long)(P.fD ? c.Db - 1 - d : d) * c.Hb + (P.fH ? c.Hb - 1 - h : h)) * c.Wb + (P.fW ? c.Wb - 1 - w : w);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    if (n == 1 && !two) break;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int cj = n * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+      if (cj < c.Cout) {
+        float* a = P.acc + (size_t)cj * P.V + dv;
+        const float v = acc[n][j] * P.weight;
+        *a = P.first ? v : *a + v;
+      }
+    }
+  }
+}
+extern "C" int mt_head_flip_accumulate(const mt_pointwise_t* p, int sample, int flipD, int flipH, int flipW, int nonlin, float weight,
+                                       float* acc, int first, mt_stream_t stream) {
+  MT_REQUIRE(p != nullptr && acc != nullptr, "head_flip_accumulate: null pointers");
+  MT_REQUIRE(p->siD == 1 && p->siH == 1 && p->siW == 1 && p->soD == 1 && p->soH == 1 && p->soW == 1 && p->Db == p->Di && p->Hb == p->Hi &&
+             p->Wb == p->Wi, "head_flip_accumulate: 1x1x1 stride-1 head only");
+  MT_REQUIRE(p->Cout >= 1 && p->Cout <= 64 && p->src.C == p->Cin && sample >= 0 && sample < p->N, "head_flip_accumulate: needs 1..64 output channels");
+  MT_REQUIRE(nonlin >= 0 && nonlin <= 2, "head_flip_accumulate: nonlin must be 0 (none), 1 (sigmoid) or 2 (softmax)");
+  HeadAccParams P;
+  P.c = *p; P.nchunks = mt_cdiv(p->Cin, PW_CK); P.V = (long)p->Db * p->Hb * p->Wb; P.nsb = mt_cdiv(P.V, 128);
+  MT_REQUIRE(P.nchunks * PW_CK <= PW_MAXC && (double)P.V * p->src.cs * 4.0 < 2147483648.0, "head_flip_accumulate: sample too large");
+  P.sample = sample; P.fD = flipD; P.fH = flipH; P.fW = flipW; P.nonlin = nonlin; P.first = first; P.weight = weight; P.acc = acc;
+  const mt_src_t& S = p->src;
+  const bool v2 = (S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0;
+  if (v2) hipLaunchKernelGGL(head_flip_accumulate_kernel<2>, dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
+  else    hipLaunchKernelGGL(head_flip_accumulate_kernel<1>, dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
+  MT_CHECK_LAUNCH("head_flip_accumulate");
+  return MT_OK;
+}
+
 extern "C" int mt_pointwise_stats_blocks(const mt_pointwise_t* p) {
   if (p == nullptr) return -1;
   return mt_cdiv((long)p->Db * p->Hb * p->Wb, 128);

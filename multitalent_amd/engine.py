@@ -494,7 +494,18 @@ class Engine:
         self._packed_version = ver
 
     # ---- execution --------------------------------------------------------------------------------
-    def forward(self, x, need_grad=True, all_heads=True):
+    def forward_to_final_head(self, x):
+        """Inference: everything but the segmentation heads.  Returns the mt_pointwise_t of the FINAL head (source = its lazily
+        activated input for all N samples, packed weights, bias) for ops.head_flip_accumulate, which fuses the head with the
+        nonlinearity, the un-flip and the accumulation of the sliding window (the logits are never stored)."""
+        self.forward(x, need_grad=False, all_heads=False, _skip_final=True)
+        op = next(o for o in self.ops if isinstance(o, HeadOp) and o.out is self.heads[self.final_head])
+        a = op.srcs[0].act
+        p = ops.fill_pointwise(a, op.geom.out, a.spatial, (1, 1, 1), (1, 1, 1), op.conv.out_channels, op.wf, op.conv.bias, op.out.act)
+        p._keep = (op.wf, op.conv.bias)         # the struct only holds raw pointers
+        return p
+
+    def forward(self, x, need_grad=True, all_heads=True, _skip_final=False):
         """x: [N,C,D,H,W] float32 HIP tensor.  Returns list of NDHWC logits buffers (module output order)."""
         if not x.is_cuda:
             raise RuntimeError("multitalent_amd: the network runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
@@ -512,7 +523,7 @@ class Engine:
         self._pack(need_grad)
         skip_heads = set()
         if not all_heads:
-            skip_heads = {id(self.heads[i]) for i in range(len(self.heads)) if i != self.final_head}
+            skip_heads = {id(self.heads[i]) for i in range(len(self.heads)) if i != self.final_head or _skip_final}
         for op in self.ops:
             if isinstance(op, HeadOp) and id(op.out) in skip_heads:
                 continue

@@ -9,6 +9,8 @@ in numpy), and the final divide + threshold/argmax is one kernel.  Accumulation 
 With tile sharding (rank, world) each process handles a contiguous run of tiles and the aggregates are summed with one
 RCCL all_reduce — functionality the reference does not have (it only strides CASES across processes,
 predict_MultiTalent.py:362)."""
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -156,17 +158,26 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
         # results do not depend on the batch, and the aggregate is still updated tile by tile in the reference's x -> y -> z
         # order with the reference's mirror order inside a tile): up to 8x larger grids on the low-resolution stages
         group = max(1, 8 // len(combos))
+        fuse_head = num_classes <= 64 and os.environ.get('MT_INFER_FUSED_HEAD', '1') != '0'
         for g0 in range(0, len(tiles), group):
             chunk = tiles[g0:g0 + group]
             inp = []
             for (xs, ys, zs) in chunk:
                 tile = vol[None, :, xs:xs + patch_size[0], ys:ys + patch_size[1], zs:zs + patch_size[2]]
                 inp += [torch.flip(tile, tuple(a + 2 for a in c)) if len(c) else tile for c in combos]
-            logits = eng.forward(torch.cat(inp, 0).contiguous(), need_grad=False, all_heads=False)[0]   # [B, D, H, W, C]
+            batch = torch.cat(inp, 0).contiguous()
+            if fuse_head:
+                # head + nonlinearity + un-flip + accumulation in one kernel per sample: the logits never reach HBM
+                hp = eng.forward_to_final_head(batch)
+            else:
+                logits = eng.forward(batch, need_grad=False, all_heads=False)[0]                      # [B, D, H, W, C]
             for t, (xs, ys, zs) in enumerate(chunk):
                 for i, c in enumerate(combos):
                     k = t * len(combos) + i
-                    ops.flip_accumulate(Act(logits[k:k + 1]), (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
+                    if fuse_head:
+                        ops.head_flip_accumulate(hp, k, (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
+                    else:
+                        ops.flip_accumulate(Act(logits[k:k + 1]), (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
                 ops.tile_accumulate(acc, mult, num_classes, patch_size, agg, nb, shp[1:], (xs, ys, zs))
     if tile_shard is not None and tile_shard[1] > 1:
         import torch.distributed as dist

@@ -388,6 +388,11 @@ def flip_accumulate(logits, flips, nonlin, weight, acc, first):
                                               _stream()), 'flip_accumulate')
 
 
+def head_flip_accumulate(p, sample, flips, nonlin, weight, acc, first):
+    _lib.check(_lib.load().mt_head_flip_accumulate(C.byref(p), int(sample), int(flips[0]), int(flips[1]), int(flips[2]), int(nonlin),
+                                                   float(weight), _ptr(acc), int(first), _stream()), 'head_flip_accumulate')
+
+
 def tile_accumulate(acc, gauss, Cn, patch, agg, nb, agg_shape, origin):
     _lib.check(_lib.load().mt_tile_accumulate(_ptr(acc), _ptr(gauss), Cn, patch[0], patch[1], patch[2], _ptr(agg), _ptr(nb),
                                               agg_shape[0], agg_shape[1], agg_shape[2], origin[0], origin[1], origin[2],
