@@ -82,7 +82,6 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
                verbose=True, mixed_precision=True, tile_shard=None, return_device_tensors=False):
     """Signature of SegmentationNetwork.predict_3D (neural_network.py:73-76) + `tile_shard=(rank, world)`.
     x: np.ndarray [C, X, Y, Z].  Returns (seg [X,Y,Z], probabilities [num_classes, X, Y, Z]) as numpy."""
-    torch.cuda.empty_cache()
     assert step_size <= 1, 'step_size must be smaller than 1. Otherwise there will be a gap between consecutive predictions'
     pad_kwargs = {'constant_values': 0} if pad_kwargs is None else pad_kwargs
     if len(mirror_axes):
@@ -137,9 +136,19 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
 
     vol = data.contiguous() if torch.is_tensor(data) else torch.from_numpy(np.ascontiguousarray(data)).to(dev)   # [C, X, Y, Z]
     V = int(np.prod(shp[1:]))
-    agg = torch.zeros((num_classes,) + tuple(shp[1:]), dtype=torch.float32, device=dev)
-    nb = torch.zeros(tuple(shp[1:]), dtype=torch.float32, device=dev)
-    acc = torch.empty((num_classes,) + patch_size, dtype=torch.float32, device=dev)
+    # The aggregates (25 GB for 47 classes at 512^3) are kept on the network between calls: allocating and freeing them per volume
+    # costs a device malloc of that size each time (0.3-1 s, varying from box to box — it dominated the un-mirrored timings).
+    # With return_device_tensors=True the returned probabilities alias this cache until the next call.
+    key = (num_classes, tuple(shp[1:]), patch_size, str(dev))
+    cache = getattr(net, '_sliding_window_cache', None)
+    if cache is None or cache[0] != key:
+        net._sliding_window_cache = None
+        cache = (key, torch.empty((num_classes,) + tuple(shp[1:]), dtype=torch.float32, device=dev),
+                 torch.empty(tuple(shp[1:]), dtype=torch.float32, device=dev),
+                 torch.empty((num_classes,) + patch_size, dtype=torch.float32, device=dev))
+        net._sliding_window_cache = cache
+    _, agg, nb, acc = cache
+    agg.zero_(); nb.zero_()
     if do_mirroring:
         combos = [(), (2,), (1,), (2, 1), (0,), (2, 0), (1, 0), (2, 1, 0)]          # neural_network.py:531-586 order
         combos = [c for c in combos if all(a in mirror_axes for a in c)]
