@@ -224,6 +224,13 @@ int mt_flip_accumulate(const float* logits, int cs, int D, int H, int W, int C, 
  * nonlinearity, un-flipped and accumulated into acc[Cout][D][H][W] like mt_flip_accumulate — the logits are never stored. */
 int mt_head_flip_accumulate(const mt_pointwise_t* p, int sample, int flipD, int flipH, int flipW, int nonlin, float weight,
                             float* acc, int first, mt_stream_t stream);
+/* All mirror combinations of one tile AND the overlap-add in one kernel: samples sample0 .. sample0+nsamples-1 of p's source are
+ * the flipped versions of the tile (flips[k]: bit 0 D, bit 1 H, bit 2 W); per output voxel
+ *   agg[c][x0+d][y0+h][z0+w] += gauss[d][h][w] * weight * sum_k nonlin(head(sample_k[flip_k(d,h,w)]))_c ;  nb[...] += gauss
+ * (neural_network.py:531-586 and :384-394).  gauss NULL = 1, nb NULL = not updated.  flips is a HOST array of nsamples ints. */
+int mt_head_mirror_accumulate(const mt_pointwise_t* p, int sample0, int nsamples, const int32_t* flips, int nonlin, float weight,
+                              const float* gauss, float* agg, float* nb, long aX, long aY, long aZ, int x0, int y0, int z0,
+                              mt_stream_t stream);
 /* agg[c, tile] += acc * gauss ; nb[tile] += gauss   (neural_network.py:388-394) */
 int mt_tile_accumulate(const float* acc, const float* gauss, int C, int D, int H, int W, float* agg,
                        float* nb, long aX, long aY, long aZ, int x0, int y0, int z0, mt_stream_t stream);

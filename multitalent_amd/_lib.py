@@ -94,6 +94,7 @@ SIGNATURES = {
     'mt_affine_sample': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _f, _i, _vp]),
     'mt_resample_classify': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _l, _l, _l, _i, _i, _i, _vp]),
     'mt_head_flip_accumulate': (_i, [_P(mt_pointwise_t), _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),
+    'mt_head_mirror_accumulate': (_i, [_P(mt_pointwise_t), _i, _i, _vp, _i, _f, _vp, _vp, _vp, _l, _l, _l, _i, _i, _i, _vp]),
     'mt_tile_accumulate': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _l, _l, _l, _i, _i, _i, _vp]),
     'mt_normalize_threshold': (_i, [_vp, _vp, _i, _l, _vp, _i, _vp, _vp]),
     'mt_ncdhw_to_ndhwc': (_i, [_vp, _vp, _i, _i, _l, _i, _vp]),

@@ -335,6 +335,181 @@ extern "C" int mt_head_flip_accumulate(const mt_pointwise_t* p, int sample, int 
   return MT_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// All mirror combinations of a tile in ONE kernel, straight into the volume aggregate: for output voxel v of the tile
+//   agg[c][tile + v] += gauss[v] * weight * sum_k nonlin(head(features_k[flip_k(v)]))_c ,   nb[tile + v] += gauss[v]
+// (neural_network.py:531-586 result += flip^-1(pred) / num_results per combination, then :384-394 result *= gaussian and the
+// overlap-add).  The sum over the samples k stays in registers, so the per-tile accumulator and its 2 x 333 MB read-modify-write
+// per mirror combination (plus the separate tile_accumulate pass) disappear: 8 x 212 MB of features in, one update of the
+// aggregate out.
+struct HeadMirParams {
+  mt_pointwise_t c;
+  int nchunks, nsb, sample0, nsamples, nonlin;
+  int flips[8];                 // bit 0: D, bit 1: H, bit 2: W
+  long V;
+  float weight;
+  const float* gauss;           // [D][H][W] or NULL (= 1)
+  float* agg; float* nb;        // agg[C][aX][aY][aZ], nb[aX][aY][aZ] (nb may be NULL)
+  long aX, aY, aZ; int x0, y0, z0;
+};
+template <int VEC>
+__global__ __launch_bounds__(256) void head_mirror_accumulate_kernel(const HeadMirParams P) {
+  const mt_pointwise_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  const int sb = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const long bv = (long)sb * 128 + wave * 32 + li;
+  const bool vok = bv < P.V;
+  const int w = (int)(bv % c.Wb), h = (int)((bv / c.Wb) % c.Hb), d = (int)(bv / ((long)c.Wb * c.Hb));
+  const mt_src_t& S = c.src;
+  const size_t in_sample = (size_t)P.V * S.cs;
+  const bool aff = S.scale != nullptr;
+  const float slope = S.slope;
+  const bool lrelu_ok = (slope >= 0.f) && (slope <= 1.f);
+  const bool two = c.Cout > 32;                      // block-uniform
+  __shared__ __attribute__((aligned(16))) float ssc[PW_MAXC], ssh[PW_MAXC];
+  f32x16 sum[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum[n][j] = 0.f;
+  float bias[2][16];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int cj = n * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+      bias[n][j] = (c.bias != nullptr && cj < c.Cout) ? c.bias[cj] : 0.f;
+    }
+
+  for (int k = 0; k < P.nsamples; ++k) {
+    const int nb_ = P.sample0 + k, f = P.flips[k];
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb_ * in_sample), 0, (int)(in_sample * 4), 0x00020000);
+    const long sv = ((long)((f & 1) ? c.Db - 1 - d : d) * c.Hb + ((f & 2) ? c.Hb - 1 - h : h)) * c.Wb + ((f & 4) ? c.Wb - 1 - w : w);
+    const int aoff = vok ? (int)((sv * S.cs + 8 * lhalf) * 4) : (int)0x80000000;
+    if (aff) {
+      __syncthreads();
+      for (int i = tid; i < P.nchunks * PW_CK; i += 256) {
+        ssc[i] = i < S.C ? S.scale[(size_t)nb_ * S.C + i] : 0.f;
+        ssh[i] = i < S.C ? S.shift[(size_t)nb_ * S.C + i] : 0.f;
+      }
+      __syncthreads();
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[n][j] = bias[n][j];
+    for (int ch = 0; ch < P.nchunks; ++ch) {
+      float x[8];
+      const int o = aoff + ch * (PW_CK * 4);
+      if constexpr (VEC == 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra, o + g * 8, 0, 0));
+          x[2 * g] = t.x; x[2 * g + 1] = t.y;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) x[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, o + g * 4, 0, 0));
+      }
+      const int cb = ch * PW_CK + 8 * lhalf;
+      if (aff) {
+        const f32x4 sc0 = *(const f32x4*)(ssc + cb), sc1 = *(const f32x4*)(ssc + cb + 4);
+        const f32x4 sh0 = *(const f32x4*)(ssh + cb), sh1 = *(const f32x4*)(ssh + cb + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = fmaf(x[e], e < 4 ? sc0[e & 3] : sc1[e & 3], e < 4 ? sh0[e & 3] : sh1[e & 3]);
+          x[e] = lrelu_ok ? fmaxf(t, t * slope) : mt_lrelu(t, slope);
+        }
+      }
+      if (cb + 8 > c.Cin || !vok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (vok && cb + e < c.Cin) ? x[e] : 0.f;
+      }
+      const float* wq = c.wpack + (size_t)ch * 512 + lane * 4;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        if (n == 1 && !two) break;
+        const float* wn = wq + (size_t)n * P.nchunks * 512;
+        const f32x4 b0 = *(const f32x4*)(wn), b1 = *(const f32x4*)(wn + 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[e], x[e], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[e], x[4 + e], acc[n], 0, 0, 0);
+      }
+    }
+    if (P.nonlin == 2) {
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (n * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhalf < c.Cout) mx = fmaxf(mx, acc[n][j]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float se = 0.f;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const bool cv = n * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhalf < c.Cout;
+          acc[n][j] = cv ? expf(acc[n][j] - mx) : 0.f;
+          se += acc[n][j];
+        }
+      se += __shfl_xor(se, 32, 64);
+      const float inv = 1.f / se;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum[n][j] += acc[n][j] * inv;
+    } else {
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum[n][j] += P.nonlin == 1 ? 1.f / (1.f + expf(-acc[n][j])) : acc[n][j];
+    }
+  }
+  if (!vok) return;
+  const float g = P.gauss ? P.gauss[bv] : 1.f;
+  const float wg = P.weight * g;
+  const size_t av = ((size_t)(P.x0 + d) * P.aY + (P.y0 + h)) * P.aZ + (P.z0 + w);
+  const size_t AV = (size_t)P.aX * P.aY * P.aZ;
+  if (P.nb != nullptr && lhalf == 0) P.nb[av] += g;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    if (n == 1 && !two) break;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int cj = n * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+      if (cj < c.Cout) P.agg[(size_t)cj * AV + av] += sum[n][j] * wg;
+    }
+  }
+}
+extern "C" int mt_head_mirror_accumulate(const mt_pointwise_t* p, int sample0, int nsamples, const int32_t* flips, int nonlin, float weight,
+                                         const float* gauss, float* agg, float* nb, long aX, long aY, long aZ, int x0, int y0, int z0,
+                                         mt_stream_t stream) {
+  MT_REQUIRE(p != nullptr && agg != nullptr && flips != nullptr, "head_mirror_accumulate: null pointers");
+  MT_REQUIRE(p->siD == 1 && p->siH == 1 && p->siW == 1 && p->soD == 1 && p->soH == 1 && p->soW == 1 && p->Db == p->Di && p->Hb == p->Hi &&
+             p->Wb == p->Wi, "head_mirror_accumulate: 1x1x1 stride-1 head only");
+  MT_REQUIRE(p->Cout >= 1 && p->Cout <= 64 && p->src.C == p->Cin, "head_mirror_accumulate: needs 1..64 output channels");
+  MT_REQUIRE(nsamples >= 1 && nsamples <= 8 && sample0 >= 0 && sample0 + nsamples <= p->N, "head_mirror_accumulate: bad sample range");
+  MT_REQUIRE(nonlin >= 0 && nonlin <= 2, "head_mirror_accumulate: nonlin must be 0, 1 (sigmoid) or 2 (softmax)");
+  MT_REQUIRE(x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + p->Db <= aX && y0 + p->Hb <= aY && z0 + p->Wb <= aZ, "head_mirror_accumulate: tile outside the aggregate");
+  HeadMirParams P;
+  P.c = *p; P.nchunks = mt_cdiv(p->Cin, PW_CK); P.V = (long)p->Db * p->Hb * p->Wb; P.nsb = mt_cdiv(P.V, 128);
+  MT_REQUIRE(P.nchunks * PW_CK <= PW_MAXC && (double)P.V * p->src.cs * 4.0 < 2147483648.0, "head_mirror_accumulate: sample too large");
+  P.sample0 = sample0; P.nsamples = nsamples; P.nonlin = nonlin; P.weight = weight; P.gauss = gauss; P.agg = agg; P.nb = nb;
+  for (int k = 0; k < 8; ++k) P.flips[k] = k < nsamples ? flips[k] : 0;
+  P.aX = aX; P.aY = aY; P.aZ = aZ; P.x0 = x0; P.y0 = y0; P.z0 = z0;
+  const mt_src_t& S = p->src;
+  const bool v2 = (S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0;
+  if (v2) hipLaunchKernelGGL(head_mirror_accumulate_kernel<2>, dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
+  else    hipLaunchKernelGGL(head_mirror_accumulate_kernel<1>, dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
+  MT_CHECK_LAUNCH("head_mirror_accumulate");
+  return MT_OK;
+}
+
 extern "C" int mt_pointwise_stats_blocks(const mt_pointwise_t* p) {
   if (p == nullptr) return -1;
   return mt_cdiv((long)p->Db * p->Hb * p->Wb, 128);

@@ -393,6 +393,14 @@ def head_flip_accumulate(p, sample, flips, nonlin, weight, acc, first):
                                                    float(weight), _ptr(acc), int(first), _stream()), 'head_flip_accumulate')
 
 
+def head_mirror_accumulate(p, sample0, flips, nonlin, weight, gauss, agg, nb, agg_shape, origin):
+    """flips: list of (fD, fH, fW) booleans, one per sample (the mirror combinations of ONE tile)."""
+    fl = (C.c_int32 * len(flips))(*[int(f[0]) | (int(f[1]) << 1) | (int(f[2]) << 2) for f in flips])
+    _lib.check(_lib.load().mt_head_mirror_accumulate(C.byref(p), int(sample0), len(flips), C.cast(fl, C.c_void_p), int(nonlin), float(weight),
+                                                     _ptr(gauss), _ptr(agg), _ptr(nb), agg_shape[0], agg_shape[1], agg_shape[2],
+                                                     origin[0], origin[1], origin[2], _stream()), 'head_mirror_accumulate')
+
+
 def tile_accumulate(acc, gauss, Cn, patch, agg, nb, agg_shape, origin):
     _lib.check(_lib.load().mt_tile_accumulate(_ptr(acc), _ptr(gauss), Cn, patch[0], patch[1], patch[2], _ptr(agg), _ptr(nb),
                                               agg_shape[0], agg_shape[1], agg_shape[2], origin[0], origin[1], origin[2],
