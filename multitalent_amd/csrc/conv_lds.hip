@@ -962,11 +962,12 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
 // fewer workgroups than the chip has CUs and each wave walks Cin/16 x 27 taps serially.  Here a workgroup owns ONE 32-voxel
 // M tile (2x4x4) x 32 output channels and its four waves split the 27 TAPS (t = wave, wave+4, ...), so the serial chain per wave
 // is 4x shorter and the grid 4x larger; the four accumulator tiles are summed through LDS in a fixed order (deterministic).
-template <int VEC>
+// BF = true (mixed precision): bf16 LDS image and one v_mfma_f32_32x32x16_bf16 per tap instead of eight fp32 MFMAs.
+template <int VEC, bool BF = false>
 __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P) {
   constexpr int TD = 2, TH = 4, TW = 4, LD = TD + 2, LH = TH + 2, LW = TW + 2;
-  constexpr int LWP = stage_lwp<LD, LH, LW, VEC>();
-  constexpr int TILE = stage_rows<LD, LH>() * LWP * FCKP;       // floats
+  constexpr int LWP = BF ? bstage_lwp<LD, LH, LW, VEC, 4>() : stage_lwp<LD, LH, LW, VEC>();
+  constexpr int PITCH = BF ? BFP : FCKP;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
   // M tile row li -> voxel (dm, r, col) = (li>>4, (li>>2)&3, li&3)
-  const int abase = (((li >> 4) * LH + ((li >> 2) & 3)) * LWP + (li & 3)) * FCKP + lhalf * 8;
+  const int abase = (((li >> 4) * LH + ((li >> 2) & 3)) * LWP + (li & 3)) * PITCH + lhalf * (BF ? 4 : 8);
 
   f32x16 acc;
 #pragma unroll
@@ -989,8 +990,25 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
 
   for (int ch = 0; ch < P.nchunks; ++ch) {
     const ConvChunk cc = P.chunk[ch];
-    const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
     __syncthreads();
+    if constexpr (BF) {
+      mt_stage_bf16<LD, LH, LW, VEC, 4>((unsigned*)lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+      __syncthreads();
+      const unsigned* ldsu = (const unsigned*)lds;
+      const unsigned* wl = (const unsigned*)c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 256) + lane * 4;
+      bf16x8 fa[7], fb[7];                 // this wave's taps: all fragments first, then the MFMAs back to back
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int tt = (wave + 4 * i) < 27 ? wave + 4 * i : 26;
+        fa[i] = *(const bf16x8*)(ldsu + abase + (((tt / 9) * LH + (tt / 3) % 3) * LWP + tt % 3) * PITCH);
+        fb[i] = *(const bf16x8*)(wl + tt * 256);
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i)
+        if (i < 6 || wave < 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[i], acc, 0, 0, 0);
+      continue;
+    }
+    const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
     mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
     __syncthreads();
     // this wave's taps: wave, wave+4, ... (7 or 6 of them); the next tap's fragments are fetched behind the current MFMAs
@@ -1737,7 +1755,7 @@ extern "C" int mt_conv3d_ck(const mt_conv3d_t* p) {
 }
 extern "C" int mt_conv3d_pack_layout(const mt_conv3d_t* p) {      // layout argument of mt_pack_conv_weights for this problem
   const int k = conv_plan(p).kind;
-  if (k == CONV_FAST_STRIDED && strided_use_bf16(p)) return 3;
+  if ((k == CONV_FAST_STRIDED || k == CONV_TAPSPLIT) && strided_use_bf16(p)) return 3;
   return k == CONV_WINO ? 2 : k == CONV_BF16 ? 3 : 1;
 }
 extern "C" int mt_conv3d_stats_blocks(const mt_conv3d_t* p) {
@@ -1868,7 +1886,10 @@ static int launch_tapsplit(const mt_conv3d_t* p, hipStream_t st) {
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
   const size_t red = (size_t)4 * 16 * 64 * sizeof(float);
-  if (conv_fast_vec(p) == 2) {
+  if (strided_use_bf16(p)) {               // same eligibility: mma == 1, >= 16 even channels, 8-byte aligned sources
+    size_t l = bstage_lds_bytes<4, 6, 6, 2, 4>(); if (l < red) l = red;
+    hipLaunchKernelGGL((conv_tapsplit_kernel<2, true>), grid, dim3(256), l, st, P);
+  } else if (conv_fast_vec(p) == 2) {
     size_t l = stage_lds_bytes<4, 6, 6, 2>(); if (l < red) l = red;
     hipLaunchKernelGGL((conv_tapsplit_kernel<2>), grid, dim3(256), l, st, P);
   } else {
@@ -2162,7 +2183,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   if (pl.kind == CONV_FAST)
     snprintf(buf, n, "conv_fast_kernel<%d, %d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p), p->KD);
   else if (pl.kind == CONV_TAPSPLIT)
-    snprintf(buf, n, "conv_tapsplit_kernel<%d>", conv_fast_vec(p));
+    snprintf(buf, n, strided_use_bf16(p) ? "conv_tapsplit_kernel<%d, true>" : "conv_tapsplit_kernel<%d, false>", conv_fast_vec(p));
   else if (pl.kind == CONV_STEM)
     snprintf(buf, n, "conv_stem_kernel");
   else if (pl.kind == CONV_WINO)

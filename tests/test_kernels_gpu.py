@@ -296,6 +296,32 @@ def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
         assert relerr(dw2.cpu(), w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("N,Cin,Cout,shape,two", [(2, 64, 64, (3, 12, 12), False), (2, 48, 40, (3, 6, 6), False), (1, 32, 64, (3, 10, 7), True)])
+def test_conv_tapsplit_bf16(dev, N, Cin, Cout, shape, two):
+    """low-resolution layers in mixed precision: conv_tapsplit_kernel<2, true> (taps split over the waves, one bf16 MFMA per tap),
+    forward with lazy input(s) + statistics against the same arithmetic on the CPU (operands rounded to bf16): 1e-4."""
+    ops = _ops()
+    ops.set_mma(1)
+    try:
+        g = torch.Generator().manual_seed(31)
+        srcs = [torch.randn((N, Cin) + shape, generator=g)]
+        lazy = [(torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)]
+        if two:
+            srcs.append(torch.randn((N, Cin) + shape, generator=g)); lazy.append(None)
+        ct = Cin * len(srcs)
+        w = torch.randn((Cout, ct, 3, 3, 3), generator=g) / np.sqrt(ct * 27)
+        b = torch.randn(Cout, generator=g)
+        acts = [ops.Act(to_ndhwc(s).to(dev)) for s in srcs]
+        pq = ops.fill_conv(acts, ops.ConvGeom(shape, (3, 3, 3), (1, 1, 1), (1, 1, 1)), Cout)
+        assert ops.conv_kernel_name(pq) == 'conv_tapsplit_kernel<2, true>'
+        out, part = run_conv(dev, srcs, w, b, (1, 1, 1), (1, 1, 1), lazy=lazy, stats=True)
+        ref = F.conv3d(_bf16_round(ref_inputs(srcs, lazy)).double(), _bf16_round(w).double(), b.double(), padding=1)
+        assert relerr(to_ncdhw(out.cpu()), ref) < 1e-4
+        assert np.allclose(part.cpu().double().sum(1)[..., 1].numpy(), (ref ** 2).sum((2, 3, 4)).numpy(), rtol=1e-4)
+    finally:
+        ops.set_mma(0)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,shape", [(2, 30, 30, (5, 18, 70)), (1, 32, 64, (3, 8, 32))])
 def test_conv_bf16_1x3x3(dev, N, Cin, Cout, shape):
     """the 1x3x3 form of conv_bf16_kernel (first stage of the residual encoder): forward with lazy input + statistics and the
