@@ -8,21 +8,20 @@ import torch
 
 
 def load_pretrained_weights(network, fname, verbose=False):
-    saved_model = torch.load(fname, map_location='cpu', weights_only=False)
-    pretrained = {(k[7:] if k.startswith('module.') else k): v for k, v in saved_model['state_dict'].items()}
-    model_dict = network.state_dict()
-    for key in model_dict:
-        if 'conv_blocks' in key and not (key in pretrained and model_dict[key].shape == pretrained[key].shape):
-            raise RuntimeError("Pretrained weights are not compatible with the current network architecture")
-    pretrained = {k: v for k, v in pretrained.items() if k in model_dict and model_dict[k].shape == v.shape}
-    model_dict.update(pretrained)
-    print("################### Loading pretrained weights from file ", fname, '###################')
+    ckpt = torch.load(fname, map_location='cpu', weights_only=False)
+    source = {(name[7:] if name.startswith('module.') else name): tensor for name, tensor in ckpt['state_dict'].items()}
+    target = network.state_dict()
+    missing = [k for k in target if 'conv_blocks' in k and (k not in source or source[k].shape != target[k].shape)]
+    if missing:
+        raise RuntimeError("Pretrained weights are not compatible with the current network architecture (first mismatch: %s)" % missing[0])
+    transferred = [k for k in source if k in target and target[k].shape == source[k].shape]
+    for k in transferred:
+        target[k] = source[k]
+    print("loading pretrained weights from %s: %d of %d tensors transferred" % (fname, len(transferred), len(target)))
     if verbose:
-        print("Below is the list of overlapping blocks in pretrained model and nnUNet architecture:")
-        for key in pretrained:
-            print(key)
-    print("################### Done ###################")
-    network.load_state_dict(model_dict)
+        for k in transferred:
+            print("  ", k)
+    network.load_state_dict(target)
     if hasattr(network, 'engine'):
         network.engine().mark_params_dirty()          # packed weights are re-derived on the next step
-    return list(pretrained.keys())
+    return transferred
