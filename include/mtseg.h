@@ -197,6 +197,13 @@ size_t mt_loss_workspace(int B, long V, int C);
 int mt_multitalent_loss_bwd(const float* logits, int cs, const float* target, int B, long V, int C,
                             const uint64_t* valid, const uint64_t* lut, const float* gstats,
                             float* dlogits, int dcs, mt_stream_t stream);
+/* Online evaluation of the MultiTalent trainers (MultiTalent_Trainer_DDP.py:372-398): hard predictions sigmoid(x) > 0.5 of the
+ * full-resolution logits against the region masks; stats[B][C][3] = exact counts (tp, fp, fn) of the channels valid for the
+ * sample's dataset, 0 elsewhere.  ws: mt_hard_stats_workspace(B, C) bytes (64-bit counters, integer atomics: order-free). */
+int mt_multitalent_hard_stats(const float* logits, int cs, const float* target, int B, long V, int C,
+                              const uint64_t* valid, const uint64_t* lut, float* stats, void* ws, size_t ws_bytes,
+                              mt_stream_t stream);
+size_t mt_hard_stats_workspace(int B, int C);
 /* Softmax Dice+CE for one level (dice_loss.py:100-195,488-545; crossentropy.py:4-11):
  * stats[B][C][4] = (ce_sum (only c=0 slot used), tp, fp, fn). */
 int mt_softmax_dice_ce_fwd(const float* logits, int cs, const float* target, int B, long V, int C,

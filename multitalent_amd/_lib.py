@@ -84,6 +84,8 @@ SIGNATURES = {
     'mt_multitalent_loss_fwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'mt_loss_workspace': (_sz, [_i, _l, _i]),
     'mt_multitalent_loss_bwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    'mt_multitalent_hard_stats': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'mt_hard_stats_workspace': (_sz, [_i, _i]),
     'mt_softmax_dice_ce_fwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _sz, _vp]),
     'mt_softmax_dice_ce_bwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),
     'mt_sumsq': (_i, [_vp, _l, _vp, _vp, _sz, _vp]),

@@ -127,6 +127,66 @@ extern "C" int mt_multitalent_loss_bwd(const float* logits, int cs, const float*
   return MT_OK;
 }
 
+// ---- online evaluation (MultiTalent_Trainer_DDP.py:372-410): hard predictions sigmoid(x) > 0.5, exact integer counts --------
+__global__ __launch_bounds__(256) void mt_hard_stats_kernel(const float* __restrict__ logits, int cs,
+                                                            const float* __restrict__ target, long V, int C,
+                                                            const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
+                                                            unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int red[4][64][3];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long v0 = (long)blockIdx.x * LS_VB;
+  const long v1 = (v0 + LS_VB < V) ? v0 + LS_VB : V;
+  const uint64_t vmask = valid[b];
+  for (int cb = 0; cb < C; cb += 64) {
+    const int c = cb + lane;
+    const bool act = (c < C) && ((vmask >> c) & 1ull);
+    const uint64_t l = act ? lut[c] : 0ull;
+    unsigned int tp = 0, fp = 0, fn = 0;
+    for (long v = v0 + wave; v < v1; v += 4) {
+      const size_t e = (size_t)b * V + v;
+      const int lab = (int)target[e];
+      if (act) {
+        const float x = logits[e * cs + c];
+        const bool y = (lab >= 0 && lab < 64 && ((l >> lab) & 1ull));
+        const float ex = __expf(-fabsf(x));
+        const float sg = (x >= 0.f) ? 1.f / (1.f + ex) : ex / (1.f + ex);
+        const bool p = sg > 0.5f;
+        tp += (p && y); fp += (p && !y); fn += (!p && y);
+      }
+    }
+    red[wave][lane][0] = tp; red[wave][lane][1] = fp; red[wave][lane][2] = fn;
+    __syncthreads();
+    if (threadIdx.x < 192) {
+      const int k = threadIdx.x % 3, cc = threadIdx.x / 3;
+      const unsigned int sum = red[0][cc][k] + red[1][cc][k] + red[2][cc][k] + red[3][cc][k];
+      if (cb + cc < C && sum) atomicAdd(&counts[((size_t)b * C + cb + cc) * 3 + k], (unsigned long long)sum);   // integer: order-free
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void mt_counts_to_float_kernel(const unsigned long long* counts, float* stats, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) stats[i] = (float)counts[i];
+}
+
+extern "C" size_t mt_hard_stats_workspace(int B, int C) { return (size_t)B * C * 3 * sizeof(unsigned long long); }
+
+extern "C" int mt_multitalent_hard_stats(const float* logits, int cs, const float* target, int B, long V, int C,
+                                         const uint64_t* valid, const uint64_t* lut, float* stats, void* ws, size_t ws_bytes,
+                                         mt_stream_t stream) {
+  MT_REQUIRE(logits && target && valid && lut && stats && B > 0 && V > 0 && C > 0 && C <= 64, "multitalent_hard_stats: bad args (C must be <= 64)");
+  if (ws == nullptr || ws_bytes < mt_hard_stats_workspace(B, C)) { mt_set_error("multitalent_hard_stats: workspace too small"); return MT_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, mt_hard_stats_workspace(B, C), st) != hipSuccess) { mt_set_error("multitalent_hard_stats: memset failed"); return MT_EHIP; }
+  hipLaunchKernelGGL(mt_hard_stats_kernel, dim3(mt_cdiv(V, LS_VB), B), dim3(256), 0, st, logits, cs, target, V, C, valid, lut,
+                     (unsigned long long*)ws);
+  hipLaunchKernelGGL(mt_counts_to_float_kernel, dim3(mt_cdiv(B * C * 3, 256)), dim3(256), 0, st, (const unsigned long long*)ws, stats, B * C * 3);
+  MT_CHECK_LAUNCH("multitalent_hard_stats");
+  return MT_OK;
+}
+
 // ---- softmax Dice + CE -------------------------------------------------------------------------------
 template <int MAXC>
 __global__ __launch_bounds__(256) void softmax_loss_fwd_kernel(const float* __restrict__ logits, int cs,

@@ -475,10 +475,12 @@ class Engine:
         ver = (self.params_version, self.flat._version, need_grad)
         if self._packed_version == ver:
             return
-        key = (self.params_version, need_grad)
+        # the program only holds POINTERS (weights inside the flat buffer, packed destinations): it stays valid until attach(),
+        # _plan() or set_precision() clear it — parameter VALUES changing (every optimizer step) just re-runs it
+        key = need_grad
         prog = self._pack_programs.get(key)
         ops.set_mma(self.mma)
-        if prog is None:            # record the ops' packing calls once; afterwards every step is one batched launch
+        if key not in self._pack_programs:   # record the ops' packing calls once; afterwards every step is one batched launch
             rec = []
             ops._pack_recorder = rec
             try:
@@ -487,7 +489,6 @@ class Engine:
             finally:
                 ops._pack_recorder = None
             prog = ops.PackProgram(rec, self.device) if rec else None
-            self._pack_programs = {k: v for k, v in self._pack_programs.items() if k[0] == key[0]}   # drop older parameter versions
             self._pack_programs[key] = prog
         if prog is not None:
             prog.run()

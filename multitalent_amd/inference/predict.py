@@ -12,7 +12,8 @@ from .sliding_window import predict_3D
 
 def predict_case_on_device(network, cropped_data, properties, target_spacing, intensityproperties, patch_size,
                            regions_class_order=None, do_mirroring=True, mirror_axes=(0, 1, 2), step_size=0.5,
-                           transpose_forward=(0, 1, 2), force_separate_z=None, tile_shard=None, verbose=False):
+                           transpose_forward=(0, 1, 2), force_separate_z=None, tile_shard=None, verbose=False,
+                           transpose_backward=None):
     """cropped_data: [C, X, Y, Z] (numpy or device tensor) already transposed by `transpose_forward`; properties: the case's
     dict (`original_spacing`, `size_after_cropping`, `original_size_of_raw_data`, `crop_bbox`).  Returns the uint8 label volume
     (device tensor, shape `original_size_of_raw_data`) and the properties with the resampling entries filled in."""
@@ -23,5 +24,11 @@ def predict_case_on_device(network, cropped_data, properties, target_spacing, in
     properties['spacing_after_resampling'] = np.array(target_spacing)
     _, probs = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
                           'constant', None, True, verbose, True, tile_shard=tile_shard, return_device_tensors=True)
+    # the reference transposes the probabilities back before the export matches them to size_after_cropping / crop_bbox
+    # (predict_MultiTalent.py:238-240: softmax.transpose([0] + [i + 1 for i in transpose_backward]))
+    if transpose_backward is None:
+        transpose_backward = [int(i) for i in np.argsort(list(transpose_forward))]
+    if list(transpose_backward) != [0, 1, 2]:
+        probs = probs.permute(0, *[int(i) + 1 for i in transpose_backward]).contiguous()
     seg = resample_and_classify(probs, properties, regions_class_order, 1, force_separate_z, 0)
     return seg, properties

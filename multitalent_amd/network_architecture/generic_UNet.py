@@ -131,7 +131,8 @@ class Generic_UNet(SegmentationNetwork):
             final_num_features = nfeatures_from_skip
             tu.append(nn.ConvTranspose3d(nfeatures_from_down, nfeatures_from_skip, pool_op_kernel_sizes[-(u + 1)],
                                          pool_op_kernel_sizes[-(u + 1)], bias=False))
-            lvl = num_pool - (u + 1)
+            lvl = num_pool - u      # reference generic_UNet.py:338-339 indexes conv_kernel_sizes[-(u + 1)] (num_pool + 1 entries): the
+                                    # first decoder stage reuses the bottleneck's kernel — an nnU-Net v1 quirk that fixes weight shapes
             localization.append(nn.Sequential(stacked(nfeatures_from_skip * 2, nfeatures_from_skip, num_conv_per_stage - 1, lvl),
                                               stacked(nfeatures_from_skip, final_num_features, 1, lvl)))
         for ds in range(len(localization)):

@@ -356,6 +356,16 @@ def multitalent_loss_bwd(logits, target, valid, lut, gstats, dlogits):
                'multitalent_loss_bwd')
 
 
+def multitalent_hard_stats(logits, target, valid, lut, stats):
+    """stats [B, C, 3] = exact (tp, fp, fn) counts of sigmoid(logits) > 0.5 per valid region (online evaluation)."""
+    lib = _lib.load()
+    n = lib.mt_hard_stats_workspace(logits.N, logits.C)
+    ws = torch.empty((n + 7) // 8, dtype=torch.int64, device=stats.device)
+    _lib.check(lib.mt_multitalent_hard_stats(C.c_void_p(logits.data_ptr()), logits.cs, _ptr(target), logits.N, logits.V, logits.C,
+                                             _ptr(valid), _ptr(lut), _ptr(stats), _ptr(ws), ws.numel() * 8, _stream()),
+               'multitalent_hard_stats')
+
+
 def softmax_dice_ce_fwd(logits, target, stats, ws):
     _lib.check(_lib.load().mt_softmax_dice_ce_fwd(C.c_void_p(logits.data_ptr()), logits.cs, _ptr(target), logits.N, logits.V,
                                                   logits.C, _ptr(stats), _ptr(ws), ws.numel() * ws.element_size(), _stream()),

@@ -27,7 +27,10 @@ class DeviceBatchFeeder:
         self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
         self.stream = torch.cuda.Stream(device=self.device)
         self.depth = max(int(depth), 1)
-        self._pinned = [dict() for _ in range(self.depth)]      # per slot: name -> pinned staging tensor
+        # depth batches are queued and one more is issued right after a batch is handed out: depth + 1 staging slots, and a slot
+        # is only re-filled after the upload that last read it has finished (per-slot event, host-side wait)
+        self._pinned = [dict() for _ in range(self.depth + 1)]  # per slot: name -> pinned staging tensor
+        self._slot_event = [None] * (self.depth + 1)
         self._queue = []                                          # in-flight (batch, event)
         self._slot = 0
         self._exhausted = False
@@ -51,7 +54,9 @@ class DeviceBatchFeeder:
             self._exhausted = True
             return
         slot = self._slot
-        self._slot = (self._slot + 1) % self.depth
+        self._slot = (self._slot + 1) % (self.depth + 1)
+        if self._slot_event[slot] is not None:
+            self._slot_event[slot].synchronize()                  # the previous upload from this slot's pinned buffers is done
         tgt_key = 'target' if 'target' in b else 'seg'
         with torch.cuda.stream(self.stream):
             out = dict(b)
@@ -65,6 +70,7 @@ class DeviceBatchFeeder:
                 out['target'] = downsample_seg_for_ds_transform2(full, scales, 0, None, remove_minus_one=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._slot_event[slot] = ev
         self._queue.append((out, ev))
 
     def __iter__(self):

@@ -14,18 +14,26 @@ def _active():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def _all_reduce_sum(t):
+    """in-place SUM over ranks of a small tensor.  RCCL ('nccl') reduces device tensors directly; under gloo (CPU tests, or two
+    ranks sharing one GPU in the single-GPU test box) a device tensor travels through the host — transport only, a few KB."""
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 class _AllReduceSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        y = x.contiguous().clone()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM)
-        return y
+        return _all_reduce_sum(x.contiguous().clone())
 
     @staticmethod
     def backward(ctx, gy):
-        g = gy.contiguous().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        return g
+        return _all_reduce_sum(gy.contiguous().clone())
 
 
 def sum_over_ranks(x):
@@ -40,3 +48,19 @@ def gather_sum_over_ranks(tp, fp, fn):
     """[B,C] x3 -> [1,B,C] x3 summed over ranks (one collective for the three tensors)."""
     s = sum_over_ranks(torch.stack((tp, fp, fn), 0))
     return s[0][None], s[1][None], s[2][None]
+
+
+def gather_over_ranks(x):
+    """[...] -> [W, ...] stacked over ranks (no gradient): awesome_allgather_function's forward as run_online_evaluation uses it
+    (MultiTalent_Trainer_DDP.py:399-401).  World size 1 (or no process group): x[None]."""
+    if not _active():
+        return x[None]
+    x = x.contiguous()
+    if x.is_cuda and dist.get_backend() == 'gloo':
+        h = x.cpu()
+        out = [torch.zeros_like(h) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, h)
+        return torch.stack(out, 0).to(x.device)
+    out = [torch.zeros_like(x) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, x)
+    return torch.stack(out, 0)

@@ -30,7 +30,11 @@ class GradAllReducer:
         self.sent = 0
         self.handles = []
         self.on_gpu = self.eng.flat_grad.is_cuda
-        if (self.world > 1 or self.force) and self.stream is None and self.on_gpu:
+        active = self.world > 1 or self.force
+        # gloo has no device path here: two ranks sharing ONE GPU (the single-GPU test box) or CPU tensors.  Device slices then
+        # travel through the host at finish() — transport only, same bucketing and arithmetic.
+        self.via_host = active and self.on_gpu and dist.get_backend() == 'gloo'
+        if active and self.stream is None and self.on_gpu and not self.via_host:
             self.stream = torch.cuda.Stream()
 
     def ready(self, lo, hi):
@@ -42,7 +46,11 @@ class GradAllReducer:
         while hi - self.sent >= self.bucket or (final and self.sent < n):
             end = n if final and (n - self.sent) < 2 * self.bucket else self.sent + self.bucket
             sl = self.eng.flat_grad[self.sent:end]
-            if self.on_gpu:
+            if self.via_host:
+                self.handles.append(sl)
+            elif self.on_gpu:
+                # the side stream waits for the kernels that produced this slice (event on the compute stream), scales and
+                # all-reduces it there; finish() makes the compute stream wait for the side stream before clip / SGD read it
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
                 with torch.cuda.stream(self.stream):
@@ -56,6 +64,13 @@ class GradAllReducer:
 
     def finish(self):
         if self.world <= 1 and not self.force:
+            return
+        if self.via_host:
+            for sl in self.handles:
+                h = sl.cpu()
+                h.div_(self.world)
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                sl.copy_(h)
             return
         for h in self.handles:
             h.wait()

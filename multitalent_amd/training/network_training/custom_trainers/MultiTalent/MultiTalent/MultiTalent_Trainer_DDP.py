@@ -26,7 +26,7 @@ class MultiTalent_trainer_ddp(nnUNetTrainerV2_DDP):
                          deterministic=deterministic, fp16=fp16, distribute_batch_size=distribute_batch_size)
         self.regions = MultiTalent_regions
         self.loss = None
-        self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], []
+        self.online_eval_foreground_dc, self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], [], []
 
     def process_plans(self, plans):
         super().process_plans(plans)
@@ -52,6 +52,83 @@ class MultiTalent_trainer_ddp(nnUNetTrainerV2_DDP):
         self.print_to_log_file('probabilities per dataset:', per_dataset)
         return p
 
+    # ---- folds (reference :433-543) ----------------------------------------------------------------------------------------
+    def _preprocessed_root(self):
+        """nnunet.paths.preprocessing_output_dir: $nnUNet_preprocessed, else the folder holding this task's dataset_directory."""
+        import os
+        return os.environ.get('nnUNet_preprocessed') or os.path.dirname(os.path.abspath(self.dataset_directory))
+
+    def _task_folder(self, task_id):
+        """convert_id_to_task_name restricted to the preprocessed root (the only place the split files live)."""
+        import os
+        root = self._preprocessed_root()
+        cands = sorted(d for d in os.listdir(root) if d.startswith("Task%03d" % task_id) and os.path.isdir(os.path.join(root, d)))
+        if len(cands) != 1:
+            raise RuntimeError("expected exactly one preprocessed folder for task id %d under %s, found %s" % (task_id, root, cands))
+        return os.path.join(root, cands[0])
+
+    def _build_custom_splits(self, keys):
+        """Folds 0-4: the five-fold splits of the individual datasets re-used (Task046 follows Task017's split for the shared
+        images and deals its own cases out with a seeded shuffle); folds 5-11: leave-one-dataset-out (train == val)."""
+        import os
+        import pickle
+        load = lambda f: pickle.load(open(f, 'rb'))
+        fivefold = [{'train': [], 'val': []} for _ in range(5)]
+        for task_id in np.unique([int(k.split("_")[0]) for k in keys]):
+            if task_id != 46:
+                per_task = load(os.path.join(self._task_folder(task_id), 'splits_final.pkl'))
+                for f in range(5):
+                    for part in ('train', 'val'):
+                        fivefold[f][part] += ["%03d_" % task_id + c for c in per_task[f][part]]
+            else:
+                own = [k for k in keys if k.startswith("046_PAN")]
+                np.random.RandomState(1234).shuffle(own)
+                t17 = load(os.path.join(self._task_folder(17), 'splits_final.pkl'))
+                for f in range(5):
+                    for part in ('train', 'val'):
+                        fivefold[f][part] += ["046_" + c for c in t17[f][part]]
+                    val = own[f::5]
+                    fivefold[f]['train'] += [k for k in own if k not in val]
+                    fivefold[f]['val'] += val
+        left_out = [("003_",), ("017_", "046_img"), ("064_",), ("010_",), ("007_",), ("055_",), ("008_",)]     # folds 5 .. 11
+        custom = []
+        for prefixes in left_out:
+            rest = [k for k in keys if not any(k.startswith(p) for p in prefixes)]
+            custom.append({'train': rest, 'val': rest})
+        return fivefold + custom
+
+    def do_split(self):
+        """splits_custom.pkl (created by rank 0 when missing, the other ranks wait for the file); cases of a split that are not in
+        the preprocessed folder are skipped with a warning."""
+        import os
+        import pickle
+        import time
+        from collections import OrderedDict
+        keys = list(self.dataset.keys())
+        if self.fold == "all":
+            tr_keys = val_keys = keys
+        else:
+            f = os.path.join(self.dataset_directory, "splits_custom.pkl")
+            if not os.path.isfile(f) and self.local_rank == 0:
+                splits = self._build_custom_splits(keys)
+                with open(f + ".tmp", 'wb') as h:
+                    pickle.dump(splits, h)
+                os.replace(f + ".tmp", f)            # atomic: another rank never unpickles a half-written file
+            while not os.path.isfile(f):
+                time.sleep(0.01)
+            with open(f, 'rb') as h:
+                splits = pickle.load(h)
+            tr_keys, val_keys = list(splits[self.fold]['train']), list(splits[self.fold]['val'])
+        tr_keys.sort()
+        val_keys.sort()
+        self.dataset_tr, self.dataset_val = OrderedDict(), OrderedDict()
+        for dst, ks in ((self.dataset_tr, tr_keys), (self.dataset_val, val_keys)):
+            for k in ks:
+                if k in self.dataset:
+                    dst[k] = self.dataset[k]
+                else:
+                    self.print_to_log_file('Warning %s is not in preprocessed folder (might be intentional)' % k)
+
     def compute_loss(self, output, target, valid_regions):
         """Signature of the reference's compute_loss (:544-623); fused statistics kernels + [B,47] glue."""
         return self.train_step.loss_fn(output, target, valid_regions)
@@ -70,20 +147,37 @@ class MultiTalent_trainer_ddp(nnUNetTrainerV2_DDP):
         return l.detach().cpu().numpy(), ce.detach().cpu().numpy(), dc.detach().cpu().numpy()
 
     def run_online_evaluation(self, output, target, valid_regions, data=None):
-        """Hard (sigmoid > 0.5) tp/fp/fn per valid region on the full-resolution output (reference :372-410): the fused
-        statistics kernel applied to saturated logits gives exactly these counts."""
-        from .....distributed_utils import sum_over_ranks
-        from .....loss_functions.fused_losses import _MultiTalentStats, _target_flat
+        """Reference :372-410: hard (sigmoid > 0.5) tp/fp/fn per valid region on the full-resolution output — one counting kernel
+        (exact integers) instead of the per-(sample, region) loop —, gathered over the ranks [W, B, C]; the lists keep the sum over
+        the RANK axis only ([B, C] per iteration), exactly like the reference."""
+        from .....distributed_utils import gather_over_ranks
+        from .....loss_functions.fused_losses import _as_ndhwc, _target_flat
+        from ...... import ops
         with torch.no_grad():
             if output is None:
-                output = [o.permute(0, 4, 1, 2, 3) for o in self.network.engine().forward(data, need_grad=False, all_heads=True)]
-            hard = torch.where(output[0] > 0, torch.full_like(output[0], 80.0), torch.full_like(output[0], -80.0))
-            valid, lut = self.train_step.loss_fn._masks(valid_regions, hard.device)
-            st = _MultiTalentStats.apply(hard, _target_flat(target[0]), valid, lut)[..., 1:]       # [B, C, 3]
-            st = st.detach().cpu().numpy()
-        self.online_eval_tp.append(list(st[..., 0].sum(0)))
-        self.online_eval_fp.append(list(st[..., 1].sum(0)))
-        self.online_eval_fn.append(list(st[..., 2].sum(0)))
+                x = self.network.engine().forward(data, need_grad=False, all_heads=True)[0]               # NDHWC
+            else:
+                x = _as_ndhwc(output[0])
+            valid, lut = self.train_step.loss_fn._masks(valid_regions, x.device)
+            a = ops.Act(x)
+            st = torch.empty((a.N, a.C, 3), dtype=torch.float32, device=x.device)
+            ops.multitalent_hard_stats(a, _target_flat(target[0]), valid, lut, st)
+            st = gather_over_ranks(st).cpu().numpy()                                                       # [W, B, C, 3]
+        tp_hard, fp_hard, fn_hard = st[..., 0], st[..., 1], st[..., 2]
+        self.online_eval_foreground_dc.append(list((2 * tp_hard) / (2 * tp_hard + fp_hard + fn_hard + 1e-8)))
+        self.online_eval_tp.append(list(tp_hard.sum(0)))
+        self.online_eval_fp.append(list(fp_hard.sum(0)))
+        self.online_eval_fn.append(list(fn_hard.sum(0)))
+
+    def finish_online_evaluation(self):
+        """Reference :412-431: per (sample slot, region) Dice of the epoch's summed counts, mean over all of them."""
+        tp, fp, fn = np.sum(self.online_eval_tp, 0), np.sum(self.online_eval_fp, 0), np.sum(self.online_eval_fn, 0)
+        global_dc_per_class = [l for l in [2 * i / (np.clip(2 * i + j + k, a_min=1e-8, a_max=None)) for i, j, k in zip(tp, fp, fn)]
+                               if not np.isnan(l).any()]
+        self.all_val_eval_metrics.append(np.mean(global_dc_per_class))
+        self.print_to_log_file("Average global foreground Dice:", str(global_dc_per_class))
+        self.print_to_log_file("(interpret this as an estimate for the Dice of the different classes. This is not exact.)")
+        self.online_eval_foreground_dc, self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], [], []
 
     def run_training(self):
         """Same epoch structure as the reference (:663-792): 250 train + 50 validation iterations, logging loss/CE/Dice."""
@@ -108,6 +202,7 @@ class MultiTalent_trainer_ddp(nnUNetTrainerV2_DDP):
                 self.network.eval()
                 va = np.array([self.run_iteration(self.val_gen, False, True) for _ in range(self.num_val_batches_per_epoch)])
                 self.all_val_losses.append(float(va[:, 0].mean()))
+            self.finish_online_evaluation()
             self.print_to_log_file("validation loss: %.4f" % self.all_val_losses[-1], "This epoch took %f s\n" % (time.time() - t0))
             cont = self.on_epoch_end()
             self.epoch += 1

@@ -375,8 +375,10 @@ class nnUNetTrainerV2(nnUNetTrainer):
                     splits.append(OrderedDict())
                     splits[-1]['train'] = np.array(all_keys_sorted)[train_idx]
                     splits[-1]['val'] = np.array(all_keys_sorted)[test_idx]
-                with open(splits_file, 'wb') as f:
-                    pickle.dump(splits, f)
+                if self.local_rank == 0:             # one writer, atomic rename: other ranks never read a partial file
+                    with open(splits_file + ".tmp", 'wb') as f:
+                        pickle.dump(splits, f)
+                    os.replace(splits_file + ".tmp", splits_file)
             else:
                 with open(splits_file, 'rb') as f:
                     splits = pickle.load(f)

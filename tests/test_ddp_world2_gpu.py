@@ -1,0 +1,185 @@
+"""World-size-2 parity of the HIP path against goldens produced by TWO gloo processes around the REAL reference
+(tests/golden/ddp_w2.npz, tools/oracle_gen/make_golden_ddp.py): cross-rank batch Dice (L1/L3/L5), online evaluation with its
+rank gather (L4) and two full DDP training iterations — gradient mean over ranks through GradAllReducer, clip 12, SGD-Nesterov
+(T1/T3).  Two processes: one per GPU over RCCL ('nccl') when the box has >= 2 GPUs, otherwise both on cuda:0 with gloo as the
+transport (a few KB of statistics and the 117 KB gradient of the toy network travel through the host; every kernel is the HIP one)."""
+import json
+import os
+import socket
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    multi = torch.cuda.device_count() >= world
+    torch.cuda.set_device(rank if multi else 0)
+    dist.init_process_group('nccl' if multi else 'gloo', rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world, torch.device('cuda', rank if multi else 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def run_world_gpu(fn, world=2):
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, "rank process failed (exit code %s)" % p.exitcode
+    return [ret[r] for r in range(world)]
+
+
+def _losses(rank, world, dev):
+    from multitalent_amd.training.distributed_utils import sum_over_ranks
+    from multitalent_amd.training.loss_functions.fused_losses import DC_and_CE_DS_loss, MultiTalentLoss
+    from multitalent_amd.training.network_training.custom_trainers.MultiTalent.MultiTalent.MultiTalent_Trainer_DDP import MultiTalent_trainer_ddp
+    z = np.load(os.path.join(G, 'ddp_w2.npz'))
+    meta = json.load(open(os.path.join(G, 'ddp_w2.json')))
+    p = 'r%d/' % rank
+    valid = meta['valid_regions'][rank]
+    # L3: gather + sum over the rank axis == one all_reduce each way
+    x = torch.from_numpy(z[p + 'ag/x']).to(dev).requires_grad_(True)
+    y = sum_over_ranks(x)
+    coef = torch.from_numpy(z[p + 'ag/coef']).to(dev)
+    (y[None] * coef).sum().backward()              # the reference's consumer sums the gathered [W,B,C] over W
+    assert np.allclose(y.detach().cpu().numpy(), z[p + 'ag/y'].sum(0), atol=1e-6)
+    # d/dx of sum_w coef[w] * y: the reference's backward all-reduces the gathered gradient and selects the own slice; with the
+    # `.sum(0)` consumer every slice of that gradient is sum_ranks(sum_w coef_r[w])
+    other = 'r%d/' % (1 - rank)
+    assert np.allclose(x.grad.cpu().numpy(), z[p + 'ag/coef'].sum(0) + z[other + 'ag/coef'].sum(0), atol=1e-5)
+    # L1: MultiTalent loss, batch Dice summed over ranks
+    for bd in (1, 0):
+        logits = [torch.from_numpy(z[p + 'mt/logits%d' % i]).to(dev).requires_grad_(True) for i in range(2)]
+        tg = [torch.from_numpy(z[p + 'mt/target%d' % i]).to(dev) for i in range(2)]
+        l, ce, dc = MultiTalentLoss(z[p + 'mt/weights'], batch_dice=bool(bd))(logits, tg, valid)
+        l.backward()
+        got = np.array([float(l.detach()), float(ce.detach()), float(dc.detach())])
+        assert np.allclose(got, z[p + 'mt/bd%d/loss' % bd], rtol=1e-4, atol=1e-4), (bd, got, z[p + 'mt/bd%d/loss' % bd])
+        for i in range(2):
+            ref = z[p + 'mt/bd%d/dlogits%d' % (bd, i)]
+            assert np.abs(logits[i].grad.cpu().numpy() - ref).max() < 1e-6 + 1e-4 * np.abs(ref).max(), (bd, i)
+    # L5 DDP flavour
+    for bd in (1, 0):
+        sl = [torch.from_numpy(z[p + 'sm/logits%d' % i]).to(dev).requires_grad_(True) for i in range(2)]
+        stg = [torch.from_numpy(z[p + 'sm/target%d' % i]).to(dev) for i in range(2)]
+        l = DC_and_CE_DS_loss(z[p + 'mt/weights'], batch_dice=bool(bd), ddp=True)(sl, stg)
+        l.backward()
+        assert abs(float(l.detach()) - float(z[p + 'sm/bd%d/loss' % bd])) < 1e-5
+        for i in range(2):
+            ref = z[p + 'sm/bd%d/dlogits%d' % (bd, i)]
+            assert np.abs(sl[i].grad.cpu().numpy() - ref).max() < 1e-7 + 1e-4 * np.abs(ref).max(), (bd, i)
+    # L4: online evaluation incl. the gather over ranks and the epoch metric
+    logs = []
+    t = SimpleNamespace(train_step=SimpleNamespace(loss_fn=MultiTalentLoss([1.0])), online_eval_foreground_dc=[], online_eval_tp=[],
+                        online_eval_fp=[], online_eval_fn=[], all_val_eval_metrics=[], print_to_log_file=lambda *a, **k: logs.append(a))
+    for it in range(2):
+        MultiTalent_trainer_ddp.run_online_evaluation(t, [torch.from_numpy(z[p + 'oe/out%d' % it]).to(dev)],
+                                                      [torch.from_numpy(z[p + 'oe/target%d' % it]).to(dev)], valid)
+    for k, lst in (('tp', t.online_eval_tp), ('fp', t.online_eval_fp), ('fn', t.online_eval_fn)):
+        assert np.array_equal(np.array(lst, dtype=np.float64), z[p + 'oe/' + k]), k          # exact integer counts
+    assert np.allclose(np.array(t.online_eval_foreground_dc, dtype=np.float64), z[p + 'oe/foreground_dc'], atol=1e-7)
+    MultiTalent_trainer_ddp.finish_online_evaluation(t)
+    assert abs(float(t.all_val_eval_metrics[0]) - float(z[p + 'oe/all_val_eval_metrics'][0])) < 1e-9
+    assert t.online_eval_tp == []
+    return dist.get_backend()
+
+
+def test_world2_losses_and_online_evaluation_match_real_reference(dev):
+    res = run_world_gpu(_losses)
+    assert res[0] == res[1]
+
+
+def _train(rank, world, dev):
+    from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
+    from multitalent_amd.training.hot_loop import FusedTrainStep
+    from multitalent_amd.training.loss_functions.fused_losses import MultiTalentLoss
+    z = np.load(os.path.join(G, 'ddp_w2.npz'))
+    meta = json.load(open(os.path.join(G, 'ddp_w2.json')))
+    p = 'r%d/train/' % rank
+    valid = meta['valid_regions'][rank]
+    pools, kernels = z[p + 'pools'].tolist(), z[p + 'kernels'].tolist()
+    net = Generic_UNet(1, 6, 47, 2, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                       {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True}, True, False,
+                       lambda x: x, None, pools, kernels, False, True, True)
+    net.load_state_dict({k[len(p) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(p + 'sd0/')})
+    net.train()
+    step = FusedTrainStep(net, MultiTalentLoss(z[p + 'weights'], batch_dice=True), lr=1e-2, ddp=True)
+    assert step.reducer is not None and step.reducer.world == 2
+    x = torch.from_numpy(z[p + 'x']).to(dev)
+    tg = [torch.from_numpy(z[p + 'target%d' % i]).to(dev) for i in range(2)]
+    for it in range(2):
+        l, ce, dc = step(x, tg, valid)
+        got = np.array([float(l), float(ce), float(dc)])
+        assert np.allclose(got, z[p + 'losses'][it], rtol=2e-4, atol=2e-4), (it, got, z[p + 'losses'][it])
+        if it == 0:
+            eng = net.engine()
+            for n, prm in net.named_parameters():
+                ref = z[p + 'grad0/' + n]               # DDP: mean over the two ranks
+                g = eng.grad_of(prm).cpu().numpy()
+                assert np.abs(g - ref).max() < 2e-3 * max(np.abs(ref).max(), 1e-3), n
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, v in net.state_dict().items():
+        worst = max(worst, float(np.abs(v.cpu().numpy() - z[p + 'sd2/' + k]).max()))
+    assert worst < 1e-4, worst
+    return worst, step.reducer.via_host
+
+
+def test_world2_two_ddp_training_iterations_match_real_reference(dev):
+    """T3: the reference wraps the network in torch DDP (MultiTalent_Trainer_DDP.py:121); here GradAllReducer averages the flat
+    gradient buffer bucket by bucket.  Both ranks must end with the reference's parameters (and therefore identical ones)."""
+    res = run_world_gpu(_train)
+    assert all(r[0] < 1e-4 for r in res)
+
+
+def _reducer_rccl(rank, world, dev):
+    """bucketed side-stream all-reduce on DEVICE tensors: uneven completion slices, more buckets than slices."""
+    from multitalent_amd.training.hot_loop import GradAllReducer
+    n = 3_000_000
+    eng = SimpleNamespace(flat_grad=torch.zeros(n, device=dev))
+    red = GradAllReducer(eng, bucket_bytes=4 * 500_000)
+    full = torch.randn(n, generator=torch.Generator().manual_seed(rank)).to(dev)
+    other = torch.randn(n, generator=torch.Generator().manual_seed(1 - rank)).to(dev)
+    for rep in range(3):                                   # the streams / events are re-used across steps
+        eng.flat_grad.zero_()
+        red.begin()
+        cuts = [0, 5000, 1_410_000, 1_410_010, 2_777_777, 2_900_000, n]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            eng.flat_grad[lo:hi] = full[lo:hi] * (rep + 1)
+            red.ready(lo, hi)
+        red.ready(n, n)
+        red.finish()
+        assert red.sent == n
+        torch.cuda.synchronize()
+        assert torch.allclose(eng.flat_grad, (full + other) * (rep + 1) / 2, atol=1e-6)
+    return True
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
+def test_grad_allreducer_on_rccl(dev):
+    assert all(run_world_gpu(_reducer_rccl))
+
+
+def test_grad_allreducer_device_tensors_world2(dev):
+    """same, on whatever transport the box offers (gloo through the host on a one-GPU box)."""
+    assert all(run_world_gpu(_reducer_rccl))

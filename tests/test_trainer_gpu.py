@@ -51,7 +51,24 @@ def test_multitalent_trainer_roundtrip(dev, pg, tmp_path, name, resenc):
     with torch.no_grad():
         tr.network.eval()
         v = tr.run_iteration(gen, False, True)
-    assert np.isfinite(v[0]) and len(tr.online_eval_tp) == 1 and len(tr.online_eval_tp[0]) == 47
+    assert np.isfinite(v[0]) and len(tr.online_eval_tp) == 1
+    # L4 (MultiTalent_Trainer_DDP.py:372-410): [B][47] hard tp/fp/fn of the full-resolution output == the oracle's restatement on
+    # the same logits (exact counts except for voxels whose logit is within 1e-5 of the decision boundary)
+    from oracle import reference_ops as R
+    from multitalent_amd.dataset_conversion.Task100_MultiTalent import MultiTalent_region_output_idx_mapping, MultiTalent_regions
+    d = next(gen)
+    with torch.no_grad():
+        logits = tr.network(tr._to_device(d['data']))[0].float().cpu()
+    tgt, valid = tr.loss_args(d)
+    otp, ofp, ofn, _ = R.multitalent_online_evaluation(logits, tgt[0].cpu(), valid, MultiTalent_regions, MultiTalent_region_output_idx_mapping)
+    near = (logits.abs() < 1e-5).flatten(2).sum(2).numpy()                         # [B, 47] undecidable voxels
+    B = logits.shape[0]
+    assert len(tr.online_eval_tp[0]) == B and len(tr.online_eval_tp[0][0]) == 47
+    for got, ref in ((tr.online_eval_tp[0], otp), (tr.online_eval_fp[0], ofp), (tr.online_eval_fn[0], ofn)):
+        assert (np.abs(np.array(got) - ref) <= near).all()
+    assert np.array(tr.online_eval_tp[0]).sum() + np.array(tr.online_eval_fp[0]).sum() + np.array(tr.online_eval_fn[0]).sum() > 0
+    tr.finish_online_evaluation()
+    assert len(tr.all_val_eval_metrics) == 1 and 0.0 <= tr.all_val_eval_metrics[0] <= 1.0 and tr.online_eval_tp == []
     f = os.path.join(str(tmp_path), 'model_latest.model')
     tr.save_checkpoint(f)
     ck = torch.load(f, map_location='cpu', weights_only=False)
@@ -69,7 +86,7 @@ def test_multitalent_trainer_roundtrip(dev, pg, tmp_path, name, resenc):
     s2, p2 = tr2.predict_preprocessed_data_return_seg_and_softmax(vol, do_mirroring=True, mirror_axes=(0, 1, 2), verbose=False)
     assert p1.shape == (47, 20, 40, 40) and s1.shape == (20, 40, 40)
     assert np.array_equal(p1, p2) and np.array_equal(s1, s2)
-    assert tr.network.training is False or True
+    assert tr.network.training is False         # the wrapper restores the mode it found (eval, set above)
 
 
 def test_single_gpu_trainer_softmax(dev, tmp_path):
