@@ -5,14 +5,22 @@ dummyLoad style (reference: nnUNet_variants/benchmarking/nnUNetTrainerV2_dummyLo
 
   python bench.py --gpus N --steps K --warmup W
 Workload (every N): BASELINE.json configs[1] = Task009_Spleen Generic_UNet, bs=2 per GPU, patch 48x192x192, fp32, softmax
-Dice+CE with deep supervision.  N > 1: launched by torch.distributed.run, one rank per GPU (RCCL), weak scaling; gradients
-all-reduced (mean) overlapped with backward on a side stream.  --workload task100 selects the nc=47 MultiTalent loss, bs=4.
-Prints ONE JSON line on rank 0.
+Dice+CE with deep supervision.  N > 1: one rank per GPU over RCCL (weak scaling; gradients all-reduced (mean) overlapped with
+backward on a side stream) — launched by torch.distributed.run; when called as plain `python bench.py --gpus N` the script
+re-executes itself under torch.distributed.run with N ranks.  --workload task100 | resenc | infer select BASELINE configs[2..4],
+--patch 96 192 192 the plans' native patch, --precision bf16 the mixed-precision mode of configs[3].
+Prints ONE JSON line on rank 0 (N = 1: with `roofline` of the dominant kernel and `cpu_baseline`).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,6 +35,7 @@ PATCH = (48, 192, 192)
 POOLS = [[2, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2]]
 KERNELS = [[3, 3, 3]] * 6
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
@@ -34,11 +43,23 @@ RESENC_POOLS = [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2], [2, 2, 2]
 RESENC_KERNELS = [[1, 3, 3]] + [[3, 3, 3]] * 5
 RESENC_BLOCKS = [1, 2, 3, 4, 4, 4]
 
+# multiplications the kernel EXECUTES on the matrix cores per algorithmic multiplication of the direct convolution
+#   conv_wino*: F(2x2x2, 3x3x3), 64 products per 2x2x2 outputs instead of 216;  conv_bwdw_wino*: F(3x3, 2x2) over (h, w), 16 products
+#   per 3x3 taps x 2x2 outputs instead of 36, kd direct
+EXECUTED_FRACTION = (('conv_wino', 64.0 / 216.0), ('conv_bwdw_wino', 16.0 / 36.0))
+
+
+def executed_fraction(kernel):
+    for prefix, f in EXECUTED_FRACTION:
+        if kernel.startswith(prefix):
+            return f
+    return 1.0
+
 
 def build_network(workload):
     from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
     from multitalent_amd.network_architecture.initialization import InitWeights_He
-    if workload == 'resenc':        # BASELINE configs[3] architecture (FabiansUNet, MultiTalent_meets_resenc.py:72-104), here in fp32
+    if workload == 'resenc':        # BASELINE configs[3] architecture (FabiansUNet, MultiTalent_meets_resenc.py:72-104)
         from multitalent_amd.network_architecture.generic_modular_residual_UNet import FabiansUNet, get_default_network_config
         return FabiansUNet(1, 30, RESENC_BLOCKS, 2, RESENC_POOLS, RESENC_KERNELS, get_default_network_config(3, None, norm_type="in"),
                            47, [1] * (len(RESENC_POOLS) - 1), True, False, 320, InitWeights_He(1e-2))
@@ -48,18 +69,18 @@ def build_network(workload):
                         True, False, lambda x: x, InitWeights_He(1e-2), POOLS, KERNELS, False, True, True)
 
 
-def make_batch(workload, B, dev, rank):
+def make_batch(workload, B, dev, rank, patch=PATCH):
     from multitalent_amd.synthetic import ds_scales, synthetic_ct, synthetic_targets
     from multitalent_amd.dataset_conversion.Task100_MultiTalent import MultiTalent_regions, MultiTalent_valid_regions
     scales = ds_scales(RESENC_POOLS, skip_first=True) if workload == 'resenc' else ds_scales(POOLS)
-    x = synthetic_ct(B, PATCH, 1234 + rank, dev)
+    x = synthetic_ct(B, patch, 1234 + rank, dev)
     if workload == 'task009':
-        t = synthetic_targets(B, PATCH, scales, [[1]] * B, 1234 + rank, dev)
+        t = synthetic_targets(B, patch, scales, [[1]] * B, 1234 + rank, dev)
         return x, (t,)
     names = list(MultiTalent_valid_regions.keys())
     valid = [MultiTalent_valid_regions[names[(rank * B + b) % len(names)]] for b in range(B)]
     label_sets = [sorted({l for r in v for l in MultiTalent_regions[r]}) for v in valid]
-    t = synthetic_targets(B, PATCH, scales, label_sets, 1234 + rank, dev)
+    t = synthetic_targets(B, patch, scales, label_sets, 1234 + rank, dev)
     return x, (t, valid)
 
 
@@ -87,122 +108,261 @@ def conv_flops(engine):
     return f
 
 
-def measure_roofline(step, x, largs, nrep=3):
-    """Per-launch HIP-event timing (on the stream the kernels are launched on = torch's current stream) of every
-    mt_conv3d_fwd launch, grouped by the device kernel that runs (same names as rocprofv3 --kernel-trace).  Reports the
-    dominant kernel: achieved = mean algorithmic FLOPs per launch / mean launch duration."""
-    from multitalent_amd import ops
-    rec = {}
-    orig = ops.conv3d_fwd
+class ConvTimer:
+    """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of EVERY convolution launch of the
+    C ABI — mt_conv3d_fwd (forward and backward-data), mt_conv3d_bwd_weight, mt_conv3d_bwd_data_strided — grouped by the device
+    kernel that runs (the names rocprofv3 --kernel-trace prints), with the algorithmic work of each launch."""
 
-    def timed(p):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig(p)
-        e1.record()
-        # algorithmic work: 2 * |out| * Cin * k^3; a zero-inserted input (backward-data of a strided conv) only carries
-        # 1/prod(dil) non-structural-zero taps
-        flops = 2.0 * p.N * p.Do * p.Ho * p.Wo * p.Cin * p.Cout * p.KD * p.KH * p.KW / (p.dilD * p.dilH * p.dilW)
-        # algorithmic bytes (SURVEY §8d): the input read once, the output written once (read+written when accumulating), fp32
-        nbytes = 4.0 * p.N * (p.Di * p.Hi * p.Wi * p.Cin + p.Do * p.Ho * p.Wo * p.Cout * (2 if p.accumulate else 1))
-        rec.setdefault(ops.conv_kernel_name(p), []).append((e0, e1, flops, nbytes))
+    def __init__(self):
+        self.rec = {}
 
-    ops.conv3d_fwd = timed
-    try:
-        for _ in range(nrep):
-            step(x, *largs)
+    def __enter__(self):
+        from multitalent_amd import ops
+        self.ops = ops
+        self.orig = (ops.conv3d_fwd, ops.conv3d_bwd_weight, ops.conv3d_bwd_data_strided)
+        esz = lambda p: 4.0          # activations and gradients are fp32 in HBM in both precisions
+
+        def timed(name, flops, nbytes, call):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            call()
+            e1.record()
+            self.rec.setdefault(name, []).append((e0, e1, flops, nbytes))
+
+        def fwd(p):
+            # algorithmic work: 2 * |out| * Cin * k^3; a zero-inserted input (backward-data of a strided conv run as a
+            # dilated-input conv) only carries 1/prod(dil) non-structural-zero taps.  Bytes (SURVEY §8d): the input read once,
+            # the output written once (read + written when accumulating)
+            fl = 2.0 * p.N * p.Do * p.Ho * p.Wo * p.Cin * p.Cout * p.KD * p.KH * p.KW / (p.dilD * p.dilH * p.dilW)
+            nb = esz(p) * p.N * (p.Di * p.Hi * p.Wi * p.Cin / (p.dilD * p.dilH * p.dilW) + p.Do * p.Ho * p.Wo * p.Cout * (2 if p.accumulate else 1))
+            timed(ops.conv_kernel_name(p), fl, nb, lambda: self.orig[0](p))
+
+        def bwdw(p, y, *a):
+            # dW = X (*) dY: both activations read once; the weight gradient itself is negligible
+            fl = 2.0 * p.N * p.Do * p.Ho * p.Wo * p.Cin * p.Cout * p.KD * p.KH * p.KW
+            nb = esz(p) * p.N * (p.Di * p.Hi * p.Wi * p.Cin + p.Do * p.Ho * p.Wo * p.Cout)
+            timed(ops.conv_bwd_weight_kernel_name(p, y), fl, nb, lambda: self.orig[1](p, y, *a))
+
+        def bwdd(p):
+            # p = FORWARD geometry with src = dY [Do..] x Cout and out = dX [Di..] x Cin
+            fl = 2.0 * p.N * p.Do * p.Ho * p.Wo * p.Cin * p.Cout * p.KD * p.KH * p.KW
+            nb = esz(p) * p.N * (p.Do * p.Ho * p.Wo * p.Cout + p.Di * p.Hi * p.Wi * p.Cin * (2 if p.accumulate else 1))
+            timed(ops.conv_bwd_data_strided_kernel_name(p), fl, nb, lambda: self.orig[2](p))
+
+        ops.conv3d_fwd, ops.conv3d_bwd_weight, ops.conv3d_bwd_data_strided = fwd, bwdw, bwdd
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.conv3d_fwd, self.ops.conv3d_bwd_weight, self.ops.conv3d_bwd_data_strided = self.orig
+        return False
+
+    def groups(self):
         torch.cuda.synchronize()
-    finally:
-        ops.conv3d_fwd = orig
-    groups = {k: (sum(a.elapsed_time(b) for a, b, _, _ in v), sum(f for _, _, f, _ in v), len(v), sum(nb for _, _, _, nb in v))
-              for k, v in rec.items()}
-    name = max(groups, key=lambda k: groups[k][0])
-    ms, fl, n, nby = groups[name]
-    ach = fl / (ms * 1e-3) / 1e12
-    all_ms = sum(g[0] for g in groups.values()); all_fl = sum(g[1] for g in groups.values())
-    out = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "launches_per_step": n // nrep,
-            "avg_launch_ms": round(ms / n, 4), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
-            "all_conv_fwd_launches": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / nrep, 3)}}
-    # HBM bytes per launch of the dominant kernel from the PMC counters: rocprofv3 --pmc cannot run inside this process, so the
-    # table is produced by tools/profile_pmc_bench.sh (separate FETCH_SIZE / WRITE_SIZE passes over THIS command, averaged over
-    # the kernel's launches of a step) and committed as profiles/r01_pmc_per_kernel.json; gfx950 correction per
-    # MI355X_MICROARCH.md §HBM: FETCH_SIZE tallies 128-B requests at 64 B -> x2 (upper bound), WRITE_SIZE as counted
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_per_kernel.json')) as f:
-            pmc = json.load(f)
-        for prec in pmc.values():
-            e = next((v for k, v in prec.items() if k.replace('void ', '').split('(')[0] == name), None)   # rocprofv3 prints "void name<...>(Params)"
-            if e is not None:
-                out["traffic"] = int((2 * e['fetch_kb_per_launch'] + e['write_kb_per_launch']) * 1024)
-                out["traffic_as_counted"] = int((e['fetch_kb_per_launch'] + e['write_kb_per_launch']) * 1024)
-                out["traffic_unit"] = "bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, profiles/r01_pmc_per_kernel.json)"
-                out["algorithmic_bytes_per_launch"] = int(nby / n)
-                break
-    except (OSError, ValueError, KeyError):
-        pass
-    if name.startswith('conv_bf16'):
-        # bf16 matrix inputs: 27 MFMAs per 16-channel chunk instead of 216 — the kernel is bound by moving the fp32 activations
-        gbs = nby / (ms * 1e-3) / 1e9
+        return {k: {"ms": sum(a.elapsed_time(b) for a, b, _, _ in v), "flops": sum(f for _, _, f, _ in v), "n": len(v),
+                    "bytes": sum(nb for _, _, _, nb in v)} for k, v in self.rec.items()}
+
+
+def roofline_from_groups(groups, nrep, precision):
+    """`roofline` object for the kernel with the largest total time.  Bound:
+      * fp32 matrix kernels: MFMA; `achieved` = EXECUTED matrix FLOP/s (Winograd kernels execute 64/216 resp. 16/36 of the
+        direct convolution's multiplications — the algorithmic-equivalent rate is reported beside it under its own key);
+      * bf16 matrix kernels: the tensors they move bound them (AI of a 32-channel 3x3x3 layer = 216 FLOP/B vs a machine balance
+        of 312 for dense bf16): HBM, `achieved` = algorithmic bytes / duration."""
+    name = max(groups, key=lambda k: groups[k]["ms"])
+    g = groups[name]
+    sec = g["ms"] * 1e-3
+    alg_tflops = g["flops"] / sec / 1e12
+    ex = executed_fraction(name)
+    out = {"kernel": name, "launches_per_step": g["n"] // nrep, "avg_launch_ms": round(g["ms"] / g["n"], 4),
+           "algorithmic_gflop_per_launch": round(g["flops"] / g["n"] / 1e9, 2),
+           "algorithmic_bytes_per_launch": int(g["bytes"] / g["n"]), "traffic": None}
+    if 'bf16' in name or name.rstrip('>').endswith('true'):
+        gbs = g["bytes"] / sec / 1e9
         out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "algorithmic_mbytes_per_launch": round(nby / n / 1e6, 1), "algorithmic_tflops": round(ach, 1)})
-    if name.startswith('conv_wino'):
-        # `achieved` counts the ALGORITHMIC FLOPs of the direct convolution; the Winograd F(2x2x2,3x3x3) kernel executes
-        # 64/216 of them on the matrix cores (plus the transforms on the vector ALU), so frac may exceed what a direct kernel can
-        out["algorithm"] = "winograd F(2x2x2,3x3x3): executed MFMA FLOPs = algorithmic / 3.375"
-        out["executed_mfma_tflops"] = round(ach / 3.375, 2)
+                    "mfma_tflops": round(alg_tflops, 1), "mfma_frac_of_bf16_peak": round(alg_tflops / MFMA_BF16_PEAK_TFLOPS, 4)})
+    else:
+        out.update({"bound": "mfma", "achieved": round(alg_tflops * ex, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(alg_tflops * ex / MFMA_F32_PEAK_TFLOPS, 4)})
+        if ex != 1.0:
+            out["executed_fraction_of_direct_multiplications"] = round(ex, 4)
+            out["algorithmic_equivalent"] = {"achieved": round(alg_tflops, 2), "frac_of_fp32_mfma_peak": round(alg_tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                                             "note": "direct-convolution FLOPs / time: may exceed 1 because Winograd executes fewer multiplications"}
+    tot_ms = sum(v["ms"] for v in groups.values())
+    out["all_conv_launches"] = {"ms_per_step": round(tot_ms / nrep, 3),
+                                "algorithmic_tflops": round(sum(v["flops"] for v in groups.values()) / (tot_ms * 1e-3) / 1e12, 2),
+                                "by_kernel_ms_per_step": {k: round(v["ms"] / nrep, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
     return out
 
 
-def cpu_baseline(workload):
-    """Oracle (CPU restatement of the reference path) timed on the host cores: one full training iteration at B=1."""
+def measure_roofline(step, x, largs, precision, nrep=3):
+    with ConvTimer() as t:
+        for _ in range(nrep):
+            step(x, *largs)
+        groups = t.groups()
+    return roofline_from_groups(groups, nrep, precision)
+
+
+def measure_traffic(kernel, argv):
+    """HBM bytes per launch of `kernel` from the PMC counters, measured NOW on this box: two child runs of this very command under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC block cannot hold both,
+    MI355X_MICROARCH.md §rocprofv3 PMC slots; no other trace domain).  gfx950 correction (same guide, §HBM): FETCH_SIZE tallies the
+    128-B requests of wide streaming reads at 64 B -> doubled (an upper bound for narrower accesses; the as-counted figure is kept);
+    WRITE_SIZE as counted.  Both counters are in KB."""
+    rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(rocprof):
+        return {"traffic": None, "traffic_error": "rocprofv3 not found"}
+    res = {}
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='mt_pmc_', dir='/tmp')
+        cmd = [rocprof, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', d, '-o', 'b', '--', sys.executable,
+               os.path.join(ROOT, 'bench.py')] + argv + ['--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-roofline', '--gpus', '1']
+        try:
+            subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=True)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            tot, n = 0.0, 0
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if r.get('Counter_Name', ctr) != ctr:
+                        continue
+                    if r['Kernel_Name'].replace('void ', '').split('(')[0].strip() == kernel:
+                        tot += float(r['Counter_Value'])
+                        n += 1
+            if n == 0:
+                return {"traffic": None, "traffic_error": "kernel %s not found in the %s pass" % (kernel, ctr)}
+            res[ctr] = tot / n
+        except Exception as e:     # noqa: BLE001 — the bench line must still be printed
+            return {"traffic": None, "traffic_error": "%s pass failed: %s" % (ctr, str(e)[:200])}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"traffic": int((2 * res['FETCH_SIZE'] + res['WRITE_SIZE']) * 1024),
+            "traffic_as_counted": int((res['FETCH_SIZE'] + res['WRITE_SIZE']) * 1024),
+            "traffic_unit": "bytes per launch, live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE x2 per MI355X_MICROARCH.md)"}
+
+
+def host_cores():
+    """(physical cores, logical cpus available to this process)."""
+    logical = os.cpu_count() or 1
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    phys = None
+    try:
+        out = subprocess.check_output(['lscpu', '-p=CORE,SOCKET'], text=True)
+        phys = len({l for l in out.splitlines() if l and not l.startswith('#')})
+    except Exception:
+        pass
+    if not phys:
+        phys = max(logical // 2, 1)
+    return min(phys, logical), logical
+
+
+def cpu_threads():
+    """BASELINE.md §3 times the CPU path on the host's physical cores.  A thread sweep of this very iteration on the GPU box's
+    host (tools/cpu_thread_sweep.py -> profiles/r02_cpu_thread_sweep.json) is committed; when it found a FASTER thread count for
+    this host's core count, that one is used — the baseline is the best the host does, and `cores` says what was used."""
+    phys, logical = host_cores()
+    try:
+        sw = json.load(open(os.path.join(ROOT, 'profiles', 'r02_cpu_thread_sweep.json')))
+        if int(sw.get('physical_cores', -1)) == phys and int(sw['best_threads']) <= logical:
+            return int(sw['best_threads']), phys
+    except (OSError, ValueError, KeyError):
+        pass
+    return phys, phys
+
+
+def cpu_iteration_fn(workload, B, patch=PATCH):
+    """One full training iteration of the oracle (CPU restatement of the reference path) -> callable."""
     from oracle import reference_ops as R
     from multitalent_amd.synthetic import ds_scales, synthetic_ct, synthetic_targets
     torch.manual_seed(0)
     net = build_network(workload)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    cores = min(cores, 32)     # oneDNN conv3d stops scaling (and 256 SMT threads thrash) well before a whole 2-socket host
-    torch.set_num_threads(cores)
-    B = 1
-    x = synthetic_ct(B, PATCH, 99, 'cpu')
-    t = synthetic_targets(B, PATCH, ds_scales(POOLS), [[1]] * B, 99, 'cpu')
-    w = R.ds_loss_weights(len(POOLS))
+    x = synthetic_ct(B, patch, 99, 'cpu')
     params = list(sd.values())
     opt = torch.optim.SGD(params, 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    if workload == 'task009':
+        t = synthetic_targets(B, patch, ds_scales(POOLS), [[1]] * B, 99, 'cpu')
+        w = R.ds_loss_weights(len(POOLS))
+        loss = lambda: R.multiple_output_loss(R.generic_unet_forward(sd, x, POOLS, KERNELS), t, w)
+    else:
+        from multitalent_amd.dataset_conversion.Task100_MultiTalent import (MultiTalent_regions, MultiTalent_region_output_idx_mapping,
+                                                                            MultiTalent_valid_regions)
+        names = list(MultiTalent_valid_regions.keys())
+        valid = [MultiTalent_valid_regions[names[b % len(names)]] for b in range(B)]
+        label_sets = [sorted({l for r in v for l in MultiTalent_regions[r]}) for v in valid]
+        if workload == 'resenc':
+            t = synthetic_targets(B, patch, ds_scales(RESENC_POOLS, skip_first=True), label_sets, 99, 'cpu')
+            w = R.ds_loss_weights(len(RESENC_POOLS) - 1)
+            fwd = lambda: R.fabians_unet_forward(sd, x, RESENC_POOLS, RESENC_KERNELS, RESENC_BLOCKS)
+        else:
+            t = synthetic_targets(B, patch, ds_scales(POOLS), label_sets, 99, 'cpu')
+            w = R.ds_loss_weights(len(POOLS))
+            fwd = lambda: R.generic_unet_forward(sd, x, POOLS, KERNELS)
+        loss = lambda: R.multitalent_loss(list(fwd()), t, valid, MultiTalent_regions, MultiTalent_region_output_idx_mapping, w)[0]
+
     def iteration():
         opt.zero_grad()
-        out = R.generic_unet_forward(sd, x, POOLS, KERNELS)
-        if workload == 'task009':
-            loss = R.multiple_output_loss(out, t, w)
-        else:
-            from multitalent_amd.dataset_conversion.Task100_MultiTalent import (MultiTalent_regions, MultiTalent_region_output_idx_mapping,
-                                                                                MultiTalent_valid_regions)
-            loss = R.multitalent_loss(list(out), t, [MultiTalent_valid_regions['Task009_Spleen']], MultiTalent_regions,
-                                      MultiTalent_region_output_idx_mapping, w)[0]
-        loss.backward()
+        loss().backward()
         torch.nn.utils.clip_grad_norm_(params, 12)
         opt.step()
+    return iteration
 
-    iteration()                       # warm-up: oneDNN primitive creation, page faults of ~10 GB of autograd buffers
-    NIT = 3
+
+def cpu_baseline(workload, patch=PATCH):
+    """the oracle's full training iteration (fwd + loss + bwd + clip + SGD) at B = 2, fp32, 3 warm-up + 5 timed
+    iterations on the host cores (`cores` = threads used)."""
+    threads, phys = cpu_threads()
+    torch.set_num_threads(threads)
+    B, WARM, NIT = 2, 3, 5
+    it = cpu_iteration_fn(workload, B, patch)
+    for _ in range(WARM):         # oneDNN primitive creation, page faults of ~20 GB of autograd buffers
+        it()
     t0 = time.time()
     for _ in range(NIT):
-        iteration()
+        it()
     dt = time.time() - t0
-    return {"value": round(NIT * B / dt, 4), "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": "%d training iterations after 1 warm-up (fwd+loss+bwd+clip+SGD), batch 1, patch 48x192x192, fp32, torch CPU oracle, %.1f s" % (NIT, dt)}
+    return {"value": round(NIT * B / dt, 4), "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": "%d timed training iterations after %d warm-up (fwd+loss+bwd+clip+SGD), batch %d, patch %s, fp32, torch-CPU oracle "
+                      "(oracle/reference_ops.py), %d threads on %d physical cores, %.1f s" % (NIT, WARM, B, 'x'.join(str(i) for i in patch), threads, phys, dt)}
+
+
+def cpu_baseline_infer(patch, tiles_total, mirror):
+    """Sliding-window CPU baseline on a reduced tile subset, extrapolated: the oracle's forward + sigmoid of ONE tile
+    (x8 flips when mirroring) timed 1 + 2 times; volumes/min = 60 / (tiles_total * t_tile).  The host-side overlap-add of the
+    reference (numpy, 333 MB per tile) is NOT included, which flatters the CPU."""
+    from oracle import reference_ops as R
+    threads, phys = cpu_threads()
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    net = build_network('task100')
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    x = torch.randn((1, 1) + tuple(patch))
+    nflip = 8 if mirror else 1
+
+    def tile():
+        with torch.no_grad():
+            for _ in range(nflip):
+                torch.sigmoid(R.generic_unet_forward(sd, x, POOLS, KERNELS, deep_supervision=False))
+    tile()
+    t0 = time.time()
+    for _ in range(2):
+        tile()
+    dt = (time.time() - t0) / 2
+    return {"value": round(60.0 / (tiles_total * dt), 5), "unit": "volumes/min", "cores": threads, "kind": "port",
+            "sample": "network forward + sigmoid of ONE %s tile (%d mirrored passes) timed twice after 1 warm-up = %.2f s per tile, extrapolated to "
+                      "%d tiles; overlap-add excluded; torch-CPU oracle, %d threads on %d physical cores" % ('x'.join(str(i) for i in patch), nflip, dt, tiles_total, threads, phys)}
 
 
 def bench_infer(args, dev, rank, world, ddp):
     """BASELINE.json configs[4]: predict_MultiTalent-style sliding-window inference of ONE synthetic CT volume, tiles sharded
     over the ranks (strong scaling), Gaussian weighting, step 0.5, optional 8-fold mirroring; a 'step' is one whole volume.
     Metric: volumes per minute, volume already resident in host memory, result left on the device."""
-    from multitalent_amd.inference.sliding_window import predict_3D
+    from multitalent_amd.inference.sliding_window import compute_steps_for_sliding_window, predict_3D
+    patch = tuple(args.patch)
     torch.manual_seed(1234)
     net = build_network('task100').to(dev)
     net.eval()
@@ -210,7 +370,7 @@ def bench_infer(args, dev, rank, world, ddp):
     net.inference_apply_nonlin = nn.Sigmoid()
     vol = np.random.RandomState(7).randn(1, *args.volume).astype(np.float32)
     shard = (rank, world) if world > 1 else None
-    run = lambda: predict_3D(net, vol, bool(args.mirror), (0, 1, 2), True, 0.5, PATCH, None, True, 'constant', None, True,
+    run = lambda: predict_3D(net, vol, bool(args.mirror), (0, 1, 2), True, 0.5, patch, None, True, 'constant', None, True,
                              False, True, tile_shard=shard, return_device_tensors=True)
     for _ in range(max(1, min(args.warmup, 1))):
         run()
@@ -229,16 +389,50 @@ def bench_infer(args, dev, rank, world, ddp):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     if rank == 0:
-        print(json.dumps({
+        steps = compute_steps_for_sliding_window(patch, tuple(args.volume), 0.5)
+        ntiles = len(steps[0]) * len(steps[1]) * len(steps[2])
+        line = {
             "metric": "sliding-window vols/min", "value": round(60.0 * args.steps / dt, 3), "unit": "volumes/min",
             "n_gpus": world, "steps": args.steps, "warmup": 1, "ms_per_step": round(dt / args.steps * 1e3, 1),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.precision == 'fp32' else "bf16", "data": "synthetic",
             "config": {"workload": "predict_MultiTalent sliding window, Generic_UNet nc=47 sigmoid", "volume": list(args.volume),
-                       "patch": list(PATCH), "step_size": 0.5, "gaussian": True, "mirror_tta": bool(args.mirror),
-                       "parallelism": "tile-shard%d" % world}}), flush=True)
+                       "patch": list(patch), "tiles": ntiles, "step_size": 0.5, "gaussian": True, "mirror_tta": bool(args.mirror),
+                       "parallelism": "tile-shard%d" % world}}
+        if world == 1 and not args.no_roofline:
+            with ConvTimer() as t:
+                run()
+                groups = t.groups()
+            line["roofline"] = roofline_from_groups(groups, 1, args.precision)
+            if not args.no_traffic:
+                line["roofline"].update(measure_traffic(line["roofline"]["kernel"], child_argv(args)))
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_infer(patch, ntiles, bool(args.mirror))
+        print(json.dumps(line), flush=True)
     if ddp:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def child_argv(args):
+    a = ['--workload', args.workload or 'task009', '--precision', args.precision, '--patch'] + [str(i) for i in args.patch]
+    if args.batch:
+        a += ['--batch', str(args.batch)]
+    if (args.workload or '') == 'infer':
+        a += ['--mirror', str(args.mirror), '--volume'] + [str(i) for i in args.volume]
+    return a
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run and hand over."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: this node exposes %d GPU(s); a data-parallel run needs one rank per GPU" % (n, have))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -247,15 +441,19 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default=None, choices=[None, 'task009', 'task100', 'resenc', 'infer'])
+    ap.add_argument('--patch', type=int, nargs=3, default=list(PATCH), help='48 192 192 (BASELINE metric) or 96 192 192 (the plans\' native patch)')
     ap.add_argument('--volume', type=int, nargs=3, default=[512, 512, 512], help='--workload infer: synthetic CT volume')
     ap.add_argument('--mirror', type=int, default=1, help='--workload infer: 8-fold mirror TTA (reference default)')
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
-                    help='bf16 = mixed precision (BASELINE configs[3]): bf16 matrix inputs, fp32 accumulation/storage; the headline metric is fp32')
+                    help='bf16 = mixed precision (BASELINE configs[3]): bf16 matrix inputs, fp32 accumulation; the headline metric is fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-traffic', action='store_true', help='skip the two rocprofv3 --pmc child passes (roofline.traffic = null)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        respawn_under_torchrun(args.gpus)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -270,6 +468,7 @@ def main():
     workload = args.workload or 'task009'      # same per-GPU workload at every N (weak scaling on BASELINE configs[1])
     if workload == 'infer':
         return bench_infer(args, dev, rank, world, ddp)
+    patch = tuple(args.patch)
     B = args.batch or {'task009': 2, 'task100': 4, 'resenc': 2}[workload]
 
     from multitalent_amd.training.hot_loop import FusedTrainStep
@@ -278,7 +477,7 @@ def main():
     net.train()
     net.engine().set_precision(args.precision)
     step = FusedTrainStep(net, make_loss(workload, ddp), lr=1e-2, ddp=ddp)
-    x, largs = make_batch(workload, B, dev, rank)
+    x, largs = make_batch(workload, B, dev, rank, patch)
 
     for _ in range(args.warmup):
         step(x, *largs)
@@ -305,27 +504,30 @@ def main():
     line = None
     if rank == 0:
         fl = conv_flops(step.eng) * 3.0
+        pname = 'x'.join(str(i) for i in patch)
         line = {
-            "metric": "CT patches/s (48x192x192) train fwd+bwd", "value": round(value, 3), "unit": "patches/s",
+            "metric": "CT patches/s (%s) train fwd+bwd" % pname, "value": round(value, 3), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == 'fp32' else "bf16", "data": "synthetic",
             "config": {"workload": {"task009": "Task009_Spleen Generic_UNet nc=2 softmax Dice+CE",
                                     "task100": "Task100_MultiTalent Generic_UNet nc=47 MultiTalent BCE+Dice loss",
                                     "resenc": "Task100_MultiTalent FabiansUNet (residual encoder) nc=47 MultiTalent BCE+Dice loss"}[workload],
-                       "patch": list(PATCH), "batch_per_gpu": B, "global_batch": B * world,
+                       "patch": list(patch), "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "step": "fwd+loss+bwd+clip12+SGD-nesterov",
                        "precision": "fp32" if args.precision == 'fp32' else
-                       "bf16 matrix inputs + fp32 accumulation in the 3x3x3 stride-1 convs (fwd, bwd-data, bwd-weight); fp32 storage, norm, loss, optimizer, other layers",
+                       "bf16 matrix inputs + fp32 accumulation in the convolutions (fwd, bwd-data, bwd-weight); fp32 master weights, norm statistics, loss, optimizer",
                        "final_loss": round(float(loss), 5)},
             "algorithmic_tflop_per_step": round(fl / 1e12, 3),
-            "step_frac_of_mfma_roofline": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            "step_frac_of_fp32_mfma_roofline": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
         }
     if rank == 0 and world == 1:
         if not args.no_roofline:
-            line["roofline"] = measure_roofline(step, x, largs)
+            line["roofline"] = measure_roofline(step, x, largs, args.precision)
+            if not args.no_traffic:
+                line["roofline"].update(measure_traffic(line["roofline"]["kernel"], child_argv(args)))
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(workload)
+            line["cpu_baseline"] = cpu_baseline(workload, patch)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if ddp:

@@ -125,6 +125,10 @@ int mt_conv3d_bwd_data_strided_pack_layout(const mt_conv3d_t* p); /* `layout` of
 int mt_set_option(const char* name, int value);
 int mt_conv3d_pack_layout(const mt_conv3d_t* p);   /* `layout` for mt_pack_conv_weights: 1; 2 when the Winograd kernel serves p; 3 (bf16) when p->mma == 1 and the bf16 kernel does */
 int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n); /* device kernel that will run (profiler name) */
+/* the same for mt_conv3d_bwd_weight(p, ysrc, ...) and mt_conv3d_bwd_data_strided(p): which kernel family the dispatcher picks
+ * (tests assert that full-size problems run on the Winograd / strided / stem kernels; bench.py groups its timings by it) */
+int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_src_t* ysrc, char* buf, size_t n);
+int mt_conv3d_bwd_data_strided_kernel_name(const mt_conv3d_t* p, char* buf, size_t n);
 
 /* ---- backward-weight -------------------------------------------------------------------------
  * dW[tap][ci][co] = sum_{n,o} X[n, o*S + t - P, ci] * Y[n, o, co]   (autograd of nn.Conv3d /
@@ -238,6 +242,11 @@ int mt_head_flip_accumulate(const mt_pointwise_t* p, int sample, int flipD, int 
 int mt_head_mirror_accumulate(const mt_pointwise_t* p, int sample0, int nsamples, const int32_t* flips, int nonlin, float weight,
                               const float* gauss, float* agg, float* nb, long aX, long aY, long aZ, int x0, int y0, int z0,
                               mt_stream_t stream);
+/* The network batch of a group of tiles, mirror flips included, straight from the (padded) volume vol[C][X][Y][Z]:
+ * out[k][C][D][H][W] = tile k at origin (x0,y0,z0) read through the reflections in `flips` (bit 0 D, bit 1 H, bit 2 W) —
+ * `x = torch.flip(x, axes)` of neural_network.py:531-586 as index arithmetic.  desc: HOST array of ntiles x (x0, y0, z0, flips). */
+int mt_extract_tiles(const float* vol, int C, long X, long Y, long Z, float* out, int ntiles, int D, int H, int W,
+                     const int32_t* desc, mt_stream_t stream);
 /* agg[c, tile] += acc * gauss ; nb[tile] += gauss   (neural_network.py:388-394) */
 int mt_tile_accumulate(const float* acc, const float* gauss, int C, int D, int H, int W, float* agg,
                        float* nb, long aX, long aY, long aZ, int x0, int y0, int z0, mt_stream_t stream);

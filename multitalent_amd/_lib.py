@@ -71,6 +71,8 @@ SIGNATURES = {
     'mt_conv3d_pack_layout': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_bwd_data_strided_pack_layout': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_kernel_name': (_i, [_P(mt_conv3d_t), C.c_char_p, _sz]),
+    'mt_conv3d_bwd_weight_kernel_name': (_i, [_P(mt_conv3d_t), _P(mt_src_t), C.c_char_p, _sz]),
+    'mt_conv3d_bwd_data_strided_kernel_name': (_i, [_P(mt_conv3d_t), C.c_char_p, _sz]),
     'mt_conv3d_bwd_weight_workspace': (_sz, [_P(mt_conv3d_t)]),
     'mt_conv3d_bwd_weight': (_i, [_P(mt_conv3d_t), _P(mt_src_t), _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp]),
     'mt_pointwise_fwd': (_i, [_P(mt_pointwise_t), _vp]),
@@ -97,6 +99,7 @@ SIGNATURES = {
     'mt_resample_classify': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _l, _l, _l, _i, _i, _i, _vp]),
     'mt_head_flip_accumulate': (_i, [_P(mt_pointwise_t), _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),
     'mt_head_mirror_accumulate': (_i, [_P(mt_pointwise_t), _i, _i, _vp, _i, _f, _vp, _vp, _vp, _l, _l, _l, _i, _i, _i, _vp]),
+    'mt_extract_tiles': (_i, [_vp, _i, _l, _l, _l, _vp, _i, _i, _i, _i, _vp, _vp]),
     'mt_tile_accumulate': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _l, _l, _l, _i, _i, _i, _vp]),
     'mt_normalize_threshold': (_i, [_vp, _vp, _i, _l, _vp, _i, _vp, _vp]),
     'mt_ncdhw_to_ndhwc': (_i, [_vp, _vp, _i, _i, _l, _i, _vp]),

@@ -2304,6 +2304,14 @@ extern "C" int mt_conv3d_bwd_data_strided_supported(const mt_conv3d_t* p) {
   if ((double)p->Di * p->Hi * p->Wi * p->ocs0 * 4.0 >= 2147483648.0) return 0;
   return 1;
 }
+extern "C" int mt_conv3d_bwd_data_strided_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) {
+  if (p == nullptr || buf == nullptr || n == 0 || !mt_conv3d_bwd_data_strided_supported(p)) return MT_EINVAL;
+  const mt_src_t& s0 = p->src[0];
+  const bool v2 = !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7));
+  if (bwdd_strided_use_bf16(p)) snprintf(buf, n, "conv_bwdd_strided_kernel<%d, 2, 2, 2, true>", p->SD);
+  else snprintf(buf, n, "conv_bwdd_strided_kernel<%d, 2, 2, %d>", p->SD, v2 ? 2 : 1);
+  return MT_OK;
+}
 extern "C" int mt_conv3d_bwd_data_strided(const mt_conv3d_t* p, mt_stream_t stream) {
   MT_REQUIRE(p != nullptr, "bwd_data_strided: null params");
   MT_REQUIRE(mt_conv3d_bwd_data_strided_supported(p), "bwd_data_strided: unsupported geometry (needs 3x3x3, pad 1, stride (1|2,2,2), one source)");
@@ -3409,6 +3417,28 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
     if (stem > generic) generic = stem;
   }
   return generic;
+}
+
+extern "C" int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_src_t* ysrc, char* buf, size_t n) {
+  if (p == nullptr || ysrc == nullptr || buf == nullptr || n == 0) return MT_EINVAL;
+  const char* e = getenv("MT_BWDW_FAST");
+  const int use_fast = e ? atoi(e) : 1;
+  if (use_fast && bwdw_is_stem(p, ysrc)) { snprintf(buf, n, "conv_bwdw_stem_kernel"); return MT_OK; }
+  const int geo = use_fast ? bwdw_fast_geo(p, ysrc) : -1;
+  if (geo < 0) { snprintf(buf, n, "conv_bwdw_kernel"); return MT_OK; }
+  if (geo == 0) {
+    if (bwdw_use_bf16(p)) snprintf(buf, n, "conv_bwdw_wino_bf16_kernel<3>");
+    else if (bwdw_use_wino(p)) snprintf(buf, n, "conv_bwdw_wino_kernel<2>");
+    else if (bwdw_use_march(p)) snprintf(buf, n, "conv_bwdw_march_kernel<3, 3, 1, 1>");
+    else snprintf(buf, n, "conv_bwdw_fast_kernel<3, 3, 3, 1, 1, 1>");
+    return MT_OK;
+  }
+  if (geo == 6 && bwdw_use_bf16_133(p)) { snprintf(buf, n, "conv_bwdw_wino_bf16_kernel<1>"); return MT_OK; }
+  static const char* kGeo[9] = {"", "3, 3, 3, 2, 2, 2", "3, 3, 3, 1, 2, 2", "2, 2, 2, 2, 2, 2", "1, 2, 2, 1, 2, 2", "1, 1, 1, 1, 1, 1",
+                                "1, 3, 3, 1, 1, 1", "1, 1, 1, 2, 2, 2", "1, 1, 1, 1, 2, 2"};
+  if (geo > 8) return MT_EINVAL;
+  snprintf(buf, n, "conv_bwdw_fast_kernel<%s>", kGeo[geo]);
+  return MT_OK;
 }
 
 extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, float* dw, long s_ci, long s_co,

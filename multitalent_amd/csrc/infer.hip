@@ -194,3 +194,38 @@ extern "C" int mt_resample_classify(const float* probs, int C, int D, int H, int
   MT_CHECK_LAUNCH("resample_classify");
   return MT_OK;
 }
+
+// ---- tile extraction with mirror flips (neural_network.py:531-586: torch.flip(x, axes) per mirror combination) ---------------
+// out[k][c][d][h][w] = vol[c][x0_k + fd(d)][y0_k + fh(h)][z0_k + fw(w)],  f(i) = flip ? size-1-i : i.  One launch builds the whole
+// network batch (all mirror combinations of up to 8 tiles) straight from the volume: the flips are index arithmetic, the
+// torch.flip / torch.cat / .contiguous() copies of the reference's loop never exist.
+struct ExtractDesc { int n; int x0[64], y0[64], z0[64], fl[64]; };
+__global__ __launch_bounds__(256) void extract_tiles_kernel(const float* __restrict__ vol, int C, long X, long Y, long Z,
+                                                            float* __restrict__ out, int D, int H, int W, ExtractDesc ds) {
+  const int k = blockIdx.z;
+  const int c = blockIdx.y / D, d = blockIdx.y % D;
+  const int fl = ds.fl[k];
+  const int sd = (fl & 1) ? D - 1 - d : d;
+  const float* src = vol + ((size_t)c * X + ds.x0[k] + sd) * (size_t)Y * Z;
+  float* dst = out + (((size_t)k * C + c) * D + d) * (size_t)H * W;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < H * W; e += gridDim.x * 256) {
+    const int h = e / W, w = e - h * W;
+    const int sh = (fl & 2) ? H - 1 - h : h, sw = (fl & 4) ? W - 1 - w : w;
+    dst[e] = src[(size_t)(ds.y0[k] + sh) * Z + ds.z0[k] + sw];
+  }
+}
+extern "C" int mt_extract_tiles(const float* vol, int C, long X, long Y, long Z, float* out, int ntiles, int D, int H, int W,
+                                const int32_t* desc, mt_stream_t stream) {
+  MT_REQUIRE(vol && out && desc && C > 0 && ntiles > 0 && ntiles <= 64 && D > 0 && H > 0 && W > 0, "extract_tiles: bad args (ntiles <= 64)");
+  ExtractDesc ds;
+  ds.n = ntiles;
+  for (int k = 0; k < ntiles; ++k) {
+    ds.x0[k] = desc[4 * k]; ds.y0[k] = desc[4 * k + 1]; ds.z0[k] = desc[4 * k + 2]; ds.fl[k] = desc[4 * k + 3];
+    MT_REQUIRE(ds.x0[k] >= 0 && ds.y0[k] >= 0 && ds.z0[k] >= 0 && ds.x0[k] + D <= X && ds.y0[k] + H <= Y && ds.z0[k] + W <= Z,
+               "extract_tiles: tile %d leaves the volume", k);
+  }
+  int bx = mt_cdiv((long)H * W, 256 * 4); if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(extract_tiles_kernel, dim3(bx, C * D, ntiles), dim3(256), 0, (hipStream_t)stream, vol, C, X, Y, Z, out, D, H, W, ds);
+  MT_CHECK_LAUNCH("extract_tiles");
+  return MT_OK;
+}

@@ -22,8 +22,18 @@ def predict_case_on_device(network, cropped_data, properties, target_spacing, in
     properties = dict(properties)
     properties['size_after_resampling'] = tuple(int(i) for i in x.shape[1:])
     properties['spacing_after_resampling'] = np.array(target_spacing)
-    _, probs = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
-                          'constant', None, True, verbose, True, tile_shard=tile_shard, return_device_tensors=True)
+    if tile_shard is not None and tile_shard[1] > 1:
+        # tiles sharded over the ranks; the export below needs whole x-columns of the probabilities, so the slabs are gathered
+        # (every rank then holds the full result)
+        from .sliding_window import gather_slabs
+        _, slab, x_range = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
+                                      'constant', None, True, verbose, True, tile_shard=tile_shard, return_device_tensors=True)
+        import torch
+        dummy = torch.empty((slab.shape[1],) + tuple(slab.shape[2:]), dtype=torch.int32, device=slab.device)
+        _, probs = gather_slabs(dummy, slab, x_range, int(x.shape[1]), tile_shard[1])
+    else:
+        _, probs = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
+                              'constant', None, True, verbose, True, return_device_tensors=True)
     # the reference transposes the probabilities back before the export matches them to size_after_cropping / crop_bbox
     # (predict_MultiTalent.py:238-240: softmax.transpose([0] + [i + 1 for i in transpose_backward]))
     if transpose_backward is None:

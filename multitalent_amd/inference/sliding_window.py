@@ -6,9 +6,9 @@ mt_flip_accumulate (fused with sigmoid/softmax and the 1/8 mean), the Gaussian-w
 into an aggregate that lives in HBM for the whole volume (the reference copies every 333 MB tile to the host and adds it
 in numpy), and the final divide + threshold/argmax is one kernel.  Accumulation order per voxel is the reference's
 (tiles in x -> y -> z loop order, fp32), so probabilities agree to rounding and masks bit-exactly away from ties.
-With tile sharding (rank, world) each process handles a contiguous run of tiles and the aggregates are summed with one
-RCCL all_reduce — functionality the reference does not have (it only strides CASES across processes,
-predict_MultiTalent.py:362)."""
+With tile sharding (rank, world) each process handles a contiguous run of tiles, holds only the x range its tiles touch, owns
+one x-slab of the result and exchanges only the zones where neighbouring ranks' tiles overlap (point-to-point over RCCL) —
+functionality the reference does not have (it only strides CASES across processes, predict_MultiTalent.py:362)."""
 import os
 
 import numpy as np
@@ -81,7 +81,9 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
                regions_class_order=None, use_gaussian=False, pad_border_mode="constant", pad_kwargs=None, all_in_gpu=False,
                verbose=True, mixed_precision=True, tile_shard=None, return_device_tensors=False):
     """Signature of SegmentationNetwork.predict_3D (neural_network.py:73-76) + `tile_shard=(rank, world)`.
-    x: np.ndarray [C, X, Y, Z].  Returns (seg [X,Y,Z], probabilities [num_classes, X, Y, Z]) as numpy."""
+    x: np.ndarray [C, X, Y, Z].  Returns (seg [X,Y,Z], probabilities [num_classes, X, Y, Z]) as numpy.
+    With tile_shard and return_device_tensors=True: (seg slab, probabilities slab, (x0, x1)) — this rank's rows [x0, x1) of the
+    result, left on its device (the per-voxel export stage works on slabs)."""
     assert step_size <= 1, 'step_size must be smaller than 1. Otherwise there will be a gap between consecutive predictions'
     pad_kwargs = {'constant_values': 0} if pad_kwargs is None else pad_kwargs
     if len(mirror_axes):
@@ -135,58 +137,63 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
     mult = gaussian if (use_gaussian and num_tiles > 1) else None          # neural_network.py:384-386
 
     vol = data.contiguous() if torch.is_tensor(data) else torch.from_numpy(np.ascontiguousarray(data)).to(dev)   # [C, X, Y, Z]
-    V = int(np.prod(shp[1:]))
-    # The aggregates (25 GB for 47 classes at 512^3) are kept on the network between calls: allocating and freeing them per volume
-    # costs a device malloc of that size each time (0.3-1 s, varying from box to box — it dominated the un-mirrored timings).
-    # With return_device_tensors=True the returned probabilities alias this cache until the next call.
-    key = (num_classes, tuple(shp[1:]), patch_size, str(dev))
-    cache = getattr(net, '_sliding_window_cache', None)
-    if cache is None or cache[0] != key:
-        net._sliding_window_cache = None
-        cache = (key, torch.empty((num_classes,) + tuple(shp[1:]), dtype=torch.float32, device=dev),
-                 torch.empty(tuple(shp[1:]), dtype=torch.float32, device=dev),
-                 torch.empty((num_classes,) + patch_size, dtype=torch.float32, device=dev))
-        net._sliding_window_cache = cache
-    _, agg, nb, acc = cache
-    agg.zero_(); nb.zero_()
     if do_mirroring:
         combos = [(), (2,), (1,), (2, 1), (0,), (2, 0), (1, 0), (2, 1, 0)]          # neural_network.py:531-586 order
         combos = [c for c in combos if all(a in mirror_axes for a in c)]
         num_results = 2 ** len(mirror_axes)
     else:
         combos, num_results = [()], 1
-    eng = net.engine()
     tiles = [(xs, ys, zs) for xs in steps[0] for ys in steps[1] for zs in steps[2]]
-    if tile_shard is not None:
+    X = shp[1]
+    if tile_shard is not None and tile_shard[1] > 1:
         rank, world = tile_shard
-        per = (len(tiles) + world - 1) // world
-        tiles = tiles[rank * per:(rank + 1) * per]           # contiguous run keeps the per-voxel order of the reference
+        plan = shard_plan(tiles, patch_size[0], X, world)
+        tiles = plan['tiles'][rank]
+        x_lo, x_hi = plan['local'][rank]                    # x range of the aggregate this rank holds while it works
+    else:
+        rank, world, plan = 0, 1, None
+        x_lo, x_hi = 0, X
+    # The aggregates (25 GB for 47 classes at 512^3) are kept on the network between calls: allocating and freeing them per volume
+    # costs a device malloc of that size each time (0.3-1 s, varying from box to box — it dominated the un-mirrored timings).
+    # With return_device_tensors=True the returned probabilities alias this cache until the next call.
+    local_shape = (x_hi - x_lo,) + tuple(shp[2:])
+    group = max(1, 8 // len(combos))
+    key = (num_classes, local_shape, patch_size, str(dev), vol.shape[0], group * len(combos))
+    cache = getattr(net, '_sliding_window_cache', None)
+    if cache is None or cache[0] != key:
+        net._sliding_window_cache = None
+        cache = (key, torch.empty((num_classes,) + local_shape, dtype=torch.float32, device=dev),
+                 torch.empty(local_shape, dtype=torch.float32, device=dev),
+                 torch.empty((num_classes,) + patch_size, dtype=torch.float32, device=dev),
+                 torch.empty((group * len(combos), vol.shape[0]) + patch_size, dtype=torch.float32, device=dev))
+        net._sliding_window_cache = cache
+    _, agg, nb, acc, batch_buf = cache
+    agg.zero_(); nb.zero_()
+    eng = net.engine()
     was_training = net.training
     with torch.no_grad():
         # all mirrored versions of a tile — and several consecutive tiles — go through the network as ONE batch (per-sample
         # results do not depend on the batch, and the aggregate is still updated tile by tile in the reference's x -> y -> z
-        # order with the reference's mirror order inside a tile): up to 8x larger grids on the low-resolution stages
-        group = max(1, 8 // len(combos))
+        # order with the reference's mirror order inside a tile): up to 8x larger grids on the low-resolution stages.  The
+        # batch is cut out of the volume by ONE kernel with the flips folded into its index arithmetic (mt_extract_tiles).
         fuse_head = num_classes <= 64 and os.environ.get('MT_INFER_FUSED_HEAD', '1') != '0'
         for g0 in range(0, len(tiles), group):
             chunk = tiles[g0:g0 + group]
-            inp = []
-            for (xs, ys, zs) in chunk:
-                tile = vol[None, :, xs:xs + patch_size[0], ys:ys + patch_size[1], zs:zs + patch_size[2]]
-                inp += [torch.flip(tile, tuple(a + 2 for a in c)) if len(c) else tile for c in combos]
-            batch = torch.cat(inp, 0).contiguous()
+            desc = [(t, (0 in c, 1 in c, 2 in c)) for t in chunk for c in combos]
+            batch = ops.extract_tiles(vol, patch_size, desc, batch_buf[:len(desc)])
             if fuse_head:
                 # head + nonlinearity + un-flip + accumulation in one kernel per sample: the logits never reach HBM
                 hp = eng.forward_to_final_head(batch)
             else:
                 logits = eng.forward(batch, need_grad=False, all_heads=False)[0]                      # [B, D, H, W, C]
             for t, (xs, ys, zs) in enumerate(chunk):
+                origin = (xs - x_lo, ys, zs)
                 if fuse_head and len(combos) > 1:
                     # every mirror combination of the tile, the Gaussian and the overlap-add in one launch (the sum over the
                     # combinations stays in registers).  Without mirroring the two-kernel form below is faster (47.4 vs 43.0
                     # volumes/min in bf16): its streaming overlap-add beats 128-byte read-modify-writes from the MFMA epilogue.
                     ops.head_mirror_accumulate(hp, t * len(combos), [(0 in c, 1 in c, 2 in c) for c in combos], nonlin,
-                                               1.0 / num_results, mult, agg, nb, shp[1:], (xs, ys, zs))
+                                               1.0 / num_results, mult, agg, nb, local_shape, origin)
                     continue
                 for i, c in enumerate(combos):
                     k = t * len(combos) + i
@@ -194,24 +201,138 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
                         ops.head_flip_accumulate(hp, k, (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
                     else:
                         ops.flip_accumulate(Act(logits[k:k + 1]), (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
-                ops.tile_accumulate(acc, mult, num_classes, patch_size, agg, nb, shp[1:], (xs, ys, zs))
-    if tile_shard is not None and tile_shard[1] > 1:
-        import torch.distributed as dist
-        dist.all_reduce(agg)
-        dist.all_reduce(nb)
-    seg = torch.empty(tuple(shp[1:]), dtype=torch.int32, device=dev)
-    if regions_class_order is not None:
-        order = torch.tensor([int(c) for c in regions_class_order], dtype=torch.int32, device=dev)
-        ops.normalize_threshold(agg, nb, num_classes, V, order, True, seg)
+                ops.tile_accumulate(acc, mult, num_classes, patch_size, agg, nb, local_shape, origin)
+    if plan is not None:
+        # slab ownership: every rank ends with the finished aggregate of ITS x-slab; only the zones where neighbouring ranks'
+        # tiles overlap travel (partial sums, added in rank order = the reference's tile order at rank granularity)
+        agg, nb = exchange_slabs(agg, nb, plan, rank, world)
+        o_lo, o_hi = plan['owned'][rank]
     else:
-        ops.normalize_threshold(agg, nb, num_classes, V, None, False, seg)
-    sl = (slice(None),) + tuple(slicer[1:])
-    probs = agg[sl]
-    seg = seg[tuple(slicer[1:])]
+        o_lo, o_hi = 0, X
+    Vs = int((o_hi - o_lo) * shp[2] * shp[3])
+    seg = torch.empty((o_hi - o_lo,) + tuple(shp[2:]), dtype=torch.int32, device=dev)
+    if Vs > 0:
+        if regions_class_order is not None:
+            order = torch.tensor([int(c) for c in regions_class_order], dtype=torch.int32, device=dev)
+            ops.normalize_threshold(agg, nb, num_classes, Vs, order, True, seg)
+        else:
+            ops.normalize_threshold(agg, nb, num_classes, Vs, None, False, seg)
+    # crop the padding (neural_network.py:397-401); in sharded mode the x crop is intersected with the owned slab
+    sx = slicer[1]
+    c_lo, c_hi = max(sx.start, o_lo), max(min(sx.stop, o_hi), max(sx.start, o_lo))
+    sl = (slice(c_lo - o_lo, c_hi - o_lo),) + tuple(slicer[2:])
+    probs = agg[(slice(None),) + sl]
+    seg = seg[sl]
     if was_training:
         net.train()
-    if return_device_tensors:
+    if plan is not None:
+        x_range = (c_lo - sx.start, c_hi - sx.start)         # rows of the UNPADDED volume this rank's slab holds
+        if return_device_tensors:
+            return seg, probs, x_range
+        seg, probs = gather_slabs(seg, probs, x_range, sx.stop - sx.start, world)
+    elif return_device_tensors:
         return seg, probs
     seg_np = seg.cpu().numpy()
     seg_np = seg_np.astype(np.float32) if regions_class_order is not None else seg_np.astype(np.int64)
     return seg_np, probs.cpu().numpy()
+
+
+# ---- multi-GPU tile sharding: slab ownership + boundary exchange ---------------------------------------------------------------
+def shard_plan(tiles, patch_x, X, world):
+    """Contiguous runs of the reference-ordered tile list (x slowest) per rank; rank r then touches the x range
+    [lo_r, hi_r) and OWNS the slab [b_r, b_{r+1}) with b_r in the middle of the zone it shares with rank r-1.  Pure function of
+    its arguments, so every rank computes the same plan.  Returns tiles / touched / owned / local (= touched U owned) per rank."""
+    per = (len(tiles) + world - 1) // world
+    runs = [tiles[r * per:(r + 1) * per] for r in range(world)]
+    touched, prev_hi = [], 0
+    for run in runs:
+        if run:
+            lo, hi = min(t[0] for t in run), max(t[0] for t in run) + patch_x
+        else:
+            lo = hi = prev_hi
+        touched.append((lo, hi))
+        prev_hi = max(prev_hi, hi)
+    b = [0]
+    for r in range(1, world):
+        mid = (touched[r][0] + touched[r - 1][1]) // 2 if runs[r] else X
+        b.append(min(max(mid, b[-1]), X))
+    b.append(X)
+    owned = [(b[r], b[r + 1]) for r in range(world)]
+    local = [(min(t[0], o[0]) if o[1] > o[0] else t[0], max(t[1], o[1]) if o[1] > o[0] else t[1]) for t, o in zip(touched, owned)]
+    return {'tiles': runs, 'touched': touched, 'owned': owned, 'local': local}
+
+
+def _intersect(a, b):
+    lo, hi = max(a[0], b[0]), min(a[1], b[1])
+    return (lo, hi) if hi > lo else None
+
+
+def exchange_slabs(agg, nb, plan, rank, world):
+    """agg [C, local x, Y, Z], nb [local x, Y, Z] (partial sums over this rank's tiles) -> finished (agg, nb) of the owned slab.
+    Rank r sends to every q != r the part of its TOUCHED range that q owns (in practice: the half-patch zones shared with its two
+    neighbours — 2 x 47 x 24 x 512 x 512 floats at 512^3 instead of the 25 GB aggregate) and folds what it receives into its own
+    slab in ascending rank order, starting from zeros, so the result does not depend on arrival order."""
+    import torch.distributed as dist
+    l_lo = plan['local'][rank][0]
+    own = plan['owned'][rank]
+    via_host = agg.is_cuda and dist.get_backend() == 'gloo'      # two ranks on one GPU in the tests: transport through the host
+    sends, recvs, ops_list = [], {}, []
+    for q in range(world):
+        if q == rank:
+            continue
+        out_rng = _intersect(plan['touched'][rank], plan['owned'][q])
+        if out_rng is not None:
+            a = agg[:, out_rng[0] - l_lo:out_rng[1] - l_lo].contiguous()
+            n = nb[out_rng[0] - l_lo:out_rng[1] - l_lo].contiguous()
+            if via_host:
+                a, n = a.cpu(), n.cpu()
+            sends.append((q, a, n))
+        in_rng = _intersect(plan['touched'][q], own)
+        if in_rng is not None:
+            shape = (in_rng[1] - in_rng[0],) + tuple(nb.shape[1:])
+            dev = 'cpu' if via_host else agg.device
+            recvs[q] = (in_rng, torch.empty((agg.shape[0],) + shape, dtype=torch.float32, device=dev),
+                        torch.empty(shape, dtype=torch.float32, device=dev))
+    for q, a, n in sends:
+        ops_list += [dist.P2POp(dist.isend, a, q), dist.P2POp(dist.isend, n, q)]
+    for q, (_, a, n) in recvs.items():
+        ops_list += [dist.P2POp(dist.irecv, a, q), dist.P2POp(dist.irecv, n, q)]
+    if ops_list:
+        for w in dist.batch_isend_irecv(ops_list):
+            w.wait()
+    fa = torch.zeros((agg.shape[0], own[1] - own[0]) + tuple(nb.shape[1:]), dtype=torch.float32, device=agg.device)
+    fn = torch.zeros((own[1] - own[0],) + tuple(nb.shape[1:]), dtype=torch.float32, device=agg.device)
+    for q in range(world):
+        if q == rank:
+            rng = _intersect(plan['local'][rank], own)
+            if rng is not None:
+                fa[:, rng[0] - own[0]:rng[1] - own[0]] += agg[:, rng[0] - l_lo:rng[1] - l_lo]
+                fn[rng[0] - own[0]:rng[1] - own[0]] += nb[rng[0] - l_lo:rng[1] - l_lo]
+        elif q in recvs:
+            rng, a, n = recvs[q]
+            fa[:, rng[0] - own[0]:rng[1] - own[0]] += a.to(agg.device)
+            fn[rng[0] - own[0]:rng[1] - own[0]] += n.to(agg.device)
+    return fa, fn
+
+
+def gather_slabs(seg, probs, x_range, X, world):
+    """the per-rank slabs -> the whole (seg, probs) on every rank (API mode; the bench leaves the result sharded)."""
+    import torch.distributed as dist
+    dev = seg.device
+    via_host = seg.is_cuda and dist.get_backend() == 'gloo'
+    ranges = [None] * world
+    dist.all_gather_object(ranges, tuple(int(i) for i in x_range))
+    full_seg = torch.empty((X,) + tuple(seg.shape[1:]), dtype=seg.dtype, device=dev)
+    full_probs = torch.empty((probs.shape[0], X) + tuple(probs.shape[2:]), dtype=probs.dtype, device=dev)
+    for q, (a, b) in enumerate(ranges):
+        if b <= a:
+            continue
+        s = seg.contiguous() if q == dist.get_rank() else torch.empty((b - a,) + tuple(seg.shape[1:]), dtype=seg.dtype, device=dev)
+        p = probs.contiguous() if q == dist.get_rank() else torch.empty((probs.shape[0], b - a) + tuple(probs.shape[2:]), dtype=probs.dtype, device=dev)
+        if via_host:
+            s, p = s.cpu(), p.cpu()
+        dist.broadcast(s, q)
+        dist.broadcast(p, q)
+        full_seg[a:b] = s.to(dev)
+        full_probs[:, a:b] = p.to(dev)
+    return full_seg, full_probs

@@ -28,11 +28,13 @@ class SegmentationNetwork(NeuralNetwork):
 
     def predict_3D(self, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=False, step_size=0.5,
                    patch_size=None, regions_class_order=None, use_gaussian=False, pad_border_mode="constant",
-                   pad_kwargs=None, all_in_gpu=False, verbose=True, mixed_precision=True):
+                   pad_kwargs=None, all_in_gpu=False, verbose=True, mixed_precision=True, tile_shard=None,
+                   return_device_tensors=False):
+        """Reference signature (neural_network.py:73-76) + the two keyword extensions of inference.sliding_window.predict_3D."""
         from ..inference.sliding_window import predict_3D
         return predict_3D(self, x, do_mirroring, mirror_axes, use_sliding_window, step_size, patch_size,
                           regions_class_order, use_gaussian, pad_border_mode, pad_kwargs, all_in_gpu, verbose,
-                          mixed_precision)
+                          mixed_precision, tile_shard=tile_shard, return_device_tensors=return_device_tensors)
 
     @staticmethod
     def _compute_steps_for_sliding_window(patch_size, image_size, step_size):

@@ -191,6 +191,19 @@ def conv_kernel_name(p):
     return buf.value.decode()
 
 
+def conv_bwd_weight_kernel_name(p, y):
+    buf = C.create_string_buffer(128)
+    ys = y.src()
+    _lib.check(_lib.load().mt_conv3d_bwd_weight_kernel_name(C.byref(p), C.byref(ys), buf, 128), 'conv3d_bwd_weight_kernel_name')
+    return buf.value.decode()
+
+
+def conv_bwd_data_strided_kernel_name(p):
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.load().mt_conv3d_bwd_data_strided_kernel_name(C.byref(p), buf, 128), 'conv3d_bwd_data_strided_kernel_name')
+    return buf.value.decode()
+
+
 def conv_stats_blocks(p):
     return _lib.load().mt_conv3d_stats_blocks(C.byref(p))
 
@@ -409,6 +422,19 @@ def head_mirror_accumulate(p, sample0, flips, nonlin, weight, gauss, agg, nb, ag
     _lib.check(_lib.load().mt_head_mirror_accumulate(C.byref(p), int(sample0), len(flips), C.cast(fl, C.c_void_p), int(nonlin), float(weight),
                                                      _ptr(gauss), _ptr(agg), _ptr(nb), agg_shape[0], agg_shape[1], agg_shape[2],
                                                      origin[0], origin[1], origin[2], _stream()), 'head_mirror_accumulate')
+
+
+def extract_tiles(vol, patch, tiles, out):
+    """vol [C,X,Y,Z] device tensor; tiles: list of ((x0,y0,z0), (fD,fH,fW)); out [len(tiles), C, *patch] — see mt_extract_tiles."""
+    _check_dev(vol, out)
+    assert vol.is_contiguous() and out.is_contiguous() and vol.dtype == torch.float32 and out.dtype == torch.float32
+    flat = []
+    for (x0, y0, z0), f in tiles:
+        flat += [int(x0), int(y0), int(z0), int(f[0]) | (int(f[1]) << 1) | (int(f[2]) << 2)]
+    desc = (C.c_int32 * len(flat))(*flat)
+    _lib.check(_lib.load().mt_extract_tiles(_ptr(vol), vol.shape[0], vol.shape[1], vol.shape[2], vol.shape[3], _ptr(out), len(tiles),
+                                            patch[0], patch[1], patch[2], C.cast(desc, C.c_void_p), _stream()), 'extract_tiles')
+    return out
 
 
 def tile_accumulate(acc, gauss, Cn, patch, agg, nb, agg_shape, origin):

@@ -183,3 +183,46 @@ def test_grad_allreducer_on_rccl(dev):
 def test_grad_allreducer_device_tensors_world2(dev):
     """same, on whatever transport the box offers (gloo through the host on a one-GPU box)."""
     assert all(run_world_gpu(_reducer_rccl))
+
+
+def _sharded_inference(rank, world, dev):
+    """predict_3D with tile_shard=(rank, world): slab ownership + boundary exchange == the unsharded run of the same process
+    (probabilities to fp32 rounding of a re-associated sum, masks identical away from ties) == the real reference's output."""
+    from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
+    z = dict(np.load(os.path.join(G, 'sliding_window.npz')))
+    pools, kernels = [[2, 2, 2], [1, 2, 2]], [[3, 3, 3]] * 3
+    net = Generic_UNet(1, 6, 5, 2, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                       {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True}, True, False,
+                       lambda x: x, None, pools, kernels, False, True, True)
+    net.load_state_dict({k[len('mt/sd/'):]: torch.from_numpy(v) for k, v in z.items() if k.startswith('mt/sd/')})
+    net.to(dev)
+    net.inference_apply_nonlin = nn.Sigmoid()
+    net.eval(); net.do_ds = False
+    worst = 0.0
+    for mirror in (True, False):
+        kw = dict(do_mirroring=mirror, mirror_axes=(0, 1, 2), use_sliding_window=True, step_size=0.5, patch_size=(8, 16, 16),
+                  regions_class_order=[3, 1, 4, 2, 5], use_gaussian=True, pad_border_mode='constant', pad_kwargs={'constant_values': 0},
+                  all_in_gpu=False, verbose=False, mixed_precision=False)
+        seg1, p1 = net.predict_3D(z['mt/vol'], **kw)
+        net._sliding_window_cache = None
+        segs, ps = net.predict_3D(z['mt/vol'], tile_shard=(rank, world), **kw)
+        net._sliding_window_cache = None
+        assert ps.shape == p1.shape and segs.shape == seg1.shape
+        d = float(np.abs(ps - p1).max())
+        worst = max(worst, d)
+        assert d < 2e-6, d
+        safe = (np.abs(p1 - 0.5) > 1e-5).all(0)
+        assert np.array_equal(segs[safe], seg1[safe])
+        ref_p, ref_s = z['mt/probs_m%d' % int(mirror)], z['mt/seg_m%d' % int(mirror)]
+        assert np.abs(ps - ref_p).max() < 1e-4
+        safe = (np.abs(ref_p - 0.5) > 1e-4).all(0)
+        assert np.array_equal(segs[safe].astype(np.int16), ref_s[safe])
+    return worst
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_sharded_inference_matches_unsharded_and_reference(dev, world):
+    if torch.cuda.device_count() >= 2 and torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs or exactly one" % world)
+    res = run_world_gpu(_sharded_inference, world)
+    assert all(r < 2e-6 for r in res)

@@ -136,3 +136,41 @@ def test_dbs_with_more_ranks_than_samples_is_rejected():
             nnUNetTrainerV2_DDP.set_batch_size_and_oversample(t)
     finally:
         dist.get_world_size, dist.get_rank = orig
+
+
+def test_tile_shard_plan_partitions_the_volume():
+    """inference/sliding_window.shard_plan (pure function, identical on every rank): contiguous tile runs, owned slabs partition
+    [0, X), every tile lies inside its rank's local range, and every contribution to an owned slab is either local or inside
+    exactly the zones exchange_slabs ships (touched_q intersect owned_r)."""
+    from multitalent_amd.inference.sliding_window import _intersect, compute_steps_for_sliding_window, shard_plan
+    rng = np.random.RandomState(3)
+    for _ in range(300):
+        patch = tuple(int(i) for i in rng.randint(4, 40, 3))
+        img = tuple(int(p + rng.randint(0, 120)) for p in patch)
+        world = int(rng.randint(1, 9))
+        steps = compute_steps_for_sliding_window(patch, img, float(rng.choice([0.5, 0.3, 1.0])))
+        tiles = [(a, b, c) for a in steps[0] for b in steps[1] for c in steps[2]]
+        plan = shard_plan(tiles, patch[0], img[0], world)
+        assert sum(plan['tiles'], []) == tiles
+        assert plan['owned'][0][0] == 0 and plan['owned'][-1][1] == img[0]
+        for r in range(world):
+            assert plan['owned'][r][0] <= plan['owned'][r][1]
+            if r:
+                assert plan['owned'][r][0] == plan['owned'][r - 1][1]
+            for t in plan['tiles'][r]:
+                assert plan['local'][r][0] <= t[0] and t[0] + patch[0] <= plan['local'][r][1]
+                assert plan['touched'][r][0] <= t[0] and t[0] + patch[0] <= plan['touched'][r][1]
+        # contributions: voxel row x of owner r receives from rank q iff some tile of q covers x; that row must be inside
+        # touched_q intersect owned_r (shipped) or q == r (local)
+        for r in range(world):
+            for q in range(world):
+                rows = set()
+                for t in plan['tiles'][q]:
+                    rows |= set(range(max(t[0], plan['owned'][r][0]), min(t[0] + patch[0], plan['owned'][r][1])))
+                if not rows:
+                    continue
+                if q == r:
+                    assert plan['local'][r][0] <= min(rows) and max(rows) < plan['local'][r][1]
+                else:
+                    z = _intersect(plan['touched'][q], plan['owned'][r])
+                    assert z is not None and z[0] <= min(rows) and max(rows) < z[1]

@@ -127,3 +127,57 @@ def test_sliding_window_predict_3d_vs_reference(dev):
                 safe = (np.abs(ref_p - 0.5) > 1e-4).all(0)
             assert np.array_equal(seg[safe].astype(np.int16), ref_s[safe])      # bit-exact masks away from ties
             assert safe.mean() > 0.99
+
+
+def test_plain_unet_nonuniform_kernel_sizes(dev):
+    """conv_kernel_sizes [[1,3,3],[3,3,3],[3,3,3],[1,3,3]]: the first decoder stage takes the bottleneck's kernel
+    (generic_UNet.py:338-339).  Logits, loss and every gradient vs the real reference."""
+    from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
+    from multitalent_amd.training.loss_functions.fused_losses import DC_and_CE_DS_loss
+    z = load('plain_unet_aniso.npz')
+    pools, kernels = z['pools'].tolist(), z['kernels'].tolist()
+    net = Generic_UNet(1, 6, 3, 3, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                       {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True}, True, False,
+                       lambda x: x, None, pools, kernels, False, True, True)
+    net.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in z.items() if k.startswith('sd0/')}, strict=True)
+    net.train()
+    x = torch.from_numpy(z['x']).to(dev)
+    tg = [torch.from_numpy(z['target%d' % i]).to(dev) for i in range(3)]
+    out = net(x)
+    for i, o in enumerate(out):
+        assert float((o.detach().cpu() - torch.from_numpy(z['out%d' % i])).abs().max()) < 1e-4
+    l = DC_and_CE_DS_loss(z['weights'], batch_dice=False)(out, tg)
+    assert abs(float(l.detach()) - float(z['loss'])) < 1e-4
+    l.backward()
+    torch.cuda.synchronize()
+    for n, p in net.named_parameters():
+        ref = z['grad0/' + n]
+        assert np.abs(p.grad.cpu().numpy() - ref).max() < 2e-3 * max(np.abs(ref).max(), 1e-3), n
+
+
+def test_sliding_window_volume_smaller_than_patch(dev):
+    """pad_nd_image path (neural_network.py:301): volumes smaller than the patch along one or two axes, odd differences; host and
+    device-resident input."""
+    from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
+    z = load('sliding_window_pad.npz')
+    pools, kernels = [[2, 2, 2], [1, 2, 2]], [[3, 3, 3]] * 3
+    net = Generic_UNet(1, 6, 5, 2, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                       {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True}, True, False,
+                       lambda x: x, None, pools, kernels, False, True, True)
+    net.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith('sd/')})
+    net.to(dev)
+    net.inference_apply_nonlin = nn.Sigmoid()
+    net.eval(); net.do_ds = False
+    for tag in ('a', 'b'):
+        for mirror in (True, False):
+            for on_device in (False, True):
+                vol = torch.from_numpy(z[tag + '/vol']).to(dev) if on_device else z[tag + '/vol']
+                seg, probs = net.predict_3D(vol, do_mirroring=mirror, mirror_axes=(0, 1, 2), use_sliding_window=True, step_size=0.5,
+                                            patch_size=(8, 16, 16), regions_class_order=[3, 1, 4, 2, 5], use_gaussian=True,
+                                            pad_border_mode='constant', pad_kwargs={'constant_values': 0}, all_in_gpu=False,
+                                            verbose=False, mixed_precision=False)
+                ref_p, ref_s = z['%s/probs_m%d' % (tag, int(mirror))], z['%s/seg_m%d' % (tag, int(mirror))]
+                assert probs.shape == ref_p.shape and seg.shape == ref_s.shape
+                assert np.abs(probs - ref_p).max() < 1e-4
+                safe = (np.abs(ref_p - 0.5) > 1e-4).all(0)
+                assert np.array_equal(seg[safe].astype(np.int16), ref_s[safe])

@@ -684,3 +684,26 @@ def test_conv_kernel_equals_stride_gather(dev, N, Cin, Cout, shape, k):
     ops.conv3d_fwd(p)
     torch.cuda.synchronize()
     assert relerr(to_ncdhw(out.cpu() - base), ref) < 1e-5
+
+
+def test_extract_tiles_matches_torch_flip(dev):
+    """mt_extract_tiles: the network batch of several tiles with mirror flips == torch.flip of the slices (neural_network.py:531-586)."""
+    from multitalent_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for Cn in (1, 2):
+        vol = torch.randn((Cn, 21, 37, 45), generator=g).to(dev)
+        patch = (8, 16, 20)
+        tiles = []
+        for i, (o, f) in enumerate([((0, 0, 0), (0, 0, 0)), ((13, 21, 25), (1, 0, 0)), ((5, 7, 9), (0, 1, 1)), ((13, 0, 25), (1, 1, 1)),
+                                     ((1, 2, 3), (0, 0, 1)), ((2, 21, 0), (1, 1, 0))]):
+            tiles.append((o, f))
+        out = torch.full((len(tiles), Cn) + patch, float('nan'), device=dev)
+        ops.extract_tiles(vol, patch, tiles, out)
+        for k, ((x0, y0, z0), f) in enumerate(tiles):
+            ref = vol[:, x0:x0 + patch[0], y0:y0 + patch[1], z0:z0 + patch[2]]
+            axes = tuple(a + 1 for a in range(3) if f[a])
+            if axes:
+                ref = torch.flip(ref, axes)
+            assert torch.equal(out[k], ref), k
+    with pytest.raises(RuntimeError):
+        ops.extract_tiles(vol, patch, [((14, 0, 0), (0, 0, 0))], out[:1])          # leaves the volume
