@@ -1995,11 +1995,13 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
 static int g_bwdw_bf16 = -1;       // -1: read MT_BWDW_BF16 (default 1): bf16 Winograd backward-weight kernel when mt_conv3d_t.mma == 1
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
 static int g_wino_waves = 8;       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
+static int g_wino_persist = 0;     // (measured 4 % SLOWER than one tile per workgroup: profiles/r02_wino_phase_cycles.txt) 8-wave kernel: 1 persistent over spatial tiles (conv_wino8p_kernel), 0 one tile per workgroup, n > 1: at most n workers
 static int g_wino_mode = -1;       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
 extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "conv_wino") == 0) { g_wino_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_wino") == 0) { g_bwdw_wino = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "wino_waves") == 0) { g_wino_waves = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "wino_persist") == 0) { g_wino_persist = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "conv_bf16") == 0) { g_bf16_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_bf16") == 0) { g_bwdw_bf16 = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
@@ -2009,6 +2011,7 @@ static bool conv_wino_ok(const mt_conv3d_t* p) {
   if (g_wino_mode < 0) {
     const char* e = getenv("MT_CONV_WINO"); g_wino_mode = e ? atoi(e) : 1;
     const char* w = getenv("MT_WINO_WAVES"); if (w) g_wino_waves = atoi(w);
+    const char* pe = getenv("MT_WINO_PERSIST"); if (pe) g_wino_persist = atoi(pe);
   }
   const int use = g_wino_mode;
   if (!use) return false;
@@ -2043,6 +2046,25 @@ static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
       hipError_t e = hipFuncSetAttribute((const void*)conv_wino8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l8);
       if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", l8, hipGetErrorString(e)); return MT_EHIP; }
       attr8 = true;
+    }
+    if (g_wino_persist && 5.0 * p->Hi * p->Wi < 1048576.0) {        // packed patch geometry of the persistent kernel: 20-bit offsets
+      static bool attrp = false;
+      static int ncu = 0;
+      if (!attrp) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wino8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(l8 + 11 * 256 * 4));
+        if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", l8, hipGetErrorString(e)); return MT_EHIP; }
+        int devid = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+        attrp = true;
+      }
+      // one resident workgroup per CU (126 KiB of LDS each): NW workers per output-channel tile walk over the spatial tiles
+      const int T = P.nsb * p->N, nct = mt_cdiv(p->Cout, 32);
+      int nw = ncu / nct; if (nw < 1) nw = 1; if (nw > T) nw = T;
+      if (g_wino_persist > 1 && nw > g_wino_persist) nw = g_wino_persist;       // tests: few workers, many tiles each
+      hipLaunchKernelGGL(conv_wino8p_kernel, dim3((unsigned)nw, (unsigned)nct, 1), dim3(512), l8 + 11 * 256 * 4, st, P);   // + the patch-geometry table
+      MT_CHECK_LAUNCH("conv3d_wino8p");
+      return MT_OK;
     }
     hipLaunchKernelGGL(conv_wino8_kernel, grid, dim3(512), l8, st, P);
     MT_CHECK_LAUNCH("conv3d_wino8");
@@ -2187,7 +2209,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   else if (pl.kind == CONV_STEM)
     snprintf(buf, n, "conv_stem_kernel");
   else if (pl.kind == CONV_WINO)
-    snprintf(buf, n, g_wino_waves == 8 ? "conv_wino8_kernel" : "conv_wino_kernel");
+    snprintf(buf, n, g_wino_waves == 8 ? ((g_wino_persist && 5.0 * p->Hi * p->Wi < 1048576.0) ? "conv_wino8p_kernel" : "conv_wino8_kernel") : "conv_wino_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
     snprintf(buf, n, strided_use_bf16(p) ? "conv_fast_strided_kernel<%d, %d, %d, %d, true>" : "conv_fast_strided_kernel<%d, %d, %d, %d, false>",
              p->SD, p->SH, p->SW, conv_fast_vec(p));

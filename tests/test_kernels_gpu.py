@@ -541,13 +541,17 @@ def test_ds_label_pyramid_on_device(dev):
     (1, 30, 30, (5, 7, 19), True),          # concat input: chunks never straddle the two sources
     (1, 16, 70, (4, 4, 16), False),         # exactly one tile, three cout tiles
 ])
-@pytest.mark.parametrize("waves", [8, 4])
+@pytest.mark.parametrize("waves", [8, 4, 803, 800])
 def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
     """conv_wino_kernel (3D Winograd F(2x2x2,3x3x3)) forced on small shapes: forward with lazy inputs + statistics, and the
     flipped-weight backward-data form with two destinations; vs F.conv3d / autograd (tolerance 1e-5: +-1 and 1/2 transforms)."""
     ops = _ops()
     ops.set_option('conv_wino', 2)
-    ops.set_option('wino_waves', waves)      # 8: wave-specialised two-waves-per-SIMD kernel (default), 4: the four-wave kernel
+    # 8: the persistent wave-specialised kernel (one worker per CU, here one tile each), 803: the same with only 3 workers per
+    # output-channel tile (every worker walks over several tiles: cross-tile pipeline, ragged last iteration), 800: the one-tile-per-
+    # workgroup 8-wave kernel (the default), 4: the four-wave kernel
+    ops.set_option('wino_waves', 8 if waves >= 8 else 4)
+    ops.set_option('wino_persist', {8: 1, 803: 3, 800: 0, 4: 0}[waves])
     try:
         g = torch.Generator().manual_seed(21)
         srcs = [torch.randn((N, Cin) + shape, generator=g)]
@@ -590,6 +594,7 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
     finally:
         ops.set_option('conv_wino', 1)
         ops.set_option('wino_waves', 8)
+        ops.set_option('wino_persist', 0)
 
 
 @pytest.mark.parametrize("N,Cin,Cout,shape,two_src", [

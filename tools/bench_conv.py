@@ -10,6 +10,7 @@ ap.add_argument('--shape', type=int, nargs=3, default=[48, 192, 192]); ap.add_ar
 ap.add_argument('--k', type=int, nargs=3, default=[3, 3, 3]); ap.add_argument('--stride', type=int, nargs=3, default=[1, 1, 1])
 ap.add_argument('--reps', type=int, default=5); ap.add_argument('--mode', default='fwd', choices=['fwd', 'bwdw'])
 ap.add_argument('--lazy', type=int, default=1); ap.add_argument('--mma', type=int, default=0)
+ap.add_argument('--ts', type=int, default=0, help='library built with -DWN_TS=1: print the per-phase cycle totals of the persistent Winograd kernel')
 a = ap.parse_args()
 ops.set_mma(a.mma)
 dev = torch.device('cuda:0')
@@ -31,6 +32,21 @@ if a.mode == 'fwd':
     p.stats_part = part.data_ptr()
     run = lambda: ops.conv3d_fwd(p)
     import os
+    if a.ts:
+        import numpy as np
+        ts = torch.zeros((256, 8, 16), dtype=torch.int64, device=dev)
+        p.out1 = ts.data_ptr()
+        run(); torch.cuda.synchronize(); ts.zero_()
+        run(); torch.cuda.synchronize()
+        t = ts.cpu().numpy().astype(float)
+        names = ['phase1 work', 'barrier A', 'MFMA phase', 'barrier B', 'epi stage1', 'epi bar1', 'epi stage2', 'epi bar2', 'epi stats/tail']
+        used = t[:, :, :9].sum(2) > 0
+        print('cycles per wave over the whole kernel (mean over workgroups): transformer waves 0-3 | stager waves 4-7')
+        for q, nm in enumerate(names):
+            tr = t[:, 0:4, q][used[:, 0:4]].mean(); sg = t[:, 4:8, q][used[:, 4:8]].mean()
+            print('  %-15s %10.0f | %10.0f' % (nm, tr, sg))
+        print('  %-15s %10.0f | %10.0f' % ('total', t[:, 0:4, :10].sum(2)[used[:, 0:4]].mean(), t[:, 4:8, :10].sum(2)[used[:, 4:8]].mean()))
+        print('  stagers: wait for the patch in flight at the top of phase 1: %.0f ; store_patch: %.0f ; (phase1 work row = issue_patch)' % (t[:, 4:8, 9][used[:, 4:8]].mean(), t[:, 4:8, 10][used[:, 4:8]].mean()))
     if int(os.environ.get('MT_CONV_DBG', '0')) & 16:
         nblk = N * ops.conv_stats_blocks(p)
         ts = torch.zeros((nblk, 4, 16), dtype=torch.int64, device=dev)
