@@ -119,8 +119,8 @@ int mt_conv3d_bwd_data_strided(const mt_conv3d_t* p, mt_stream_t stream);
 int mt_conv3d_bwd_data_strided_supported(const mt_conv3d_t* p);   /* 1 when the geometry is handled, else 0 */
 int mt_conv3d_bwd_data_strided_pack_layout(const mt_conv3d_t* p); /* `layout` of its packed weights: 1, or 3 (bf16) when p->mma == 1 */
 /* Runtime options (tests, A/B measurements): "conv_wino" = 0 direct kernels only, 1 Winograd where the grid fills the chip
- * (default, also MT_CONV_WINO), 2 Winograd wherever the geometry is eligible; "wino_waves" 8 | 4; "wino_persist" 0 | 1 | n (8-wave
- * kernel: one tile per workgroup (default) or persistent over spatial tiles with at most n workers per output-channel tile); "bwdw_wino" 0 | 1;
+ * (default, also MT_CONV_WINO), 2 Winograd wherever the geometry is eligible; "wino_waves" 8 | 4; "wino_persist" 1 | 0 | n (8-wave
+ * kernel: persistent over spatial tiles (default; n > 1: at most n workers per output-channel tile) or one tile per workgroup); "bwdw_wino" 0 | 1;
  * "conv_bf16" (problems with mma == 1) = 0 never, 1 where the grid fills the chip (default), 2 wherever eligible;
  * "bwdw_bf16" 0 | 1. */
 int mt_set_option(const char* name, int value);

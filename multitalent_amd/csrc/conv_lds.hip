@@ -1995,7 +1995,7 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
 static int g_bwdw_bf16 = -1;       // -1: read MT_BWDW_BF16 (default 1): bf16 Winograd backward-weight kernel when mt_conv3d_t.mma == 1
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
 static int g_wino_waves = 8;       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
-static int g_wino_persist = 0;     // (measured 4 % SLOWER than one tile per workgroup: profiles/r02_wino_phase_cycles.txt) 8-wave kernel: 1 persistent over spatial tiles (conv_wino8p_kernel), 0 one tile per workgroup, n > 1: at most n workers
+static int g_wino_persist = 1;     // 8-wave kernel: 1 persistent over spatial tiles (conv_wino8p_kernel), 0 one tile per workgroup, n > 1: at most n workers
 static int g_wino_mode = -1;       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
 extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "conv_wino") == 0) { g_wino_mode = value; return MT_OK; }

@@ -65,8 +65,110 @@ __global__ __launch_bounds__(64) void loss_stats_finalize_kernel(const float* pa
   if (threadIdx.x == 0) stats[(size_t)b * C * 4 + ck] = (float)a;
 }
 
+// ---- contiguous logits (cs == C): flat, fully coalesced form ------------------------------------------------------------------
+// The [V][C] slab of a sample is one linear array.  A = (256 / C) * C threads are active; thread t handles the flat elements
+// base + t + k*A, whose channel is t % C for every k (A and the block base are multiples of C): per-channel constants (validity,
+// label set) and the four running sums live in registers, consecutive lanes read consecutive floats, and all lanes work (the
+// wave-per-voxel kernel above keeps 47 of 64 lanes busy and touches 188-byte rows).  Threads of invalid channels skip their loads.
+#define LF_KMAX 240          // elements per thread per block (block covers LF_KMAX * (A / C) voxels)
+__global__ __launch_bounds__(256) void mt_loss_fwd_flat_kernel(const float* __restrict__ logits, const float* __restrict__ target, long V, int C,
+                                                               const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
+                                                               int nblk, int A, float* __restrict__ part) {
+  __shared__ float red[256][4];
+  const int b = blockIdx.y, t = threadIdx.x;
+  const int c = t % C, sub = t / C, nsub = A / C;                  // `sub`-th voxel of every group of nsub voxels
+  const bool act = (t < A) && ((valid[b] >> c) & 1ull);
+  const uint64_t l = act ? lut[c] : 0ull;
+  const long vpb = (long)LF_KMAX * nsub;                           // voxels per block
+  const long v0 = (long)blockIdx.x * vpb;
+  const long v1 = (v0 + vpb < V) ? v0 + vpb : V;
+  const float* x = logits + ((size_t)b * V) * C + c;
+  const float* tg = target + (size_t)b * V;
+  float bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
+  if (act) {
+    for (long vb = v0 + sub; vb < v1; vb += 4 * nsub) {
+      float xv[4]; int lab[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long v = vb + (long)u * nsub;
+        const bool in = v < v1;
+        xv[u] = in ? x[(size_t)v * C] : 0.f;
+        lab[u] = in ? (int)tg[v] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (vb + (long)u * nsub < v1) {
+          const float xx = xv[u];
+          const float y = (lab[u] >= 0 && lab[u] < 64 && ((l >> lab[u]) & 1ull)) ? 1.f : 0.f;
+          const float ex = __expf(-fabsf(xx));
+          bce += fmaxf(xx, 0.f) - xx * y + log1pf(ex);               // BCEWithLogits: max(x,0) - x*y + log1p(exp(-|x|))
+          const float sg = (xx >= 0.f) ? 1.f / (1.f + ex) : ex / (1.f + ex);
+          tp += sg * y;
+          fp += sg * (1.f - y);
+          fn += (1.f - sg) * y;
+        }
+      }
+    }
+  }
+  red[t][0] = bce; red[t][1] = tp; red[t][2] = fp; red[t][3] = fn;
+  __syncthreads();
+  if (t < C * 4) {                                                  // fixed-order sum over the nsub threads of a channel
+    const int cc = t >> 2, k = t & 3;
+    float sum = 0.f;
+    for (int q = 0; q < nsub; ++q) sum += red[q * C + cc][k];
+    part[(((size_t)b * nblk + blockIdx.x) * C + cc) * 4 + k] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void mt_loss_bwd_flat_kernel(const float* __restrict__ logits, const float* __restrict__ target, long V, int C,
+                                                               const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
+                                                               const float* __restrict__ gstats, int A, float* __restrict__ dlogits) {
+  const int b = blockIdx.y, t = threadIdx.x;
+  if (t >= A) return;
+  const int c = t % C, sub = t / C, nsub = A / C;
+  const bool act = (valid[b] >> c) & 1ull;
+  const uint64_t l = act ? lut[c] : 0ull;
+  const float* gs = gstats + ((size_t)b * C + c) * 4;
+  const float bce_coef = act ? gs[0] : 0.f, a_tp = act ? gs[1] : 0.f, a_fp = act ? gs[2] : 0.f, a_fn = act ? gs[3] : 0.f;
+  const long vpb = (long)LF_KMAX * nsub;
+  const long v0 = (long)blockIdx.x * vpb;
+  const long v1 = (v0 + vpb < V) ? v0 + vpb : V;
+  const float* x = logits + ((size_t)b * V) * C + c;
+  float* dx = dlogits + ((size_t)b * V) * C + c;
+  const float* tg = target + (size_t)b * V;
+  for (long vb = v0 + sub; vb < v1; vb += 4 * nsub) {
+    float xv[4]; int lab[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long v = vb + (long)u * nsub;
+      const bool in = act && v < v1;
+      xv[u] = in ? x[(size_t)v * C] : 0.f;
+      lab[u] = in ? (int)tg[v] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long v = vb + (long)u * nsub;
+      if (v < v1) {
+        float d = 0.f;
+        if (act) {
+          const float xx = xv[u];
+          const float y = (lab[u] >= 0 && lab[u] < 64 && ((l >> lab[u]) & 1ull)) ? 1.f : 0.f;
+          const float ex = __expf(-fabsf(xx));
+          const float sg = (xx >= 0.f) ? 1.f / (1.f + ex) : ex / (1.f + ex);
+          d = bce_coef * (sg - y) + sg * (1.f - sg) * (y * (a_tp - a_fn) + (1.f - y) * a_fp);
+        }
+        dx[(size_t)v * C] = d;
+      }
+    }
+  }
+}
+static inline int lf_A(int C) { return (256 / C) * C; }
+static inline int lf_blocks(long V, int C) { return mt_cdiv(V, (long)LF_KMAX * (lf_A(C) / C)); }
+
 extern "C" size_t mt_loss_workspace(int B, long V, int C) {
-  return (size_t)B * mt_cdiv(V, LS_VB) * C * 4 * sizeof(float);
+  size_t nb = (size_t)mt_cdiv(V, LS_VB);
+  if (C > 0 && C <= 64 && (size_t)lf_blocks(V, C) > nb) nb = (size_t)lf_blocks(V, C);
+  return (size_t)B * nb * C * 4 * sizeof(float);
 }
 
 extern "C" int mt_multitalent_loss_fwd(const float* logits, int cs, const float* target, int B, long V, int C,
@@ -74,9 +176,15 @@ extern "C" int mt_multitalent_loss_fwd(const float* logits, int cs, const float*
                                        size_t ws_bytes, mt_stream_t stream) {
   MT_REQUIRE(logits && target && valid && lut && stats && B > 0 && V > 0 && C > 0 && C <= 64, "multitalent_loss_fwd: bad args (C must be <= 64)");
   if (ws == nullptr || ws_bytes < mt_loss_workspace(B, V, C)) { mt_set_error("multitalent_loss_fwd: workspace too small"); return MT_EWORKSPACE; }
-  const int nblk = mt_cdiv(V, LS_VB);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(mt_loss_fwd_kernel, dim3(nblk, B), dim3(256), 0, st, logits, cs, target, V, C, valid, lut, nblk, (float*)ws);
+  int nblk;
+  if (cs == C) {            // contiguous logits (what the engine produces): flat coalesced kernel
+    nblk = lf_blocks(V, C);
+    hipLaunchKernelGGL(mt_loss_fwd_flat_kernel, dim3(nblk, B), dim3(256), 0, st, logits, target, V, C, valid, lut, nblk, lf_A(C), (float*)ws);
+  } else {
+    nblk = mt_cdiv(V, LS_VB);
+    hipLaunchKernelGGL(mt_loss_fwd_kernel, dim3(nblk, B), dim3(256), 0, st, logits, cs, target, V, C, valid, lut, nblk, (float*)ws);
+  }
   hipLaunchKernelGGL(loss_stats_finalize_kernel, dim3(C * 4, B), dim3(64), 0, st, (const float*)ws, nblk, C, stats);
   MT_CHECK_LAUNCH("multitalent_loss_fwd");
   return MT_OK;
@@ -121,8 +229,12 @@ extern "C" int mt_multitalent_loss_bwd(const float* logits, int cs, const float*
                                        const uint64_t* valid, const uint64_t* lut, const float* gstats,
                                        float* dlogits, int dcs, mt_stream_t stream) {
   MT_REQUIRE(logits && target && valid && lut && gstats && dlogits && B > 0 && V > 0 && C > 0 && C <= 64, "multitalent_loss_bwd: bad args");
-  hipLaunchKernelGGL(mt_loss_bwd_kernel, dim3(mt_cdiv(V, LS_VB), B), dim3(256), 0, (hipStream_t)stream, logits, cs, target, V, C,
-                     valid, lut, gstats, dlogits, dcs);
+  if (cs == C && dcs == C)
+    hipLaunchKernelGGL(mt_loss_bwd_flat_kernel, dim3(lf_blocks(V, C), B), dim3(256), 0, (hipStream_t)stream, logits, target, V, C, valid, lut,
+                       gstats, lf_A(C), dlogits);
+  else
+    hipLaunchKernelGGL(mt_loss_bwd_kernel, dim3(mt_cdiv(V, LS_VB), B), dim3(256), 0, (hipStream_t)stream, logits, cs, target, V, C,
+                       valid, lut, gstats, dlogits, dcs);
   MT_CHECK_LAUNCH("multitalent_loss_bwd");
   return MT_OK;
 }

@@ -547,11 +547,11 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
     flipped-weight backward-data form with two destinations; vs F.conv3d / autograd (tolerance 1e-5: +-1 and 1/2 transforms)."""
     ops = _ops()
     ops.set_option('conv_wino', 2)
-    # 8: the persistent wave-specialised kernel (one worker per CU, here one tile each), 803: the same with only 3 workers per
+    # 8: the persistent wave-specialised kernel (default: one worker per CU, here one tile each), 803: the same with only 3 workers per
     # output-channel tile (every worker walks over several tiles: cross-tile pipeline, ragged last iteration), 800: the one-tile-per-
-    # workgroup 8-wave kernel (the default), 4: the four-wave kernel
+    # workgroup 8-wave kernel, 4: the four-wave kernel
     ops.set_option('wino_waves', 8 if waves >= 8 else 4)
-    ops.set_option('wino_persist', {8: 1, 803: 3, 800: 0, 4: 0}[waves])
+    ops.set_option('wino_persist', {8: 1, 803: 3, 800: 0, 4: 1}[waves])
     try:
         g = torch.Generator().manual_seed(21)
         srcs = [torch.randn((N, Cin) + shape, generator=g)]
@@ -594,7 +594,7 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
     finally:
         ops.set_option('conv_wino', 1)
         ops.set_option('wino_waves', 8)
-        ops.set_option('wino_persist', 0)
+        ops.set_option('wino_persist', 1)
 
 
 @pytest.mark.parametrize("N,Cin,Cout,shape,two_src", [
@@ -712,3 +712,42 @@ def test_extract_tiles_matches_torch_flip(dev):
             assert torch.equal(out[k], ref), k
     with pytest.raises(RuntimeError):
         ops.extract_tiles(vol, patch, [((14, 0, 0), (0, 0, 0))], out[:1])          # leaves the volume
+
+
+@pytest.mark.parametrize("B,C,V,wide", [(3, 47, 5 * 7 * 11, False), (2, 47, 48 * 20 * 21, False), (2, 5, 1237, False), (1, 64, 4099, False),
+                                         (2, 47, 3001, True)])
+def test_multitalent_loss_kernels_flat_and_strided(dev, B, C, V, wide):
+    """mt_multitalent_loss_fwd / _bwd: the flat coalesced kernels (contiguous logits) and the channel-strided fallback (logits are a
+    channel slice of a wider buffer) against the formula of MultiTalent_Trainer_DDP.py:574-594 in torch fp64."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    cs = C + 3 if wide else C
+    buf = (2.5 * torch.randn((B, V, 1, 1, cs), generator=g)).to(dev)
+    a = ops.Act(buf, 0, C)
+    target = torch.randint(-1, 50, (B, V), generator=g).float().to(dev)
+    lut_h = torch.randint(0, 2 ** 62, (C,), generator=g, dtype=torch.int64)
+    valid_h = torch.randint(0, 2 ** 62, (B,), generator=g, dtype=torch.int64) & ((1 << C) - 1 if C < 63 else -1)
+    lut, valid = lut_h.to(dev), valid_h.to(dev)
+    stats = torch.empty((B, C, 4), device=dev)
+    ws = torch.empty(ops.loss_workspace(B, V, C) // 4 + 16, device=dev)
+    ops.multitalent_loss_fwd(a, target, valid, lut, stats, ws)
+    x = buf[..., :C].reshape(B, V, C).double().cpu()
+    t = target.cpu().long()
+    y = torch.zeros((B, V, C), dtype=torch.float64)
+    for c in range(C):
+        m = int(lut_h[c])
+        y[:, :, c] = ((t >= 0) & (t < 64) & (((torch.tensor(m, dtype=torch.int64) >> t.clamp(0, 63)) & 1) == 1)).double()
+    act = torch.tensor([[(int(valid_h[b]) >> c) & 1 for c in range(C)] for b in range(B)], dtype=torch.float64)[:, None, :]
+    sg = torch.sigmoid(x)
+    bce = torch.clamp(x, min=0) - x * y + torch.log1p(torch.exp(-x.abs()))
+    ref = torch.stack(((bce * act).sum(1), (sg * y * act).sum(1), (sg * (1 - y) * act).sum(1), ((1 - sg) * y * act).sum(1)), -1)
+    assert torch.allclose(stats.cpu().double(), ref, rtol=2e-5, atol=1e-3)
+    gst = torch.randn((B, C, 4), generator=g)
+    dbuf = torch.full((B, V, 1, 1, cs), float('nan'), device=dev)
+    ops.multitalent_loss_bwd(a, target, valid, lut, gst.to(dev), ops.Act(dbuf, 0, C))
+    gd = gst.double()[:, None]
+    dref = act * (gd[..., 0] * (sg - y) + sg * (1 - sg) * (y * (gd[..., 1] - gd[..., 3]) + (1 - y) * gd[..., 2]))
+    got = dbuf[..., :C].reshape(B, V, C).cpu().double()
+    assert torch.allclose(got, dref, rtol=1e-4, atol=1e-5)
+    if wide:
+        assert torch.isnan(dbuf[..., C:]).all()            # the neighbouring channels of the wider buffer are untouched
