@@ -1216,10 +1216,12 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
   __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)(aff ? S.shift + (size_t)nb * S.C : S.ptr), 0, aff ? S.C * 4 : 0, 0x00020000);
   const int ntaps = P.ntaps, total = P.nchunks * ntaps;
 
-  auto load_a = [&](int it, float (&x)[8]) {           // it = chunk * ntaps + tap
-    const int ch = it / ntaps, tap = it - ch * ntaps;
-    const int kw = tap % c.KW, kh = (tap / c.KW) % c.KH, kd = tap / (c.KW * c.KH);
-    const int so = __builtin_amdgcn_readfirstlane((((kd * c.Hi + kh) * c.Wi + kw) * S.cs + ch * FCK) * 4);
+  // (chunk, kd, kh, kw) of the NEXT load advance as counters: `it / ntaps`, `tap % KW` ... with run-time divisors are ~40
+  // instructions each on this hardware (no integer divider), three of them per 8 MFMAs in the first version
+  int l_ch = 0, l_kd = 0, l_kh = 0, l_kw = 0;
+  auto load_a = [&](float (&x)[8]) {
+    const int so = __builtin_amdgcn_readfirstlane((((l_kd * c.Hi + l_kh) * c.Wi + l_kw) * S.cs + l_ch * FCK) * 4);
+    if (++l_kw == c.KW) { l_kw = 0; if (++l_kh == c.KH) { l_kh = 0; if (++l_kd == c.KD) { l_kd = 0; ++l_ch; } } }
     if constexpr (VEC == 4) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
@@ -1242,10 +1244,9 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = 0.f;
   float xa[8], xn[8], sc[8], sh[8];
-  load_a(0, xa);
-  for (int it = 0; it < total; ++it) {
-    const int ch = it / ntaps, tap = it - ch * ntaps;
-    if (it + 1 < total) load_a(it + 1, xn);
+  load_a(xa);
+  for (int it = 0, ch = 0, tap = 0; it < total; ++it) {
+    if (it + 1 < total) load_a(xn);
     const int cb = ch * FCK + 8 * lhalf;
     if (tap == 0) {                                      // per-chunk lazy-activation constants (0 for channels beyond Cin)
 #pragma unroll
@@ -1269,6 +1270,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[4 + e], b1[e], acc, 0, 0, 0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) xa[e] = xn[e];
+    if (++tap == ntaps) { tap = 0; ++ch; }
   }
 
   const int co = ntile * 32 + li;

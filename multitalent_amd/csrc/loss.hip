@@ -70,39 +70,49 @@ __global__ __launch_bounds__(64) void loss_stats_finalize_kernel(const float* pa
 // base + t + k*A, whose channel is t % C for every k (A and the block base are multiples of C): per-channel constants (validity,
 // label set) and the four running sums live in registers, consecutive lanes read consecutive floats, and all lanes work (the
 // wave-per-voxel kernel above keeps 47 of 64 lanes busy and touches 188-byte rows).  Threads of invalid channels skip their loads.
-#define LF_KMAX 240          // elements per thread per block (block covers LF_KMAX * (A / C) voxels)
+#define LF_KMAX 240          // elements per thread per block (block covers LF_KMAX * (A / C) voxels, at most LF_VMAX)
+#define LF_VMAX 4096
+__host__ __device__ static inline long lf_vpb(int nsub) { const long v = (long)LF_KMAX * nsub; return v < LF_VMAX ? v : LF_VMAX; }
 __global__ __launch_bounds__(256) void mt_loss_fwd_flat_kernel(const float* __restrict__ logits, const float* __restrict__ target, long V, int C,
                                                                const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
                                                                int nblk, int A, float* __restrict__ part) {
   __shared__ float red[256][4];
+  __shared__ signed char slab[LF_VMAX];                            // the block's labels (-1 = none of the 64 label values)
   const int b = blockIdx.y, t = threadIdx.x;
   const int c = t % C, sub = t / C, nsub = A / C;                  // `sub`-th voxel of every group of nsub voxels
   const bool act = (t < A) && ((valid[b] >> c) & 1ull);
   const uint64_t l = act ? lut[c] : 0ull;
-  const long vpb = (long)LF_KMAX * nsub;                           // voxels per block
+  const long vpb = lf_vpb(nsub);                                   // voxels per block
   const long v0 = (long)blockIdx.x * vpb;
   const long v1 = (v0 + vpb < V) ? v0 + vpb : V;
   const float* x = logits + ((size_t)b * V) * C + c;
   const float* tg = target + (size_t)b * V;
+  for (int i = t; i < (int)(v1 - v0); i += 256) {                  // every label is read once per block, not once per channel
+    const int lab = (int)tg[v0 + i];
+    slab[i] = (signed char)((lab >= 0 && lab < 64) ? lab : -1);
+  }
+  __syncthreads();
   float bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
   if (act) {
     for (long vb = v0 + sub; vb < v1; vb += 4 * nsub) {
-      float xv[4]; int lab[4];
+      float xv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long v = vb + (long)u * nsub;
-        const bool in = v < v1;
-        xv[u] = in ? x[(size_t)v * C] : 0.f;
-        lab[u] = in ? (int)tg[v] : -1;
+        xv[u] = (v < v1) ? x[(size_t)v * C] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (vb + (long)u * nsub < v1) {
+        const long v = vb + (long)u * nsub;
+        if (v < v1) {
           const float xx = xv[u];
-          const float y = (lab[u] >= 0 && lab[u] < 64 && ((l >> lab[u]) & 1ull)) ? 1.f : 0.f;
-          const float ex = __expf(-fabsf(xx));
-          bce += fmaxf(xx, 0.f) - xx * y + log1pf(ex);               // BCEWithLogits: max(x,0) - x*y + log1p(exp(-|x|))
-          const float sg = (xx >= 0.f) ? 1.f / (1.f + ex) : ex / (1.f + ex);
+          const int lab = slab[v - v0];
+          const float y = (lab >= 0 && ((l >> lab) & 1ull)) ? 1.f : 0.f;
+          const float ex = __expf(-fabsf(xx));                       // in (0, 1]
+          const float r = __builtin_amdgcn_rcpf(1.f + ex);
+          // BCEWithLogits: max(x,0) - x*y + log1p(exp(-|x|)); log(1 + ex) with 1 + ex rounded: absolute error <= 6e-8
+          bce += fmaxf(xx, 0.f) - xx * y + __logf(1.f + ex);
+          const float sg = (xx >= 0.f) ? r : ex * r;
           tp += sg * y;
           fp += sg * (1.f - y);
           fn += (1.f - sg) * y;
@@ -123,27 +133,33 @@ __global__ __launch_bounds__(256) void mt_loss_fwd_flat_kernel(const float* __re
 __global__ __launch_bounds__(256) void mt_loss_bwd_flat_kernel(const float* __restrict__ logits, const float* __restrict__ target, long V, int C,
                                                                const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
                                                                const float* __restrict__ gstats, int A, float* __restrict__ dlogits) {
+  __shared__ signed char slab[LF_VMAX];
   const int b = blockIdx.y, t = threadIdx.x;
-  if (t >= A) return;
   const int c = t % C, sub = t / C, nsub = A / C;
-  const bool act = (valid[b] >> c) & 1ull;
+  const bool act = (t < A) && ((valid[b] >> c) & 1ull);
   const uint64_t l = act ? lut[c] : 0ull;
+  {
+    const long vpb_ = lf_vpb(nsub), a0 = (long)blockIdx.x * vpb_, a1 = (a0 + vpb_ < V) ? a0 + vpb_ : V;
+    for (int i = t; i < (int)(a1 - a0); i += 256) {
+      const int lab = (int)target[(size_t)b * V + a0 + i];
+      slab[i] = (signed char)((lab >= 0 && lab < 64) ? lab : -1);
+    }
+    __syncthreads();
+  }
+  if (t >= A) return;
   const float* gs = gstats + ((size_t)b * C + c) * 4;
   const float bce_coef = act ? gs[0] : 0.f, a_tp = act ? gs[1] : 0.f, a_fp = act ? gs[2] : 0.f, a_fn = act ? gs[3] : 0.f;
-  const long vpb = (long)LF_KMAX * nsub;
+  const long vpb = lf_vpb(nsub);
   const long v0 = (long)blockIdx.x * vpb;
   const long v1 = (v0 + vpb < V) ? v0 + vpb : V;
   const float* x = logits + ((size_t)b * V) * C + c;
   float* dx = dlogits + ((size_t)b * V) * C + c;
-  const float* tg = target + (size_t)b * V;
   for (long vb = v0 + sub; vb < v1; vb += 4 * nsub) {
-    float xv[4]; int lab[4];
+    float xv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long v = vb + (long)u * nsub;
-      const bool in = act && v < v1;
-      xv[u] = in ? x[(size_t)v * C] : 0.f;
-      lab[u] = in ? (int)tg[v] : -1;
+      xv[u] = (act && v < v1) ? x[(size_t)v * C] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -152,9 +168,11 @@ __global__ __launch_bounds__(256) void mt_loss_bwd_flat_kernel(const float* __re
         float d = 0.f;
         if (act) {
           const float xx = xv[u];
-          const float y = (lab[u] >= 0 && lab[u] < 64 && ((l >> lab[u]) & 1ull)) ? 1.f : 0.f;
+          const int lab = slab[v - v0];
+          const float y = (lab >= 0 && ((l >> lab) & 1ull)) ? 1.f : 0.f;
           const float ex = __expf(-fabsf(xx));
-          const float sg = (xx >= 0.f) ? 1.f / (1.f + ex) : ex / (1.f + ex);
+          const float r = __builtin_amdgcn_rcpf(1.f + ex);
+          const float sg = (xx >= 0.f) ? r : ex * r;
           d = bce_coef * (sg - y) + sg * (1.f - sg) * (y * (a_tp - a_fn) + (1.f - y) * a_fp);
         }
         dx[(size_t)v * C] = d;
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(256) void mt_loss_bwd_flat_kernel(const float* __re
   }
 }
 static inline int lf_A(int C) { return (256 / C) * C; }
-static inline int lf_blocks(long V, int C) { return mt_cdiv(V, (long)LF_KMAX * (lf_A(C) / C)); }
+static inline int lf_blocks(long V, int C) { return mt_cdiv(V, lf_vpb(lf_A(C) / C)); }
 
 extern "C" size_t mt_loss_workspace(int B, long V, int C) {
   size_t nb = (size_t)mt_cdiv(V, LS_VB);

@@ -39,7 +39,25 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   // ---- A operand: this lane's base voxel, channels 8*lhalf .. +7 of each chunk
   const long bv = m0 + li;
   const bool vok = bv < P.Vb;
-  const int wb = (int)(bv % c.Wb), hb = (int)((bv / c.Wb) % c.Hb), db = (int)(bv / ((long)c.Wb * c.Hb));
+  // (d, h, w) of the wave's first voxel by ONE wave-uniform division; a row 0..31 further only carries once into h and once into
+  // d when the rows are at least 32 voxels long (otherwise: the general division per lane).  The per-row divisions of the first
+  // version (1 + 16 of them per lane, ~40 VALU each) cost more than the 16 MFMAs of the tile.
+  const int w0 = (int)(m0 % c.Wb), h0 = (int)((m0 / c.Wb) % c.Hb), d0 = (int)(m0 / ((long)c.Wb * c.Hb));
+  const bool longrows = c.Wb >= 32;
+  auto row_dhw = [&](int iv, int& d, int& h, int& w) {
+    if (longrows) {
+      w = w0 + iv; h = h0; d = d0;
+      const bool cw = w >= c.Wb;
+      w = cw ? w - c.Wb : w; h = cw ? h + 1 : h;
+      const bool chh = h >= c.Hb;
+      h = chh ? h - c.Hb : h; d = chh ? d + 1 : d;
+    } else {
+      const long v = m0 + iv;
+      w = (int)(v % c.Wb); h = (int)((v / c.Wb) % c.Hb); d = (int)(v / ((long)c.Wb * c.Hb));
+    }
+  };
+  int wb, hb, db;
+  row_dhw(li, db, hb, wb);
   const size_t in_sample = (size_t)c.Di * c.Hi * c.Wi * S.cs;
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0,
                                                                 (int)(in_sample * 4), 0x00020000);
@@ -133,7 +151,8 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   for (int j = 0; j < 16; ++j) {
     const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf;
     const long v = m0 + iv;
-    const int w2 = (int)(v % c.Wb), h2 = (int)((v / c.Wb) % c.Hb), d2 = (int)(v / ((long)c.Wb * c.Hb));
+    int w2, h2, d2;
+    row_dhw(iv, d2, h2, w2);
     const bool ok = covalid && v < P.Vb;
     obase[j] = ok ? ((((d2 * c.soD) * Ho + h2 * c.soH) * Wo + w2 * c.soW) * c.ocs + co) * 4 : (int)0x80000000;
   }
