@@ -226,3 +226,56 @@ def test_tile_sharded_inference_matches_unsharded_and_reference(dev, world):
         pytest.skip("needs %d GPUs or exactly one" % world)
     res = run_world_gpu(_sharded_inference, world)
     assert all(r < 2e-6 for r in res)
+
+
+def _rccl_world1(rank, world, dev):
+    """One rank, backend nccl (= RCCL): the bucketed side-stream all-reduce runs real RCCL kernels (MT_FORCE_REDUCER=1 keeps the
+    world-size-1 short cut off) between backward and the optimizer; the result must equal the step without a reducer bit for bit."""
+    from multitalent_amd.network_architecture.generic_UNet import Generic_UNet
+    from multitalent_amd.training.hot_loop import FusedTrainStep
+    from multitalent_amd.training.loss_functions.fused_losses import DC_and_CE_DS_loss
+    os.environ['MT_FORCE_REDUCER'] = '1'
+    pools, kernels = [[2, 2, 2], [2, 2, 2], [1, 2, 2]], [[3, 3, 3]] * 4
+    res = []
+    for ddp in (False, True):
+        torch.manual_seed(3)
+        net = Generic_UNet(1, 16, 3, 3, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                           {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True}, True, False,
+                           lambda x: x, None, pools, kernels, False, True, True)
+        net.train()
+        step = FusedTrainStep(net, DC_and_CE_DS_loss([4 / 7, 2 / 7, 1 / 7], batch_dice=False, ddp=True), lr=1e-2, ddp=ddp)
+        if ddp:
+            step.reducer.bucket = 20000               # many buckets: several all-reduces in flight on the side stream
+            assert step.reducer.force and not step.reducer.__dict__.get('via_host', False)
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn((2, 1, 16, 32, 32), generator=g).to(dev)
+        t0 = torch.randint(0, 3, (2, 1, 16, 32, 32), generator=g).float()
+        tg = [t0.to(dev), t0[:, :, ::2, ::2, ::2].contiguous().to(dev), t0[:, :, ::4, ::4, ::4].contiguous().to(dev)]
+        losses = [float(step(x, tg)) for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()))
+        if ddp:
+            assert len(step.reducer.handles) > 3 and step.reducer.stream is not None
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    return True
+
+
+def _worker_nccl1(fn, ret, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        ret[0] = fn(0, 1, torch.device('cuda', 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_allreducer_side_stream_on_rccl_world1(dev):
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_worker_nccl1, args=(_rccl_world1, ret, _free_port()))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0 and ret[0] is True
