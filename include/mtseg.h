@@ -162,6 +162,20 @@ typedef struct {
 } mt_pointwise_t;
 int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream);
 int mt_pointwise_stats_blocks(const mt_pointwise_t* p);
+/* Backward of a 1x1x1 segmentation head (generic_UNet.py:349-351, generic_modular_UNet.py:244,251: seg_outputs / deep_supervision_outputs)
+ * in ONE pass over (x, dY):  dX[n,v,ci] (+)= sum_co dY[n,v,co] W[co,ci] (gradient w.r.t. the lazily ACTIVATED head input),
+ * dW[co*s_co + ci*s_ci] (+)= sum_{n,v} act(x)[n,v,ci] dY[n,v,co], dbias[co] (+)= sum dY.  Cin, Cout <= 64; mt_head_bwd_supported says
+ * where it beats the separate kernels (Cin <= 32: the full-resolution heads).
+ * x: the head's input (lazy activation allowed); dy [N][V][dycs]; wpack_bwd = mt_pack_conv_weights(w, C0 = Cout, C1 = 0, Cout' = Cin,
+ * 1x1x1, strides with ci/co swapped, flip 0, ck 16, layout 1) — the packing mt_pointwise_fwd takes for the same backward-data.
+ * *dbias_done = 1 when dbias was produced (Cin not a multiple of 32: a spare MFMA row carries 1.0), else the caller sums dY
+ * (mt_channel_sum).  ws: mt_head_bwd_workspace bytes (per-wave partials, summed in fp64 in a fixed order). */
+int mt_head_bwd_supported(int Cin, int Cout);
+size_t mt_head_bwd_workspace(int N, long V, int Cin, int Cout);
+int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, long V, int Cin, int Cout, const float* wpack_bwd,
+                float* dx, int dxcs, int accumulate_dx, float* dw, long s_ci, long s_co, float* dbias, int accumulate_dw,
+                int* dbias_done, void* ws, size_t ws_bytes, mt_stream_t stream);
+
 
 /* ---- InstanceNorm3d(eps, affine) + LeakyReLU (generic_UNet.py:63-64,69-70) ------------------- */
 /* partials [N][nsb][C][2] -> mean,rstd,scale,shift each [N][C]; scale = gamma*rstd, shift = beta - mean*scale */

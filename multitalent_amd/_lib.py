@@ -77,6 +77,9 @@ SIGNATURES = {
     'mt_conv3d_bwd_weight': (_i, [_P(mt_conv3d_t), _P(mt_src_t), _vp, _l, _l, _l, _l, _l, _i, _vp, _sz, _vp]),
     'mt_pointwise_fwd': (_i, [_P(mt_pointwise_t), _vp]),
     'mt_pointwise_stats_blocks': (_i, [_P(mt_pointwise_t)]),
+    'mt_head_bwd_supported': (_i, [_i, _i]),
+    'mt_head_bwd_workspace': (_sz, [_i, _l, _i, _i]),
+    'mt_head_bwd': (_i, [_P(mt_src_t), _vp, _i, _i, _l, _i, _i, _vp, _vp, _i, _i, _vp, _l, _l, _vp, _i, _P(C.c_int), _vp, _sz, _vp]),
     'mt_inorm_finalize': (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     'mt_inorm_lrelu_apply': (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _vp]),
     'mt_inorm_bwd_workspace': (_sz, [_i, _l, _i]),

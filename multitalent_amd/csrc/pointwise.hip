@@ -553,9 +553,13 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   MT_REQUIRE(P.ntaps == 1 || P.ntaps == 2 || P.ntaps == 4 || P.ntaps == 8, "pointwise: unsupported tap count %d", P.ntaps);
   MT_REQUIRE(P.nchunks * PW_CK <= PW_MAXC, "pointwise: Cin = %d exceeds %d", p->Cin, PW_MAXC);
   const mt_src_t& S = p->src;
-  int vec = 1;
-  if ((S.cs % 4) == 0 && (((uintptr_t)S.ptr) & 15) == 0) vec = 4;
-  else if ((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0) vec = 2;
+  // 16-byte loads whatever the alignment: a raw buffer_load_dwordx4 only needs dword alignment and range-checks per dword
+  // (tools/ubench/oob128.hip); the 47-channel gradient of the heads (188-byte rows) went through eight scalar loads per chunk before
+  static int force_vec = -1;
+  if (force_vec < 0) { const char* e = getenv("MT_PW_VEC"); force_vec = e ? atoi(e) : 0; }
+  int vec = 4;
+  if (force_vec == 1 || force_vec == 2 || force_vec == 4) vec = force_vec;
+  if (vec == 2 && !((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0)) vec = 1;
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
   hipStream_t st = (hipStream_t)stream;
 #define PW_LAUNCH(NT)                                                                              \
@@ -572,5 +576,245 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   }
 #undef PW_LAUNCH
   MT_CHECK_LAUNCH("pointwise");
+  return MT_OK;
+}
+
+
+// ================================================================================================
+// Backward of a 1x1x1 segmentation head in ONE pass over (x, dY) — generic_UNet.py:349-351 / generic_modular_UNet.py:244,251:
+//   dX[n,v,ci] (+)= sum_co dY[n,v,co] W[co,ci]                 (gradient w.r.t. the ACTIVATED head input a = lrelu(x*scale+shift))
+//   dW[co,ci]  (+)= sum_{n,v} a[n,v,ci] dY[n,v,co],   dbias[co] (+)= sum_{n,v} dY[n,v,co]
+// The separate kernels (pointwise backward-data + tiled backward-weight) moved 2 x |x| + 3 x |dY| + |dX| at 1.2-2.5 TB/s: with 47
+// output channels at full resolution the heads cost 3.2 ms of a 74 ms Task100 step.  Here a wave walks over 32-voxel tiles:
+//   * dX tile = dY tile (A operand: the lane's voxel row, 8 contiguous channels per 16-chunk, 16-byte loads) x W^T (packed B
+//     fragments, held in registers for the whole kernel);
+//   * dW += a^T dY with the VOXELS as the contraction index: both operands are then "lane = channel" rows of one voxel (coalesced
+//     120 / 188-byte reads that hit the lines the dX part just fetched), two voxels per MFMA; row 31 of the last input-channel tile,
+//     when free, carries 1.0 so that the same MFMAs produce dbias;
+//   * every wave keeps its dW partial (NCI x 2 accumulator tiles) in registers and writes it once; head_bwd_reduce_kernel sums the
+//     partials in fp64 in a fixed order (deterministic, no atomics).
+struct HeadBwdParams {
+  mt_src_t x; const float* dy; int dycs; int N; long V; int Cin, Cout;
+  const float* wpack; float* dx; int dxcs; int accumulate_dx;
+  float* part; int nwaves; long ntiles;
+};
+template <int NCI>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  const int gw = blockIdx.x * 4 + wave;
+  const mt_src_t& S = P.x;
+  const bool aff = S.scale != nullptr;
+  const float slope = aff ? S.slope : 1.f;
+  const int nchunks = (P.Cout + 15) / 16;                          // K chunks of the dX product (K = Cout <= 64)
+  // packed W^T fragments: [ci tile][co chunk][2][64 lanes][4] — constant for the whole kernel
+  f32x4 wb[NCI][4][2];
+#pragma unroll
+  for (int t = 0; t < NCI; ++t)
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const float* wq = P.wpack + (size_t)(t * nchunks + ch) * 512 + lane * 4;
+      wb[t][ch][0] = ch < nchunks ? *(const f32x4*)(wq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      wb[t][ch][1] = ch < nchunks ? *(const f32x4*)(wq + 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  f32x16 aw[NCI][2];
+#pragma unroll
+  for (int t = 0; t < NCI; ++t)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) aw[t][n][j] = 0.f;
+  // the ones row (dbias): the last row of the last ci tile, when no input channel lives there
+  const bool ones_free = (P.Cin % 32) != 0;
+  const long tiles_per_sample = (P.V + 31) / 32;
+  int cur_nb = -1;
+  float xsc[NCI], xsh[NCI];
+#pragma unroll
+  for (int t = 0; t < NCI; ++t) { xsc[t] = 0.f; xsh[t] = 0.f; }
+  for (long tile = gw; tile < P.ntiles; tile += P.nwaves) {
+    const int nb = (int)(tile / tiles_per_sample);
+    const long m0 = (tile - (long)nb * tiles_per_sample) * 32;
+    if (nb != cur_nb) {                                            // (wave-uniform) per-(sample, channel) lazy-activation constants
+      cur_nb = nb;
+#pragma unroll
+      for (int t = 0; t < NCI; ++t) {
+        const int ci = t * 32 + li;
+        const bool cv = ci < P.Cin;
+        xsc[t] = cv ? (aff ? S.scale[(size_t)nb * S.C + ci] : 1.f) : 0.f;
+        xsh[t] = (cv && aff) ? S.shift[(size_t)nb * S.C + ci] : 0.f;
+      }
+    }
+    const size_t ysample = (size_t)P.V * P.dycs, xsample = (size_t)P.V * S.cs, dsample = (size_t)P.V * P.dxcs;
+    __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dy + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * xsample), 0, (int)(xsample * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dx + (size_t)nb * dsample), 0, (int)(dsample * 4), 0x00020000);
+    // ---- dX = dY W^T: A operand = this lane's voxel row of dY, channels 16 ch + 8 lhalf .. +7
+    const long bv = m0 + li;
+    const bool vok = bv < P.V;
+    const int yoff = vok ? (int)((bv * P.dycs + 8 * lhalf) * 4) : (int)0x80000000;
+    f32x16 ax[NCI];
+#pragma unroll
+    for (int t = 0; t < NCI; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) ax[t][j] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      if (ch < nchunks) {
+        float xa[8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, yoff + (ch * 16 + g * 4) * 4, 0, 0));
+          xa[4 * g] = v[0]; xa[4 * g + 1] = v[1]; xa[4 * g + 2] = v[2]; xa[4 * g + 3] = v[3];
+        }
+        const int cb = ch * 16 + 8 * lhalf;                        // a row's tail runs into the next voxel's first channels: zero them
+        if (cb + 8 > P.Cout) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xa[e] = (cb + e < P.Cout) ? xa[e] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NCI; ++t) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ax[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], wb[t][ch][0][e], ax[t], 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ax[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[4 + e], wb[t][ch][1][e], ax[t], 0, 0, 0);
+        }
+      }
+    }
+    // ---- dW += a^T dY, two voxels per MFMA (k = lhalf): operands are channel rows of voxel m0 + 2 s + lhalf
+#pragma unroll 4
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const long v = m0 + 2 * s2 + lhalf;
+      const bool in = v < P.V;
+      const int vo = in ? (int)(v * 4) : (int)0x80000000;          // (scaled below; bit 31 survives the multiplications as a mask)
+      float av[NCI], bvv[2];
+#pragma unroll
+      for (int t = 0; t < NCI; ++t) {
+        const int ci = t * 32 + li;
+        const int o = (in && ci < P.Cin) ? (int)((v * S.cs + ci) * 4) : (int)0x80000000;
+        const float raw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        const float tt = fmaf(raw, xsc[t], xsh[t]);
+        av[t] = in ? fmaxf(tt, tt * slope) : 0.f;
+        if (ones_free && t == NCI - 1 && li == 31) av[t] = in ? 1.f : 0.f;
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int co = n * 32 + li;
+        const int o = (in && co < P.Cout) ? (int)((v * P.dycs + co) * 4) : (int)0x80000000;
+        bvv[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, o, 0, 0));
+      }
+      (void)vo;
+#pragma unroll
+      for (int t = 0; t < NCI; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) aw[t][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bvv[n], aw[t][n], 0, 0, 0);
+    }
+    // ---- store dX (C layout: lane = input channel column, registers = voxel rows)
+#pragma unroll
+    for (int t = 0; t < NCI; ++t) {
+      const int ci = t * 32 + li;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const long v = m0 + (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+        const int o = (ci < P.Cin && v < P.V) ? (int)((v * P.dxcs + ci) * 4) : (int)0x80000000;
+        float val = ax[t][j];
+        if (P.accumulate_dx) val += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, o, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rd, o, 0, 0);
+      }
+    }
+  }
+  // ---- this wave's dW partial: [wave][t][n][j 16][lane 64]
+  float* pp = P.part + (size_t)gw * (NCI * 2 * 1024);
+#pragma unroll
+  for (int t = 0; t < NCI; ++t)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) pp[((t * 2 + n) * 16 + j) * 64 + lane] = aw[t][n][j];
+}
+
+#define HB_SLICES 32
+struct HeadBwdReduce { const float* part; double* tmp; int nwaves, nci, Cin, Cout; float* dw; long s_ci, s_co; float* dbias; int accumulate; };
+// stage A: tmp[slice][e] = sum over the slice's partials (fp64, fixed order) — 32 x fewer dependent loads per thread than one pass
+__global__ __launch_bounds__(256) void head_bwd_reduce_a_kernel(const HeadBwdReduce R) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int per = R.nci * 2 * 1024;
+  if (e >= per) return;
+  const int sl = blockIdx.y;
+  const int w0 = (int)((long)R.nwaves * sl / HB_SLICES), w1 = (int)((long)R.nwaves * (sl + 1) / HB_SLICES);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;                   // four fixed chains: loads in flight, order independent of timing
+  int w = w0;
+  for (; w + 4 <= w1; w += 4) {
+    s0 += (double)R.part[(size_t)w * per + e];
+    s1 += (double)R.part[(size_t)(w + 1) * per + e];
+    s2 += (double)R.part[(size_t)(w + 2) * per + e];
+    s3 += (double)R.part[(size_t)(w + 3) * per + e];
+  }
+  for (; w < w1; ++w) s0 += (double)R.part[(size_t)w * per + e];
+  R.tmp[(size_t)sl * per + e] = (s0 + s1) + (s2 + s3);
+}
+// stage B: element e = ((t*2 + n)*16 + j)*64 + lane of the accumulator layout -> dW[co][ci] / dbias[co]
+__global__ __launch_bounds__(256) void head_bwd_reduce_b_kernel(const HeadBwdReduce R) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int per = R.nci * 2 * 1024;
+  if (e >= per) return;
+  const int lane = e & 63, j = (e >> 6) & 15, tn = e >> 10, n = tn & 1, t = tn >> 1;
+  const int row = (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5), col = lane & 31;
+  const int ci = t * 32 + row, co = n * 32 + col;
+  const bool is_bias = (R.Cin % 32) != 0 && t == R.nci - 1 && row == 31;
+  if (co >= R.Cout || (ci >= R.Cin && !is_bias)) return;
+  double a = 0.0;
+  for (int sl = 0; sl < HB_SLICES; ++sl) a += R.tmp[(size_t)sl * per + e];
+  const float s = (float)a;
+  if (is_bias) { if (R.dbias != nullptr) R.dbias[co] = R.accumulate ? R.dbias[co] + s : s; return; }
+  float* o = R.dw + (long)ci * R.s_ci + (long)co * R.s_co;
+  *o = R.accumulate ? *o + s : s;
+}
+
+static inline int head_bwd_waves(int N, long V) {
+  const long ntiles = (long)N * ((V + 31) / 32);
+  long w = ntiles / 32;                                            // >= 32 tiles per wave: the 8 - 16 KiB partial of a wave is written once
+  if (w > 256 * 4 * 4) w = 256 * 4 * 4;                            // at most 4 workgroups of 4 waves per CU
+  if (w < 4) w = 4;
+  return (int)((w + 3) / 4 * 4);
+}
+// Cin <= 32 only: the two-input-tile instantiation (Cin <= 64) needs 182 VGPRs (one wave per SIMD) and measured 0.70 ms on the
+// 24x96x96 level — slower than the generic kernels there; it stays compiled for the tests of the accumulation logic (MT_HEAD_BWD_WIDE=1)
+extern "C" int mt_head_bwd_supported(int Cin, int Cout) {
+  static int wide = -1;
+  if (wide < 0) { const char* e = getenv("MT_HEAD_BWD_WIDE"); wide = e ? atoi(e) : 0; }
+  return Cin >= 1 && Cin <= (wide ? 64 : 32) && Cout >= 1 && Cout <= 64;
+}
+extern "C" size_t mt_head_bwd_workspace(int N, long V, int Cin, int Cout) {
+  if (!(Cin >= 1 && Cin <= 64 && Cout >= 1 && Cout <= 64)) return 0;
+  const size_t per = (size_t)((Cin + 31) / 32) * 2 * 1024;
+  return (size_t)head_bwd_waves(N, V) * per * sizeof(float) + HB_SLICES * per * sizeof(double) + 64;
+}
+extern "C" int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, long V, int Cin, int Cout, const float* wpack_bwd,
+                           float* dx, int dxcs, int accumulate_dx, float* dw, long s_ci, long s_co, float* dbias, int accumulate_dw,
+                           int* dbias_done, void* ws, size_t ws_bytes, mt_stream_t stream) {
+  MT_REQUIRE(x && x->ptr && dy && wpack_bwd && dx && dw && N > 0 && V > 0, "head_bwd: null / empty argument");
+  MT_REQUIRE(Cin >= 1 && Cin <= 64 && Cout >= 1 && Cout <= 64, "head_bwd: Cin (%d) and Cout (%d) must be <= 64", Cin, Cout);
+  MT_REQUIRE(x->C == Cin, "head_bwd: x->C != Cin");
+  MT_REQUIRE((double)V * x->cs * 4.0 < 2147483648.0 && (double)V * dycs * 4.0 < 2147483648.0 && (double)V * dxcs * 4.0 < 2147483648.0, "head_bwd: sample larger than 2 GiB");
+  if (ws == nullptr || ws_bytes < mt_head_bwd_workspace(N, V, Cin, Cout)) { mt_set_error("head_bwd: workspace too small"); return MT_EWORKSPACE; }
+  HeadBwdParams P;
+  P.x = *x; P.dy = dy; P.dycs = dycs; P.N = N; P.V = V; P.Cin = Cin; P.Cout = Cout; P.wpack = wpack_bwd;
+  P.dx = dx; P.dxcs = dxcs; P.accumulate_dx = accumulate_dx; P.part = (float*)ws;
+  P.nwaves = head_bwd_waves(N, V); P.ntiles = (long)N * ((V + 31) / 32);
+  const int nci = (Cin + 31) / 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (nci == 1) hipLaunchKernelGGL(head_bwd_kernel<1>, dim3(P.nwaves / 4), dim3(256), 0, st, P);
+  else          hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(P.nwaves / 4), dim3(256), 0, st, P);
+  MT_CHECK_LAUNCH("head_bwd");
+  HeadBwdReduce R;
+  R.part = (const float*)ws; R.nwaves = P.nwaves; R.nci = nci; R.Cin = Cin; R.Cout = Cout; R.dw = dw; R.s_ci = s_ci; R.s_co = s_co;
+  R.dbias = dbias; R.accumulate = accumulate_dw;
+  const size_t per = (size_t)nci * 2 * 1024;
+  R.tmp = (double*)(((uintptr_t)((float*)ws + (size_t)P.nwaves * per) + 7) & ~(uintptr_t)7);
+  hipLaunchKernelGGL(head_bwd_reduce_a_kernel, dim3(mt_cdiv((long)per, 256), HB_SLICES), dim3(256), 0, st, R);
+  hipLaunchKernelGGL(head_bwd_reduce_b_kernel, dim3(mt_cdiv((long)per, 256)), dim3(256), 0, st, R);
+  MT_CHECK_LAUNCH("head_bwd_reduce");
+  if (dbias_done != nullptr) *dbias_done = ((Cin % 32) != 0) ? 1 : 0;      // 0: the caller sums dY itself (mt_channel_sum)
   return MT_OK;
 }

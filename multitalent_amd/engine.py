@@ -349,6 +349,30 @@ class HeadOp(ConvNormOp):
     def __init__(self, name, src, out, conv):
         super().__init__(name, [src], out, conv, None, lrelu=False, pointwise=True)
 
+    def backward(self, eng):
+        """dX, dW and dbias of the head in ONE pass over (x, dlogits) (mt_head_bwd) when the head is narrow enough (<= 64 channels
+        in and out: the full-resolution heads, where 47 logit channels make the separate kernels cost 3 ms of a Task100 step);
+        otherwise the generic pointwise backward-data + tiled backward-weight of ConvNormOp."""
+        import os
+        s0 = self.srcs[0]
+        Cout = self.conv.out_channels
+        if (os.environ.get('MT_HEAD_BWD_FUSED', '1') == '0' or s0.grad is None or self.wb is None
+                or not ops.head_bwd_supported(s0.C, Cout) or self.stride != (1, 1, 1)):
+            return super().backward(eng)
+        g = self.out.grad
+        assert g is not None and self.out.grad_init, "gradient of %s was never produced" % self.name
+        gact = Act(g)
+        a = s0.act
+        dbias = eng.grad_of(self.conv.bias) if self.conv.bias is not None else None
+        ws = eng.workspace(ops.head_bwd_workspace(a.N, a.V, s0.C, Cout))
+        w = self.conv.weight
+        st = _strides(w)                                 # (s_ci, s_co, ...) of the [Cout, Cin, 1, 1, 1] weight
+        done = ops.head_bwd(a, gact, self.wb, Act(s0.grad), s0.grad_init, eng.grad_of(w), st[0], st[1], dbias, False, ws)
+        if dbias is not None and not done:
+            ws2 = eng.workspace(4 * gact.N * ((gact.V + 2047) // 2048) * gact.C)
+            ops.channel_sum(gact, dbias, False, ws2)
+        s0.grad_init = True
+
 
 class Engine:
     def __init__(self, module, ops_list, x_val, head_vals, final_head_index):

@@ -316,6 +316,26 @@ def pointwise_fwd(p):
     _lib.check(_lib.load().mt_pointwise_fwd(C.byref(p), _stream()), 'pointwise_fwd')
 
 
+def head_bwd_supported(Cin, Cout):
+    return bool(_lib.load().mt_head_bwd_supported(int(Cin), int(Cout)))
+
+
+def head_bwd(x, dy, wpack_bwd, dx, accumulate_dx, dw, s_ci, s_co, dbias, accumulate_dw, ws):
+    """Fused backward of a 1x1x1 head: x = Act (head input, lazy), dy = Act over the dense gradient of the logits, dx = Act over the
+    gradient buffer of the head's input.  Returns True when dbias was produced (see mt_head_bwd)."""
+    lib = _lib.load()
+    xs = x.src()
+    done = C.c_int(0)
+    _lib.check(lib.mt_head_bwd(C.byref(xs), C.c_void_p(dy.data_ptr()), dy.cs, x.N, x.V, x.C, dy.C, _ptr(wpack_bwd),
+                               C.c_void_p(dx.data_ptr()), dx.cs, int(accumulate_dx), _ptr(dw), int(s_ci), int(s_co), _ptr(dbias),
+                               int(accumulate_dw), C.byref(done), _ptr(ws), ws.numel() * ws.element_size(), _stream()), 'head_bwd')
+    return bool(done.value)
+
+
+def head_bwd_workspace(N, V, Cin, Cout):
+    return _lib.load().mt_head_bwd_workspace(int(N), int(V), int(Cin), int(Cout))
+
+
 def pointwise_stats_blocks(p):
     return _lib.load().mt_pointwise_stats_blocks(C.byref(p))
 

@@ -751,3 +751,44 @@ def test_multitalent_loss_kernels_flat_and_strided(dev, B, C, V, wide):
     assert torch.allclose(got, dref, rtol=1e-4, atol=1e-5)
     if wide:
         assert torch.isnan(dbuf[..., C:]).all()            # the neighbouring channels of the wider buffer are untouched
+
+
+@pytest.mark.parametrize("N,Cin,Cout,V,lazy,acc,bias", [(2, 30, 47, 48 * 20 * 21 + 5, True, False, True), (1, 30, 2, 1000, True, True, False),
+                                                        (2, 60, 47, 777, False, True, True), (1, 64, 5, 4096, True, False, True), (3, 8, 64, 33, True, False, True)])
+def test_head_bwd_fused(dev, N, Cin, Cout, V, lazy, acc, bias):
+    """mt_head_bwd: dX, dW and dbias of a 1x1x1 head in one pass vs autograd of F.conv3d on the activated input (fp64)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(Cin * 100 + Cout)
+    x = torch.randn((N, V, 1, 1, Cin), generator=g)
+    sc = torch.rand((N, Cin), generator=g) + 0.5
+    sh = torch.randn((N, Cin), generator=g)
+    w = torch.randn((Cout, Cin, 1, 1, 1), generator=g) / np.sqrt(Cin)
+    dy = torch.randn((N, V, 1, 1, Cout), generator=g)
+    dx0 = torch.randn((N, V, 1, 1, Cin), generator=g)
+    xd = x.to(dev)
+    a = ops.Act(xd, scale=sc.to(dev), shift=sh.to(dev), slope=0.01) if lazy else ops.Act(xd)
+    wd = w.to(dev).contiguous()
+    wb = ops.pack_conv_weights(wd, Cout, 0, Cin, (1, 1, 1), ops.conv_weight_strides(wd, as_bwd_data=True), False, ops.POINTWISE_CK)
+    dxd = dx0.to(dev).clone()
+    dw = torch.full_like(wd, float('nan'))
+    db = torch.full((Cout,), float('nan'), device=dev) if bias else None
+    ws = torch.empty(ops.head_bwd_workspace(N, V, Cin, Cout) // 4 + 16, device=dev)
+    st = ops.conv_weight_strides(wd)
+    dyd = dy.to(dev)
+    done = ops.head_bwd(a, ops.Act(dyd), wb, ops.Act(dxd), acc, dw, st[0], st[1], db, False, ws)
+    torch.cuda.synchronize()
+    # reference
+    xa = x.double()
+    if lazy:
+        t = xa * sc.double()[:, None, None, None, :] + sh.double()[:, None, None, None, :]
+        xa = torch.where(t > 0, t, 0.01 * t)
+    xa = xa.reshape(N * V, Cin)
+    dyf = dy.double().reshape(N * V, Cout)
+    w2 = w.double().reshape(Cout, Cin)
+    ref_dx = (dyf @ w2).reshape(N, V, 1, 1, Cin) + (dx0.double() if acc else 0)
+    ref_dw = (dyf.t() @ xa).reshape(Cout, Cin, 1, 1, 1)
+    assert relerr(dxd.cpu().double(), ref_dx) < 1e-5
+    assert relerr(dw.cpu().double(), ref_dw) < 1e-5
+    assert done == (Cin % 32 != 0)
+    if bias and done:
+        assert relerr(db.cpu().double(), dyf.sum(0)) < 1e-5
