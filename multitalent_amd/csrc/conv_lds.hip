@@ -2098,9 +2098,13 @@ static int launch_gather(const mt_conv3d_t* p, hipStream_t st) {
   P.tilesD = P.tilesH = P.tilesW = 1; P.nsb = (int)((V + 127) / 128);
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
   const mt_src_t& S = p->src[0];
-  int vec = 1;
-  if ((S.cs % 4) == 0 && (((uintptr_t)S.ptr) & 15) == 0) vec = 4;
-  else if ((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0) vec = 2;
+  // 16-byte loads at any alignment (dword-aligned dwordx4 buffer loads are legal and range-checked per dword: tools/ubench/oob128.hip)
+  static int force_vec = -1;
+  if (force_vec < 0) { const char* e = getenv("MT_GATHER_VEC"); force_vec = e ? atoi(e) : 0; }
+  int vec = 4;
+  if (force_vec == 1 || force_vec == 2) vec = force_vec;
+  if (vec == 2 && !((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0)) vec = 1;
+  (void)S;
   if (vec == 4) hipLaunchKernelGGL(conv_gather_kernel<4>, grid, dim3(256), 0, st, P);
   else if (vec == 2) hipLaunchKernelGGL(conv_gather_kernel<2>, grid, dim3(256), 0, st, P);
   else hipLaunchKernelGGL(conv_gather_kernel<1>, grid, dim3(256), 0, st, P);
