@@ -540,6 +540,8 @@ def test_ds_label_pyramid_on_device(dev):
     (1, 64, 40, (12, 20, 33), False),
     (1, 30, 30, (5, 7, 19), True),          # concat input: chunks never straddle the two sources
     (1, 16, 70, (4, 4, 16), False),         # exactly one tile, three cout tiles
+    (2, 20, 16, (8, 8, 32), False),         # odd chunk count (8,8,4): the persistent kernel's pairs end in a phantom chunk
+    (1, 24, 32, (6, 9, 20), True),          # 3 + 3 chunks: the middle pair straddles the two sources
 ])
 @pytest.mark.parametrize("waves", [8, 4, 803, 800])
 def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
