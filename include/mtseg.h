@@ -32,7 +32,7 @@ extern "C" {
 #define MT_EHIP (-3)    /* HIP runtime error on launch */
 
 #define MT_ABI_VERSION 1
-#define MT_MAX_CHUNKS 48
+#define MT_MAX_CHUNKS 64
 
 typedef void* mt_stream_t; /* hipStream_t */
 

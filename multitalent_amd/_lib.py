@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MT_LIB_VARIANT selects an instrumented build of the same ABI (tools/build_variant.sh) for kernel timing experiments
 LIB_PATH = os.path.join(_HERE, os.environ.get('MT_LIB_VARIANT', 'libmtseg_hip.so'))
 
-MT_MAX_CHUNKS = 48
+MT_MAX_CHUNKS = 64
 c_float_p = C.POINTER(C.c_float)
 
 
