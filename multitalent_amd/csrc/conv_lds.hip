@@ -3290,6 +3290,9 @@ static void bwdw_march_plan(const mt_conv3d_t* p, BwdWParams* P);
 static int conv_fast_vec(const mt_conv3d_t* p);
 static bool bwdw_use_wino(const mt_conv3d_t* p) {
   if (g_bwdw_wino < 0) { const char* e = getenv("MT_BWDW_WINO"); g_bwdw_wino = e ? atoi(e) : 1; }
+  // (its X path applies LeakyReLU as max(t, slope * t): lazy sources need 0 <= slope <= 1)
+  for (int i = 0; i < p->nsrc; ++i)
+    if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
   return g_bwdw_wino && bwdw_use_march(p) && p->Wo > 16 && p->Ho >= 2 && conv_fast_vec(p) == 2;
 }
 static bool bwdw_use_bf16(const mt_conv3d_t* p) {
