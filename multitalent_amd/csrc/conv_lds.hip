@@ -1530,6 +1530,9 @@ template <int S> __host__ __device__ constexpr int bd_par(int k) { return S == 2
 template <int S> __host__ __device__ constexpr int bd_off(int k) { return S == 2 ? (k == 0 ? 1 : 0) : 2 - k; }
 
 // BF = true (mixed precision): bf16 LDS image (mt_stage_bf16) and one v_mfma_f32_32x32x16_bf16 per tap.
+#ifndef BDS_ABL
+#define BDS_ABL 0      // timing ablations: 1 skip the dY staging, 2 skip the weight-fragment loads, 4 skip the epilogue, 8 skip the MFMAs
+#endif
 template <int SD, int SH, int SW, int VEC, bool BF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_bwdd_strided_kernel(const ConvKParams P) {
   constexpr int TD = 2, TH = 4, TW = 16;                       // dY positions per workgroup: 4 waves x 32
@@ -1591,8 +1594,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       }
       continue;
     }
-    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
+    if (!(BDS_ABL & 1)) mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
     __syncthreads();
+    if (BDS_ABL & 2) wlane = c.wpack + lane * 4;       // (every fragment from the same cached 8 KiB)
     // all 27 taps unrolled in natural order; tap t reads the A fragment at its compile-time offset (jd, jh, jw) and accumulates
     // into the tile of its parity class.  Weight fragments are prefetched 3 taps ahead through a register ring, A fragments
     // one tap ahead (same software pipeline as fast_chunk — the plain loop nest left every L2 round trip exposed).
@@ -1612,7 +1616,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       }
 #pragma unroll
       for (int t = 0; t < 27; ++t) {
-        if (t + 3 < 27) {
+        if (t + 3 < 27 && !(BDS_ABL & 2)) {
           b[(t + 3) % NB][0] = *(const f32x4*)(wlane + (t + 3) * 512);
           b[(t + 3) % NB][1] = *(const f32x4*)(wlane + (t + 3) * 512 + 256);
         }
@@ -1624,6 +1628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         }
         __builtin_amdgcn_sched_barrier(0);
         const int q = (bd_par<SD>(t / 9) * SH + bd_par<SH>((t / 3) % 3)) * SW + bd_par<SW>(t % 3);
+        if (BDS_ABL & 8) { acc[q][0] += a[t & 1][0][0] + a[t & 1][1][3] + b[t % NB][0][1] + b[t % NB][1][2]; continue; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1][0][e], b[t % NB][0][e], acc[q], 0, 0, 0);
 #pragma unroll
@@ -1641,8 +1646,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
                                                                 (int)(out_sample * ocs * 4), 0x00020000);
   const int md = md0 + dm;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  if (BDS_ABL & 4) { float t = 0.f; for (int q = 0; q < NC; ++q) t += acc[q][3] + acc[q][9]; if (t == 1234.5f) c.out0[0] = t; return; }
+  // Accumulating into dX (the skip connection wrote it first) is a read-modify-write of 16 x NC scattered dwords per lane: the
+  // NC loads of accumulator row j+1 are requested before the NC stores of row j go out, so a row's round trip hides behind the
+  // previous row's stores (one load -> add -> store chain per element cost 0.26 of 0.81 ms on 30 <- 60 @ 48x192x192)
+  auto row_off = [&](int j, int (&off)[NC]) {
     const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf;
     const int mh = mh0 + rbase + (iv >> 4), mw = mw0 + (iv & 15);
 #pragma unroll
@@ -1650,10 +1658,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       const int pd = q / (SH * SW), ph = (q / SW) % SH, pw = q % SW;
       const int xd = md * SD + pd, xh = mh * SH + ph, xw = mw * SW + pw;
       const bool ok = covalid && xd < c.OD && xh < c.OH && xw < c.OW;
-      const int off = ok ? (((xd * c.OH + xh) * c.OW + xw) * ocs + co) * 4 : (int)0x80000000;
+      off[q] = ok ? (((xd * c.OH + xh) * c.OW + xw) * ocs + co) * 4 : (int)0x80000000;
+    }
+  };
+  int off[2][NC];
+  float prev[2][NC];
+  row_off(0, off[0]);
+  if (c.accumulate) {
+#pragma unroll
+    for (int q = 0; q < NC; ++q) prev[0][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off[0][q], 0, 0));
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j + 1 < 16) {
+      row_off(j + 1, off[(j + 1) & 1]);
+      if (c.accumulate) {
+#pragma unroll
+        for (int q = 0; q < NC; ++q)
+          prev[(j + 1) & 1][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off[(j + 1) & 1][q], 0, 0));
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
       float v = acc[q][j];
-      if (c.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, 0);
+      if (c.accumulate) v += prev[j & 1][q];
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off[j & 1][q], 0, 0);
     }
   }
 }

@@ -8,7 +8,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--cin', type=int, default=30); ap.add_argument('--cout', type=int, default=30)
 ap.add_argument('--shape', type=int, nargs=3, default=[48, 192, 192]); ap.add_argument('--n', type=int, default=2)
 ap.add_argument('--k', type=int, nargs=3, default=[3, 3, 3]); ap.add_argument('--stride', type=int, nargs=3, default=[1, 1, 1])
-ap.add_argument('--reps', type=int, default=5); ap.add_argument('--mode', default='fwd', choices=['fwd', 'bwdw'])
+ap.add_argument('--reps', type=int, default=5); ap.add_argument('--mode', default='fwd', choices=['fwd', 'bwdw', 'bwdd'])
+ap.add_argument('--acc', type=int, default=1, help='bwdd: accumulate into dX (the skip connection already wrote it)')
 ap.add_argument('--lazy', type=int, default=1); ap.add_argument('--mma', type=int, default=0)
 ap.add_argument('--ts', type=int, default=0, help='library built with -DWN_TS=1: print the per-phase cycle totals of the persistent Winograd kernel')
 a = ap.parse_args()
@@ -65,6 +66,16 @@ if a.mode == 'fwd':
         # concurrency: how many blocks start within the first 1000 cycles
         st = np.sort(tsc[:, 0, 0] - t0)
         print('  blocks started in first 5k cycles: %d ; start times of blocks 500..520: %s' % ((st < 5000).sum(), st[500:520:4]))
+elif a.mode == 'bwdd':          # backward-data of the strided conv in one launch (mt_conv3d_bwd_data_strided): dY [Cout] -> dX [Cin]
+    dy = torch.randn_like(out)
+    dx = torch.zeros((N,) + tuple(a.shape) + (Cin,), device=dev)
+    p = ops.fill_conv([ops.Act(dy)], geom, Cout, out0=ops.Act(dx), accumulate=bool(a.acc))
+    p.Cin = Cin
+    assert ops.conv3d_bwd_data_strided_supported(p)
+    wp = ops.pack_conv_weights(w, Cout, 0, Cin, a.k, ops.conv_weight_strides(w, as_bwd_data=True), False, 16,
+                               layout=ops.conv_bwd_data_strided_pack_layout(p))
+    p.wpack = wp.data_ptr()
+    run = lambda: ops.conv3d_bwd_data_strided(p)
 else:
     dy = torch.randn_like(out)
     p = ops.fill_conv([xa], geom, Cout)
