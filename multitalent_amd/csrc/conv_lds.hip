@@ -815,31 +815,43 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
     const int dm = mt / RH, rh = mt % RH;
     const int od = od0 + dm;
     const int vox0 = ((od * c.Ho) + (oh0 + rh * MH)) * c.Wo + ow0;    // within the sample, wave-uniform
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      constexpr int dummy = 0; (void)dummy;
+    auto jgeom = [&](int j, int& off, int& so0, int& so1) {
       const int ivj = (j & 3) + 8 * (j >> 2);           // lane-independent part of the voxel index in the M tile
       const int r = ivj / MW, colj = ivj % MW;          // (4*lhalf never crosses an MW boundary: MW >= 8)
-      int off = loff;
+      off = loff;
       if (!interior) {
         const bool ok = (od < c.Do) && (oh0 + rh * MH + r < c.Ho) && (ow0 + colj + lane_col < c.Wo);
         off = ok ? loff : (int)0x80000000;
       }
-      float v = acc[m][j] + bv;
       // scalar offsets differ per destination only through ocs: compute both (SALU) and select per lane once
-      const int so0 = (vox0 + r * c.Wo + colj) * c.ocs0 * 4;
-      const int so1 = (vox0 + r * c.Wo + colj) * c.ocs1 * 4;
+      so0 = (vox0 + r * c.Wo + colj) * c.ocs0 * 4;
+      so1 = (vox0 + r * c.Wo + colj) * c.ocs1 * 4;
+    };
+    // accumulate: the 16 old values of this M tile are requested together, before the first store (one load -> add -> store
+    // round trip per element otherwise: the residual encoder's 30 -> 30 backward-data at full resolution)
+    float prev[16];
+    if (c.accumulate) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        int off, so0, so1; jgeom(j, off, so0, so1);
+        if (!split) prev[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0d, off, so0, 0));
+        else {
+          const int offa = use1 ? (int)0x80000000 : off, offb = use1 ? off : (int)0x80000000;
+          prev[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0d, offa, so0, 0)) +
+                    __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1d, offb, so1, 0));
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int off, so0, so1; jgeom(j, off, so0, so1);
+      float v = acc[m][j] + bv;
+      if (c.accumulate) v += prev[j];
       if (!split) {
-        if (c.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0d, off, so0, 0));
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r0d, off, so0, 0);
       } else {
         // lanes of the two destinations take different descriptors: predicate by offset (OOB = no-op)
         const int offa = use1 ? (int)0x80000000 : off, offb = use1 ? off : (int)0x80000000;
-        if (c.accumulate) {
-          const float o0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0d, offa, so0, 0));
-          const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1d, offb, so1, 0));
-          v += o0 + o1;
-        }
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r0d, offa, so0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r1d, offb, so1, 0);
       }
@@ -1484,19 +1496,28 @@ __global__ __launch_bounds__(256) void conv_rt_kernel(const ConvKParams P) {
     const int mt = wave * MT + m;
     const int dm = mt / RH, rh = mt % RH;
     const int od = od0 + dm;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    auto jgeom = [&](int j, bool& ok) -> int {
       const int ivj = (j & 3) + 8 * (j >> 2);
       const int r = ivj / MW, colj = ivj % MW;
       const int oh = oh0 + rh * MH + r, ow = ow0 + colj + lane_col;
-      const bool ok = covalid && (od < c.Do) && (oh < c.Ho) && (ow < c.Wo);
+      ok = covalid && (od < c.Do) && (oh < c.Ho) && (ow < c.Wo);
       const int vox = ((od * osD + ooD) * OH + (oh * osH + ooH)) * OW + (ow * osW + ooW);
-      const int off = ok ? (vox * ocs + cofs) * 4 : (int)0x80000000;
-      float v = acc[m][j] + bv;
-      if (c.accumulate) {
-        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off | m0, 0, 0));
-        if (split) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd1, off | m1, 0, 0));
+      return ok ? (vox * ocs + cofs) * 4 : (int)0x80000000;
+    };
+    float prev[16];                                    // accumulate: the 16 old values are requested together, before the first store
+    if (c.accumulate) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        bool ok; const int off = jgeom(j, ok);
+        prev[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off | m0, 0, 0));
+        if (split) prev[j] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd1, off | m1, 0, 0));
       }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      bool ok; const int off = jgeom(j, ok);
+      float v = acc[m][j] + bv;
+      if (c.accumulate) v += prev[j];
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off | m0, 0, 0);
       if (split) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd1, off | m1, 0, 0);
       if (ok) { s1 += v; s2 = fmaf(v, v, s2); }

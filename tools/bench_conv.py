@@ -9,7 +9,7 @@ ap.add_argument('--cin', type=int, default=30); ap.add_argument('--cout', type=i
 ap.add_argument('--shape', type=int, nargs=3, default=[48, 192, 192]); ap.add_argument('--n', type=int, default=2)
 ap.add_argument('--k', type=int, nargs=3, default=[3, 3, 3]); ap.add_argument('--stride', type=int, nargs=3, default=[1, 1, 1])
 ap.add_argument('--reps', type=int, default=5); ap.add_argument('--mode', default='fwd', choices=['fwd', 'bwdw', 'bwdd'])
-ap.add_argument('--acc', type=int, default=1, help='bwdd: accumulate into dX (the skip connection already wrote it)')
+ap.add_argument('--acc', type=int, default=-1, help='accumulate into the output (bwdd: default 1 — the skip connection already wrote dX; fwd: default 0)')
 ap.add_argument('--lazy', type=int, default=1); ap.add_argument('--mma', type=int, default=0)
 ap.add_argument('--ts', type=int, default=0, help='library built with -DWN_TS=1: print the per-phase cycle totals of the persistent Winograd kernel')
 a = ap.parse_args()
@@ -25,7 +25,7 @@ geom = ops.ConvGeom(a.shape, a.k, a.stride)
 out = torch.empty((N,) + geom.out + (Cout,), device=dev)
 flops = 2.0 * N * geom.out[0] * geom.out[1] * geom.out[2] * Cin * Cout * a.k[0] * a.k[1] * a.k[2]
 if a.mode == 'fwd':
-    p = ops.fill_conv([xa], geom, Cout, bias=b, out0=ops.Act(out))
+    p = ops.fill_conv([xa], geom, Cout, bias=b, out0=ops.Act(out), accumulate=(a.acc == 1))
     ck = ops.conv_ck(p)
     wp = ops.pack_conv_weights(w, Cin, 0, Cout, a.k, ops.conv_weight_strides(w), False, ck, layout=ops.conv_pack_layout(p))
     p.wpack = wp.data_ptr()
@@ -69,7 +69,7 @@ if a.mode == 'fwd':
 elif a.mode == 'bwdd':          # backward-data of the strided conv in one launch (mt_conv3d_bwd_data_strided): dY [Cout] -> dX [Cin]
     dy = torch.randn_like(out)
     dx = torch.zeros((N,) + tuple(a.shape) + (Cin,), device=dev)
-    p = ops.fill_conv([ops.Act(dy)], geom, Cout, out0=ops.Act(dx), accumulate=bool(a.acc))
+    p = ops.fill_conv([ops.Act(dy)], geom, Cout, out0=ops.Act(dx), accumulate=(a.acc != 0))
     p.Cin = Cin
     assert ops.conv3d_bwd_data_strided_supported(p)
     wp = ops.pack_conv_weights(w, Cout, 0, Cin, a.k, ops.conv_weight_strides(w, as_bwd_data=True), False, 16,
