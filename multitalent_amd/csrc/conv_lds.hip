@@ -18,6 +18,7 @@
 #include "mt_common.h"
 #include <cstring>
 #include <stdlib.h>
+#include <type_traits>
 
 struct ConvChunk { short src, c0, ck, cglob; };
 
