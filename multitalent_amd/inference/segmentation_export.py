@@ -72,7 +72,8 @@ def resample_and_classify(segmentation_softmax, properties_dict, region_class_or
     out = torch.zeros(full, dtype=torch.uint8, device=p.device)
     order_t = None
     if region_class_order is not None:
-        order_t = torch.tensor([int(c) for c in region_class_order], dtype=torch.int32, device=p.device)
+        # an entry may be a 1-tuple: the drivers pass ((1,),) for a single-region mask (predict_MultiTalent.py:259)
+        order_t = torch.tensor([int(np.asarray(c).reshape(-1)[0]) for c in region_class_order], dtype=torch.int32, device=p.device)
         assert order_t.numel() == C, "one class per channel expected in region_class_order"
     lib = _lib.load()
     _lib.check(lib.mt_resample_classify(p.data_ptr(), C, D, H, W, after[0], after[1], after[2], sep_axis,
@@ -82,11 +83,40 @@ def resample_and_classify(segmentation_softmax, properties_dict, region_class_or
     return out
 
 
+def resample_softmax(p, after, sep_axis):
+    """The resampled multi-channel volume itself (only for `resampled_npz_fname`, i.e. ensembling exports; torch glue): order 1
+    at x = (o + 0.5) in/out - 0.5 with edge clamp, = `F.interpolate(align_corners=False)`; with a separate-z axis every slice is
+    resized in-plane and the slices are picked with nearest neighbour (floor(x + 0.5)), preprocessing.py:109-197."""
+    import torch.nn.functional as F
+    shape = tuple(int(i) for i in p.shape[1:])
+    after = tuple(int(i) for i in after)
+    if shape == after:
+        return p
+    if sep_axis < 0:
+        return F.interpolate(p[None], size=after, mode='trilinear', align_corners=False)[0]
+    perm = [0, 1 + sep_axis] + [1 + i for i in range(3) if i != sep_axis]
+    inv = [perm.index(i) for i in range(4)]
+    q = p.permute(perm)                                                       # [C, Z, A, B]
+    rest = [after[i] for i in range(3) if i != sep_axis]
+    C, Z = int(q.shape[0]), int(q.shape[1])
+    q = F.interpolate(q.reshape(1, C * Z, q.shape[2], q.shape[3]), size=rest, mode='bilinear', align_corners=False)
+    q = q.reshape(C, Z, rest[0], rest[1])
+    nz = after[sep_axis]
+    if nz != Z:
+        o = torch.arange(nz, device=p.device, dtype=torch.float64)
+        idx = torch.floor((o + 0.5) * (Z / nz) - 0.5 + 0.5).clamp_(0, Z - 1).long()
+        q = q.index_select(1, idx)
+    return q.permute(inv).contiguous()
+
+
 def save_segmentation_nifti_from_softmax(segmentation_softmax, out_fname, properties_dict, order=1, region_class_order=None,
                                          seg_postprogess_fn=None, seg_postprocess_args=None, resampled_npz_fname=None,
                                          non_postprocessed_fname=None, force_separate_z=None, interpolation_order_z=0, verbose=True):
-    """Same signature as the reference (segmentation_export.py:27-33).  Returns the uint8 array that is written.  Writing needs
-    SimpleITK like the reference does; `resample_and_classify` is the device-only core for callers with their own writer."""
+    """Same signature as the reference (segmentation_export.py:27-33).  Returns the uint8 array that is written.  Files are
+    written through SimpleITK when it is installed, otherwise by `utilities.nifti_io`'s NIfTI-1 writer; `resample_and_classify`
+    is the device-only core for callers with their own writer."""
+    import pickle
+    from ..utilities.nifti_io import write_image
     if verbose:
         print("force_separate_z:", force_separate_z, "interpolation order:", order)
     if isinstance(segmentation_softmax, str):
@@ -95,22 +125,30 @@ def save_segmentation_nifti_from_softmax(segmentation_softmax, out_fname, proper
         segmentation_softmax = np.load(del_file) if del_file.endswith('.npy') else np.load(del_file)['softmax']
         os.remove(del_file)
     if resampled_npz_fname is not None:
-        raise NotImplementedError("exporting the resampled softmax (resampled_npz_fname) needs the multi-channel volume this "
-                                  "path never materialises")
+        # the reference stores the RESAMPLED probabilities as float16 (+ the properties) for ensembling (:117-122)
+        if order != 1 or interpolation_order_z != 0:
+            raise NotImplementedError("device export supports interpolation order 1 (order_z 0), the reference's defaults")
+        p = segmentation_softmax if torch.is_tensor(segmentation_softmax) else torch.from_numpy(np.ascontiguousarray(segmentation_softmax))
+        if not p.is_cuda:
+            if not torch.cuda.is_available():
+                raise RuntimeError("multitalent_amd: export post-processing runs on a HIP device only; there is no CPU fallback")
+            p = p.cuda()
+        p = p.float()
+        after = [int(i) for i in properties_dict.get('size_after_cropping')]
+        sep = _separate_z_axis(properties_dict, force_separate_z) if any(i != j for i, j in zip(p.shape[1:], after)) else -1
+        np.savez_compressed(resampled_npz_fname, softmax=resample_softmax(p, after, sep).cpu().numpy().astype(np.float16))
+        if region_class_order is not None:
+            properties_dict['regions_class_order'] = region_class_order
+        with open(resampled_npz_fname[:-4] + ".pkl", 'wb') as f:
+            pickle.dump(properties_dict, f)
+        segmentation_softmax = p
     seg = resample_and_classify(segmentation_softmax, properties_dict, region_class_order, order, force_separate_z,
                                 interpolation_order_z).cpu().numpy()
     post = seg_postprogess_fn(np.copy(seg), *seg_postprocess_args) if seg_postprogess_fn is not None else seg
-    try:
-        import SimpleITK as sitk
-    except ImportError as e:
-        raise RuntimeError("SimpleITK is required to write %s (the label map itself is returned by resample_and_classify)" % out_fname) from e
 
     def write(arr, fname):
-        img = sitk.GetImageFromArray(arr.astype(np.uint8))
-        img.SetSpacing(properties_dict['itk_spacing'])
-        img.SetOrigin(properties_dict['itk_origin'])
-        img.SetDirection(properties_dict['itk_direction'])
-        sitk.WriteImage(img, fname)
+        write_image(arr.astype(np.uint8), fname, properties_dict['itk_spacing'], properties_dict['itk_origin'],
+                    properties_dict['itk_direction'])
 
     write(post, out_fname)
     if non_postprocessed_fname is not None and seg_postprogess_fn is not None:

@@ -53,14 +53,24 @@ def load_model_and_checkpoint_files(folder, folds=None, mixed_precision=None, ch
     """reference :109-148: returns (trainer, list of checkpoint dicts)."""
     if isinstance(folds, str):
         folds = [os.path.join(folder, "all")]
+        assert os.path.isdir(folds[0]), "no output folder for fold %s found" % folds
     elif isinstance(folds, (list, tuple)):
-        folds = [os.path.join(folder, "fold_%d" % i) if i != 'all' else os.path.join(folder, 'all') for i in folds]
+        if len(folds) == 1 and folds[0] == "all":
+            folds = [os.path.join(folder, "all")]
+        else:
+            folds = [os.path.join(folder, "fold_%d" % i) for i in folds]
+        assert all(os.path.isdir(i) for i in folds), "list of folds specified but not all output folders are present"
     elif isinstance(folds, int):
         folds = [os.path.join(folder, "fold_%d" % folds)]
+        assert os.path.isdir(folds[0]), "output folder missing for fold %s" % folds
     elif folds is None:
-        folds = sorted(os.path.join(folder, d) for d in os.listdir(folder) if d.startswith("fold"))
+        folds = sorted(os.path.join(folder, d) for d in os.listdir(folder) if d.startswith("fold") and os.path.isdir(os.path.join(folder, d)))
+    else:
+        raise ValueError("Unknown value for folds. Type: %s. Expected: list of int, int, str or None" % str(type(folds)))
     trainer = restore_model(os.path.join(folds[0], "%s.model.pkl" % checkpoint_name), fp16=mixed_precision)
     trainer.output_folder = folder
+    trainer.output_folder_base = folder
+    trainer.update_fold(0)
     trainer.initialize(False)
     files = [os.path.join(i, "%s.model" % checkpoint_name) for i in folds]
     params = [torch.load(i, map_location='cpu', weights_only=False) for i in files]

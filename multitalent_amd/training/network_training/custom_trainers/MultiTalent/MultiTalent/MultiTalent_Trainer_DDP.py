@@ -179,37 +179,80 @@ class MultiTalent_trainer_ddp(nnUNetTrainerV2_DDP):
         self.print_to_log_file("(interpret this as an estimate for the Dice of the different classes. This is not exact.)")
         self.online_eval_foreground_dc, self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], [], []
 
-    def run_training(self):
-        """Same epoch structure as the reference (:663-792): 250 train + 50 validation iterations, logging loss/CE/Dice."""
+    def _log_epoch_losses(self, tr, va):
+        """the reference logs loss, BCE and Dice of the epoch (:702-724); run_iteration returns the three."""
+        tr, va = np.asarray(tr, dtype=np.float64), np.asarray(va, dtype=np.float64)
+        self.all_tr_losses.append(float(tr[:, 0].mean()))
+        self.print_to_log_file("train loss : %.4f  ce: %.4f  dice: %.4f" % tuple(tr.mean(0)))
+        self.all_val_losses.append(float(va[:, 0].mean()))
+        self.print_to_log_file("validation loss: %.4f  ce: %.4f  dice: %.4f" % tuple(va.mean(0)))
+
+    # ---- validation on the held-out cases (reference :129-322) ----------------------------------------------------------
+    def validate(self, do_mirroring=True, use_sliding_window=True, step_size=0.5, save_softmax=True, use_gaussian=True,
+                 overwrite=True, validation_folder_name='validation_raw', debug=False, all_in_gpu=False,
+                 segmentation_export_kwargs=None, run_postprocessing_on_folds=False):
+        """Cases strided over the ranks (`all_keys[local_rank::world]`); per case the sliding window, then from the SAME
+        device-resident probabilities (a) one binary mask per region -> `<folder>_individual/<case>__<region>.nii.gz` and (b) the
+        dataset's own label map (its valid regions painted in `MultiTalent_regions_class_order`) -> `<folder>/<case>.nii.gz`;
+        rank 0 writes `summary_<dataset>.json`.  `run_postprocessing_on_folds` is ignored like in the reference."""
         import os
-        import time
-        if not self.was_initialized:
-            self.initialize(True)
-        self.maybe_update_lr(self.epoch)
-        self.maybe_setup_data_generators()
-        if self.tr_gen is None:
-            self.tr_gen = self._default_generator()
-        if self.val_gen is None:
-            self.val_gen = self.tr_gen
-        while self.epoch < self.max_num_epochs:
-            t0 = time.time()
-            self.network.train()
-            tr = np.array([self.run_iteration(self.tr_gen, True) for _ in range(self.num_batches_per_epoch)])
-            self.all_tr_losses.append(float(tr[:, 0].mean()))
-            self.print_to_log_file("\nepoch: ", self.epoch)
-            self.print_to_log_file("train loss : %.4f  ce: %.4f  dice: %.4f" % tuple(tr.mean(0)))
-            with torch.no_grad():
-                self.network.eval()
-                va = np.array([self.run_iteration(self.val_gen, False, True) for _ in range(self.num_val_batches_per_epoch)])
-                self.all_val_losses.append(float(va[:, 0].mean()))
-            self.finish_online_evaluation()
-            self.print_to_log_file("validation loss: %.4f" % self.all_val_losses[-1], "This epoch took %f s\n" % (time.time() - t0))
-            cont = self.on_epoch_end()
-            self.epoch += 1
-            if not cont:
-                break
-        if self.output_folder is not None:
-            self.save_checkpoint(os.path.join(self.output_folder, "model_final_checkpoint.model"))
+        import pickle
+        from ......dataset_conversion.Task100_MultiTalent import MultiTalent_regions_class_order
+        from ......evaluation.evaluator import aggregate_scores
+        from ......inference.segmentation_export import save_segmentation_nifti_from_softmax
+        current_mode = self.network.training
+        self.network.eval()
+        args = {'do_mirroring': do_mirroring, 'use_sliding_window': use_sliding_window, 'step_size': step_size,
+                'save_softmax': save_softmax, 'use_gaussian': use_gaussian, 'overwrite': overwrite,
+                'validation_folder_name': validation_folder_name, 'debug': debug, 'all_in_gpu': all_in_gpu,
+                'segmentation_export_kwargs': segmentation_export_kwargs}
+        out, mirror_axes = self._open_validation(do_mirroring, validation_folder_name, args)
+        out_individual = os.path.join(self.output_folder, validation_folder_name + '_individual')
+        os.makedirs(out_individual, exist_ok=True)
+        force_separate_z, order, order_z = self._export_params(segmentation_export_kwargs)
+        rank, world = self._validation_world()
+        all_keys = list(self.dataset_val.keys())
+        my_keys = all_keys[rank::world]
+        pred_gt_tuples, valid_labels = {}, {}
+        for k in all_keys:                 # every rank walks ALL keys: rank 0 needs the file pairs of every case (reference :198-201)
+            with open(self.dataset[k]['properties_file'], 'rb') as f:
+                properties = pickle.load(f)
+            names = [i for i in MultiTalent_valid_regions.keys() if i.startswith("Task%03.0d_" % int(k.split('_')[0]))]
+            assert len(names) == 1
+            dataset_name = names[0]
+            valid_labels.setdefault(dataset_name, properties['valid_labels'])
+            fname = properties['list_of_data_files'][0].split("/")[-1][:-12]
+            pred_gt_tuples.setdefault(dataset_name, []).append([os.path.join(out, fname + ".nii.gz"),
+                                                                os.path.join(self.gt_niftis_folder or '', fname + ".nii.gz")])
+            needed = overwrite or not os.path.isfile(os.path.join(out, fname + ".nii.gz")) or \
+                (save_softmax and not os.path.isfile(os.path.join(out, fname + ".npz"))) or \
+                any(not os.path.isfile(os.path.join(out_individual, fname + '__' + r + ".nii.gz")) for r in MultiTalent_regions)
+            if not (needed and k in my_keys):
+                continue
+            probs = self._predict_validation_case(k, do_mirroring, mirror_axes, use_sliding_window, step_size, use_gaussian,
+                                                  all_in_gpu)
+            for r in MultiTalent_regions.keys():
+                ch = MultiTalent_region_output_idx_mapping[r]
+                save_segmentation_nifti_from_softmax(probs[ch:ch + 1], os.path.join(out_individual, fname + '__' + r + ".nii.gz"),
+                                                     properties, order, ((1,),), None, None, None, None, force_separate_z,
+                                                     order_z, verbose=False)
+            idx = [MultiTalent_region_output_idx_mapping[i] for i in MultiTalent_valid_regions[dataset_name]]
+            save_segmentation_nifti_from_softmax(probs[idx], os.path.join(out, fname + ".nii.gz"), properties, order,
+                                                 MultiTalent_regions_class_order[dataset_name], None, None,
+                                                 os.path.join(out, fname + ".npz") if save_softmax else None, None,
+                                                 force_separate_z, order_z, verbose=False)
+        self._validation_barrier()
+        self.print_to_log_file("finished prediction")
+        if rank == 0 and self.gt_niftis_folder is not None and os.path.isdir(self.gt_niftis_folder):
+            self.print_to_log_file("evaluation of raw predictions")
+            task = (self.dataset_directory or "").split("/")[-1]
+            for dataset in pred_gt_tuples:
+                aggregate_scores(pred_gt_tuples[dataset], labels=valid_labels[dataset],
+                                 json_output_file=os.path.join(out, "summary_%s.json" % dataset),
+                                 json_name=self.experiment_name + " val tiled %s" % str(use_sliding_window), json_author="Fabian",
+                                 json_task=task)
+        self.network.train(current_mode)
+        self._validation_barrier()
 
 
 class MultiTalent_trainer_ddp_2000ep(MultiTalent_trainer_ddp):

@@ -4,9 +4,10 @@ Restates, minimally and in its own words, what the drivers call on a trainer in 
 (network_trainer.py, nnUNetTrainer.py, nnUNetTrainerV2.py, nnUNetTrainerV2_DDP.py): constructor signature, plans
 parsing, network / optimizer construction, poly learning rate, `run_iteration`, checkpoint save/load in the reference's
 file format (`.model` = torch.save(dict), `.model.pkl` = {'init','name','class','plans'}), and
-`predict_preprocessed_data_return_seg_and_softmax`.  Data loading / augmentation, validation on files and plotting are
-out of scope: a trainer consumes any generator yielding {'data','target','properties'} batches; without
-one it uses device-resident synthetic batches like the reference's dummyLoad benchmarking trainer.
+`predict_preprocessed_data_return_seg_and_softmax`, `preprocess_patient`, `validate` and the epoch-end bookkeeping that
+writes `model_best.model`.  Plotting and the postprocessing search are out of scope.  A trainer consumes any
+generator yielding {'data','target','properties'} batches; without one it uses device-resident synthetic batches like the
+reference's dummyLoad benchmarking trainer.
 """
 import os
 import pickle
@@ -61,6 +62,16 @@ class nnUNetTrainer(object):
         self.all_tr_losses, self.all_val_losses, self.all_val_losses_tr_mode, self.all_val_eval_metrics = [], [], [], []
         self.best_epoch_based_on_MA_tr_loss = self.best_MA_tr_loss_for_patience = self.best_val_eval_criterion_MA = None
         self.save_every = 50
+        # network_trainer.py:73-135 / nnUNetTrainer.py:113-117: moving averages, patience, what gets saved
+        self.train_loss_MA_alpha, self.train_loss_MA_eps, self.val_eval_criterion_alpha = 0.93, 5e-4, 0.9
+        self.patience, self.lr_threshold = 50, 1e-6
+        self.train_loss_MA = self.val_eval_criterion_MA = None
+        self.save_latest_only = self.save_intermediate_checkpoints = self.save_best_checkpoint = self.save_final_checkpoint = True
+        self.also_val_in_tr_mode = False
+        self.dataset = self.dataset_tr = self.dataset_val = None
+        self.output_folder_base = output_folder
+        self.experiment_name = self.__class__.__name__
+        self.gt_niftis_folder = os.path.join(dataset_directory, "gt_segmentations") if dataset_directory is not None else None
         self.log_file = None
         self.regions_class_order = None
         self.classes = self.num_classes = self.patch_size = self.batch_size = None
@@ -69,6 +80,21 @@ class nnUNetTrainer(object):
         self.data_aug_params = {'do_mirror': True, 'mirror_axes': (0, 1, 2)}
         self.local_rank = 0
         self.train_step = None
+        self.update_fold(fold)
+
+    def update_fold(self, fold):
+        """nnUNetTrainer.py:134-152: checkpoints and validation output live in <output_folder>/fold_<k> (or /all)."""
+        if fold is None or self.output_folder is None:
+            self.fold = fold if fold is not None else self.fold
+            return
+        name = "%s" % str(fold) if isinstance(fold, str) else "fold_%s" % str(fold)
+        if isinstance(fold, str):
+            assert fold == "all", "if self.fold is a string then it must be 'all'"
+        old = "%s" % str(self.fold) if isinstance(self.fold, str) else "fold_%s" % str(self.fold)
+        if self.output_folder.endswith(old):
+            self.output_folder = self.output_folder_base
+        self.output_folder = os.path.join(self.output_folder, name)
+        self.fold = fold
 
     # ---- plans (nnUNetTrainer.py:319-392) ----------------------------------------------------------------
     def load_plans_file(self):
@@ -214,7 +240,9 @@ class nnUNetTrainer(object):
     def predict_preprocessed_data_return_seg_and_softmax(self, data, do_mirroring=True, mirror_axes=None,
                                                          use_sliding_window=True, step_size=0.5, use_gaussian=True,
                                                          pad_border_mode='constant', pad_kwargs=None, all_in_gpu=False,
-                                                         verbose=True, mixed_precision=True):
+                                                         verbose=True, mixed_precision=True, return_device_tensors=False):
+        """`return_device_tensors=True` (extension): (seg, probabilities) stay on the device; the probabilities alias the
+        network's sliding-window cache until the next prediction."""
         if pad_border_mode == 'constant' and pad_kwargs is None:
             pad_kwargs = {'constant_values': 0}
         if do_mirroring and mirror_axes is None:
@@ -230,7 +258,8 @@ class nnUNetTrainer(object):
             ret = net.predict_3D(data, do_mirroring=do_mirroring, mirror_axes=mirror_axes, use_sliding_window=use_sliding_window,
                                  step_size=step_size, patch_size=self.patch_size, regions_class_order=self.regions_class_order,
                                  use_gaussian=use_gaussian, pad_border_mode=pad_border_mode, pad_kwargs=pad_kwargs,
-                                 all_in_gpu=all_in_gpu, verbose=verbose, mixed_precision=mixed_precision)
+                                 all_in_gpu=all_in_gpu, verbose=verbose, mixed_precision=mixed_precision,
+                                 return_device_tensors=return_device_tensors)
         finally:
             net.train(was_training)
             self._set_ds(net, ds)
@@ -243,6 +272,176 @@ class nnUNetTrainer(object):
     @staticmethod
     def _set_ds(net, v):
         net.do_ds = v
+
+    # ---- epoch-end bookkeeping (network_trainer.py:509-640) -------------------------------------------------------
+    def finish_online_evaluation(self):
+        """may fill all_val_eval_metrics (network_trainer.py:676-681); the softmax trainers here do not evaluate online,
+        so the moving average below falls back to -validation loss exactly like the reference does for an empty list."""
+
+    def update_train_loss_MA(self):
+        last = self.all_tr_losses[-1]
+        self.train_loss_MA = last if self.train_loss_MA is None else \
+            self.train_loss_MA_alpha * self.train_loss_MA + (1 - self.train_loss_MA_alpha) * last
+
+    def update_eval_criterion_MA(self):
+        """network_trainer.py:527-551: moving average of the validation metric (or of -validation loss)."""
+        new = self.all_val_eval_metrics[-1] if len(self.all_val_eval_metrics) > 0 else -self.all_val_losses[-1]
+        if self.val_eval_criterion_MA is None:
+            self.val_eval_criterion_MA = new
+        else:
+            a = self.val_eval_criterion_alpha
+            self.val_eval_criterion_MA = a * self.val_eval_criterion_MA + (1 - a) * new
+
+    def maybe_save_checkpoint(self):
+        """network_trainer.py:509-525."""
+        if self.output_folder is None:
+            return
+        if self.save_intermediate_checkpoints and (self.epoch % self.save_every == (self.save_every - 1)):
+            self.print_to_log_file("saving scheduled checkpoint file...")
+            if not self.save_latest_only:
+                self.save_checkpoint(os.path.join(self.output_folder, "model_ep_%03.0d.model" % (self.epoch + 1)))
+            self.save_checkpoint(os.path.join(self.output_folder, "model_latest.model"))
+            self.print_to_log_file("done")
+
+    def manage_patience(self):
+        """network_trainer.py:553-617: `model_best.model` whenever the validation moving average improves; the patience
+        counter on the training-loss moving average (its verdict is ignored by the V2 trainers, which always run all epochs)."""
+        if self.patience is None:
+            return True
+        if self.best_MA_tr_loss_for_patience is None:
+            self.best_MA_tr_loss_for_patience = self.train_loss_MA
+        if self.best_epoch_based_on_MA_tr_loss is None:
+            self.best_epoch_based_on_MA_tr_loss = self.epoch
+        if self.best_val_eval_criterion_MA is None:
+            self.best_val_eval_criterion_MA = self.val_eval_criterion_MA
+        if self.val_eval_criterion_MA > self.best_val_eval_criterion_MA:
+            self.best_val_eval_criterion_MA = self.val_eval_criterion_MA
+            if self.save_best_checkpoint and self.output_folder is not None:
+                self.save_checkpoint(os.path.join(self.output_folder, "model_best.model"))
+        if self.train_loss_MA + self.train_loss_MA_eps < self.best_MA_tr_loss_for_patience:
+            self.best_MA_tr_loss_for_patience = self.train_loss_MA
+            self.best_epoch_based_on_MA_tr_loss = self.epoch
+        if self.epoch - self.best_epoch_based_on_MA_tr_loss > self.patience:
+            if getattr(self, 'optimizer_lr', self.initial_lr) > self.lr_threshold:
+                self.best_epoch_based_on_MA_tr_loss = self.epoch - self.patience // 2
+            else:
+                return False
+        return True
+
+    # ---- unseen data (nnUNetTrainer.py:417-443) -------------------------------------------------------------------
+    def preprocess_patient(self, input_files, return_device=False):
+        """Read + crop the case on the host, resample to the plan's spacing and normalise on the device.  Returns
+        (data [C, X, Y, Z] float32, seg, properties) like the reference (numpy; `return_device=True` keeps the volume in HBM)."""
+        name = self.plans.get('preprocessor_name') or "GenericPreprocessor"
+        if name != "GenericPreprocessor":
+            raise NotImplementedError("preprocessor %s is not on this path (3D GenericPreprocessor only)" % name)
+        from ...preprocessing.preprocessing import GenericPreprocessor
+        print("using preprocessor", name)
+        pre = GenericPreprocessor(self.normalization_schemes, self.use_mask_for_norm, self.transpose_forward, self.intensity_properties)
+        return pre.preprocess_test_case(input_files, self.plans['plans_per_stage'][self.stage]['current_spacing'],
+                                        return_device=return_device)
+
+    # ---- validation on the held-out cases (nnUNetTrainer.py:526-674) --------------------------------------------------
+    def _export_params(self, segmentation_export_kwargs):
+        if segmentation_export_kwargs is None:
+            p = self.plans.get('segmentation_export_params')
+            if p is not None:
+                return p['force_separate_z'], p['interpolation_order'], p['interpolation_order_z']
+            return None, 1, 0
+        k = segmentation_export_kwargs
+        return k['force_separate_z'], k['interpolation_order'], k['interpolation_order_z']
+
+    def _validation_world(self):
+        """(rank, world): cases are strided over the ranks of a DDP trainer (nnUNetTrainerV2_DDP.py:476)."""
+        if getattr(self, 'ddp', False) and dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def _validation_barrier(self):
+        if getattr(self, 'ddp', False) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
+
+    def _open_validation(self, do_mirroring, validation_folder_name, args):
+        import json
+        assert self.was_initialized, "must initialize, ideally with checkpoint (or train first)"
+        if self.dataset_val is None:
+            self.load_dataset()
+            self.do_split()
+        out = os.path.join(self.output_folder, validation_folder_name)
+        os.makedirs(out, exist_ok=True)
+        if self.local_rank == 0:
+            with open(os.path.join(out, "validation_args.json"), 'w') as f:
+                json.dump(args, f, sort_keys=True, indent=4)
+        if do_mirroring:
+            if not self.data_aug_params['do_mirror']:
+                raise RuntimeError("We did not train with mirroring so you cannot do inference with mirroring enabled")
+            return out, self.data_aug_params['mirror_axes']
+        return out, ()
+
+    def _predict_validation_case(self, k, do_mirroring, mirror_axes, use_sliding_window, step_size, use_gaussian, all_in_gpu):
+        """probabilities of one preprocessed case on the device, transposed back ([C, *original axis order])."""
+        data = np.load(self.dataset[k]['data_file'])['data']
+        print(k, data.shape)
+        net = self.network
+        ds = self._get_ds(net)
+        self._set_ds(net, False)
+        try:
+            probs = net.predict_3D(np.ascontiguousarray(data[:-1]), do_mirroring=do_mirroring, mirror_axes=mirror_axes,
+                                   use_sliding_window=use_sliding_window, step_size=step_size, patch_size=self.patch_size,
+                                   regions_class_order=self.regions_class_order, use_gaussian=use_gaussian,
+                                   pad_border_mode='constant', pad_kwargs={'constant_values': 0}, all_in_gpu=all_in_gpu,
+                                   verbose=False, mixed_precision=self.fp16, return_device_tensors=True)[1]
+        finally:
+            self._set_ds(net, ds)
+        if list(self.transpose_backward) != [0, 1, 2]:
+            probs = probs.permute(0, *[int(i) + 1 for i in self.transpose_backward]).contiguous()
+        return probs
+
+    def validate(self, do_mirroring=True, use_sliding_window=True, step_size=0.5, save_softmax=True, use_gaussian=True,
+                 overwrite=True, validation_folder_name='validation_raw', debug=False, all_in_gpu=False,
+                 segmentation_export_kwargs=None, run_postprocessing_on_folds=True):
+        """nnUNetTrainer.py:526-674 (DDP: nnUNetTrainerV2_DDP.py:431-599): every validation case through the sliding window
+        and the device export (probabilities never leave HBM), `summary.json` from `aggregate_scores` when the ground-truth
+        folder exists.  The connected-component postprocessing search (`run_postprocessing_on_folds`) is not on this path."""
+        import pickle
+        from ...evaluation.evaluator import aggregate_scores
+        from ...inference.segmentation_export import save_segmentation_nifti_from_softmax
+        current_mode = self.network.training
+        self.network.eval()
+        args = {'do_mirroring': do_mirroring, 'use_sliding_window': use_sliding_window, 'step_size': step_size,
+                'save_softmax': save_softmax, 'use_gaussian': use_gaussian, 'overwrite': overwrite,
+                'validation_folder_name': validation_folder_name, 'debug': debug, 'all_in_gpu': all_in_gpu,
+                'segmentation_export_kwargs': segmentation_export_kwargs}
+        out, mirror_axes = self._open_validation(do_mirroring, validation_folder_name, args)
+        force_separate_z, order, order_z = self._export_params(segmentation_export_kwargs)
+        rank, world = self._validation_world()
+        all_keys = list(self.dataset_val.keys())
+        my_keys = all_keys[rank::world]
+        pred_gt_tuples = []
+        for k in all_keys:
+            with open(self.dataset[k]['properties_file'], 'rb') as f:
+                properties = pickle.load(f)
+            fname = properties['list_of_data_files'][0].split("/")[-1][:-12]
+            pred_gt_tuples.append([os.path.join(out, fname + ".nii.gz"), os.path.join(self.gt_niftis_folder or '', fname + ".nii.gz")])
+            if k not in my_keys:
+                continue
+            if overwrite or not os.path.isfile(os.path.join(out, fname + ".nii.gz")) or \
+                    (save_softmax and not os.path.isfile(os.path.join(out, fname + ".npz"))):
+                probs = self._predict_validation_case(k, do_mirroring, mirror_axes, use_sliding_window, step_size, use_gaussian,
+                                                      all_in_gpu)
+                save_segmentation_nifti_from_softmax(probs, os.path.join(out, fname + ".nii.gz"), properties, order,
+                                                     self.regions_class_order, None, None,
+                                                     os.path.join(out, fname + ".npz") if save_softmax else None, None,
+                                                     force_separate_z, order_z, verbose=False)
+        self._validation_barrier()
+        self.print_to_log_file("finished prediction")
+        if rank == 0 and self.gt_niftis_folder is not None and os.path.isdir(self.gt_niftis_folder):
+            self.print_to_log_file("evaluation of raw predictions")
+            aggregate_scores(pred_gt_tuples, labels=list(range(self.num_classes)), json_output_file=os.path.join(out, "summary.json"),
+                             json_name=self.experiment_name + " val tiled %s" % str(use_sliding_window), json_author="Fabian",
+                             json_task=(self.dataset_directory or "").split("/")[-1])
+        self.network.train(current_mode)
+        self._validation_barrier()
 
 
 class nnUNetTrainerV2(nnUNetTrainer):
@@ -336,9 +535,18 @@ class nnUNetTrainerV2(nnUNetTrainer):
         return l.detach().cpu().numpy()
 
     def on_epoch_end(self):
+        """network_trainer.py:619-633 followed by nnUNetTrainerV2.py:410-430: the V2 trainers ignore the patience verdict and
+        run all epochs; at epoch 100 a validation Dice of exactly 0 lowers the momentum to 0.95 and re-initialises the weights."""
+        self.finish_online_evaluation()
         self.maybe_update_lr()
-        if self.output_folder is not None and (self.epoch + 1) % self.save_every == 0:
-            self.save_checkpoint(os.path.join(self.output_folder, "model_latest.model"))
+        self.maybe_save_checkpoint()
+        self.update_eval_criterion_MA()
+        self.manage_patience()
+        if self.epoch == 100 and len(self.all_val_eval_metrics) > 0 and self.all_val_eval_metrics[-1] == 0:
+            self.train_step.mom = 0.95
+            self.network.apply(InitWeights_He(1e-2))
+            self.network.engine().mark_params_dirty()
+            self.print_to_log_file("At epoch 100, the mean foreground Dice was 0: momentum reduced to 0.95, weights reinitialized")
         return self.epoch < self.max_num_epochs
 
     def _default_generator(self):
@@ -457,8 +665,17 @@ class nnUNetTrainerV2(nnUNetTrainer):
         else:
             self.tr_gen = SegToTargetGenerator(dl_tr, tuple(int(i) for i in self.patch_size))
 
+    def _log_epoch_losses(self, tr, va):
+        """tr / va: per-iteration return values of run_iteration (scalars here, (loss, ce, dc) for the MultiTalent trainers)."""
+        tr, va = np.asarray(tr, dtype=np.float64), np.asarray(va, dtype=np.float64)
+        self.all_tr_losses.append(float(tr.mean()))
+        self.print_to_log_file("train loss : %.4f" % self.all_tr_losses[-1])
+        self.all_val_losses.append(float(va.mean()))
+        self.print_to_log_file("validation loss: %.4f" % self.all_val_losses[-1])
+
     def run_training(self):
-        """epoch loop of network_trainer.py:411-470 without plotting / early stopping bookkeeping."""
+        """epoch loop of network_trainer.py:411-505 (with nnUNetTrainerV2.run_training's lr reset) without plotting: train
+        iterations, validation iterations with online evaluation, moving averages, checkpoints (latest / best / final)."""
         if not self.was_initialized:
             self.initialize(True)
         self.maybe_update_lr(self.epoch)
@@ -467,24 +684,32 @@ class nnUNetTrainerV2(nnUNetTrainer):
             self.tr_gen = self._default_generator()
         if self.val_gen is None:
             self.val_gen = self.tr_gen
+        if self.output_folder is not None and self.local_rank == 0:
+            os.makedirs(self.output_folder, exist_ok=True)
         while self.epoch < self.max_num_epochs:
+            self.print_to_log_file("\nepoch: ", self.epoch)
             t0 = time.time()
             self.network.train()
             tr = [self.run_iteration(self.tr_gen, True) for _ in range(self.num_batches_per_epoch)]
-            self.all_tr_losses.append(float(np.mean(tr)))
-            self.print_to_log_file("\nepoch:", self.epoch, "train loss : %.4f" % self.all_tr_losses[-1])
             with torch.no_grad():
                 self.network.eval()
                 va = [self.run_iteration(self.val_gen, False, True) for _ in range(self.num_val_batches_per_epoch)]
-                self.all_val_losses.append(float(np.mean(va)))
-            self.print_to_log_file("validation loss: %.4f" % self.all_val_losses[-1],
-                                   "This epoch took %f s\n" % (time.time() - t0))
+            self._log_epoch_losses(tr, va)
+            self.update_train_loss_MA()
             cont = self.on_epoch_end()
-            self.epoch += 1
             if not cont:
                 break
+            self.epoch += 1
+            self.print_to_log_file("This epoch took %f s\n" % (time.time() - t0))
+        self.epoch -= 1             # network_trainer.py:493: the final checkpoint stores epoch + 1 == max_num_epochs
         if self.output_folder is not None:
-            self.save_checkpoint(os.path.join(self.output_folder, "model_final_checkpoint.model"))
+            if self.save_final_checkpoint:
+                self.save_checkpoint(os.path.join(self.output_folder, "model_final_checkpoint.model"))
+            if self.local_rank == 0:
+                for n in ("model_latest.model", "model_latest.model.pkl"):      # identical to the final one
+                    f = os.path.join(self.output_folder, n)
+                    if os.path.isfile(f):
+                        os.remove(f)
 
 
 class nnUNetTrainerV2_DDP(nnUNetTrainerV2):

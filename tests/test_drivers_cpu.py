@@ -1,0 +1,134 @@
+"""Host-side pieces of the driver tails (no GPU): the NIfTI-1 codec, cropping to the non-zero region, the evaluation metrics, the
+epoch-end bookkeeping that writes model_best.model, and the product's sliding-window step computation against the reference's
+own known-answer table."""
+import gzip
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_nifti_roundtrip_and_header(tmp_path):
+    from multitalent_amd.utilities import nifti_io as N
+    rs = np.random.RandomState(0)
+    th = 0.3
+    rot = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    for dt, direction in ((np.float32, np.eye(3)), (np.uint8, rot), (np.int16, np.diag([1.0, -1.0, 1.0]))):
+        arr = (rs.rand(5, 7, 9) * 100).astype(dt)
+        f = str(tmp_path / ('a_%s.nii.gz' % np.dtype(dt).name))
+        N._write_nifti(N.Image(arr, (0.8, 0.9, 2.5), (-12.5, 30.0, 7.25), direction.ravel()), f)
+        im = N._read_nifti(f)
+        assert im.array.dtype == np.dtype(dt) and np.array_equal(im.array, arr)
+        assert np.allclose(im.spacing, (0.8, 0.9, 2.5), rtol=1e-6) and np.allclose(im.origin, (-12.5, 30.0, 7.25), rtol=1e-6)
+        assert np.allclose(np.array(im.direction).reshape(3, 3), direction, atol=1e-6)
+        assert im.GetSize() == (9, 7, 5)
+        raw = gzip.open(f, 'rb').read()
+        # NIfTI-1 fixed points: sizeof_hdr, magic, vox_offset, dim (x fastest), and the RAS affine = diag(-1,-1,1) . LPS
+        assert struct.unpack('<i', raw[:4])[0] == 348 and raw[344:348] == b'n+1\0' and struct.unpack('<f', raw[108:112])[0] == 352.0
+        assert struct.unpack('<8h', raw[40:56])[:4] == (3, 9, 7, 5) and len(raw) == 352 + arr.nbytes
+        srow_x = struct.unpack('<4f', raw[280:296])
+        assert np.isclose(srow_x[3], 12.5) and np.isclose(srow_x[0], -direction[0, 0] * 0.8, atol=1e-6)
+        # qform-only files (sform_code = 0) give the same geometry
+        b = bytearray(raw)
+        struct.pack_into('<h', b, 254, 0)
+        g = str(tmp_path / 'q.nii')
+        open(g, 'wb').write(bytes(b))
+        iq = N._read_nifti(g)
+        assert np.allclose(np.array(iq.direction).reshape(3, 3), direction, atol=1e-5) and np.allclose(iq.origin, im.origin, rtol=1e-6)
+    with pytest.raises(IOError):
+        open(str(tmp_path / 'bad.nii'), 'wb').write(b'\0' * 400)
+        N._read_nifti(str(tmp_path / 'bad.nii'))
+
+
+def test_crop_to_nonzero_and_case_loading(tmp_path):
+    from multitalent_amd.preprocessing.cropping import ImageCropper, get_case_identifier
+    from multitalent_amd.utilities.nifti_io import write_image
+    vol = np.zeros((10, 12, 14), dtype=np.float32)
+    vol[2:7, 3:10, 1:12] = 5.0
+    vol[4, 5, 5] = 0.0                                       # a hole inside the body: filled by binary_fill_holes, stays inside the mask
+    f = str(tmp_path / 'liver_3_0000.nii.gz')
+    write_image(vol, f, (0.7, 0.8, 3.0), (1.0, 2.0, 3.0))
+    data, seg, props = ImageCropper.crop_from_list_of_files([f])
+    assert data.shape == (1, 5, 7, 11) and props['crop_bbox'] == [[2, 7], [3, 10], [1, 12]]
+    assert tuple(props['original_size_of_raw_data']) == (10, 12, 14) and np.allclose(props['original_spacing'], (3.0, 0.8, 0.7))
+    assert tuple(props['size_after_cropping']) == (5, 7, 11) and np.allclose(props['itk_spacing'], (0.7, 0.8, 3.0))
+    assert seg.shape == (1, 5, 7, 11) and (seg == 0).all()              # everything inside the box is inside the filled mask
+    assert get_case_identifier([f]) == 'liver_3'
+
+
+def test_evaluator_metrics(tmp_path):
+    from multitalent_amd.evaluation.evaluator import aggregate_scores, confusion_metrics
+    t = np.zeros((4, 4, 4), dtype=bool); r = np.zeros_like(t)
+    t[:2] = True; r[1:3] = True                                         # tp 16, fp 16, fn 16, tn 16
+    m = confusion_metrics(t, r)
+    assert m['Dice'] == 0.5 and np.isclose(m['Jaccard'], 1 / 3) and m['Precision'] == 0.5 and m['Recall'] == 0.5
+    assert m['Accuracy'] == 0.5 and m['Total Positives Test'] == 32 and m['False Positive Rate'] == 0.5
+    e = confusion_metrics(np.zeros_like(t), np.zeros_like(t))           # nothing anywhere: NaN like the reference (metrics.py:113-117)
+    assert np.isnan(e['Dice']) and np.isnan(e['Precision']) and e['Accuracy'] == 1.0
+    test = np.zeros((4, 4, 4), dtype=np.uint8); ref = np.zeros_like(test)
+    test[:2] = 1; ref[1:3] = 1; ref[3] = 2
+    out = str(tmp_path / 'summary.json')
+    s = aggregate_scores([(test, ref), (ref, ref)], labels=[1, 2, (1, 2)], json_output_file=out, json_name='x', json_task='T')
+    assert s['mean']['1']['Dice'] == 0.75 and s['mean']['2']['Dice'] == 0.5           # label 2 missed entirely in case 1
+    assert np.isclose(s['mean']['(1, 2)']['Dice'], (2 * 16 / (32 + 48) + 1.0) / 2)
+    j = json.load(open(out))
+    assert set(j) == {'name', 'description', 'timestamp', 'task', 'author', 'results', 'id'} and len(j['id']) == 12
+
+
+def test_sliding_window_steps_of_the_product_vs_reference_table():
+    """The reference's own known answers (tests/test_steps_for_sliding_window_prediction.py:96-163, dumped with the real function by
+    tools/oracle_gen/make_golden.py) against the PRODUCT's SegmentationNetwork._compute_steps_for_sliding_window."""
+    from multitalent_amd.network_architecture.neural_network import SegmentationNetwork
+    table = json.load(open(os.path.join(HERE, 'golden', 'sliding_window_steps.json')))
+    assert len(table) >= 9
+    for c in table:
+        got = SegmentationNetwork._compute_steps_for_sliding_window(tuple(c['patch']), tuple(c['image']), c['step'])
+        assert [list(map(int, g)) for g in got] == c['steps'], c
+    # the hand-verified cases of the reference's test file, literally
+    f = SegmentationNetwork._compute_steps_for_sliding_window
+    assert f((128, 128, 128), (146, 176, 148), 0.5) == [[0, 18], [0, 48], [0, 20]]
+    assert f((30, 224, 224), (30, 224, 224), 1) == [[0], [0], [0]]
+    assert f((48, 192, 192), (512, 512, 512), 0.5)[0] == [int(np.round(i * 464 / 20)) for i in range(21)]
+
+
+def test_epoch_end_bookkeeping_writes_model_best(tmp_path):
+    """network_trainer.py:527-633: moving averages, model_best.model on improvement of the validation MA, scheduled model_latest."""
+    from multitalent_amd import plans as P
+    from multitalent_amd.training.model_restore import find_trainer_class
+    sp = {'batch_size': 2, 'patch_size': np.array([8, 16, 16]), 'pool_op_kernel_sizes': [[2, 2, 2]], 'conv_kernel_sizes': [[3, 3, 3]] * 2,
+          'do_dummy_2D_data_aug': False}
+    tr = find_trainer_class('nnUNetTrainerV2')(P.make_plans(sp, base_num_features=4, num_classes=1, stage=0), 0,
+                                               output_folder=str(tmp_path), stage=0)
+    assert tr.output_folder == os.path.join(str(tmp_path), 'fold_0') and tr.output_folder_base == str(tmp_path)
+    tr.initialize(False)
+    tr.save_every = 2
+    saved = []
+    tr.save_checkpoint = lambda f, save_optimizer=True: saved.append(os.path.basename(f))
+    val = [1.0, 0.8, 0.9, 0.5]
+    ma_t = ma_v = None
+    for ep, v in enumerate(val):
+        tr.epoch = ep
+        tr.all_tr_losses.append(v + 0.1)
+        tr.all_val_losses.append(v)
+        tr.update_train_loss_MA()
+        cont = tr.on_epoch_end()
+        ma_t = v + 0.1 if ma_t is None else 0.93 * ma_t + 0.07 * (v + 0.1)
+        ma_v = -v if ma_v is None else 0.9 * ma_v - 0.1 * v
+        assert np.isclose(tr.train_loss_MA, ma_t) and np.isclose(tr.val_eval_criterion_MA, ma_v) and cont
+    # -val loss MA: -1, -0.98, -0.972, -0.9248 -> improvements at epochs 1, 2, 3; scheduled checkpoints at epochs 1 and 3
+    assert saved == ['model_latest.model', 'model_best.model', 'model_best.model', 'model_latest.model', 'model_best.model']
+    assert np.isclose(tr.best_val_eval_criterion_MA, ma_v)
+    # with an evaluation metric the MA follows it instead of the loss (network_trainer.py:536-551)
+    tr.all_val_eval_metrics = [0.3]
+    tr.val_eval_criterion_MA = None
+    tr.update_eval_criterion_MA()
+    assert tr.val_eval_criterion_MA == 0.3
+    # fold switch for ensembling (nnUNetTrainer.py:134-152)
+    tr.update_fold(3)
+    assert tr.output_folder == os.path.join(str(tmp_path), 'fold_3')
+    tr.update_fold('all')
+    assert tr.output_folder == os.path.join(str(tmp_path), 'all')
