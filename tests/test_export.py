@@ -72,12 +72,39 @@ def test_device_export_matches_reference(dev, name):
 
 @pytest.mark.gpu
 def test_device_export_rejects_unsupported_modes(dev):
-    from multitalent_amd.inference.segmentation_export import resample_and_classify, save_segmentation_nifti_from_softmax
+    from multitalent_amd.inference.segmentation_export import resample_and_classify
     probs, props, order, force, _ = _case(np.load(G), 'iso_regions')
     with pytest.raises(NotImplementedError):
         resample_and_classify(probs, props, order, 3, force, 0)
-    with pytest.raises(NotImplementedError):
-        save_segmentation_nifti_from_softmax(probs, 'x.nii.gz', props, 1, order, resampled_npz_fname='x.npz', verbose=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ['iso_regions', 'sepz_regions', 'sep_axis2', 'identity'])
+def test_device_export_writes_file_and_resampled_softmax(dev, tmp_path, name):
+    """`resampled_npz_fname` (validate(save_softmax=True), segmentation_export.py:117-122): the resampled probabilities as
+    float16 + the properties pickle; and the label map written as a NIfTI file carries the case's geometry."""
+    import pickle
+    from multitalent_amd.inference.segmentation_export import save_segmentation_nifti_from_softmax
+    from multitalent_amd.utilities.nifti_io import read_image
+    from oracle.reference_ops import resample_probabilities, get_do_separate_z, get_lowres_axis
+    probs, props, order, force, seg = _case(np.load(G), name)
+    props = dict(props, itk_spacing=(0.8, 0.9, 2.5), itk_origin=(1.0, -2.0, 3.0), itk_direction=tuple(np.eye(3).ravel()))
+    out, npz = str(tmp_path / 'c.nii.gz'), str(tmp_path / 'c.npz')
+    ret = save_segmentation_nifti_from_softmax(probs, out, props, 1, order, None, None, npz, None, force, 0, verbose=False)
+    im = read_image(out)
+    assert np.array_equal(np.asarray(im.array), ret) and np.allclose(im.spacing, (0.8, 0.9, 2.5)) and np.allclose(im.origin, (1.0, -2.0, 3.0))
+    sm = np.load(npz)['softmax']
+    assert sm.dtype == np.float16 and sm.shape[1:] == tuple(props['size_after_cropping'])
+    if get_do_separate_z(props['original_spacing']):
+        sep, axis = True, get_lowres_axis(props['original_spacing'])
+    elif get_do_separate_z(props['spacing_after_resampling']):
+        sep, axis = True, get_lowres_axis(props['spacing_after_resampling'])
+    else:
+        sep, axis = False, None
+    ref = resample_probabilities(probs.astype(np.float64), props['size_after_cropping'], axis=axis, do_separate_z=sep)
+    assert np.abs(sm.astype(np.float64) - ref).max() < 1e-3                      # float16 storage
+    saved = pickle.load(open(npz[:-4] + '.pkl', 'rb'))
+    assert ('regions_class_order' in saved) == (order is not None)
 
 
 @pytest.mark.gpu
