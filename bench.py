@@ -87,7 +87,9 @@ def make_batch(workload, B, dev, rank, patch=PATCH):
 def make_loss(workload, ddp):
     from multitalent_amd.training.ds_weights import ds_loss_weights
     from multitalent_amd.training.loss_functions.fused_losses import DC_and_CE_DS_loss, MultiTalentLoss
-    w = ds_loss_weights(len(RESENC_POOLS) - 1 if workload == 'resenc' else len(POOLS))
+    # MultiTalent_meets_resenc.py:157-170: net_numpool = len(net_num_pool_op_kernel_sizes) = 6 (the stem's [1,1,1] included), so all
+    # five outputs of the residual-encoder network carry a weight (1, 1/2, 1/4, 1/8, 1/16) / 1.9375
+    w = ds_loss_weights(len(RESENC_POOLS) if workload == 'resenc' else len(POOLS))
     if workload == 'task009':
         return DC_and_CE_DS_loss(w, batch_dice=False, ddp=ddp)
     return MultiTalentLoss(w, batch_dice=True)
@@ -296,7 +298,7 @@ def cpu_iteration_fn(workload, B, patch=PATCH):
         label_sets = [sorted({l for r in v for l in MultiTalent_regions[r]}) for v in valid]
         if workload == 'resenc':
             t = synthetic_targets(B, patch, ds_scales(RESENC_POOLS, skip_first=True), label_sets, 99, 'cpu')
-            w = R.ds_loss_weights(len(RESENC_POOLS) - 1)
+            w = R.ds_loss_weights(len(RESENC_POOLS))
             fwd = lambda: R.fabians_unet_forward(sd, x, RESENC_POOLS, RESENC_KERNELS, RESENC_BLOCKS)
         else:
             t = synthetic_targets(B, patch, ds_scales(POOLS), label_sets, 99, 'cpu')
@@ -357,7 +359,7 @@ def cpu_baseline_infer(patch, tiles_total, mirror):
                       "%d tiles; overlap-add excluded; torch-CPU oracle, %d threads on %d physical cores" % ('x'.join(str(i) for i in patch), nflip, dt, tiles_total, threads, phys)}
 
 
-def bench_infer(args, dev, rank, world, ddp):
+def bench_infer(args, dev, rank, world, ddp, emit=True):
     """BASELINE.json configs[4]: predict_MultiTalent-style sliding-window inference of ONE synthetic CT volume, tiles sharded
     over the ranks (strong scaling), Gaussian weighting, step 0.5, optional 8-fold mirroring; a 'step' is one whole volume.
     Metric: volumes per minute, volume already resident in host memory, result left on the device."""
@@ -407,10 +409,18 @@ def bench_infer(args, dev, rank, world, ddp):
                 line["roofline"].update(measure_traffic(line["roofline"]["kernel"], child_argv(args)))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_infer(patch, ntiles, bool(args.mirror))
-        print(json.dumps(line), flush=True)
-    if ddp:
+        stats = getattr(net, '_slab_exchange_stats', None)
+        if stats is not None:
+            line["comm"] = stats
+        if emit:
+            print(json.dumps(line), flush=True)
+    else:
+        line = None
+    del net
+    if emit and ddp:
         dist.barrier()
         dist.destroy_process_group()
+    return line
 
 
 def child_argv(args):
@@ -435,6 +445,102 @@ def respawn_under_torchrun(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+DEFAULT_BATCH = {'task009': 2, 'task100': 4, 'resenc': 2}
+WORKLOAD_NAMES = {"task009": "Task009_Spleen Generic_UNet nc=2 softmax Dice+CE",
+                  "task100": "Task100_MultiTalent Generic_UNet nc=47 MultiTalent BCE+Dice loss",
+                  "resenc": "Task100_MultiTalent FabiansUNet (residual encoder) nc=47 MultiTalent BCE+Dice loss"}
+
+
+def time_training(workload, precision, patch, B, steps, warmup, dev, rank, world, ddp):
+    """W untimed + K timed training iterations of `workload`, bracketed by barrier + synchronize, max over ranks."""
+    from multitalent_amd.training.hot_loop import FusedTrainStep
+    torch.manual_seed(1234)           # identical initial weights on all ranks (DDP broadcast semantics)
+    net = build_network(workload)
+    net.train()
+    net.engine().set_precision(precision)
+    step = FusedTrainStep(net, make_loss(workload, ddp), lr=1e-2, ddp=ddp)
+    x, largs = make_batch(workload, B, dev, rank, patch)
+    for _ in range(warmup):
+        step(x, *largs)
+    torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if step.reducer is not None:
+        step.reducer.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step(x, *largs)
+    torch.cuda.synchronize()
+    if ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if ddp:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = res[0] if isinstance(res, tuple) else res
+    return {'dt': dt, 'ms': dt / steps * 1e3, 'value': world * B * steps / dt, 'loss': float(loss), 'step': step, 'x': x, 'largs': largs,
+            'net': net, 'comm': step.reducer.stats() if step.reducer is not None else None}
+
+
+def training_line(r, workload, precision, patch, B, steps, warmup, world):
+    fl = conv_flops(r['step'].eng) * 3.0
+    pname = 'x'.join(str(i) for i in patch)
+    line = {
+        "metric": "CT patches/s (%s) train fwd+bwd" % pname, "value": round(r['value'], 3), "unit": "patches/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(r['ms'], 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if precision == 'fp32' else "bf16", "data": "synthetic",
+        "config": {"workload": WORKLOAD_NAMES[workload], "patch": list(patch), "batch_per_gpu": B, "global_batch": B * world,
+                   "parallelism": "dp%d" % world, "step": "fwd+loss+bwd+clip12+SGD-nesterov",
+                   "precision": "fp32" if precision == 'fp32' else
+                   "bf16 matrix inputs + fp32 accumulation in the convolutions (fwd, bwd-data, bwd-weight); fp32 master weights, norm statistics, loss, optimizer",
+                   "final_loss": round(r['loss'], 5)},
+        "algorithmic_tflop_per_step": round(fl / 1e12, 3),
+        "step_frac_of_fp32_mfma_roofline": round(fl / (r['ms'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+    }
+    if r.get('comm') is not None:
+        line["comm"] = r['comm']
+    return line
+
+
+def measure_also(args, dev, rank, world, ddp):
+    """The other BASELINE configs in the same process, after the headline workload (a few seconds each): configs[2] Task100 B = 4
+    (the workload north_star's scaling target names), configs[3] residual encoder in fp32 and bf16, configs[4] sliding window of a
+    512^3 volume without mirroring.  At N > 1 the training workloads run data-parallel over the same process group and the
+    sliding window shards its tiles; each entry is whole-job throughput like `value`."""
+    also = {}
+    patch = tuple(args.patch)
+    todo = [('task100', 'fp32'), ('resenc', 'fp32'), ('resenc', 'bf16')] if world == 1 else [('task100', 'fp32'), ('resenc', 'bf16')]
+    for workload, precision in todo:
+        B = DEFAULT_BATCH[workload]
+        r = time_training(workload, precision, patch, B, args.also_steps, 2, dev, rank, world, ddp)
+        if rank == 0:
+            e = training_line(r, workload, precision, patch, B, args.also_steps, 2, world)
+            e = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "algorithmic_tflop_per_step",
+                                   "step_frac_of_fp32_mfma_roofline", "comm") if k in e}
+            if world == 1 and not args.no_roofline:
+                e["roofline"] = measure_roofline(r['step'], r['x'], r['largs'], precision, nrep=2)
+            also[workload + ('' if precision == 'fp32' else '_bf16')] = e
+        del r
+        torch.cuda.empty_cache()
+    ia = argparse.Namespace(**vars(args))
+    ia.workload, ia.mirror, ia.steps, ia.warmup, ia.no_cpu_baseline, ia.no_traffic, ia.precision = 'infer', 0, 1, 1, True, True, 'fp32'
+    e = bench_infer(ia, dev, rank, world, ddp, emit=False)
+    if rank == 0:
+        also['infer_512_nomirror'] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "scaling", "comm") if k in e}
+    net_cache_clear()
+    return also
+
+
+def net_cache_clear():
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -449,6 +555,8 @@ def main():
                     help='bf16 = mixed precision (BASELINE configs[3]): bf16 matrix inputs, fp32 accumulation; the headline metric is fp32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-also', action='store_true', help='headline workload only (default run: + the other BASELINE configs under "also")')
+    ap.add_argument('--also-steps', type=int, default=5)
     ap.add_argument('--no-traffic', action='store_true', help='skip the two rocprofv3 --pmc child passes (roofline.traffic = null)')
     args = ap.parse_args()
 
@@ -469,65 +577,24 @@ def main():
     if workload == 'infer':
         return bench_infer(args, dev, rank, world, ddp)
     patch = tuple(args.patch)
-    B = args.batch or {'task009': 2, 'task100': 4, 'resenc': 2}[workload]
-
-    from multitalent_amd.training.hot_loop import FusedTrainStep
-    torch.manual_seed(1234)           # identical initial weights on all ranks (DDP broadcast semantics)
-    net = build_network(workload)
-    net.train()
-    net.engine().set_precision(args.precision)
-    step = FusedTrainStep(net, make_loss(workload, ddp), lr=1e-2, ddp=ddp)
-    x, largs = make_batch(workload, B, dev, rank, patch)
-
-    for _ in range(args.warmup):
-        step(x, *largs)
-    torch.cuda.synchronize()
-    if ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step(x, *largs)
-    torch.cuda.synchronize()
-    if ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if ddp:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    loss = res[0] if isinstance(res, tuple) else res
-    ms = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
-
+    B = args.batch or DEFAULT_BATCH[workload]
+    r = time_training(workload, args.precision, patch, B, args.steps, args.warmup, dev, rank, world, ddp)
     line = None
     if rank == 0:
-        fl = conv_flops(step.eng) * 3.0
-        pname = 'x'.join(str(i) for i in patch)
-        line = {
-            "metric": "CT patches/s (%s) train fwd+bwd" % pname, "value": round(value, 3), "unit": "patches/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == 'fp32' else "bf16", "data": "synthetic",
-            "config": {"workload": {"task009": "Task009_Spleen Generic_UNet nc=2 softmax Dice+CE",
-                                    "task100": "Task100_MultiTalent Generic_UNet nc=47 MultiTalent BCE+Dice loss",
-                                    "resenc": "Task100_MultiTalent FabiansUNet (residual encoder) nc=47 MultiTalent BCE+Dice loss"}[workload],
-                       "patch": list(patch), "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": "dp%d" % world, "step": "fwd+loss+bwd+clip12+SGD-nesterov",
-                       "precision": "fp32" if args.precision == 'fp32' else
-                       "bf16 matrix inputs + fp32 accumulation in the convolutions (fwd, bwd-data, bwd-weight); fp32 master weights, norm statistics, loss, optimizer",
-                       "final_loss": round(float(loss), 5)},
-            "algorithmic_tflop_per_step": round(fl / 1e12, 3),
-            "step_frac_of_fp32_mfma_roofline": round(fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-        }
+        line = training_line(r, workload, args.precision, patch, B, args.steps, args.warmup, world)
     if rank == 0 and world == 1:
         if not args.no_roofline:
-            line["roofline"] = measure_roofline(step, x, largs, args.precision)
+            line["roofline"] = measure_roofline(r['step'], r['x'], r['largs'], args.precision)
             if not args.no_traffic:
                 line["roofline"].update(measure_traffic(line["roofline"]["kernel"], child_argv(args)))
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(workload, patch)
+    del r
+    torch.cuda.empty_cache()
+    if args.workload is None and not args.no_also:
+        also = measure_also(args, dev, rank, world, ddp)
+        if rank == 0:
+            line["also"] = also
     if rank == 0:
         print(json.dumps(line), flush=True)
     if ddp:

@@ -30,6 +30,7 @@ extern "C" {
 #define MT_EINVAL (-1)  /* bad argument / unsupported shape */
 #define MT_EWORKSPACE (-2) /* workspace too small */
 #define MT_EHIP (-3)    /* HIP runtime error on launch */
+#define MT_EUNSUPPORTED (-4) /* the device is not the one this library is built for (gfx950) */
 
 #define MT_ABI_VERSION 1
 #define MT_MAX_CHUNKS 64
@@ -124,6 +125,24 @@ int mt_conv3d_bwd_data_strided_pack_layout(const mt_conv3d_t* p); /* `layout` of
  * "conv_bf16" (problems with mma == 1) = 0 never, 1 where the grid fills the chip (default), 2 wherever eligible;
  * "bwdw_bf16" 0 | 1. */
 int mt_set_option(const char* name, int value);
+/* Process-wide tuning knobs.  mt_set_option and the environment variables below choose BETWEEN KERNELS THAT COMPUTE THE SAME
+ * RESULT (to fp32 rounding); they are the only mutable state of the library (atomics: setting one while other threads launch is
+ * safe, it simply takes effect for later launches on every device).  Per-DEVICE one-time setup (raising a kernel's dynamic-LDS
+ * limit, the CU count that sizes persistent grids) is keyed by the current HIP device, so one process may drive several GPUs.
+ * Environment, read once at first use (0 disables the named kernel family and falls back to the generic one unless noted):
+ *   MT_CONV_WINO (0|1|2), MT_WINO_WAVES (4|8), MT_WINO_PERSIST (0|1|n), MT_BWDW_WINO, MT_BWDW_MARCH, MT_BWDW_FAST, MT_BWDW_TALL,
+ *   MT_CONV_BF16 (0|1|2), MT_BWDW_BF16, MT_STRIDED_BF16, MT_CONV_FASTV2, MT_CONV_RT, MT_CONV_STEM, MT_CONV_TAPSPLIT,
+ *   MT_CONV_FAST133, MT_CONV_GATHER, MT_CONV_VEC1 (1: dword staging loads),
+ *   MT_PW_VEC / MT_GATHER_VEC (1|2|4: floats per load instruction of pw_fast_kernel / conv_gather_kernel; default 4 = 16-byte
+ *   buffer loads on dword-aligned addresses, see mt_probe_device), MT_HEAD_BWD_WIDE, MT_CONV_CFG / MT_BF16_CFG (force a tile
+ *   configuration), MT_CONV_STAGGER, MT_CONV_DBG (debugging). */
+
+/* Device probe (SYNCHRONOUS, call once per device before the first launch; the Python binding does so when it loads the
+ * library): checks that the current device is gfx950 and that raw buffer loads behave the way the vector-load kernels assume —
+ * a dword-aligned buffer_load_dwordx4 returns its four dwords, and a load that straddles num_records returns the in-range dwords
+ * and zeros for the rest.  `scratch`: >= 32 KiB of device memory owned by the caller.  *vector_loads_ok = 1 / 0; `arch` receives
+ * the gcnArchName.  Returns MT_EUNSUPPORTED on a non-gfx950 device. */
+int mt_probe_device(void* scratch, size_t scratch_bytes, int* vector_loads_ok, char* arch, size_t arch_len, mt_stream_t stream);
 int mt_conv3d_pack_layout(const mt_conv3d_t* p);   /* `layout` for mt_pack_conv_weights: 1; 2 when the Winograd kernel serves p; 3 (bf16) when p->mma == 1 and the bf16 kernel does */
 int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n); /* device kernel that will run (profiler name) */
 /* the same for mt_conv3d_bwd_weight(p, ysrc, ...) and mt_conv3d_bwd_data_strided(p): which kernel family the dispatcher picks

@@ -57,6 +57,7 @@ _P = C.POINTER
 SIGNATURES = {
     'mt_last_error': (C.c_char_p, []),
     'mt_abi_version': (_i, []),
+    'mt_probe_device': (_i, [_vp, _sz, _P(_i), C.c_char_p, _sz, _vp]),
     'mt_pack_conv_weights': (_i, [_vp, _vp, _P(_sz), _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _i, _vp, _vp]),
     'mt_conv3d_fwd': (_i, [_P(mt_conv3d_t), _vp]),
     'mt_conv3d_stats_blocks': (_i, [_P(mt_conv3d_t)]),
@@ -132,7 +133,36 @@ def load():
     if lib.mt_abi_version() != 1:
         raise RuntimeError("libmtseg_hip.so ABI version mismatch")
     _lib = lib
+    probe_device()          # fail loudly on a device the vector-load kernels are not valid for (no-op without a GPU)
     return lib
+
+
+_probed = {}
+
+
+def probe_device(index=None):
+    """Once per device: the library is built for gfx950 only and its vector-load kernels assume per-dword range checks and
+    dword-aligned 16-byte buffer loads (mt_probe_device).  A device that behaves differently must fail HERE, loudly, not compute
+    garbage later.  Called by Engine.attach and ops.Act construction paths through `ensure_device`."""
+    import torch
+    if not torch.cuda.is_available():
+        return None
+    index = torch.cuda.current_device() if index is None else int(index)
+    if index in _probed:
+        return _probed[index]
+    lib = load()
+    with torch.cuda.device(index):
+        scratch = torch.zeros(8192, dtype=torch.float32, device='cuda')
+        ok = C.c_int(0)
+        arch = C.create_string_buffer(64)
+        rc = lib.mt_probe_device(scratch.data_ptr(), scratch.numel() * 4, C.byref(ok), arch, 64, torch.cuda.current_stream().cuda_stream)
+        check(rc, 'probe_device')
+    if not ok.value:
+        raise RuntimeError("libmtseg_hip: device %d (%s) does not return per-dword range-checked, dword-aligned 16-byte buffer loads; "
+                           "the vector-load kernels of this library would compute wrong results on it (see include/mtseg.h, "
+                           "mt_probe_device)" % (index, arch.value.decode()))
+    _probed[index] = arch.value.decode()
+    return _probed[index]
 
 
 def check(rc, what=''):

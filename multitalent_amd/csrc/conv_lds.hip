@@ -2047,9 +2047,9 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
 
 static int g_bwdw_bf16 = -1;       // -1: read MT_BWDW_BF16 (default 1): bf16 Winograd backward-weight kernel when mt_conv3d_t.mma == 1
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
-static int g_wino_waves = 8;       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
-static int g_wino_persist = 1;     // 8-wave kernel: 1 persistent over spatial tiles (conv_wino8p_kernel), 0 one tile per workgroup, n > 1: at most n workers
-static int g_wino_mode = -1;       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
+static std::atomic<int> g_wino_waves{8};       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
+static std::atomic<int> g_wino_persist{1};     // 8-wave kernel: 1 persistent over spatial tiles (conv_wino8p_kernel), 0 one tile per workgroup, n > 1: at most n workers
+static std::atomic<int> g_wino_mode{-1};       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
 extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "conv_wino") == 0) { g_wino_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_wino") == 0) { g_bwdw_wino = value; return MT_OK; }
@@ -2075,6 +2075,10 @@ static bool conv_wino_ok(const mt_conv3d_t* p) {
   const long wgs = (long)p->N * mt_cdiv(p->Do, 4) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 16) * mt_cdiv(p->Cout, 32);
   return wgs >= 256 || use == 2;          // MT_CONV_WINO=2 forces it (tests on small shapes)
 }
+// Packed patch geometry of the persistent kernel: a task's linear offset (ld*Hi + lh)*Wi + lw with ld, lh <= 5 and lw <= 17 lives
+// in bits 0-19 of a table entry, so its maximum (5*Hi + 5)*Wi + 17 must stay below 2^20 (beyond that the offset would spill into
+// the ld bits); larger planes run the one-tile-per-workgroup kernel.
+static bool wino_persist_geometry_ok(const mt_conv3d_t* p) { return (5.0 * p->Hi + 5.0) * p->Wi + 17.0 < 1048576.0; }
 static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
   ConvKParams P;
   P.c = *p;
@@ -2085,32 +2089,30 @@ static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
   P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, WCK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks for the Winograd kernel (Cin=%d)", p->Cin);
   const size_t ldsb = (size_t)(W_RAWF + W_VF) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  const int devid = mt_current_device();
+  static std::atomic<uint64_t> attr_set{0};
+  if (mt_device_pending(attr_set, devid)) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
-    attr_set = true;
+    mt_mark_device_done(attr_set, devid);
   }
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
   if (g_wino_waves == 8) {
     const size_t l8 = (size_t)(2 * W_RAWF + W_VF) * sizeof(float);
-    static bool attr8 = false;
-    if (!attr8) {
+    static std::atomic<uint64_t> attr8{0};
+    if (mt_device_pending(attr8, devid)) {
       hipError_t e = hipFuncSetAttribute((const void*)conv_wino8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l8);
       if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", l8, hipGetErrorString(e)); return MT_EHIP; }
-      attr8 = true;
+      mt_mark_device_done(attr8, devid);
     }
-    if (g_wino_persist && 5.0 * p->Hi * p->Wi < 1048576.0) {        // packed patch geometry of the persistent kernel: 20-bit offsets
-      static bool attrp = false;
-      static int ncu = 0;
-      if (!attrp) {
+    if (g_wino_persist && wino_persist_geometry_ok(p)) {
+      static std::atomic<uint64_t> attrp{0};
+      if (mt_device_pending(attrp, devid)) {
         hipError_t e = hipFuncSetAttribute((const void*)conv_wino8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(l8 + 11 * 256 * 4));
         if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", l8, hipGetErrorString(e)); return MT_EHIP; }
-        int devid = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-        attrp = true;
+        mt_mark_device_done(attrp, devid);
       }
+      const int ncu = mt_device_cus(devid);
       // one resident workgroup per CU (126 KiB of LDS each): NW workers per output-channel tile walk over the spatial tiles
       const int T = P.nsb * p->N, nct = mt_cdiv(p->Cout, 32);
       int nw = ncu / nct; if (nw < 1) nw = 1; if (nw > T) nw = T;
@@ -2266,7 +2268,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   else if (pl.kind == CONV_STEM)
     snprintf(buf, n, "conv_stem_kernel");
   else if (pl.kind == CONV_WINO)
-    snprintf(buf, n, g_wino_waves == 8 ? ((g_wino_persist && 5.0 * p->Hi * p->Wi < 1048576.0) ? "conv_wino8p_kernel" : "conv_wino8_kernel") : "conv_wino_kernel");
+    snprintf(buf, n, g_wino_waves == 8 ? ((g_wino_persist && wino_persist_geometry_ok(p)) ? "conv_wino8p_kernel" : "conv_wino8_kernel") : "conv_wino_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
     snprintf(buf, n, strided_use_bf16(p) ? "conv_fast_strided_kernel<%d, %d, %d, %d, true>" : "conv_fast_strided_kernel<%d, %d, %d, %d, false>",
              p->SD, p->SH, p->SW, conv_fast_vec(p));
@@ -3580,11 +3582,12 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
         }
         if (bwdw_use_wino(p)) {
           const size_t ldsb = (size_t)BWW_LDS_FLOATS * sizeof(float);
-          static bool attr = false;
-          if (!attr) {
+          static std::atomic<uint64_t> attr{0};
+          const int devid = mt_current_device();
+          if (mt_device_pending(attr, devid)) {
             hipError_t e = hipFuncSetAttribute((const void*)conv_bwdw_wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
             if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
-            attr = true;
+            mt_mark_device_done(attr, devid);
           }
           hipLaunchKernelGGL(conv_bwdw_wino_kernel<2>, dim3(P.nsg, P.ncot, P.nchunks), dim3(256), ldsb, st, P);
           MT_CHECK_LAUNCH("conv_bwdw_wino");

@@ -53,3 +53,23 @@ __device__ __forceinline__ double mt_wave_sum_d(double v) {
 }
 
 static inline int mt_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// One-time per-DEVICE setup (hipFuncSetAttribute is a per-device property of a kernel): `done` is a bit mask over device ids.
+// Returns true when the setup still has to run for the current device; the caller marks it done with mt_mark_device_done.
+// Racing threads at worst repeat an idempotent call.
+#include <atomic>
+static inline int mt_current_device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? d : 0; }
+static inline bool mt_device_pending(const std::atomic<uint64_t>& done, int dev) { return dev >= 64 || !(done.load(std::memory_order_acquire) >> dev & 1ull); }
+static inline void mt_mark_device_done(std::atomic<uint64_t>& done, int dev) { if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release); }
+// compute units of the current device (cached per device id)
+static inline int mt_device_cus(int dev) {
+  static std::atomic<int> cus[64];
+  int n = dev < 64 ? cus[dev].load(std::memory_order_relaxed) : 0;
+  if (n <= 0) {
+    hipDeviceProp_t prop;
+    n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    if (n <= 0) n = 256;
+    if (dev < 64) cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}

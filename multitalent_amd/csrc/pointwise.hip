@@ -818,3 +818,64 @@ extern "C" int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, 
   if (dbias_done != nullptr) *dbias_done = ((Cin % 32) != 0) ? 1 : 0;      // 0: the caller sums dY itself (mt_channel_sum)
   return MT_OK;
 }
+
+
+// ---- device probe --------------------------------------------------------------------------------------------------------------
+// pw_fast_kernel, conv_gather_kernel, head_bwd_kernel and the Winograd stagers issue buffer_load_dwordx4 on addresses that are
+// only dword-aligned (188-byte rows at 47 channels) and rely on raw buffers range-checking every dword of a load on its own (a
+// 16-byte load that straddles num_records returns its in-range dwords and zeros for the rest).  Both are properties of gfx950 in
+// the unaligned-access mode the ROCm driver configures; the probe below verifies them ON THE DEVICE IN USE so that a differently
+// configured system fails loudly at library load instead of computing garbage.
+__global__ void probe_straddle_kernel(const float* p, int nrec_bytes, float* out) {
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, nrec_bytes, 0x00020000);
+  const int off = threadIdx.x * 8;      // lane i reads floats 2i .. 2i+3
+  f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  for (int e = 0; e < 4; ++e) out[threadIdx.x * 4 + e] = v[e];
+}
+__global__ void probe_unaligned_kernel(const float* p, int nrec_bytes, float* out) {     // rows of 47 floats: 4-byte aligned only
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, nrec_bytes, 0x00020000);
+  const int off = (threadIdx.x * 47 + 1) * 4;
+  f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  for (int e = 0; e < 4; ++e) out[threadIdx.x * 4 + e] = v[e];
+}
+
+extern "C" int mt_probe_device(void* scratch, size_t scratch_bytes, int* vector_loads_ok, char* arch, size_t arch_len, mt_stream_t stream) {
+  MT_REQUIRE(scratch != nullptr && scratch_bytes >= 32768 && vector_loads_ok != nullptr, "probe_device: needs 32 KiB of device scratch");
+  hipStream_t st = (hipStream_t)stream;
+  *vector_loads_ok = 0;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { mt_set_error("probe_device: no device"); return MT_EHIP; }
+  if (arch != nullptr && arch_len > 0) snprintf(arch, arch_len, "%s", prop.gcnArchName);
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { mt_set_error("probe_device: built for gfx950, the device is %s", prop.gcnArchName); return MT_EUNSUPPORTED; }
+  float* in = (float*)scratch;                 // 64 * 47 + 8 floats of input, then 256 floats of output
+  const int n = 64 * 47 + 8;
+  float* out = in + 4096;
+  float* h = (float*)malloc((size_t)n * sizeof(float));
+  float r[256];
+  if (h == nullptr) { mt_set_error("probe_device: out of host memory"); return MT_EHIP; }
+  for (int i = 0; i < n; ++i) h[i] = (float)(i + 1);
+  bool ok = hipMemcpyAsync(in, h, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st) == hipSuccess;
+  // (1) 30 floats in range: lanes 13 / 14 straddle the end of the buffer, lanes >= 15 are entirely outside
+  hipLaunchKernelGGL(probe_straddle_kernel, dim3(1), dim3(64), 0, st, in, 30 * 4, out);
+  ok = ok && hipMemcpyAsync(r, out, sizeof(r), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+  if (ok)
+    for (int i = 0; i < 64; ++i)
+      for (int e = 0; e < 4; ++e) {
+        const int idx = 2 * i + e;
+        if (r[4 * i + e] != (idx < 30 ? (float)(idx + 1) : 0.f)) ok = false;
+      }
+  // (2) dword-aligned 16-byte loads return the right four values
+  if (ok) {
+    hipLaunchKernelGGL(probe_unaligned_kernel, dim3(1), dim3(64), 0, st, in, n * 4, out);
+    ok = hipMemcpyAsync(r, out, sizeof(r), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    if (ok)
+      for (int i = 0; i < 64; ++i)
+        for (int e = 0; e < 4; ++e)
+          if (r[4 * i + e] != (float)(i * 47 + 1 + e + 1)) ok = false;
+  }
+  free(h);
+  if (hipGetLastError() != hipSuccess) ok = false;
+  *vector_loads_ok = ok ? 1 : 0;
+  return MT_OK;
+}

@@ -441,6 +441,9 @@ class Engine:
         if ok:
             return
         self.device = device
+        if device.type == 'cuda':
+            from . import _lib
+            _lib.probe_device(device.index if device.index is not None else None)
         offs, n = [], 0
         for p in params:
             offs.append(n)

@@ -28,9 +28,7 @@ def predict_case_on_device(network, cropped_data, properties, target_spacing, in
         from .sliding_window import gather_slabs
         _, slab, x_range = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
                                       'constant', None, True, verbose, True, tile_shard=tile_shard, return_device_tensors=True)
-        import torch
-        dummy = torch.empty((slab.shape[1],) + tuple(slab.shape[2:]), dtype=torch.int32, device=slab.device)
-        _, probs = gather_slabs(dummy, slab, x_range, int(x.shape[1]), tile_shard[1])
+        _, probs = gather_slabs(None, slab, x_range, int(x.shape[1]), tile_shard[1])
     else:
         _, probs = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
                               'constant', None, True, verbose, True, return_device_tensors=True)

@@ -205,7 +205,10 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
     if plan is not None:
         # slab ownership: every rank ends with the finished aggregate of ITS x-slab; only the zones where neighbouring ranks'
         # tiles overlap travel (partial sums, added in rank order = the reference's tile order at rank granularity)
-        agg, nb = exchange_slabs(agg, nb, plan, rank, world)
+        if getattr(net, '_slab_cache', None) is None:
+            net._slab_cache = {}
+        net._slab_exchange_stats = {}
+        agg, nb = exchange_slabs(agg, nb, plan, rank, world, cache=net._slab_cache, stats=net._slab_exchange_stats)
         o_lo, o_hi = plan['owned'][rank]
     else:
         o_lo, o_hi = 0, X
@@ -267,12 +270,26 @@ def _intersect(a, b):
     return (lo, hi) if hi > lo else None
 
 
-def exchange_slabs(agg, nb, plan, rank, world):
+def exchange_slabs(agg, nb, plan, rank, world, cache=None, stats=None):
     """agg [C, local x, Y, Z], nb [local x, Y, Z] (partial sums over this rank's tiles) -> finished (agg, nb) of the owned slab.
     Rank r sends to every q != r the part of its TOUCHED range that q owns (in practice: the half-patch zones shared with its two
     neighbours — 2 x 47 x 24 x 512 x 512 floats at 512^3 instead of the 25 GB aggregate) and folds what it receives into its own
-    slab in ascending rank order, starting from zeros, so the result does not depend on arrival order."""
+    slab in ascending rank order, starting from zeros, so the result does not depend on arrival order.  `cache` (a dict kept on the
+    network) holds the receive buffers and the finished slab between volumes — no multi-GB device allocation per volume; `stats`
+    (a dict) receives the bytes this rank sent / received and the wall time of the exchange."""
+    import time
     import torch.distributed as dist
+    cache = {} if cache is None else cache
+
+    def buf(tag, shape, dev, zero=False):
+        k = (tag, tuple(shape), str(dev))
+        t = cache.get(k)
+        if t is None:
+            t = cache[k] = torch.empty(shape, dtype=torch.float32, device=dev)
+        return t.zero_() if zero else t
+    if stats is not None and agg.is_cuda:
+        torch.cuda.synchronize(agg.device)
+    t_start = time.perf_counter()
     l_lo = plan['local'][rank][0]
     own = plan['owned'][rank]
     via_host = agg.is_cuda and dist.get_backend() == 'gloo'      # two ranks on one GPU in the tests: transport through the host
@@ -291,8 +308,7 @@ def exchange_slabs(agg, nb, plan, rank, world):
         if in_rng is not None:
             shape = (in_rng[1] - in_rng[0],) + tuple(nb.shape[1:])
             dev = 'cpu' if via_host else agg.device
-            recvs[q] = (in_rng, torch.empty((agg.shape[0],) + shape, dtype=torch.float32, device=dev),
-                        torch.empty(shape, dtype=torch.float32, device=dev))
+            recvs[q] = (in_rng, buf('ra%d' % q, (agg.shape[0],) + shape, dev), buf('rn%d' % q, shape, dev))
     for q, a, n in sends:
         ops_list += [dist.P2POp(dist.isend, a, q), dist.P2POp(dist.isend, n, q)]
     for q, (_, a, n) in recvs.items():
@@ -300,8 +316,8 @@ def exchange_slabs(agg, nb, plan, rank, world):
     if ops_list:
         for w in dist.batch_isend_irecv(ops_list):
             w.wait()
-    fa = torch.zeros((agg.shape[0], own[1] - own[0]) + tuple(nb.shape[1:]), dtype=torch.float32, device=agg.device)
-    fn = torch.zeros((own[1] - own[0],) + tuple(nb.shape[1:]), dtype=torch.float32, device=agg.device)
+    fa = buf('fa', (agg.shape[0], own[1] - own[0]) + tuple(nb.shape[1:]), agg.device, zero=True)
+    fn = buf('fn', (own[1] - own[0],) + tuple(nb.shape[1:]), agg.device, zero=True)
     for q in range(world):
         if q == rank:
             rng = _intersect(plan['local'][rank], own)
@@ -312,27 +328,40 @@ def exchange_slabs(agg, nb, plan, rank, world):
             rng, a, n = recvs[q]
             fa[:, rng[0] - own[0]:rng[1] - own[0]] += a.to(agg.device)
             fn[rng[0] - own[0]:rng[1] - own[0]] += n.to(agg.device)
+    if stats is not None:
+        if agg.is_cuda:
+            torch.cuda.synchronize(agg.device)
+        stats.update({'exchange': 'batch_isend_irecv of the zones shared with neighbouring ranks',
+                      'bytes_sent': int(sum(a.numel() + n.numel() for _, a, n in sends) * 4),
+                      'bytes_received': int(sum(a.numel() + n.numel() for _, a, n in recvs.values()) * 4),
+                      'peers': sorted(set([q for q, _, _ in sends]) | set(recvs.keys())),
+                      'exchange_ms': round((time.perf_counter() - t_start) * 1e3, 2)})
     return fa, fn
 
 
 def gather_slabs(seg, probs, x_range, X, world):
-    """the per-rank slabs -> the whole (seg, probs) on every rank (API mode; the bench leaves the result sharded)."""
+    """the per-rank slabs -> the whole (seg, probs) on every rank (API mode; the bench leaves the result sharded).  `seg` may be
+    None (callers that classify after their own resampling only need the probabilities): then only `probs` travels."""
     import torch.distributed as dist
-    dev = seg.device
-    via_host = seg.is_cuda and dist.get_backend() == 'gloo'
+    dev = probs.device
+    via_host = probs.is_cuda and dist.get_backend() == 'gloo'
     ranges = [None] * world
     dist.all_gather_object(ranges, tuple(int(i) for i in x_range))
-    full_seg = torch.empty((X,) + tuple(seg.shape[1:]), dtype=seg.dtype, device=dev)
+    full_seg = torch.empty((X,) + tuple(seg.shape[1:]), dtype=seg.dtype, device=dev) if seg is not None else None
     full_probs = torch.empty((probs.shape[0], X) + tuple(probs.shape[2:]), dtype=probs.dtype, device=dev)
+    me = dist.get_rank()
     for q, (a, b) in enumerate(ranges):
         if b <= a:
             continue
-        s = seg.contiguous() if q == dist.get_rank() else torch.empty((b - a,) + tuple(seg.shape[1:]), dtype=seg.dtype, device=dev)
-        p = probs.contiguous() if q == dist.get_rank() else torch.empty((probs.shape[0], b - a) + tuple(probs.shape[2:]), dtype=probs.dtype, device=dev)
+        p = probs.contiguous() if q == me else torch.empty((probs.shape[0], b - a) + tuple(probs.shape[2:]), dtype=probs.dtype, device=dev)
         if via_host:
-            s, p = s.cpu(), p.cpu()
-        dist.broadcast(s, q)
+            p = p.cpu()
         dist.broadcast(p, q)
-        full_seg[a:b] = s.to(dev)
         full_probs[:, a:b] = p.to(dev)
+        if seg is not None:
+            s = seg.contiguous() if q == me else torch.empty((b - a,) + tuple(seg.shape[1:]), dtype=seg.dtype, device=dev)
+            if via_host:
+                s = s.cpu()
+            dist.broadcast(s, q)
+            full_seg[a:b] = s.to(dev)
     return full_seg, full_probs

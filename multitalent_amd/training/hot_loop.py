@@ -25,6 +25,28 @@ class GradAllReducer:
         # MT_FORCE_REDUCER=1 runs the full bucketed / side-stream code path even at world size 1 (single-GPU validation)
         import os
         self.force = bool(int(os.environ.get('MT_FORCE_REDUCER', '0'))) and dist.is_available() and dist.is_initialized()
+        self.reset_stats()
+
+    # ---- communication accounting (shown by bench.py as `comm`): is the all-reduce hidden behind backward? ----------------
+    def reset_stats(self):
+        self._steps = 0
+        self._bytes = 0
+        self._buckets = 0
+        self._ev_wait = []        # (before, after) on the compute stream around wait_stream(side): what backward did NOT hide
+        self._ev_comm = []        # (before, after) on the side stream around each bucket's scale + all-reduce
+
+    def stats(self):
+        """per-step averages since reset_stats(): bytes all-reduced, buckets, side-stream busy time and the time the compute
+        stream had to wait for the side stream before clip / SGD (0 = fully overlapped)."""
+        if self._steps == 0:
+            return None
+        out = {"allreduce_bytes_per_step": int(self._bytes / self._steps), "buckets_per_step": round(self._buckets / self._steps, 2),
+               "bucket_bytes": int(self.bucket * 4), "world": self.world}
+        if self._ev_wait:
+            torch.cuda.synchronize()
+            out["exposed_wait_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in self._ev_wait) / self._steps, 3)
+            out["side_stream_busy_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in self._ev_comm) / self._steps, 3)
+        return out
 
     def begin(self):
         self.sent = 0
@@ -53,18 +75,27 @@ class GradAllReducer:
                 # all-reduces it there; finish() makes the compute stream wait for the side stream before clip / SGD read it
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 with torch.cuda.stream(self.stream):
                     self.stream.wait_event(ev)
+                    c0.record(self.stream)
                     sl.div_(self.world)
                     self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+                    self.handles[-1].wait()          # orders the side stream behind the collective (no host block for NCCL work)
+                    c1.record(self.stream)
+                if len(self._ev_comm) < 4096:
+                    self._ev_comm.append((c0, c1))
             else:       # host tensors (gloo): used by the CPU tests of the bucketing logic
                 sl.div_(self.world)
                 self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
+            self._bytes += int(sl.numel()) * 4
+            self._buckets += 1
             self.sent = end
 
     def finish(self):
         if self.world <= 1 and not self.force:
             return
+        self._steps += 1
         if self.via_host:
             for sl in self.handles:
                 h = sl.cpu()
@@ -72,10 +103,19 @@ class GradAllReducer:
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
                 sl.copy_(h)
             return
-        for h in self.handles:
-            h.wait()
         if self.on_gpu:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur = torch.cuda.current_stream()
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0.record(cur)
+            for h in self.handles:          # stream-level waits (RCCL work objects do not block the host)
+                h.wait()
+            cur.wait_stream(self.stream)
+            w1.record(cur)
+            if len(self._ev_wait) < 4096:
+                self._ev_wait.append((w0, w1))
+        else:
+            for h in self.handles:
+                h.wait()
 
 
 class FusedTrainStep:

@@ -215,8 +215,8 @@ def _sharded_inference(rank, world, dev):
         assert np.array_equal(segs[safe], seg1[safe])
         ref_p, ref_s = z['mt/probs_m%d' % int(mirror)], z['mt/seg_m%d' % int(mirror)]
         assert np.abs(ps - ref_p).max() < 1e-4
-        safe = (np.abs(ref_p - 0.5) > 1e-4).all(0)
-        assert np.array_equal(segs[safe].astype(np.int16), ref_s[safe])
+        from mask_check import check_masks
+        check_masks(segs, ref_s, ps, ref_p, [3, 1, 4, 2, 5], 1e-4, 'tile-sharded predict_3D rank %d/%d mirror=%d' % (rank, world, int(mirror)))
     return worst
 
 
@@ -256,6 +256,8 @@ def _rccl_world1(rank, world, dev):
         res.append((losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()))
         if ddp:
             assert len(step.reducer.handles) > 3 and step.reducer.stream is not None
+            st = step.reducer.stats()
+            assert st['allreduce_bytes_per_step'] == 4 * net.engine().flat_grad.numel() and st['exposed_wait_ms_per_step'] >= 0 and st['side_stream_busy_ms_per_step'] > 0
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1])
     return True
@@ -279,3 +281,23 @@ def test_grad_allreducer_side_stream_on_rccl_world1(dev):
     p.start()
     p.join(600)
     assert p.exitcode == 0 and ret[0] is True
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
+@pytest.mark.parametrize("extra", [[], ['--workload', 'task100'], ['--workload', 'infer', '--mirror', '0', '--volume', '160', '256', '256']])
+def test_bench_two_ranks_smoke(extra):
+    """`bench.py --gpus 2` (self-spawning under torch.distributed.run) for the headline workload, Task100 and the tile-sharded sliding
+    window: one JSON line with n_gpus 2 and the communication accounting (`comm`) of the gradient all-reduce / slab exchange."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-also'] + extra,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and 'comm' in line, line
+    if 'infer' in extra:
+        assert line['comm']['bytes_sent'] > 0 and line['scaling'] == 'strong'
+    else:
+        assert line['comm']['allreduce_bytes_per_step'] > 1e8 and line['comm']['world'] == 2 and line['scaling'] == 'weak'

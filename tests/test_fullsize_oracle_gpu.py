@@ -198,7 +198,7 @@ def _resenc(dev, precision, B=1):
     label_sets = [sorted({l for r in v for l in MultiTalent_regions[r]}) for v in valid]
     x = synthetic_ct(B, PATCH, 79, dev)
     tg = synthetic_targets(B, PATCH, ds_scales(bench.RESENC_POOLS, skip_first=True), label_sets, 79, dev)
-    w = R.ds_loss_weights(len(bench.RESENC_POOLS) - 1)
+    w = R.ds_loss_weights(len(bench.RESENC_POOLS))      # all five outputs weighted (MultiTalent_meets_resenc.py:157-170)
     with recorded_kernels() as names:
         logits, loss, grads = hip_forward_backward(net, MultiTalentLoss(w, batch_dice=True), x, (tg, valid))
     return sd0, x, tg, valid, w, logits, loss, grads, names
@@ -253,7 +253,7 @@ def _resenc_fp32_and_bf16(dev):
     print("resenc bf16 vs fp32/fp64 oracle: logits (max err / max, rel. L2) per level %s; loss %s vs %s; gradient cos %.5f, rel. L2 %.3e"
           % (['%.3f / %.4f' % r for r in lrel], lossb, [float(r) for r in rl], cos, float((ga - gr).norm() / gr.norm())))
     for i, (mx, l2) in enumerate(lrel):
-        lowest = i == len(lrel) - 1                      # deep-supervision weight 0 (ds_loss_weights masks the lowest level)
+        lowest = i == len(lrel) - 1                      # 3x6x6 voxels per sample: the level with the fewest voxels to average the rounding over
         assert mx < (0.12 if lowest else 0.06) and l2 < (0.10 if lowest else 0.05), "bf16 logits level %d: %.3f of max, rel. L2 %.4f" % (i, mx, l2)
     for a, b in zip(lossb, rl):
         assert abs(a - float(b)) < 1e-2 * max(1.0, abs(float(b))), (lossb, [float(r) for r in rl])

@@ -794,3 +794,35 @@ def test_head_bwd_fused(dev, N, Cin, Cout, V, lazy, acc, bias):
     assert done == (Cin % 32 != 0)
     if bias and done:
         assert relerr(db.cpu().double(), dyf.sum(0)) < 1e-5
+
+
+def test_device_probe_and_per_device_setup(dev):
+    """mt_probe_device: the device is gfx950 and raw buffer loads behave as the vector-load kernels assume (per-dword range
+    check, dword-aligned 16-byte loads) — the library refuses to load otherwise."""
+    from multitalent_amd import _lib
+    arch = _lib.probe_device(0)
+    assert arch.startswith('gfx950'), arch
+    assert _lib._probed[0] == arch
+
+
+@pytest.mark.parametrize("Wi,kernel", [(522, 'conv_wino8p_kernel'), (524, 'conv_wino8_kernel')])
+def test_winograd_plane_near_the_packed_offset_limit(dev, Wi, kernel):
+    """Persistent Winograd kernel: a task's linear offset (ld*Hi + lh)*Wi + lw (ld, lh <= 5, lw <= 17) is packed into 20 bits.
+    Hi = 400: Wi = 522 is the largest even width that fits ((5*400+5)*522+17 < 2^20), Wi = 524 must run the one-tile-per-workgroup
+    kernel (the old guard 5*Hi*Wi < 2^20 let it through and the offset spilled into the ld bits).  Both against F.conv3d."""
+    ops = _ops()
+    Hi, D, cin, cout = 400, 4, 16, 32
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, cin, D, Hi, Wi), generator=g)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g) / np.sqrt(cin * 27)
+    b = torch.randn(cout, generator=g)
+    ops.set_option('conv_wino', 2)
+    try:
+        xa = ops.Act(to_ndhwc(x).to(dev))
+        p = ops.fill_conv([xa], ops.ConvGeom((D, Hi, Wi), (3, 3, 3), (1, 1, 1), (1, 1, 1)), cout)
+        assert ops.conv_kernel_name(p) == kernel, ops.conv_kernel_name(p)
+        out, _ = run_conv(dev, [x], w, b, (1, 1, 1), (1, 1, 1))
+        ref = F.conv3d(x, w, b, padding=1)
+        assert relerr(to_ncdhw(out.cpu()), ref) < 2e-5
+    finally:
+        ops.set_option('conv_wino', 1)
