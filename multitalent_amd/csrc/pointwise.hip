@@ -8,6 +8,8 @@
 // For a transposed conv every tap is an independent GEMM whose rows are scattered to out[base*so + tap] — written
 // directly into the first half of the skip-concat buffer (ocs).  Weights: mt_pack_conv_weights(layout 1, ck 16).
 #include "mt_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 struct PwKParams {
   mt_pointwise_t c;
