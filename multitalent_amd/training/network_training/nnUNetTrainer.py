@@ -540,8 +540,10 @@ class nnUNetTrainerV2(nnUNetTrainer):
         self.finish_online_evaluation()
         self.maybe_update_lr()
         self.maybe_save_checkpoint()
-        self.update_eval_criterion_MA()
-        self.manage_patience()
+        if len(self.all_val_eval_metrics) > 0 or len(self.all_val_losses) > 0:       # nothing to average before the first validation
+            self.update_eval_criterion_MA()
+            if self.train_loss_MA is not None:
+                self.manage_patience()
         if self.epoch == 100 and len(self.all_val_eval_metrics) > 0 and self.all_val_eval_metrics[-1] == 0:
             self.train_step.mom = 0.95
             self.network.apply(InitWeights_He(1e-2))
