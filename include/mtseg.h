@@ -320,6 +320,11 @@ int mt_resample_classify(const float* probs, int C, int D, int H, int W, int OD,
 int mt_downsample_seg_nearest(const float* src, int NC, int Di, int Hi, int Wi, float* dst, int Do, int Ho, int Wo,
                               int remove_minus_one, mt_stream_t stream);
 
+/* GaussianBlurTransform (data_augmentation_moreDA.py:87-88 -> scipy.ndimage.gaussian_filter per channel): ONE axis pass of the
+ * separable filter, dst = correlate1d(src, w) along axis (0 D, 1 H, 2 W) with w[k] ~ exp(-k^2 / 2 sigma^2), radius int(4 sigma + 0.5),
+ * 'reflect' boundaries; sigma[NC] per (sample, channel), sigma <= 0 copies that channel.  src != dst. */
+int mt_gaussian_blur_axis(const float* src, float* dst, int NC, int D, int H, int W, int axis, const float* sigma, mt_stream_t stream);
+
 /* NCDHW <-> NDHWC transposes used at the module boundary */
 int mt_ncdhw_to_ndhwc(const float* in, float* out, int N, int C, long V, int ocs, mt_stream_t stream);
 int mt_ndhwc_to_ncdhw(const float* in, int ics, float* out, int N, int C, long V, mt_stream_t stream);

@@ -68,6 +68,7 @@ SIGNATURES = {
     'mt_conv3d_bwd_data_strided': (_i, [_P(mt_conv3d_t), _vp]),
     'mt_conv3d_bwd_data_strided_supported': (_i, [_P(mt_conv3d_t)]),
     'mt_downsample_seg_nearest': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    'mt_gaussian_blur_axis': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'mt_set_option': (_i, [C.c_char_p, _i]),
     'mt_conv3d_pack_layout': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_bwd_data_strided_pack_layout': (_i, [_P(mt_conv3d_t)]),

@@ -224,3 +224,63 @@ extern "C" int mt_affine_sample(const float* src, int N, int C, int D, int H, in
   MT_CHECK_LAUNCH("affine_sample");
   return MT_OK;
 }
+
+// ================================================================================================
+// GaussianBlurTransform of nnU-Net's moreDA chain (data_augmentation_moreDA.py:87-88; batchgenerators' augment_gaussian_blur =
+// scipy.ndimage.gaussian_filter(channel, sigma, order=0) per chosen channel): separable, per axis a correlation with
+// w[k] = exp(-k^2 / (2 sigma^2)) / sum, k = -r..r, r = int(4 sigma + 0.5) (truncate = 4) and scipy's default 'reflect' boundary
+// (half-sample symmetric: d c b a | a b c d | d c b a).  One launch per axis; sigma per (sample, channel) — sigma <= 0 copies the
+// channel (the transform blurs only some channels of some samples).  HBM-bound: one read (the 2r+1 taps of neighbouring threads
+// overlap in L1/L2) and one write per element and pass.
+struct BlurParams { const float* src; float* dst; const float* sigma; int NC, D, H, W, axis; };
+#define MT_BLUR_MAXR 32
+__global__ __launch_bounds__(256) void gaussian_blur_axis_kernel(const BlurParams P) {
+  __shared__ float wsh[2 * MT_BLUR_MAXR + 1];
+  const int nc = blockIdx.y;
+  const float sg = P.sigma[nc];
+  const long V = (long)P.D * P.H * P.W;
+  const float* src = P.src + (size_t)nc * V;
+  float* dst = P.dst + (size_t)nc * V;
+  int r = 0;
+  if (sg > 0.f) {
+    r = (int)(4.0 * (double)sg + 0.5);
+    if (r > MT_BLUR_MAXR) r = MT_BLUR_MAXR;
+    if (threadIdx.x == 0) {
+      double s = 0.0;
+      for (int k = -r; k <= r; ++k) s += exp(-0.5 * (double)k * k / ((double)sg * sg));
+      for (int k = -r; k <= r; ++k) wsh[k + r] = (float)(exp(-0.5 * (double)k * k / ((double)sg * sg)) / s);
+    }
+  }
+  __syncthreads();
+  const int len = P.axis == 0 ? P.D : (P.axis == 1 ? P.H : P.W);
+  const long stride = P.axis == 0 ? (long)P.H * P.W : (P.axis == 1 ? P.W : 1);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < V; i += (long)gridDim.x * 256) {
+    if (sg <= 0.f) { dst[i] = src[i]; continue; }
+    const int pos = (int)((i / stride) % len);
+    const long base = i - (long)pos * stride;
+    double acc = 0.0;                                     // scipy's correlate1d accumulates in double
+    for (int k = -r; k <= r; ++k) {
+      int q = pos + k;
+      // 'reflect': period 2 len, q -> q mod 2 len, mirrored in the upper half
+      if (q < 0 || q >= len) {
+        const int p2 = 2 * len;
+        q %= p2; if (q < 0) q += p2;
+        if (q >= len) q = p2 - 1 - q;
+      }
+      acc += (double)wsh[k + r] * (double)src[base + (long)q * stride];
+    }
+    dst[i] = (float)acc;
+  }
+}
+
+extern "C" int mt_gaussian_blur_axis(const float* src, float* dst, int NC, int D, int H, int W, int axis, const float* sigma, mt_stream_t stream) {
+  MT_REQUIRE(src != nullptr && dst != nullptr && sigma != nullptr && src != dst, "gaussian_blur_axis: null or aliased pointers");
+  MT_REQUIRE(NC > 0 && NC <= 65535 && D > 0 && H > 0 && W > 0 && axis >= 0 && axis <= 2, "gaussian_blur_axis: bad geometry");
+  BlurParams P;
+  P.src = src; P.dst = dst; P.sigma = sigma; P.NC = NC; P.D = D; P.H = H; P.W = W; P.axis = axis;
+  const long V = (long)D * H * W;
+  int blocks = mt_cdiv(V, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gaussian_blur_axis_kernel, dim3(blocks, NC), dim3(256), 0, (hipStream_t)stream, P);
+  MT_CHECK_LAUNCH("gaussian_blur_axis");
+  return MT_OK;
+}

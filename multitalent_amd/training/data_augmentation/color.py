@@ -1,11 +1,15 @@
 """Intensity augmentations of nnU-Net's moreDA chain on the device (data_augmentation_moreDA.py:86-106): GaussianNoise,
-BrightnessMultiplicative, ContrastAugmentation and the two GammaTransforms — elementwise passes plus per-channel min/max/mean/std,
-written with torch elementwise ops (glue: < 1 % of a training step).  They restate batchgenerators' augment_* functions (third
-party, absent in the build container, batchgenerators>=0.23) from the published source: parity UNPINNED.  Not on this path:
-GaussianBlurTransform and SimulateLowResolutionTransform (separable filtering / resampling passes; the reference applies them to
-20-25 % of the samples)."""
+GaussianBlur, BrightnessMultiplicative, ContrastAugmentation, SimulateLowResolution and the two GammaTransforms.  The elementwise
+ones (+ per-channel min/max/mean/std) are torch glue (< 1 % of a training step); the two filtering / resampling transforms run on
+HIP kernels: GaussianBlur on `mt_gaussian_blur_axis` (= scipy.ndimage.gaussian_filter), SimulateLowResolution on
+`mt_downsample_seg_nearest` (order-0 resize) followed by `mt_spline_prefilter3` + `mt_affine_sample` (order-3 resize), each pinned
+against its scipy formulation in tests/test_spatial_gpu.py.  The RANDOM-PARAMETER logic (which samples / channels, sigma and zoom
+draws) restates batchgenerators' augment_* functions (third party, absent in the build container, batchgenerators>=0.23) from
+the published source: parity UNPINNED."""
 import numpy as np
 import torch
+
+from ... import _lib
 
 
 def _range_pick(lo, hi):
@@ -24,6 +28,90 @@ class GaussianNoiseDevice:
             if np.random.uniform() < self.p:
                 v = self.var[0] if self.var[0] == self.var[1] else np.random.uniform(self.var[0], self.var[1])
                 data[b] += torch.randn_like(data[b]) * v          # augment_gaussian_noise passes the "variance" as the std
+        return data
+
+
+def gaussian_filter_device(x, sigma):
+    """scipy.ndimage.gaussian_filter(x[n, c], sigma[n, c], order=0) (mode 'reflect', truncate 4) for every (sample, channel) of a
+    [N, C, D, H, W] device tensor; sigma <= 0 leaves that channel untouched.  Axis order D, H, W like scipy; every pass rounds to
+    float32 like scipy does for float32 input."""
+    assert x.is_cuda and x.dim() == 5 and x.dtype == torch.float32
+    lib = _lib.load()
+    st = torch.cuda.current_stream(x.device).cuda_stream
+    N, C, D, H, W = (int(i) for i in x.shape)
+    sg = torch.as_tensor(np.asarray(sigma, dtype=np.float32).reshape(N * C)).to(x.device)
+    src = x.contiguous()
+    t0, t1 = torch.empty_like(src), torch.empty_like(src)          # D: src -> t0, H: t0 -> t1, W: t1 -> t0 (the input is never written)
+    for axis, (a, b) in enumerate(((src, t0), (t0, t1), (t1, t0))):
+        _lib.check(lib.mt_gaussian_blur_axis(a.data_ptr(), b.data_ptr(), N * C, D, H, W, axis, sg.data_ptr(), st), 'gaussian_blur_axis')
+    a = t0
+    return a
+
+
+class GaussianBlurDevice:
+    """GaussianBlurTransform((0.5, 1.), different_sigma_per_channel=True, p_per_sample=0.2, p_per_channel=0.5)
+    (data_augmentation_moreDA.py:87-88; batchgenerators augment_gaussian_blur): per chosen sample, every channel is blurred with
+    probability p_per_channel with its own sigma ~ U(blur_sigma)."""
+
+    def __init__(self, blur_sigma=(0.5, 1.), different_sigma_per_channel=True, p_per_channel=0.5, p_per_sample=0.2):
+        self.sigma, self.per_channel, self.ppc, self.p = blur_sigma, different_sigma_per_channel, p_per_channel, p_per_sample
+
+    def _draw(self):
+        return self.sigma[0] if self.sigma[0] == self.sigma[1] else np.random.uniform(self.sigma[0], self.sigma[1])
+
+    def __call__(self, data):
+        N, C = int(data.shape[0]), int(data.shape[1])
+        sg = np.zeros((N, C), dtype=np.float32)
+        for b in range(N):
+            if np.random.uniform() < self.p:
+                shared = None if self.per_channel else self._draw()
+                for c in range(C):
+                    if np.random.uniform() <= self.ppc:
+                        sg[b, c] = self._draw() if self.per_channel else shared
+        if not (sg > 0).any():
+            return data
+        return gaussian_filter_device(data, sg)
+
+
+def simulate_low_resolution_device(x, target_shape, planar=False):
+    """resize(resize(x, target_shape, order=0), x.shape, order=3) with skimage's mode='edge', anti_aliasing=False for ONE channel
+    volume x [D, H, W] (augment_linear_downsampling_scipy's body): nearest sampling at floor((o + 0.5) in/out), then the cubic
+    B-spline resize at (o + 0.5) in/out - 0.5 behind 12 voxels of edge padding.  planar: axis 0 keeps its size (ignore_axes=(0,)),
+    every slice is resized on its own."""
+    from ... import ops
+    from ...preprocessing.device_preprocessing import _zoom3
+    shp = tuple(int(i) for i in x.shape)
+    tgt = tuple(int(i) for i in target_shape)
+    if tgt == shp:
+        return x
+    low = ops.downsample_seg_nearest(x[None, None].contiguous(), tgt)
+    return _zoom3(low, shp, planar=planar and tgt[0] == shp[0])[0, 0]
+
+
+class SimulateLowResolutionDevice:
+    """SimulateLowResolutionTransform(zoom_range=(0.5, 1), per_channel=True, p_per_channel=0.5, order_downsample=0,
+    order_upsample=3, p_per_sample=0.25, ignore_axes) (data_augmentation_moreDA.py:100-103)."""
+
+    def __init__(self, zoom_range=(0.5, 1), per_channel=True, p_per_channel=0.5, p_per_sample=0.25, ignore_axes=None):
+        self.zoom, self.per_channel, self.ppc, self.p, self.ignore = zoom_range, per_channel, p_per_channel, p_per_sample, ignore_axes
+
+    def __call__(self, data):
+        shp = np.array([int(i) for i in data.shape[2:]])
+        planar = self.ignore is not None and tuple(self.ignore) == (0,)
+        for b in range(data.shape[0]):
+            if np.random.uniform() < self.p:
+                target = None
+                if not self.per_channel:
+                    target = np.round(shp * np.random.uniform(self.zoom[0], self.zoom[1])).astype(int)
+                for c in range(data.shape[1]):
+                    if np.random.uniform() < self.ppc:
+                        if self.per_channel:
+                            target = np.round(shp * np.random.uniform(self.zoom[0], self.zoom[1])).astype(int)
+                        t = target.copy()
+                        if self.ignore is not None:
+                            for i in self.ignore:
+                                t[i] = shp[i]
+                        data[b, c] = simulate_low_resolution_device(data[b, c], t, planar)
         return data
 
 
@@ -96,10 +184,10 @@ class GammaDevice:
 
 
 class MoreDADeviceAugmenter:
-    """DataLoader3D batches (loader patch = basic_generator_patch_size) -> device -> SpatialTransform -> noise, brightness,
-    contrast, gamma (inverted), gamma -> mirror -> {'data', 'target' (one label map; the trainers build the pyramid and remove
-    label -1 on the device), 'properties', 'keys'}: get_moreDA_augmentation's order (data_augmentation_moreDA.py:41-153) without
-    blur / simulated low resolution, the cascade transforms and the CPU worker pool."""
+    """DataLoader3D batches (loader patch = basic_generator_patch_size) -> device -> SpatialTransform -> noise, blur, brightness,
+    contrast, simulated low resolution, gamma (inverted), gamma -> mirror -> {'data', 'target' (one label map; the trainers build
+    the pyramid and remove label -1 on the device), 'properties', 'keys'}: get_moreDA_augmentation's order
+    (data_augmentation_moreDA.py:41-153) without the cascade transforms and the CPU worker pool."""
 
     def __init__(self, loader, patch_size, params, device, border_val_seg=-1, order_seg=1, order_data=3):
         from .spatial import MirrorTransformDevice, SpatialTransformDevice
@@ -112,8 +200,12 @@ class MoreDADeviceAugmenter:
             border_mode_seg="constant", border_cval_seg=border_val_seg, order_seg=order_seg, random_crop=params.get("random_crop"),
             p_el_per_sample=params.get("p_eldef"), p_scale_per_sample=params.get("p_scale"), p_rot_per_sample=params.get("p_rot"),
             independent_scale_for_each_axis=params.get("independent_scale_factor_for_each_axis"), dummy_2d=bool(params.get("dummy_2D")))
-        self.color = [GaussianNoiseDevice(p_per_sample=0.1), BrightnessMultiplicativeDevice((0.75, 1.25), p_per_sample=0.15),
+        ignore_axes = (0,) if params.get("dummy_2D") else None               # data_augmentation_moreDA.py:55-64
+        self.color = [GaussianNoiseDevice(p_per_sample=0.1),
+                      GaussianBlurDevice((0.5, 1.), different_sigma_per_channel=True, p_per_sample=0.2, p_per_channel=0.5),
+                      BrightnessMultiplicativeDevice((0.75, 1.25), p_per_sample=0.15),
                       ContrastAugmentationDevice(p_per_sample=0.15),
+                      SimulateLowResolutionDevice((0.5, 1), per_channel=True, p_per_channel=0.5, p_per_sample=0.25, ignore_axes=ignore_axes),
                       GammaDevice(params.get("gamma_range"), True, True, params.get("gamma_retain_stats"), 0.1)]
         if params.get("do_gamma"):
             self.color.append(GammaDevice(params.get("gamma_range"), False, True, params.get("gamma_retain_stats"), params["p_gamma"]))

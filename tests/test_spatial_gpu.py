@@ -130,3 +130,54 @@ def test_spatial_transform_shapes_and_identity(dev):
     assert set(np.unique(g.cpu().numpy())) <= {-1.0, 0.0, 1.0, 2.0}
     d2, g2 = MirrorTransformDevice((0, 1, 2))(d.clone(), g.clone())
     assert d2.shape == d.shape and float(d2.abs().sum()) == pytest.approx(float(d.abs().sum()), rel=1e-5)
+
+
+def test_gaussian_blur_matches_scipy(dev):
+    """GaussianBlurTransform's compute core = scipy.ndimage.gaussian_filter(channel, sigma, order=0) (mode 'reflect', truncate 4):
+    sigma over the transform's range (0.5, 1) and beyond (radius up to 12, wider than a short axis: multiple reflections), untouched
+    channels (sigma 0) bit-identical."""
+    from multitalent_amd.training.data_augmentation.color import gaussian_filter_device
+    rs = np.random.RandomState(3)
+    x = (rs.randn(2, 3, 7, 19, 26) * 3 + 1).astype(np.float32)
+    sg = np.array([[0.5, 0.0, 1.0], [0.73, 3.0, 0.0]], dtype=np.float32)
+    t = torch.from_numpy(x).to(dev)
+    got = gaussian_filter_device(t, sg).cpu().numpy()
+    assert np.array_equal(t.cpu().numpy(), x)                         # the input is not modified
+    for n in range(2):
+        for c in range(3):
+            if sg[n, c] <= 0:
+                assert np.array_equal(got[n, c], x[n, c])
+            else:
+                ref = ndimage.gaussian_filter(x[n, c], float(sg[n, c]), order=0)
+                assert np.abs(got[n, c] - ref).max() < 2e-6 * np.abs(x).max(), (n, c)
+
+
+@pytest.mark.parametrize("shape,target,planar", [((12, 30, 26), (7, 17, 15), False), ((9, 33, 20), (9, 21, 11), True),
+                                                 ((16, 16, 16), (8, 8, 8), False), ((10, 21, 18), (10, 21, 18), False),
+                                                 ((11, 20, 23), (10, 19, 22), False)])
+def test_simulate_low_resolution_matches_scipy(dev, shape, target, planar):
+    """SimulateLowResolutionTransform's body (augment_linear_downsampling_scipy): resize(order 0) then resize(order 3) with
+    mode='edge', anti_aliasing=False = scipy.ndimage.zoom(order, mode='nearest', grid_mode=True) (skimage's delegate).  Tolerance
+    2e-5 of the range (fp32 spline coefficients; the prefilter's boundary rule behind 12 voxels of edge padding)."""
+    from multitalent_amd.training.data_augmentation.color import simulate_low_resolution_device
+    rs = np.random.RandomState(4)
+    x = ndimage.gaussian_filter(rs.randn(*shape), 0.7).astype(np.float32) * 4
+    zoom = lambda a, new, order: ndimage.zoom(a.astype(float), [n / o for n, o in zip(new, a.shape)], order=order, mode='nearest', grid_mode=True)
+    ref = zoom(zoom(x, target, 0), shape, 3) if tuple(target) != tuple(shape) else x
+    got = simulate_low_resolution_device(torch.from_numpy(x).to(dev), target, planar).cpu().numpy()
+    assert got.shape == tuple(shape)
+    assert np.abs(got - ref).max() < 2e-5 * (x.max() - x.min()), np.abs(got - ref).max()
+
+
+def test_blur_and_lowres_transforms_draw_like_the_reference_chain(dev):
+    """The two transform objects at their positions in MoreDADeviceAugmenter: probabilities 1 -> every channel changes; probabilities
+    0 -> the batch passes through untouched (same storage)."""
+    from multitalent_amd.training.data_augmentation.color import GaussianBlurDevice, SimulateLowResolutionDevice
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.randn(2, 2, 8, 20, 24).astype(np.float32)).to(dev)
+    np.random.seed(0)
+    assert GaussianBlurDevice(p_per_sample=0.0)(x) is x and SimulateLowResolutionDevice(p_per_sample=0.0)(x) is x
+    b = GaussianBlurDevice(p_per_sample=1.0, p_per_channel=1.0)(x.clone())
+    assert float((b - x).abs().amax(dim=(2, 3, 4)).min()) > 1e-2 and float(b.std()) < float(x.std())
+    l = SimulateLowResolutionDevice(p_per_sample=1.0, p_per_channel=1.0, ignore_axes=(0,))(x.clone())
+    assert l.shape == x.shape and float((l - x).abs().amax(dim=(2, 3, 4)).min()) > 1e-2

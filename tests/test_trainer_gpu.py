@@ -164,4 +164,4 @@ def test_training_from_preprocessed_cases_on_disk(dev, pg, tmp_path):
     assert b['data'].is_cuda and tuple(b['data'].shape) == (2, 1, 16, 32, 32) and tuple(b['target'].shape) == (2, 1, 16, 32, 32)
     assert any(f.endswith('.npy') for f in os.listdir(str(folder)))                    # unpacked for memory-mapped reads
     assert len(tr.all_tr_losses) == 2 and np.isfinite(tr.all_tr_losses).all() and np.isfinite(tr.all_val_losses).all()
-    assert os.path.isfile(str(tmp_path / 'out' / 'model_final_checkpoint.model'))
+    assert os.path.isfile(str(tmp_path / 'out' / 'all' / 'model_final_checkpoint.model'))      # <output_folder>/all (nnUNetTrainer.py:134-152)
