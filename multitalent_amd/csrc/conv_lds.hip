@@ -2049,12 +2049,17 @@ static int g_bwdw_bf16 = -1;       // -1: read MT_BWDW_BF16 (default 1): bf16 Wi
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
 static std::atomic<int> g_wino_waves{8};       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
 static std::atomic<int> g_wino_persist{1};     // 8-wave kernel: 1 persistent over spatial tiles (conv_wino8p_kernel), 0 one tile per workgroup, n > 1: at most n workers
+#ifndef WINO_DMA_DEFAULT
+#define WINO_DMA_DEFAULT 0
+#endif
+static std::atomic<int> g_wino_dma{-1};        // persistent kernel with LDS-DMA patch staging (conv_wino8d_kernel): -1 read MT_WINO_DMA (default 1)
 static std::atomic<int> g_wino_mode{-1};       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
 extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "conv_wino") == 0) { g_wino_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_wino") == 0) { g_bwdw_wino = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "wino_waves") == 0) { g_wino_waves = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "wino_persist") == 0) { g_wino_persist = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "wino_dma") == 0) { g_wino_dma = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "conv_bf16") == 0) { g_bf16_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_bf16") == 0) { g_bwdw_bf16 = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
@@ -2066,6 +2071,7 @@ static bool conv_wino_ok(const mt_conv3d_t* p) {
     const char* w = getenv("MT_WINO_WAVES"); if (w) g_wino_waves = atoi(w);
     const char* pe = getenv("MT_WINO_PERSIST"); if (pe) g_wino_persist = atoi(pe);
   }
+  if (g_wino_dma < 0) { const char* de = getenv("MT_WINO_DMA"); g_wino_dma = de ? atoi(de) : WINO_DMA_DEFAULT; }
   const int use = g_wino_mode;
   if (!use) return false;
   if (p->Cin < 16 || conv_fast_vec(p) != 2) return false;
@@ -2113,6 +2119,21 @@ static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
         mt_mark_device_done(attrp, devid);
       }
       const int ncu = mt_device_cus(devid);
+      if (g_wino_dma > 0) {
+        const size_t ld = (size_t)(WD_NRAW * WD_RB + W_VF) * sizeof(float);
+        static std::atomic<uint64_t> attrd{0};
+        if (mt_device_pending(attrd, devid)) {
+          hipError_t e = hipFuncSetAttribute((const void*)conv_wino8d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ld);
+          if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ld, hipGetErrorString(e)); return MT_EHIP; }
+          mt_mark_device_done(attrd, devid);
+        }
+        const int T = P.nsb * p->N, nct = mt_cdiv(p->Cout, 32);
+        int nw = ncu / nct; if (nw < 1) nw = 1; if (nw > T) nw = T;
+        if (g_wino_persist > 1 && nw > g_wino_persist) nw = g_wino_persist;
+        hipLaunchKernelGGL(conv_wino8d_kernel, dim3((unsigned)nw, (unsigned)nct, 1), dim3(512), ld, st, P);
+        MT_CHECK_LAUNCH("conv3d_wino8d");
+        return MT_OK;
+      }
       // one resident workgroup per CU (126 KiB of LDS each): NW workers per output-channel tile walk over the spatial tiles
       const int T = P.nsb * p->N, nct = mt_cdiv(p->Cout, 32);
       int nw = ncu / nct; if (nw < 1) nw = 1; if (nw > T) nw = T;
@@ -2268,7 +2289,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   else if (pl.kind == CONV_STEM)
     snprintf(buf, n, "conv_stem_kernel");
   else if (pl.kind == CONV_WINO)
-    snprintf(buf, n, g_wino_waves == 8 ? ((g_wino_persist && wino_persist_geometry_ok(p)) ? "conv_wino8p_kernel" : "conv_wino8_kernel") : "conv_wino_kernel");
+    snprintf(buf, n, g_wino_waves == 8 ? ((g_wino_persist && wino_persist_geometry_ok(p)) ? (g_wino_dma > 0 ? "conv_wino8d_kernel" : "conv_wino8p_kernel") : "conv_wino8_kernel") : "conv_wino_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
     snprintf(buf, n, strided_use_bf16(p) ? "conv_fast_strided_kernel<%d, %d, %d, %d, true>" : "conv_fast_strided_kernel<%d, %d, %d, %d, false>",
              p->SD, p->SH, p->SW, conv_fast_vec(p));

@@ -543,7 +543,7 @@ def test_ds_label_pyramid_on_device(dev):
     (2, 20, 16, (8, 8, 32), False),         # odd chunk count (8,8,4): the persistent kernel's pairs end in a phantom chunk
     (1, 24, 32, (6, 9, 20), True),          # 3 + 3 chunks: the middle pair straddles the two sources
 ])
-@pytest.mark.parametrize("waves", [8, 4, 803, 800])
+@pytest.mark.parametrize("waves", [8, 4, 803, 800, 810, 813])
 def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
     """conv_wino_kernel (3D Winograd F(2x2x2,3x3x3)) forced on small shapes: forward with lazy inputs + statistics, and the
     flipped-weight backward-data form with two destinations; vs F.conv3d / autograd (tolerance 1e-5: +-1 and 1/2 transforms)."""
@@ -552,8 +552,10 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
     # 8: the persistent wave-specialised kernel (default: one worker per CU, here one tile each), 803: the same with only 3 workers per
     # output-channel tile (every worker walks over several tiles: cross-tile pipeline, ragged last iteration), 800: the one-tile-per-
     # workgroup 8-wave kernel, 4: the four-wave kernel
+    # 810 / 813: the persistent kernel with LDS-DMA patch staging (conv_wino8d_kernel), one tile per worker / three workers
     ops.set_option('wino_waves', 8 if waves >= 8 else 4)
-    ops.set_option('wino_persist', {8: 1, 803: 3, 800: 0, 4: 1}[waves])
+    ops.set_option('wino_persist', {8: 1, 803: 3, 800: 0, 4: 1, 810: 1, 813: 3}[waves])
+    ops.set_option('wino_dma', 1 if waves in (810, 813) else 0)
     try:
         g = torch.Generator().manual_seed(21)
         srcs = [torch.randn((N, Cin) + shape, generator=g)]
@@ -597,6 +599,7 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
         ops.set_option('conv_wino', 1)
         ops.set_option('wino_waves', 8)
         ops.set_option('wino_persist', 1)
+        ops.set_option('wino_dma', -1)
 
 
 @pytest.mark.parametrize("N,Cin,Cout,shape,two_src", [

@@ -48,6 +48,7 @@ if a.mode == 'fwd':
             print('  %-15s %10.0f | %10.0f' % (nm, tr, sg))
         print('  %-15s %10.0f | %10.0f' % ('total', t[:, 0:4, :10].sum(2)[used[:, 0:4]].mean(), t[:, 4:8, :10].sum(2)[used[:, 4:8]].mean()))
         print('  stagers: wait for the patch in flight at the top of phase 1: %.0f ; store_patch: %.0f ; (phase1 work row = issue_patch)' % (t[:, 4:8, 9][used[:, 4:8]].mean(), t[:, 4:8, 10][used[:, 4:8]].mean()))
+        print('  stagers, slot 11 (DMA kernel: activation in place; slot 9 = fragment issue + wait, slot 10 = scale/shift + request): %.0f' % t[:, 4:8, 11][used[:, 4:8]].mean())
     if int(os.environ.get('MT_CONV_DBG', '0')) & 16:
         nblk = N * ops.conv_stats_blocks(p)
         ts = torch.zeros((nblk, 4, 16), dtype=torch.int64, device=dev)
@@ -110,4 +111,5 @@ for _ in range(a.reps):
     run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
-print("%s cin=%d cout=%d shape=%s k=%s s=%s: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)" % (a.mode, Cin, Cout, a.shape, a.k, a.stride, ms, flops / ms / 1e9, flops / ms / 1e9 / 1.573))
+kn = ops.conv_kernel_name(p) if a.mode == 'fwd' else ''
+print("%s %s cin=%d cout=%d shape=%s k=%s s=%s: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)" % (a.mode, kn, Cin, Cout, a.shape, a.k, a.stride, ms, flops / ms / 1e9, flops / ms / 1e9 / 1.573))
