@@ -1,0 +1,26 @@
+# rocprofv3 kernel statistics of bench.py for every workload (fp32 + bf16): gpurun_out/prof_r3/<tag>_kernel_stats.csv + the bench lines
+# usage: bash tools/profile_r2.sh [tags...]   (default: all)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r3
+mkdir -p $O
+run() {  # tag, bench args...
+  tag=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$tag -o b -- python $R/bench.py "$@" --no-cpu-baseline --no-traffic --no-also > $O/${tag}_profiled.json 2> $O/${tag}.err
+  f=$(find $O/$tag -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp $f $O/${tag}_kernel_stats.csv
+  rm -rf $O/$tag
+}
+TAGS=${@:-task009_fp32 task009_bf16 task100_fp32 task100_bf16 resenc_fp32 resenc_bf16 infer_nomirror_fp32}
+for t in $TAGS; do
+  case $t in
+    task009_fp32) run $t --steps 5 --warmup 2 ;;
+    task009_bf16) run $t --steps 5 --warmup 2 --precision bf16 ;;
+    task100_fp32) run $t --steps 4 --warmup 2 --workload task100 ;;
+    task100_bf16) run $t --steps 4 --warmup 2 --workload task100 --precision bf16 ;;
+    resenc_fp32) run $t --steps 4 --warmup 2 --workload resenc ;;
+    resenc_bf16) run $t --steps 4 --warmup 2 --workload resenc --precision bf16 ;;
+    infer_nomirror_fp32) run $t --steps 1 --warmup 1 --workload infer --mirror 0 --volume 256 512 512 ;;
+    infer_mirror_fp32) run $t --steps 1 --warmup 1 --workload infer --mirror 1 --volume 128 384 384 ;;
+  esac
+done
+ls -la $O
