@@ -50,6 +50,23 @@ typedef struct {
   int32_t _pad;
 } mt_src_t;
 
+/* Fused statistics for the InstanceNorm + LeakyReLU backward that runs next (generic_UNet.py:63-64 in reverse).  A convolution that
+ * is the LAST writer of a gradient tensor g = dL/d lrelu(IN(y)) (the backward-data of the layer's consumer) can emit, per block,
+ * the two sums the normalisation backward needs over g,
+ *     A = sum dz,   B = sum dz * zhat,      dz = g * lrelu'(z),  zhat = (y - mean) * rstd,  z = zhat * gamma + beta,
+ * for its output channels [c0, c0 + C) (one of its two destinations) — the separate reduction pass over (g, y) disappears
+ * (mt_inorm_lrelu_bwd with `part`).  The partials go to stats_part ([N][nsb][Cout][2], slot (.., c0 + c, 0 / 1) = A / B; channels
+ * outside the range hold 0).  Supported by the kernels mt_conv3d_bwd_stats_supported() says yes to. */
+typedef struct {
+  const float* y;        /* raw forward output of the normalised layer [N, Do, Ho, Wo, ycs]; NULL = off */
+  const float* mean;     /* [N][C] */
+  const float* rstd;     /* [N][C] */
+  const float* gamma;    /* [C] or NULL (1) */
+  const float* beta;     /* [C] or NULL (0) */
+  int32_t ycs, c0, C;
+  float slope;
+} mt_bwd_stats_t;
+
 /* Convolution problem.  Forward conv (nn.Conv3d, generic_UNet.py:57,67; conv_blocks.py:49-85,116-213):
  *   out[n,o,co] = bias[co] + sum_{t,ci} in[n, o*S + t - P, ci] * W[t][ci][co]
  * with the input being the channel concatenation of src[0..nsrc) (torch.cat((x, skip), 1),
@@ -77,6 +94,7 @@ typedef struct {
   int32_t OD, OH, OW, osD, osH, osW, ooD, ooH, ooW;
   int32_t mma;                /* matrix input type of the convolution: 0 fp32 (exact), 1 bf16 inputs with fp32 accumulation
                                  (mixed precision, the reference's autocast mode); packed weights must match (mt_conv3d_pack_layout) */
+  mt_bwd_stats_t bstats;      /* bstats.y != NULL: fused first pass of the NEXT InstanceNorm backward (see mt_bwd_stats_t) */
 } mt_conv3d_t;
 
 const char* mt_last_error(void);
@@ -145,6 +163,7 @@ int mt_set_option(const char* name, int value);
 int mt_probe_device(void* scratch, size_t scratch_bytes, int* vector_loads_ok, char* arch, size_t arch_len, mt_stream_t stream);
 int mt_conv3d_pack_layout(const mt_conv3d_t* p);   /* `layout` for mt_pack_conv_weights: 1; 2 when the Winograd kernel serves p; 3 (bf16) when p->mma == 1 and the bf16 kernel does */
 int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n); /* device kernel that will run (profiler name) */
+int mt_conv3d_bwd_stats_supported(const mt_conv3d_t* p); /* 1 when the kernel that serves p (geometry, ignoring p->bstats) honours p->bstats */
 /* the same for mt_conv3d_bwd_weight(p, ysrc, ...) and mt_conv3d_bwd_data_strided(p): which kernel family the dispatcher picks
  * (tests assert that full-size problems run on the Winograd / strided / stem kernels; bench.py groups its timings by it) */
 int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_src_t* ysrc, char* buf, size_t n);
@@ -206,12 +225,15 @@ int mt_inorm_lrelu_apply(const float* y, int ycs, const float* scale, const floa
                          const float* res, int rcs, const float* rscale, const float* rshift, float rslope,
                          float* out, int ocs, int N, long V, int C, mt_stream_t stream);
 /* Backward of out = lrelu(IN(y)): given g = dL/dout (in place), produce dy in place, plus
- * dgamma[C] += , dbeta[C] +=, dbias[C] (= sum dy, may be NULL).  ws: mt_inorm_bwd_workspace bytes. */
+ * dgamma[C] += , dbeta[C] +=, dbias[C] (= sum dy, may be NULL).  ws: mt_inorm_bwd_workspace bytes.
+ * part != NULL: the first pass (sum dz, sum dz zhat per block) was fused into the convolution that produced g
+ * (mt_conv3d_t.bstats): part = its stats_part [N][part_nblk][part_cs][2], this layer's channels at columns part_c0 ..; the
+ * reduction pass over (g, y) is skipped.  part == NULL: computed here. */
 size_t mt_inorm_bwd_workspace(int N, long V, int C);
 int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, float slope, int N, long V, int C,
-                       float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                       mt_stream_t stream);
+                       float* dgamma, float* dbeta, float* dbias, const float* part, int part_nblk, int part_cs, int part_c0,
+                       void* ws, size_t ws_bytes, mt_stream_t stream);
 /* g *= lrelu'(y*scale+shift) in place, optionally also writes a copy (residual branch gradient) */
 int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale, const float* shift,
                  float slope, const float* y2, int y2cs, const float* scale2, const float* shift2,

@@ -19,6 +19,11 @@ class mt_src_t(C.Structure):
                 ('shift', C.c_void_p), ('slope', C.c_float), ('_pad', C.c_int32)]
 
 
+class mt_bwd_stats_t(C.Structure):
+    _fields_ = [('y', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('ycs', C.c_int32), ('c0', C.c_int32), ('C', C.c_int32), ('slope', C.c_float)]
+
+
 class mt_conv3d_t(C.Structure):
     _fields_ = [('src', mt_src_t * 2), ('nsrc', C.c_int32),
                 ('N', C.c_int32), ('Di', C.c_int32), ('Hi', C.c_int32), ('Wi', C.c_int32),
@@ -35,7 +40,7 @@ class mt_conv3d_t(C.Structure):
                 ('stats_part', C.c_void_p),
                 ('OD', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
                 ('osD', C.c_int32), ('osH', C.c_int32), ('osW', C.c_int32),
-                ('ooD', C.c_int32), ('ooH', C.c_int32), ('ooW', C.c_int32), ('mma', C.c_int32)]
+                ('ooD', C.c_int32), ('ooH', C.c_int32), ('ooW', C.c_int32), ('mma', C.c_int32), ('bstats', mt_bwd_stats_t)]
 
 
 class mt_pointwise_t(C.Structure):
@@ -73,6 +78,7 @@ SIGNATURES = {
     'mt_conv3d_pack_layout': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_bwd_data_strided_pack_layout': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_kernel_name': (_i, [_P(mt_conv3d_t), C.c_char_p, _sz]),
+    'mt_conv3d_bwd_stats_supported': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_bwd_weight_kernel_name': (_i, [_P(mt_conv3d_t), _P(mt_src_t), C.c_char_p, _sz]),
     'mt_conv3d_bwd_data_strided_kernel_name': (_i, [_P(mt_conv3d_t), C.c_char_p, _sz]),
     'mt_conv3d_bwd_weight_workspace': (_sz, [_P(mt_conv3d_t)]),
@@ -85,7 +91,7 @@ SIGNATURES = {
     'mt_inorm_finalize': (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     'mt_inorm_lrelu_apply': (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _vp]),
     'mt_inorm_bwd_workspace': (_sz, [_i, _l, _i]),
-    'mt_inorm_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _i, _l, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'mt_inorm_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _i, _l, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     'mt_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _vp]),
     'mt_channel_sum': (_i, [_vp, _i, _i, _l, _i, _vp, _i, _vp, _sz, _vp]),
     'mt_multitalent_loss_fwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

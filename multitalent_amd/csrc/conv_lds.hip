@@ -2085,7 +2085,14 @@ static bool conv_wino_ok(const mt_conv3d_t* p) {
 // in bits 0-19 of a table entry, so its maximum (5*Hi + 5)*Wi + 17 must stay below 2^20 (beyond that the offset would spill into
 // the ld bits); larger planes run the one-tile-per-workgroup kernel.
 static bool wino_persist_geometry_ok(const mt_conv3d_t* p) { return (5.0 * p->Hi + 5.0) * p->Wi + 17.0 < 1048576.0; }
+// mt_bwd_stats_t is implemented in the epilogue of the persistent register-staged Winograd kernel (conv_wino8p_kernel)
+static bool wino_serves_bwd_stats(const mt_conv3d_t* p) {
+  return g_wino_waves == 8 && g_wino_persist && wino_persist_geometry_ok(p) && g_wino_dma <= 0;
+}
 static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
+  MT_REQUIRE(p->bstats.y == nullptr || (wino_serves_bwd_stats(p) && p->stats_part != nullptr && p->bstats.mean && p->bstats.rstd &&
+                                        p->bstats.c0 >= 0 && p->bstats.C > 0 && p->bstats.c0 + p->bstats.C <= p->Cout),
+             "conv3d: bstats set on a problem this kernel does not compute them for (ask mt_conv3d_bwd_stats_supported)");
   ConvKParams P;
   P.c = *p;
   if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
@@ -2302,12 +2309,20 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   return MT_OK;
 }
 
+extern "C" int mt_conv3d_bwd_stats_supported(const mt_conv3d_t* p) {
+  if (p == nullptr || conv_validate(p) != MT_OK) return 0;
+  const ConvPlan pl = conv_plan(p);
+  return (pl.cfg >= 0 && pl.kind == CONV_WINO && wino_serves_bwd_stats(p)) ? 1 : 0;
+}
+
 extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   int rc = conv_validate(p);
   if (rc != MT_OK) return rc;
   const ConvPlan pl = conv_plan(p);
   const int i = pl.cfg;
   MT_REQUIRE(i >= 0, "conv3d: no tile configuration fits LDS");
+  MT_REQUIRE(p->bstats.y == nullptr || pl.kind == CONV_WINO, "conv3d: bstats set on a problem whose kernel does not compute them "
+             "(ask mt_conv3d_bwd_stats_supported)");
   if (pl.kind == CONV_BF16) return launch_bf16(p, i, (hipStream_t)stream);
   const ConvCfg& g = kCfgs[i];
   hipStream_t st = (hipStream_t)stream;

@@ -104,6 +104,9 @@ struct InBwdParams {
   float* part1;  // [N][nvb][C][2]
   float* m;      // [N][C][2]  (A/V, B/V)
   float* part2;  // [N][nvb][C]
+  // first-pass partials as the finalize kernel reads them: [N][p1_nblk][p1_cs][2], channel c at column p1_c0 + c (own reduce
+  // pass: part1, nvb, C, 0; fused into the producing convolution: its stats_part, its nsb, its Cout, bstats.c0)
+  const float* p1; int p1_nblk, p1_cs, p1_c0;
 };
 __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const InBwdParams P) {
   __shared__ float red[8][32][2];
@@ -145,9 +148,10 @@ __global__ __launch_bounds__(64) void inorm_bwd_finalize_kernel(const InBwdParam
   double ta = 0.0, tb = 0.0;
   for (int n = 0; n < N; ++n) {
     double a = 0.0, b = 0.0;
-    for (int s = threadIdx.x; s < P.nvb; s += 64) {
-      a += (double)P.part1[(((size_t)n * P.nvb + s) * P.C + c) * 2];
-      b += (double)P.part1[(((size_t)n * P.nvb + s) * P.C + c) * 2 + 1];
+    for (int s = threadIdx.x; s < P.p1_nblk; s += 64) {
+      const float* q = P.p1 + (((size_t)n * P.p1_nblk + s) * P.p1_cs + P.p1_c0 + c) * 2;
+      a += (double)q[0];
+      b += (double)q[1];
     }
     a = mt_wave_sum_d(a); b = mt_wave_sum_d(b);
     if (threadIdx.x == 0) {
@@ -315,9 +319,10 @@ extern "C" size_t mt_inorm_bwd_workspace(int N, long V, int C) {
 }
 extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, float slope, int N, long V, int C,
-                                  float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                                  mt_stream_t stream) {
+                                  float* dgamma, float* dbeta, float* dbias, const float* part, int part_nblk, int part_cs, int part_c0,
+                                  void* ws, size_t ws_bytes, mt_stream_t stream) {
   MT_REQUIRE(g && y && mean && rstd && N > 0 && V > 0 && C > 0, "inorm_lrelu_bwd: bad args");
+  MT_REQUIRE(part == nullptr || (part_nblk > 0 && part_cs >= part_c0 + C && part_c0 >= 0), "inorm_lrelu_bwd: bad external partials");
   if (ws == nullptr || ws_bytes < mt_inorm_bwd_workspace(N, V, C)) { mt_set_error("inorm_lrelu_bwd: workspace too small"); return MT_EWORKSPACE; }
   InBwdParams P;
   P.g = g; P.gcs = gcs; P.y = y; P.ycs = ycs; P.mean = mean; P.rstd = rstd; P.gamma = gamma; P.beta = beta; P.slope = slope;
@@ -326,6 +331,7 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
   P.part1 = w; w += (size_t)N * P.nvb * C * 2;
   P.m = w; w += (size_t)N * C * 2;
   P.part2 = dbias ? w : nullptr;
+  P.p1 = part ? part : P.part1; P.p1_nblk = part ? part_nblk : P.nvb; P.p1_cs = part ? part_cs : C; P.p1_c0 = part ? part_c0 : 0;
   hipStream_t st = (hipStream_t)stream;
   // contiguous tensors take the vectorised lane-constant-channel path
   const int vec = (C % 4 == 0) ? 4 : (C % 2 == 0) ? 2 : 1;
@@ -337,15 +343,17 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
     F.nvec = (long)V * C / vec; F.C = C; F.G = C / vec; F.A = (256 / F.G) * F.G; F.nblk = P.nvb;
     F.part1 = P.part1; F.m = P.m; F.part2 = P.part2;
     dim3 grid(P.nvb, N);
-    if (vec == 4) hipLaunchKernelGGL((inorm_bwd_fast_kernel<4, false>), grid, dim3(256), 0, st, F);
-    else if (vec == 2) hipLaunchKernelGGL((inorm_bwd_fast_kernel<2, false>), grid, dim3(256), 0, st, F);
-    else hipLaunchKernelGGL((inorm_bwd_fast_kernel<1, false>), grid, dim3(256), 0, st, F);
+    if (part == nullptr) {           // (the first pass was not fused into the kernel that produced g)
+      if (vec == 4) hipLaunchKernelGGL((inorm_bwd_fast_kernel<4, false>), grid, dim3(256), 0, st, F);
+      else if (vec == 2) hipLaunchKernelGGL((inorm_bwd_fast_kernel<2, false>), grid, dim3(256), 0, st, F);
+      else hipLaunchKernelGGL((inorm_bwd_fast_kernel<1, false>), grid, dim3(256), 0, st, F);
+    }
     hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, P, N, dgamma, dbeta);
     if (vec == 4) hipLaunchKernelGGL((inorm_bwd_fast_kernel<4, true>), grid, dim3(256), 0, st, F);
     else if (vec == 2) hipLaunchKernelGGL((inorm_bwd_fast_kernel<2, true>), grid, dim3(256), 0, st, F);
     else hipLaunchKernelGGL((inorm_bwd_fast_kernel<1, true>), grid, dim3(256), 0, st, F);
   } else {
-    hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
+    if (part == nullptr) hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
     hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, P, N, dgamma, dbeta);
     hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
   }

@@ -11,6 +11,8 @@ libmtseg_hip.so.  Design points (MI355X-first):
     likewise, so clip/SGD are single kernels and the DDP all-reduce streams contiguous slices as
     soon as they are final (overlap with the rest of backward on a side stream).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -40,6 +42,10 @@ class _Op:
     def param_list(self):
         return []
 
+    def inputs(self):
+        """the Vals whose gradient buffers this op's backward writes (used to find the LAST writer of a gradient)."""
+        return []
+
 
 def _strides(w, **kw):
     return ops.conv_weight_strides(w, **kw)
@@ -56,6 +62,10 @@ class ConvNormOp(_Op):
         self.pad = tuple(conv.padding)
         self.slope = LRELU_DEFAULT
         self.pointwise = pointwise   # 1x1x1 (possibly strided) conv on the pointwise kernel
+        self.bwd_part = None         # (partials, first column): first pass of this layer's norm backward, fused into the last writer of out.grad
+
+    def inputs(self):
+        return list(self.srcs)
 
     def param_list(self):
         ps = [self.conv.weight]
@@ -182,8 +192,10 @@ class ConvNormOp(_Op):
         if self.norm is not None:
             a = self.out.act
             ws = eng.workspace(ops.inorm_bwd_workspace(a.N, a.V, a.C))
+            part, part_c0 = self.bwd_part if self.bwd_part is not None else (None, 0)
+            self.bwd_part = None
             ops.inorm_lrelu_bwd(gact, a, self.norm.weight, self.norm.bias, eng.grad_of(self.norm.weight),
-                                eng.grad_of(self.norm.bias), dbias, ws)
+                                eng.grad_of(self.norm.bias), dbias, ws, part=part, part_c0=part_c0)
         elif dbias is not None:
             ws = eng.workspace(4 * gact.N * ((gact.V + 2047) // 2048) * gact.C)
             ops.channel_sum(gact, dbias, False, ws)
@@ -238,9 +250,29 @@ class ConvNormOp(_Op):
                 p.ocs1 = self.srcs[1].C
                 p.csplit = self.srcs[0].C
             p.accumulate = 1 if acc else 0
+            self._fuse_norm_bwd_stats(eng, p)
             ops.conv3d_fwd(p)
         for s in self.srcs:
             s.grad_init = True
+
+    def _fuse_norm_bwd_stats(self, eng, p):
+        """When this launch is the LAST writer of a source's gradient and that source is the output of a conv + InstanceNorm layer,
+        the kernel also emits the first pass of that layer's norm backward (sum dz, sum dz zhat per block; mt_bwd_stats_t): the
+        separate reduction over (g, y) — 45 % of the norm backward's time — disappears.  One source per launch."""
+        if not eng.fuse_norm_bwd:
+            return
+        c0 = 0
+        for s in self.srcs:
+            prod = eng.producer.get(id(s))
+            if (eng.pending.get(id(s), 0) == 1 and isinstance(prod, ConvNormOp) and not isinstance(prod, HeadOp) and prod.norm is not None
+                    and s.act.mean is not None and ops.conv_bwd_stats_supported(p)):
+                nsb = ops.conv_stats_blocks(p)
+                part = eng.buffer(self.name + '.bwdpart', (s.act.N, nsb, int(p.Cout), 2))
+                p.stats_part = part.data_ptr()
+                ops.set_bwd_stats(p, s.act, prod.norm.weight, prod.norm.bias, c0)
+                prod.bwd_part = (part, c0)
+                return
+            c0 += s.C
 
 
 class TConvOp(_Op):
@@ -253,6 +285,9 @@ class TConvOp(_Op):
 
     def param_list(self):
         return [self.tu.weight]
+
+    def inputs(self):
+        return [self.src]
 
     def plan(self, eng, N):
         sp = self.src.spatial
@@ -307,6 +342,9 @@ class ResAddOp(_Op):
     def __init__(self, name, main, res, out):
         self.name, self.main, self.res, self.out = name, main, res, out
         self.slope = LRELU_DEFAULT
+
+    def inputs(self):
+        return [self.main, self.res]
 
     def plan(self, eng, N):
         self.out.spatial = self.main.spatial
@@ -394,6 +432,8 @@ class Engine:
         self.grad_ready_hook = None         # callable(lo, hi) on flat_grad element ranges, in completion order
         self.dummy = None
         self.mma = 0                        # matrix input type of the convolutions: 0 fp32, 1 bf16 (mixed precision)
+        self.fuse_norm_bwd = os.environ.get('MT_FUSE_NORM_BWD', '1') != '0'    # ConvNormOp._fuse_norm_bwd_stats
+        self.producer, self.pending = {}, {}
 
     def set_precision(self, precision):
         """'fp32' (exact, default) or 'bf16': mixed precision — the reference's autocast mode (nnUNetTrainerV2.py:236-249) on
@@ -574,10 +614,19 @@ class Engine:
             else:
                 h.grad_init = False
         done_hi = 0
+        # how many backward launches still write each gradient buffer (the last writer may fuse the next norm backward's first pass)
+        will_run = [op for op in self.ops if not (isinstance(op, HeadOp) and not op.out.grad_init)]
+        self.producer = {id(op.out): op for op in self.ops}
+        self.pending = {}
+        for op in will_run:
+            for v in op.inputs():
+                self.pending[id(v)] = self.pending.get(id(v), 0) + 1
         for op in reversed(self.ops):
             if isinstance(op, HeadOp) and not op.out.grad_init:
                 continue
             op.backward(self)
+            for v in op.inputs():
+                self.pending[id(v)] -= 1
             if self.grad_ready_hook is not None and op.param_list():
                 lo = min(self._views[id(p)][0] for p in op.param_list())
                 hi = max(self._views[id(p)][0] + (p.numel() + 3) // 4 * 4 for p in op.param_list())
@@ -714,6 +763,9 @@ class _MaterialiseOp(_Op):
 
     def __init__(self, name, src, out):
         self.name, self.src, self.out = name, src, out
+
+    def inputs(self):
+        return [self.src]
 
     def plan(self, eng, N):
         self.out.spatial = self.src.spatial

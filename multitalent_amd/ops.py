@@ -359,12 +359,31 @@ def inorm_bwd_workspace(N, V, Cn):
     return _lib.load().mt_inorm_bwd_workspace(N, V, Cn)
 
 
-def inorm_lrelu_bwd(g, y, gamma, beta, dgamma, dbeta, dbias, ws):
-    """g (Act over the gradient buffer, in place -> dy); y: Act with mean/rstd/slope of the forward."""
+def inorm_lrelu_bwd(g, y, gamma, beta, dgamma, dbeta, dbias, ws, part=None, part_c0=0):
+    """g (Act over the gradient buffer, in place -> dy); y: Act with mean/rstd/slope of the forward.  part: [N, nblk, cs, 2] first-pass
+    partials written by the convolution that produced g (mt_conv3d_t.bstats), this layer's channels at columns part_c0 .."""
+    if part is not None:
+        assert part.dim() == 4 and part.shape[0] == y.N and part.shape[3] == 2 and part.is_contiguous()
     _lib.check(_lib.load().mt_inorm_lrelu_bwd(
         C.c_void_p(g.data_ptr()), g.cs, C.c_void_p(y.data_ptr()), y.cs, _ptr(y.mean), _ptr(y.rstd), _ptr(gamma), _ptr(beta),
-        y.slope, y.N, y.V, y.C, _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(ws), ws.numel() * ws.element_size(), _stream()),
+        y.slope, y.N, y.V, y.C, _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(part), int(part.shape[1]) if part is not None else 0,
+        int(part.shape[2]) if part is not None else 0, int(part_c0), _ptr(ws), ws.numel() * ws.element_size(), _stream()),
         'inorm_lrelu_bwd')
+
+
+def conv_bwd_stats_supported(p):
+    return bool(_lib.load().mt_conv3d_bwd_stats_supported(C.byref(p)))
+
+
+def set_bwd_stats(p, y_act, gamma, beta, c0):
+    """fused first pass of the InstanceNorm backward of `y_act`'s layer in the epilogue of the convolution p (the last writer of that
+    layer's output gradient): see mt_bwd_stats_t.  The caller keeps the tensors alive and provides p.stats_part."""
+    b = p.bstats
+    b.y, b.ycs, b.c0, b.C = y_act.buf.data_ptr() + 4 * y_act.c0, y_act.cs, int(c0), y_act.C
+    b.mean, b.rstd = y_act.mean.data_ptr(), y_act.rstd.data_ptr()
+    b.gamma = gamma.data_ptr() if gamma is not None else None
+    b.beta = beta.data_ptr() if beta is not None else None
+    b.slope = float(y_act.slope)
 
 
 def channel_sum(x, out, accumulate, ws):

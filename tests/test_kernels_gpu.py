@@ -829,3 +829,69 @@ def test_winograd_plane_near_the_packed_offset_limit(dev, Wi, kernel):
         assert relerr(to_ncdhw(out.cpu()), ref) < 2e-5
     finally:
         ops.set_option('conv_wino', 1)
+
+
+@pytest.mark.parametrize("split,acc", [(False, False), (True, True), (False, True)])
+def test_winograd_backward_data_emits_norm_backward_statistics(dev, split, acc):
+    """mt_bwd_stats_t: the persistent Winograd kernel, as the last writer of g = dL/d lrelu(IN(y)), also emits per block
+    A = sum dz and B = sum dz zhat (dz = g lrelu'(z), zhat = (y - mean) rstd, z = zhat gamma + beta) for one destination's channels;
+    mt_inorm_lrelu_bwd consumes them (`part`) instead of running its own reduction.  Against the same quantities in torch and
+    against the un-fused mt_inorm_lrelu_bwd on the same (g, y)."""
+    ops = _ops()
+    ops.set_option('conv_wino', 2)
+    try:
+        g_ = torch.Generator().manual_seed(77)
+        N, Cd, shape, C0 = 2, 32, (6, 10, 36), 30            # the conv writes C0 (+ C1) gradient channels from Cd dY channels
+        C1 = 16 if split else 0
+        Ct = C0 + C1
+        dyd = torch.randn((N,) + shape + (Cd,), generator=g_).to(dev)
+        w = (torch.randn((Cd, Ct, 3, 3, 3), generator=g_) / np.sqrt(Cd * 27)).to(dev)            # forward weight [Cout = Cd, Cin = Ct]
+        d0 = torch.randn((N,) + shape + (C0,), generator=g_).to(dev) if acc else torch.full((N,) + shape + (C0,), float('nan'), device=dev)
+        d1 = (torch.randn((N,) + shape + (C1,), generator=g_).to(dev) if acc else torch.full((N,) + shape + (C1,), float('nan'), device=dev)) if split else None
+        base0 = d0.clone() if acc else torch.zeros_like(d0)
+        base1 = (d1.clone() if acc else torch.zeros_like(d1)) if split else None
+        # the normalised layer whose output gradient is destination `which` (the second one when split)
+        Cn, c0 = (C1, C0) if split else (C0, 0)
+        y = torch.randn((N,) + shape + (Cn,), generator=g_).to(dev) * 2 + 0.5
+        mean = y.mean((1, 2, 3)); rstd = 1.0 / torch.sqrt(y.var((1, 2, 3), unbiased=False) + 1e-5)
+        gamma = (torch.rand(Cn, generator=g_) + 0.5).to(dev); beta = torch.randn(Cn, generator=g_).to(dev) * 0.3
+        yact = ops.Act(y, scale=(gamma * rstd).contiguous(), shift=(beta - mean * gamma * rstd).contiguous(), slope=0.01, mean=mean.contiguous(), rstd=rstd.contiguous())
+        geomT = ops.ConvGeom(shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+        p = ops.fill_conv([ops.Act(dyd)], geomT, Ct, out0=ops.Act(d0), out1=ops.Act(d1) if split else None, csplit=C0, accumulate=acc)
+        assert ops.conv_kernel_name(p) == 'conv_wino8p_kernel' and ops.conv_bwd_stats_supported(p)
+        wp = ops.pack_conv_weights(w, Cd, 0, Ct, (3, 3, 3), ops.conv_weight_strides(w, as_bwd_data=True), True, ops.conv_ck(p), layout=ops.conv_pack_layout(p))
+        p.wpack = wp.data_ptr()
+        part = torch.full((N, ops.conv_stats_blocks(p), Ct, 2), float('nan'), device=dev)
+        p.stats_part = part.data_ptr()
+        ops.set_bwd_stats(p, yact, gamma, beta, c0)
+        ops.conv3d_fwd(p)
+        torch.cuda.synchronize()
+        g = (d1 if split else d0)                              # the finished gradient of the normalised layer's output
+        zh = (y - mean[:, None, None, None, :]) * rstd[:, None, None, None, :]
+        z = zh * gamma + beta
+        dz = torch.where(z > 0, g, g * 0.01)
+        A, B = dz.double().sum((1, 2, 3)), (dz * zh).double().sum((1, 2, 3))
+        got = part.double().sum(1)                              # [N, Ct, 2]
+        sl = slice(c0, c0 + Cn)
+        scale = float(dz.abs().double().sum((1, 2, 3)).max())
+        assert float((got[:, sl, 0] - A).abs().max()) < 1e-5 * scale and float((got[:, sl, 1] - B).abs().max()) < 1e-5 * scale * 3
+        other = torch.ones(Ct, dtype=torch.bool); other[sl] = False
+        assert float(got[:, other].abs().max()) == 0.0          # channels of the other destination: zeros
+        # the gradient itself is what the plain kernel writes
+        q = ops.fill_conv([ops.Act(dyd)], geomT, Ct, out0=ops.Act(base0), out1=ops.Act(base1) if split else None, csplit=C0, accumulate=acc, wpack=wp)
+        ops.conv3d_fwd(q)
+        torch.cuda.synchronize()
+        assert torch.equal(base0, d0) and (not split or torch.equal(base1, d1))
+        # mt_inorm_lrelu_bwd with the fused partials == without
+        outs = []
+        for use in (False, True):
+            gg = g.clone()
+            dga, dbe, dbi = torch.zeros(Cn, device=dev), torch.zeros(Cn, device=dev), torch.zeros(Cn, device=dev)
+            ws = torch.empty(ops.inorm_bwd_workspace(N, yact.V, Cn) // 4 + 16, device=dev)
+            ops.inorm_lrelu_bwd(ops.Act(gg), yact, gamma, beta, dga, dbe, dbi, ws, part=part if use else None, part_c0=c0)
+            torch.cuda.synchronize()
+            outs.append((gg, dga, dbe, dbi))
+        for a_, b_ in zip(outs[0], outs[1]):
+            assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(a_.abs().max()), 1e-6)
+    finally:
+        ops.set_option('conv_wino', 1)
