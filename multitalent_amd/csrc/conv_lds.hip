@@ -2145,6 +2145,17 @@ static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
       const int T = P.nsb * p->N, nct = mt_cdiv(p->Cout, 32);
       int nw = ncu / nct; if (nw < 1) nw = 1; if (nw > T) nw = T;
       if (g_wino_persist > 1 && nw > g_wino_persist) nw = g_wino_persist;       // tests: few workers, many tiles each
+      if (p->bstats.y != nullptr) {
+        static std::atomic<uint64_t> attrb{0};
+        if (mt_device_pending(attrb, devid)) {
+          hipError_t e = hipFuncSetAttribute((const void*)conv_wino8pb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(l8 + 11 * 256 * 4));
+          if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", l8, hipGetErrorString(e)); return MT_EHIP; }
+          mt_mark_device_done(attrb, devid);
+        }
+        hipLaunchKernelGGL(conv_wino8pb_kernel, dim3((unsigned)nw, (unsigned)nct, 1), dim3(512), l8 + 11 * 256 * 4, st, P);
+        MT_CHECK_LAUNCH("conv3d_wino8pb");
+        return MT_OK;
+      }
       hipLaunchKernelGGL(conv_wino8p_kernel, dim3((unsigned)nw, (unsigned)nct, 1), dim3(512), l8 + 11 * 256 * 4, st, P);   // + the patch-geometry table
       MT_CHECK_LAUNCH("conv3d_wino8p");
       return MT_OK;
@@ -2296,7 +2307,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   else if (pl.kind == CONV_STEM)
     snprintf(buf, n, "conv_stem_kernel");
   else if (pl.kind == CONV_WINO)
-    snprintf(buf, n, g_wino_waves == 8 ? ((g_wino_persist && wino_persist_geometry_ok(p)) ? (g_wino_dma > 0 ? "conv_wino8d_kernel" : "conv_wino8p_kernel") : "conv_wino8_kernel") : "conv_wino_kernel");
+    snprintf(buf, n, g_wino_waves == 8 ? ((g_wino_persist && wino_persist_geometry_ok(p)) ? (g_wino_dma > 0 ? "conv_wino8d_kernel" : (p->bstats.y != nullptr ? "conv_wino8pb_kernel" : "conv_wino8p_kernel")) : "conv_wino8_kernel") : "conv_wino_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
     snprintf(buf, n, strided_use_bf16(p) ? "conv_fast_strided_kernel<%d, %d, %d, %d, true>" : "conv_fast_strided_kernel<%d, %d, %d, %d, false>",
              p->SD, p->SH, p->SW, conv_fast_vec(p));
