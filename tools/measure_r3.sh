@@ -1,0 +1,32 @@
+# every bench line quoted in DESIGN.md / README.md for round 3, one MI355X: gpurun_out/meas_r3/*.json (copied to profiles/r03_*.json),
+# rocprofv3 kernel statistics of the same commands and the SQ counters of the dominant kernel
+O=gpurun_out/meas_r3; mkdir -p $O
+python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/default.err
+python bench.py --workload task100 --steps 8 --warmup 2 --no-also > $O/bench_task100_fp32.json 2> $O/task100.err
+python bench.py --workload resenc --steps 8 --warmup 2 --no-also > $O/bench_resenc_fp32.json 2> $O/resenc.err
+python bench.py --workload resenc --precision bf16 --steps 8 --warmup 2 --no-cpu-baseline --no-also > $O/bench_resenc_bf16.json 2>> $O/resenc.err
+python bench.py --precision bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-also > $O/bench_task009_bf16.json 2>> $O/default.err
+python bench.py --workload task100 --precision bf16 --steps 8 --warmup 2 --no-cpu-baseline --no-also > $O/bench_task100_bf16.json 2>> $O/task100.err
+python bench.py --workload infer --mirror 0 --steps 2 --warmup 1 --no-also > $O/bench_infer_nomirror_fp32.json 2> $O/infer.err
+python bench.py --workload infer --mirror 1 --steps 1 --warmup 1 --no-traffic --no-cpu-baseline --no-also > $O/bench_infer_mirror_fp32.json 2>> $O/infer.err
+python bench.py --workload infer --mirror 0 --precision bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --no-also > $O/bench_infer_nomirror_bf16.json 2>> $O/infer.err
+bash tools/profile_r3.sh task009_fp32 task100_fp32 resenc_bf16 infer_nomirror_fp32 > $O/profile.log 2>&1
+cp gpurun_out/prof_r3/*_kernel_stats.csv $O/ 2>/dev/null
+# SQ counters of the dominant kernel (two passes of <= 8 counters; no other trace domain)
+( cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmc1 -o a -- python $R/tools/bench_conv.py --reps 3 > $R/$O/pmc1.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/pmc2 -o a -- python $R/tools/bench_conv.py --reps 3 > $R/$O/pmc2.log 2>&1
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $R/gpurun_out/pmc3 -o a -- python $R/tools/bench_conv.py --reps 3 > $R/$O/pmc3.log 2>&1 )
+python tools/pmc_report3.py conv_wino8p > $O/pmc_conv_wino8p.txt 2>&1
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob('gpurun_out/meas_r3/bench_*.json')):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        r = d.get('roofline', {}); c = d.get('cpu_baseline', {})
+        print('%-34s %8.3f %-12s %9.2f ms | %s frac %s traffic %s | cpu %s' % (f.split('/')[-1], d['value'], d['unit'], d['ms_per_step'], r.get('kernel'), r.get('frac'), r.get('traffic'), c.get('value')))
+        for k, v in d.get('also', {}).items():
+            print('     also %-22s %8.3f %-12s %9.2f ms | %s frac %s' % (k, v['value'], v['unit'], v['ms_per_step'], v.get('roofline', {}).get('kernel'), v.get('roofline', {}).get('frac')))
+    except Exception as e:
+        print(f, 'FAILED', e)
+PY
