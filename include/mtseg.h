@@ -5,8 +5,10 @@
  * (SURVEY.md §8b).  This ABI sits UNDER that surface: the Python modules that mirror
  * `Generic_UNet` / `FabiansUNet` / the trainers call these entry points through ctypes with raw
  * device pointers owned by the caller (torch), a hipStream_t and plain sizes.  No torch types,
- * no allocation, no synchronisation inside; every function returns 0 on success or a negative
- * MT_E* code (text via mt_last_error()).
+ * no allocation, no synchronisation inside (mt_probe_device excepted, see there); every function returns 0
+ * on success or a negative MT_E* code (text via mt_last_error(), thread-local).  Threading: launches are
+ * re-entrant per stream and per device; the only mutable state are the process-wide kernel-selection knobs
+ * of mt_set_option (atomics) and per-device one-time kernel attributes.
  *
  * Layout: activations are NDHWC fp32 ("channels last"), possibly a channel slice of a wider
  * buffer (channel stride `cs`, first channel folded into the pointer).  A "lazy activation" is a
