@@ -536,6 +536,113 @@ extern "C" int mt_pointwise_stats_blocks(const mt_pointwise_t* p) {
   return mt_cdiv((long)p->Db * p->Hb * p->Wb, 128);
 }
 
+// ---- 1x1x1 head with 33..64 output channels into a DENSE [V][Cout] tensor (the 47 MultiTalent logits, generic_UNet.py:349-351) ----
+// pw_fast_kernel serves it with two workgroups per 128 voxels (channels 0-31 and 32-46): the input is read twice and every voxel's
+// 188-byte row is written as a 128-byte and a 60-byte piece, neither aligned to anything (measured 1.8 TB/s).  Here one workgroup
+// computes both channel tiles from one read of the input, transposes its 128 x Cout block through LDS and writes it as ONE linear run
+// of 16-byte stores (128 * 47 * 4 = 24 064 contiguous bytes).  Requires V % 32 == 0, unit strides, no accumulation / statistics.
+#define PWH_MAXCO 64
+__global__ __launch_bounds__(256) void pw_head_kernel(const PwKParams P) {
+  const mt_pointwise_t& c = P.c;
+  __shared__ __attribute__((aligned(16))) float ssc[PW_MAXC], ssh[PW_MAXC];
+  __shared__ __attribute__((aligned(16))) float stage[4][32 * PWH_MAXCO];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  const int bx = mt_xcd_remap(blockIdx.x, gridDim.x);
+  const int nb = bx / P.nsb, sb = bx % P.nsb;
+  const long m0 = (long)sb * 128 + wave * 32;
+  const mt_src_t& S = c.src;
+  const bool wok = m0 < P.Vb;                              // (whole waves: V % 32 == 0)
+  const size_t in_sample = (size_t)P.Vb * S.cs;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0, (int)(in_sample * 4), 0x00020000);
+  const int aoff = wok ? (int)(((m0 + li) * S.cs + 8 * lhalf) * 4) : (int)0x80000000;
+  const bool aff = S.scale != nullptr;
+  const float slope = S.slope;
+  if (aff) {
+    for (int i = tid; i < P.nchunks * PW_CK; i += 256) {
+      ssc[i] = i < S.C ? S.scale[(size_t)nb * S.C + i] : 0.f;
+      ssh[i] = i < S.C ? S.shift[(size_t)nb * S.C + i] : 0.f;
+    }
+    __syncthreads();
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+  f32x4 xa[2], xn[2];
+  auto load_a = [&](int ch, f32x4 (&x)[2]) {
+    const int o = aoff + ch * (PW_CK * 4);
+    x[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, o, 0, 0));
+    x[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, o + 16, 0, 0));
+  };
+  load_a(0, xa);
+  for (int ch = 0; ch < P.nchunks; ++ch) {
+    if (ch + 1 < P.nchunks) load_a(ch + 1, xn);
+    const int cb = ch * PW_CK + 8 * lhalf;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = xa[e >> 2][e & 3];
+    if (aff) {
+      const f32x4 sc0 = *(const f32x4*)(ssc + cb), sc1 = *(const f32x4*)(ssc + cb + 4);
+      const f32x4 sh0 = *(const f32x4*)(ssh + cb), sh1 = *(const f32x4*)(ssh + cb + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = fmaf(x[e], e < 4 ? sc0[e & 3] : sc1[e & 3], e < 4 ? sh0[e & 3] : sh1[e & 3]);
+        x[e] = mt_lrelu(t, slope);
+      }
+    }
+    if (cb + 8 > c.Cin) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = (cb + e < c.Cin) ? x[e] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float* wq = c.wpack + (size_t)(t * P.nchunks + ch) * 512 + lane * 4;
+      const f32x4 b0 = *(const f32x4*)(wq);
+      const f32x4 b1 = *(const f32x4*)(wq + 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[e], b0[e], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[4 + e], b1[e], acc[t], 0, 0, 0);
+    }
+    xa[0] = xn[0]; xa[1] = xn[1];
+  }
+  // ---- epilogue: [32 voxels][Cout] of this wave through LDS, then a linear run of 16-byte stores
+  float* sg = stage[wave];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int co = t * 32 + li;
+    const float bias = (c.bias != nullptr && co < c.Cout) ? c.bias[co] : 0.f;
+    if (co < c.Cout) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+        sg[iv * c.Cout + co] = acc[t][j] + bias;
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's own LDS writes (no other wave touches stage[wave])
+  __builtin_amdgcn_wave_barrier();
+  if (wok) {
+    const size_t out_sample = (size_t)P.Vb * c.Cout;
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out + (size_t)nb * out_sample), 0, (int)(out_sample * 4), 0x00020000);
+    const int n4 = 8 * c.Cout;                             // float4 per wave block (32 * Cout / 4)
+    const int obase = (int)(m0 * c.Cout * 4);
+    for (int i = lane; i < n4; i += 64) {
+      const f32x4 v = *(const f32x4*)(sg + 4 * i);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ro, obase + i * 16, 0, 0);
+    }
+  }
+}
+
+// the dense-output head form (pw_head_kernel): 1x1x1, unit strides, 33..64 output channels written densely, whole waves of voxels
+static bool pw_head_ok(const mt_pointwise_t* p, const PwKParams& P) {
+  return P.ntaps == 1 && p->siD == 1 && p->siH == 1 && p->siW == 1 && p->Cout > 32 && p->Cout <= PWH_MAXCO && p->ocs == p->Cout &&
+         !p->accumulate && p->stats_part == nullptr && (P.Vb % 32) == 0 && p->Di == p->Db && p->Hi == p->Hb && p->Wi == p->Wb &&
+         ((((uintptr_t)p->out) & 15) == 0) && ((P.Vb * p->Cout) % 4 == 0);
+}
 extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   MT_REQUIRE(p != nullptr, "pointwise: null params");
   MT_REQUIRE(p->N > 0 && p->Db > 0 && p->Hb > 0 && p->Wb > 0 && p->Cin > 0 && p->Cout > 0, "pointwise: empty problem");
@@ -562,8 +669,17 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   int vec = 4;
   if (force_vec == 1 || force_vec == 2 || force_vec == 4) vec = force_vec;
   if (vec == 2 && !((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0)) vec = 1;
-  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
   hipStream_t st = (hipStream_t)stream;
+  {
+    static int use_head = -1;
+    if (use_head < 0) { const char* e = getenv("MT_PW_HEAD"); use_head = e ? atoi(e) : 1; }
+    if (use_head && pw_head_ok(p, P)) {
+      hipLaunchKernelGGL(pw_head_kernel, dim3((unsigned)(P.nsb * p->N)), dim3(256), 0, st, P);
+      MT_CHECK_LAUNCH("pointwise_head");
+      return MT_OK;
+    }
+  }
+  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
 #define PW_LAUNCH(NT)                                                                              \
   do {                                                                                             \
     if (vec == 4) hipLaunchKernelGGL((pw_fast_kernel<NT, 4>), grid, dim3(256), 0, st, P);           \
