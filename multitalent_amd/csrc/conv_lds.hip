@@ -2024,9 +2024,7 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
   const size_t ldsb = bstage_lds_bytes<TD + KD - 1, TH + 2, TW + 2, VEC, NW>();
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(mt_cdiv(p->Cout, 32), NT), 1);
-  auto kfn = p->bstats.y != nullptr ? conv_bf16_kernel<MW, RH, TD, VEC, NT, NW, KD, true> : conv_bf16_kernel<MW, RH, TD, VEC, NT, NW, KD, false>;
-  MT_REQUIRE(p->bstats.y == nullptr || (p->stats_part != nullptr && p->bstats.mean && p->bstats.rstd && p->bstats.c0 >= 0 && p->bstats.C > 0 &&
-                                        p->bstats.c0 + p->bstats.C <= p->Cout), "conv3d: incomplete bstats");
+  auto kfn = conv_bf16_kernel<MW, RH, TD, VEC, NT, NW, KD>;
   if (ldsb > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
@@ -2297,8 +2295,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   const int i = pl.cfg;
   if (i < 0) return MT_EINVAL;
   if (pl.kind == CONV_BF16) {
-    snprintf(buf, n, p->bstats.y != nullptr ? "conv_bf16_kernel<%d, %d, %d, %d, 1, 4, %d, true>" : "conv_bf16_kernel<%d, %d, %d, %d, 1, 4, %d>",
-             kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, conv_bf16_vec(p), p->KD);
+    snprintf(buf, n, "conv_bf16_kernel<%d, %d, %d, %d, 1, 4, %d>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, conv_bf16_vec(p), p->KD);
     return MT_OK;
   }
   const ConvCfg& g = kCfgs[i];
@@ -2326,8 +2323,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
 extern "C" int mt_conv3d_bwd_stats_supported(const mt_conv3d_t* p) {
   if (p == nullptr || conv_validate(p) != MT_OK) return 0;
   const ConvPlan pl = conv_plan(p);
-  if (pl.cfg < 0) return 0;
-  return ((pl.kind == CONV_WINO && wino_serves_bwd_stats(p)) || pl.kind == CONV_BF16) ? 1 : 0;
+  return (pl.cfg >= 0 && pl.kind == CONV_WINO && wino_serves_bwd_stats(p)) ? 1 : 0;
 }
 
 extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
@@ -2336,7 +2332,7 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   const ConvPlan pl = conv_plan(p);
   const int i = pl.cfg;
   MT_REQUIRE(i >= 0, "conv3d: no tile configuration fits LDS");
-  MT_REQUIRE(p->bstats.y == nullptr || pl.kind == CONV_WINO || pl.kind == CONV_BF16, "conv3d: bstats set on a problem whose kernel does not compute them "
+  MT_REQUIRE(p->bstats.y == nullptr || pl.kind == CONV_WINO, "conv3d: bstats set on a problem whose kernel does not compute them "
              "(ask mt_conv3d_bwd_stats_supported)");
   if (pl.kind == CONV_BF16) return launch_bf16(p, i, (hipStream_t)stream);
   const ConvCfg& g = kCfgs[i];

@@ -831,17 +831,14 @@ def test_winograd_plane_near_the_packed_offset_limit(dev, Wi, kernel):
         ops.set_option('conv_wino', 1)
 
 
-@pytest.mark.parametrize("mma", [0, 1])
 @pytest.mark.parametrize("split,acc", [(False, False), (True, True), (False, True)])
-def test_winograd_backward_data_emits_norm_backward_statistics(dev, split, acc, mma):
+def test_winograd_backward_data_emits_norm_backward_statistics(dev, split, acc):
     """mt_bwd_stats_t: the persistent Winograd kernel, as the last writer of g = dL/d lrelu(IN(y)), also emits per block
     A = sum dz and B = sum dz zhat (dz = g lrelu'(z), zhat = (y - mean) rstd, z = zhat gamma + beta) for one destination's channels;
     mt_inorm_lrelu_bwd consumes them (`part`) instead of running its own reduction.  Against the same quantities in torch and
     against the un-fused mt_inorm_lrelu_bwd on the same (g, y)."""
     ops = _ops()
     ops.set_option('conv_wino', 2)
-    ops.set_mma(mma)                                           # 1: the bf16 kernel's instance of the same epilogue (conv_bf16_kernel<.., true>)
-    ops.set_option('conv_bf16', 2 if mma else 1)
     try:
         g_ = torch.Generator().manual_seed(77)
         N, Cd, shape, C0 = 2, 32, (6, 10, 36), 30            # the conv writes C0 (+ C1) gradient channels from Cd dY channels
@@ -863,11 +860,11 @@ def test_winograd_backward_data_emits_norm_backward_statistics(dev, split, acc, 
         p = ops.fill_conv([ops.Act(dyd)], geomT, Ct, out0=ops.Act(d0), out1=ops.Act(d1) if split else None, csplit=C0, accumulate=acc)
         wp = ops.pack_conv_weights(w, Cd, 0, Ct, (3, 3, 3), ops.conv_weight_strides(w, as_bwd_data=True), True, ops.conv_ck(p), layout=ops.conv_pack_layout(p))
         p.wpack = wp.data_ptr()
-        assert ops.conv_kernel_name(p) == ('conv_bf16_kernel<32, 4, 2, 2, 1, 4, 3>' if mma else 'conv_wino8p_kernel') and ops.conv_bwd_stats_supported(p)
+        assert ops.conv_kernel_name(p) == 'conv_wino8p_kernel' and ops.conv_bwd_stats_supported(p)
         part = torch.full((N, ops.conv_stats_blocks(p), Ct, 2), float('nan'), device=dev)
         p.stats_part = part.data_ptr()
         ops.set_bwd_stats(p, yact, gamma, beta, c0)
-        assert ops.conv_kernel_name(p) in ('conv_wino8pb_kernel', 'conv_bf16_kernel<32, 4, 2, 2, 1, 4, 3, true>')
+        assert ops.conv_kernel_name(p) == 'conv_wino8pb_kernel'
         ops.conv3d_fwd(p)
         torch.cuda.synchronize()
         g = (d1 if split else d0)                              # the finished gradient of the normalised layer's output
@@ -901,8 +898,6 @@ def test_winograd_backward_data_emits_norm_backward_statistics(dev, split, acc, 
             assert float((a_ - b_).abs().max()) <= 2e-5 * ref_scale, i_
     finally:
         ops.set_option('conv_wino', 1)
-        ops.set_option('conv_bf16', 1)
-        ops.set_mma(0)
 
 
 @pytest.mark.parametrize("Cin,Cout,shape,lazy,bias", [(30, 47, (4, 8, 16), True, True), (32, 64, (2, 8, 32), False, False),
