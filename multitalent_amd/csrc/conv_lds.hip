@@ -31,6 +31,50 @@ struct ConvKParams {
   ConvChunk chunk[MT_MAX_CHUNKS];
 };
 
+// Block -> (spatial tile, output-channel tile).  Workgroups are dispatched in linear order (x fastest, then y) round-robin over the
+// eight XCDs, each with its own L2.  MT_TILE_ORDER 1: an XCD walks a CONTIGUOUS range of (spatial tile, channel tile) pairs with
+// the channel tile fastest — all channel tiles of a spatial tile read the same input patch while it is in that L2 — and the
+// spatial tiles in the order D, H, W (W slowest): the tiles resident on an XCD at one time then form a compact D x H block at one
+// w position, so the halo rows (TH + 2 rows fetched for TH outputs: the expensive direction) are shared in L2 instead of being
+// fetched again a whole D x W plane later.  0: the previous order (channel tile = blockIdx.y slowest; D, W, H).
+#ifndef MT_TILE_ORDER
+#define MT_TILE_ORDER 1
+#endif
+__device__ __forceinline__ int mt_block_decode(int& ntile) {
+#if MT_TILE_ORDER
+  const int ny = (int)gridDim.y;
+  const int b = mt_xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * ny));
+  const int t = b / ny;
+  ntile = b - t * ny;
+  return t;
+#else
+  ntile = blockIdx.y;
+  return mt_xcd_remap(blockIdx.x, gridDim.x);
+#endif
+}
+// spatial tile index -> (td, th, tw, sample); OLD = the kernel's order under MT_TILE_ORDER 0 (0: D, W, H; 1: W, H, D)
+template <int OLD = 0>
+__device__ __forceinline__ void mt_tile_coords(int tile, int tilesD, int tilesH, int tilesW, int& td, int& th, int& tw, int& nb) {
+#if MT_TILE_ORDER
+  td = tile % tilesD; tile /= tilesD;
+  th = tile % tilesH; tile /= tilesH;
+  tw = tile % tilesW;
+  nb = tile / tilesW;
+#else
+  if constexpr (OLD == 0) {
+    td = tile % tilesD; tile /= tilesD;
+    tw = tile % tilesW; tile /= tilesW;
+    th = tile % tilesH;
+    nb = tile / tilesH;
+  } else {
+    tw = tile % tilesW; tile /= tilesW;
+    th = tile % tilesH; tile /= tilesH;
+    td = tile % tilesD;
+    nb = tile / tilesD;
+  }
+#endif
+}
+
 // Split the concatenated input channels (C0 | C1) into chunks of <= ck channels that never straddle
 // the two sources.  Shared by packing and kernels so the packed order always matches.
 static int mt_build_chunks(int C0, int C1, int ck, ConvChunk* out) {
@@ -310,12 +354,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvKParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lhalf = lane >> 5;
 
-  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
-  const int ntile = blockIdx.y;
-  const int tw = tile % P.tilesW; tile /= P.tilesW;
-  const int th = tile % P.tilesH; tile /= P.tilesH;
-  const int td = tile % P.tilesD;
-  const int nb = tile / P.tilesD;
+  int ntile, td, th, tw, nb;
+  mt_tile_coords<1>(mt_block_decode(ntile), P.tilesD, P.tilesH, P.tilesW, td, th, tw, nb);
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
 
   // FAST: 3x3x3, stride 1, pad 1, no zero insertion -> the whole tile geometry is compile-time
@@ -754,12 +794,8 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lhalf = lane >> 5;
-  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
-  const int ntile = blockIdx.y;
-  const int tw = tile % P.tilesW; tile /= P.tilesW;
-  const int th = tile % P.tilesH; tile /= P.tilesH;
-  const int td = tile % P.tilesD;
-  const int nb = tile / P.tilesD;
+  int ntile, td, th, tw, nb;
+  mt_tile_coords<1>(mt_block_decode(ntile), P.tilesD, P.tilesH, P.tilesW, td, th, tw, nb);
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
 
@@ -896,15 +932,12 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lhalf = lane >> 5;
-  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
+  int by, td, th, tw, nb;
+  mt_tile_coords<1>(mt_block_decode(by), P.tilesD, P.tilesH, P.tilesW, td, th, tw, nb);
   const int dm = wave & 1, nt2 = wave >> 1;
-  const int ntile_raw = blockIdx.y * 2 + nt2;
+  const int ntile_raw = by * 2 + nt2;
   const bool nt_ok = ntile_raw * 32 < c.Cout;           // wave-uniform: an odd number of 32-channel tiles leaves one wave idle
   const int ntile = nt_ok ? ntile_raw : 0;
-  const int tw = tile % P.tilesW; tile /= P.tilesW;
-  const int th = tile % P.tilesH; tile /= P.tilesH;
-  const int td = tile % P.tilesD;
-  const int nb = tile / P.tilesD;
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
 
@@ -959,7 +992,7 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
     __syncthreads();
     if (tid < 64) {                                      // thread t: N tile t/32 of this pair, channel t%32
       const int n2 = tid >> 5, cl = tid & 31;
-      const int cg = (blockIdx.y * 2 + n2) * 32 + cl;
+      const int cg = (by * 2 + n2) * 32 + cl;
       if (cg < c.Cout) {
         const float t1 = lds[((n2 * 2) * 32 + cl) * 2] + lds[((n2 * 2 + 1) * 32 + cl) * 2];
         const float t2 = lds[((n2 * 2) * 32 + cl) * 2 + 1] + lds[((n2 * 2 + 1) * 32 + cl) * 2 + 1];
@@ -986,12 +1019,8 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lhalf = lane >> 5;
-  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
-  const int ntile = blockIdx.y;
-  const int tw = tile % P.tilesW; tile /= P.tilesW;
-  const int th = tile % P.tilesH; tile /= P.tilesH;
-  const int td = tile % P.tilesD;
-  const int nb = tile / P.tilesD;
+  int ntile, td, th, tw, nb;
+  mt_tile_coords<1>(mt_block_decode(ntile), P.tilesD, P.tilesH, P.tilesW, td, th, tw, nb);
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
   // M tile row li -> voxel (dm, r, col) = (li>>4, (li>>2)&3, li&3)
@@ -1129,12 +1158,8 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvKParams P) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lhalf = lane >> 5;
-  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
-  const int ntile = blockIdx.y;
-  const int tw = tile % P.tilesW; tile /= P.tilesW;
-  const int th = tile % P.tilesH; tile /= P.tilesH;
-  const int td = tile % P.tilesD;
-  const int nb = tile / P.tilesD;
+  int ntile, td, th, tw, nb;
+  mt_tile_coords<1>(mt_block_decode(ntile), P.tilesD, P.tilesH, P.tilesW, td, th, tw, nb);
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
   stem_stage<TD, TH, TW>(xs, c, nb, od0, oh0, ow0, tid);
@@ -1212,9 +1237,9 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
   const int li = lane & 31, lhalf = lane >> 5;
   const long V = (long)c.Do * c.Ho * c.Wo;
   const int nsb = (int)((V + 127) / 128);
-  const int bx = mt_xcd_remap(blockIdx.x, gridDim.x);
+  int ntile;
+  const int bx = mt_block_decode(ntile);
   const int nb = bx / nsb, sb = bx % nsb;
-  const int ntile = blockIdx.y;
   const long m0 = (long)sb * 128 + wave * 32;
   const mt_src_t& S = c.src[0];
   const long mv = m0 + li;
@@ -1411,12 +1436,8 @@ __global__ __launch_bounds__(256) void conv_rt_kernel(const ConvKParams P) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lhalf = lane >> 5;
-  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
-  const int ntile = blockIdx.y;
-  const int tw = tile % P.tilesW; tile /= P.tilesW;
-  const int th = tile % P.tilesH; tile /= P.tilesH;
-  const int td = tile % P.tilesD;
-  const int nb = tile / P.tilesD;
+  int ntile, td, th, tw, nb;
+  mt_tile_coords<1>(mt_block_decode(ntile), P.tilesD, P.tilesH, P.tilesW, td, th, tw, nb);
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
   const int LD = (TD - 1) * c.SD + c.KD, LH = (TH - 1) * c.SH + c.KH, LW = (TW - 1) * c.SW + c.KW;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
@@ -1566,12 +1587,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lhalf = lane >> 5;
-  int tile = mt_xcd_remap(blockIdx.x, gridDim.x);
-  const int ntile = blockIdx.y;
-  const int tw = tile % P.tilesW; tile /= P.tilesW;
-  const int th = tile % P.tilesH; tile /= P.tilesH;
-  const int td = tile % P.tilesD;
-  const int nb = tile / P.tilesD;
+  int ntile, td, th, tw, nb;
+  mt_tile_coords<1>(mt_block_decode(ntile), P.tilesD, P.tilesH, P.tilesW, td, th, tw, nb);
   const int md0 = td * TD, mh0 = th * TH, mw0 = tw * TW;
 
   // this wave's M tile: dm = wave/2, rows (wave%2)*2 + {0,1}, 16 columns
