@@ -11,6 +11,7 @@ libmtseg_hip.so.  Design points (MI355X-first):
     likewise, so clip/SGD are single kernels and the DDP all-reduce streams contiguous slices as
     soon as they are final (overlap with the rest of backward on a side stream).
 """
+import contextlib
 import os
 
 import torch
@@ -202,9 +203,10 @@ class ConvNormOp(_Op):
         # backward-weight straight into the flat gradient buffer (torch parameter layout)
         acts = [s.act for s in self.srcs]
         pw = ops.fill_conv(acts, self.geom, self.conv.out_channels)
-        ws = eng.workspace(ops.conv3d_bwd_weight_workspace(pw))
         dw = eng.grad_of(self.conv.weight)
-        ops.conv3d_bwd_weight(pw, gact, dw, _strides(self.conv.weight), False, ws)
+        with eng.weight_stream() as side:
+            ws = eng.workspace(ops.conv3d_bwd_weight_workspace(pw), side=side)
+            ops.conv3d_bwd_weight(pw, gact, dw, _strides(self.conv.weight), False, ws)
         # backward-data into the sources' gradient buffers
         dsts = [s for s in self.srcs if s.grad is not None]
         if not dsts:
@@ -323,8 +325,9 @@ class TConvOp(_Op):
         w = self.tu.weight
         p = self._bwd_params()
         # backward-weight: X = dOut (channels = Cout_t), Y = tconv input (lazy act, channels = Cin_t)
-        ws = eng.workspace(ops.conv3d_bwd_weight_workspace(p))
-        ops.conv3d_bwd_weight(p, self.src.act, eng.grad_of(w), _strides(w, transposed_layout=True, as_bwd_data=True), False, ws)
+        with eng.weight_stream() as side:
+            ws = eng.workspace(ops.conv3d_bwd_weight_workspace(p), side=side)
+            ops.conv3d_bwd_weight(p, self.src.act, eng.grad_of(w), _strides(w, transposed_layout=True, as_bwd_data=True), False, ws)
         if self.src.grad is not None:
             p.wpack = self.wb.data_ptr()
             p.out0 = self.src.grad.data_ptr()
@@ -429,6 +432,11 @@ class Engine:
         self.flat_grad = None
         self._views = {}
         self.params_version = 0
+        self.wstreams = []                  # side streams of the backward-weight launches (Engine.weight_stream)
+        self._wnext = 0
+        self._late_pack = None
+        self._ws_side = {}
+        self.bwdw_streams = int(os.environ.get('MT_BWDW_STREAMS', '1'))
         self.grad_ready_hook = None         # callable(lo, hi) on flat_grad element ranges, in completion order
         self.dummy = None
         self.mma = 0                        # matrix input type of the convolutions: 0 fp32, 1 bf16 (mixed precision)
@@ -454,11 +462,44 @@ class Engine:
             self._buffers[name] = t
         return t
 
-    def workspace(self, nbytes):
+    def workspace(self, nbytes, side=None):
+        """Scratch for one launch.  side = index of the weight-gradient stream the launch runs on (None: the main stream): every
+        stream has its own scratch, launches of one stream are ordered."""
         n = (int(nbytes) + 3) // 4 + 16
+        if side is not None:
+            t = self._ws_side.get(side)
+            if t is None or t.numel() < n:
+                if t is not None:
+                    torch.cuda.synchronize()    # an earlier launch may still be using the smaller one
+                t = self._ws_side[side] = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=self.device)
+            return t
         if self._ws is None or self._ws.numel() < n:
             self._ws = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=self.device)
         return self._ws
+
+    def _side_stream(self):
+        prio = int(os.environ.get('MT_BWDW_PRIO', '0'))
+        return torch.cuda.Stream(priority=prio)
+
+    @contextlib.contextmanager
+    def weight_stream(self):
+        """Context of a backward-weight launch; yields the index of the side stream it runs on (None: the main stream).
+        The weight gradients are off the critical path of backward — only the clip / optimizer and the gradient all-reduce read them —
+        while the backward-data chain is a sequence of dependent launches whose tails, low-resolution layers and small reductions
+        leave CUs idle.  With side streams (MT_BWDW_STREAMS, default 1, 0 = off; more than one measured no different) a layer's backward-weight (+ its ordered reduction)
+        is issued behind an event of the main stream (its output gradient is final) on one of the side streams, round-robin, and
+        overlaps whatever follows; Engine.backward joins the streams at the end, GradAllReducer.ready orders its bucket behind them."""
+        if not self.wstreams:
+            yield None
+            return
+        i = self._wnext
+        self._wnext = (i + 1) % len(self.wstreams)
+        st = self.wstreams[i]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
+            yield i
 
     def ordered_params(self):
         """Parameters in backward-completion order (reverse op order) — the flat-buffer layout."""
@@ -548,17 +589,39 @@ class Engine:
         prog = self._pack_programs.get(key)
         ops.set_mma(self.mma)
         if key not in self._pack_programs:   # record the ops' packing calls once; afterwards every step is one batched launch
-            rec = []
-            ops._pack_recorder = rec
-            try:
-                for op in self.ops:
-                    op.pack(self, need_grad)
-            finally:
-                ops._pack_recorder = None
-            prog = ops.PackProgram(rec, self.device) if rec else None
+            def record(bwd):
+                rec = []
+                ops._pack_recorder = rec
+                try:
+                    for op in self.ops:
+                        op.pack(self, bwd)
+                finally:
+                    ops._pack_recorder = None
+                return rec
+            rec = record(need_grad)
+            late = []
+            if need_grad and self.bwdw_streams > 0 and self.flat.is_cuda:
+                # the packings only backward reads (flipped / transposed weights of the backward-data launches) go to the side stream
+                # and overlap the forward pass; Engine.backward waits for them
+                fwd_dst = {r[1].data_ptr() for r in record(False)}
+                late = [r for r in rec if r[1].data_ptr() not in fwd_dst]
+                rec = [r for r in rec if r[1].data_ptr() in fwd_dst]
+            prog = (ops.PackProgram(rec, self.device) if rec else None, ops.PackProgram(late, self.device) if late else None)
             self._pack_programs[key] = prog
-        if prog is not None:
-            prog.run()
+        self._late_pack = None
+        if prog[0] is not None:
+            prog[0].run()
+        if prog[1] is not None:
+            if not self.wstreams:
+                self.wstreams = [self._side_stream() for _ in range(self.bwdw_streams)]
+            st = self.wstreams[0]
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())      # behind the optimizer step that wrote the weights
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                prog[1].run()
+                self._late_pack = torch.cuda.Event()
+                self._late_pack.record(st)
         self._packed_version = ver
 
     # ---- execution --------------------------------------------------------------------------------
@@ -604,6 +667,13 @@ class Engine:
         """dlogits: list (module output order) of NDHWC gradient tensors or None.  Fills flat_grad."""
         self.flat_grad.zero_()
         ops.set_mma(self.mma)
+        nside = self.bwdw_streams if self.flat_grad.is_cuda else 0
+        if len(self.wstreams) != nside:
+            self.wstreams = [self._side_stream() for _ in range(nside)]
+        self._wnext = 0
+        if self._late_pack is not None:         # the backward-only weight packings of this step (Engine._pack)
+            torch.cuda.current_stream().wait_event(self._late_pack)
+            self._late_pack = None
         for op in self.ops:
             op.out.grad_init = False
         for h, g in zip(self.heads, dlogits):
@@ -632,6 +702,8 @@ class Engine:
                 hi = max(self._views[id(p)][0] + (p.numel() + 3) // 4 * 4 for p in op.param_list())
                 done_hi = max(done_hi, hi)
                 self.grad_ready_hook(lo, done_hi)
+        for st in self.wstreams:
+            torch.cuda.current_stream().wait_stream(st)
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(self.flat_grad.numel(), self.flat_grad.numel())
 

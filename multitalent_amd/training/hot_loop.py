@@ -75,9 +75,15 @@ class GradAllReducer:
                 # all-reduces it there; finish() makes the compute stream wait for the side stream before clip / SGD read it
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
+                evs = [ev]
+                for st in getattr(self.eng, 'wstreams', ()):      # the weight gradients are produced on the engine's side streams
+                    e2 = torch.cuda.Event()
+                    e2.record(st)
+                    evs.append(e2)
                 c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 with torch.cuda.stream(self.stream):
-                    self.stream.wait_event(ev)
+                    for e in evs:
+                        self.stream.wait_event(e)
                     c0.record(self.stream)
                     sl.div_(self.world)
                     self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
