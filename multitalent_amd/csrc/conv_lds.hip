@@ -2647,9 +2647,16 @@ extern "C" int mt_pack_desc_fill(void* desc, const float* w, float* dst, int C0,
   MT_REQUIRE(desc != nullptr && w != nullptr && dst != nullptr, "pack_desc_fill: null pointers");
   return pack_fill(*(PackParams*)desc, nullptr, w, dst, C0, C1, Cout, KD, KH, KW, s_ci, s_co, s_kd, s_kh, s_kw, flip, ck, layout, tapmap);
 }
+// workgroups per descriptor of the batched packing: the launch lasts as long as its LARGEST descriptor (a 320 x 320 x 27 layer is 2.8 M
+// scattered 4-byte reads), so that one needs the whole chip; the small descriptors' surplus workgroups exit at once
+static unsigned g_pack_blocks() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MT_PACK_BLOCKS"); v = e ? atoi(e) : 256; if (v < 1) v = 1; }
+  return (unsigned)v;
+}
 extern "C" int mt_pack_batched(const void* descs_device, int n, mt_stream_t stream) {
   MT_REQUIRE(descs_device != nullptr && n > 0, "pack_batched: empty table");
-  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(48, (unsigned)n, 1), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(g_pack_blocks(), (unsigned)n, 1), dim3(256), 0, (hipStream_t)stream,
                      (const PackParams*)descs_device);
   MT_CHECK_LAUNCH("pack_weights_batched");
   return MT_OK;

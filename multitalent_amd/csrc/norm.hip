@@ -143,22 +143,31 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const InBwdParams
   }
 }
 // finalize pass 1: m[n][c] = (A/V, B/V); dgamma[c] += sum_n B; dbeta[c] += sum_n A
-__global__ __launch_bounds__(64) void inorm_bwd_finalize_kernel(const InBwdParams P, int N, float* dgamma, float* dbeta) {
+__global__ __launch_bounds__(256) void inorm_bwd_finalize_kernel(const InBwdParams P, int N, float* dgamma, float* dbeta) {
+  // one workgroup per channel, four waves over the blocks of a sample (a chain of dependent loads per thread: 54 deep with one
+  // wave at full resolution); the waves' sums are combined in a fixed order
+  __shared__ double red[4][2];
   const int c = blockIdx.x;
+  const int wave = threadIdx.x >> 6;
   double ta = 0.0, tb = 0.0;
   for (int n = 0; n < N; ++n) {
     double a = 0.0, b = 0.0;
-    for (int s = threadIdx.x; s < P.p1_nblk; s += 64) {
+    for (int s = threadIdx.x; s < P.p1_nblk; s += 256) {
       const float* q = P.p1 + (((size_t)n * P.p1_nblk + s) * P.p1_cs + P.p1_c0 + c) * 2;
       a += (double)q[0];
       b += (double)q[1];
     }
     a = mt_wave_sum_d(a); b = mt_wave_sum_d(b);
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = a; red[wave][1] = b; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+      a = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+      b = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
       P.m[((size_t)n * P.C + c) * 2] = (float)(a / (double)P.V);
       P.m[((size_t)n * P.C + c) * 2 + 1] = (float)(b / (double)P.V);
+      ta += a; tb += b;
     }
-    ta += a; tb += b;
+    __syncthreads();
   }
   if (threadIdx.x == 0) {
     if (dgamma) dgamma[c] += (float)tb;
@@ -348,13 +357,13 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
       else if (vec == 2) hipLaunchKernelGGL((inorm_bwd_fast_kernel<2, false>), grid, dim3(256), 0, st, F);
       else hipLaunchKernelGGL((inorm_bwd_fast_kernel<1, false>), grid, dim3(256), 0, st, F);
     }
-    hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, P, N, dgamma, dbeta);
+    hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, P, N, dgamma, dbeta);
     if (vec == 4) hipLaunchKernelGGL((inorm_bwd_fast_kernel<4, true>), grid, dim3(256), 0, st, F);
     else if (vec == 2) hipLaunchKernelGGL((inorm_bwd_fast_kernel<2, true>), grid, dim3(256), 0, st, F);
     else hipLaunchKernelGGL((inorm_bwd_fast_kernel<1, true>), grid, dim3(256), 0, st, F);
   } else {
     if (part == nullptr) hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, P, N, dgamma, dbeta);
+    hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, P, N, dgamma, dbeta);
     hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
   }
   if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(64), 0, st, (const float*)P.part2, (long)N * P.nvb, C, dbias, 0);

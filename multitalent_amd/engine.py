@@ -478,8 +478,7 @@ class Engine:
         return self._ws
 
     def _side_stream(self):
-        prio = int(os.environ.get('MT_BWDW_PRIO', '0'))
-        return torch.cuda.Stream(priority=prio)
+        return torch.cuda.Stream()              # (a lower or higher stream priority than the main stream's: measured no different)
 
     @contextlib.contextmanager
     def weight_stream(self):

@@ -10,7 +10,7 @@ python bench.py --workload task100 --precision bf16 --steps 8 --warmup 2 --no-cp
 python bench.py --workload infer --mirror 0 --steps 2 --warmup 1 --no-also > $O/bench_infer_nomirror_fp32.json 2> $O/infer.err
 python bench.py --workload infer --mirror 1 --steps 1 --warmup 1 --no-traffic --no-cpu-baseline --no-also > $O/bench_infer_mirror_fp32.json 2>> $O/infer.err
 python bench.py --workload infer --mirror 0 --precision bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --no-also > $O/bench_infer_nomirror_bf16.json 2>> $O/infer.err
-bash tools/profile_r3.sh task009_fp32 task100_fp32 resenc_bf16 infer_nomirror_fp32 > $O/profile.log 2>&1
+bash tools/profile_r3.sh task009_fp32 task009_fp32_overlap task100_fp32 resenc_bf16 infer_nomirror_fp32 > $O/profile.log 2>&1
 cp gpurun_out/prof_r3/*_kernel_stats.csv $O/ 2>/dev/null
 # SQ counters of the dominant kernel (two passes of <= 8 counters; no other trace domain)
 ( cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT

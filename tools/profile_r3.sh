@@ -1,5 +1,8 @@
 # rocprofv3 kernel statistics of bench.py for every workload (fp32 + bf16): gpurun_out/prof_r3/<tag>_kernel_stats.csv + the bench lines
-# usage: bash tools/profile_r2.sh [tags...]   (default: all)
+# usage: bash tools/profile_r3.sh [tags...]   (default: all)
+# The statistics are taken with the weight-gradient stream serialised (MT_BWDW_STREAMS=0: every kernel runs alone, its duration is
+# the kernel's — what bench.py's `roofline` pass measures); the tag *_overlap keeps the default overlap (durations then include
+# the time two streams' kernels share the CUs).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r3
 mkdir -p $O
@@ -10,10 +13,12 @@ run() {  # tag, bench args...
   [ -n "$f" ] && cp $f $O/${tag}_kernel_stats.csv
   rm -rf $O/$tag
 }
+export MT_BWDW_STREAMS=0
 TAGS=${@:-task009_fp32 task009_bf16 task100_fp32 task100_bf16 resenc_fp32 resenc_bf16 infer_nomirror_fp32}
 for t in $TAGS; do
   case $t in
     task009_fp32) run $t --steps 5 --warmup 2 ;;
+    task009_fp32_overlap) MT_BWDW_STREAMS=1 run $t --steps 5 --warmup 2 ;;
     task009_bf16) run $t --steps 5 --warmup 2 --precision bf16 ;;
     task100_fp32) run $t --steps 4 --warmup 2 --workload task100 ;;
     task100_bf16) run $t --steps 4 --warmup 2 --workload task100 --precision bf16 ;;
