@@ -2651,7 +2651,7 @@ extern "C" int mt_pack_desc_fill(void* desc, const float* w, float* dst, int C0,
 // scattered 4-byte reads), so that one needs the whole chip; the small descriptors' surplus workgroups exit at once
 static unsigned g_pack_blocks() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("MT_PACK_BLOCKS"); v = e ? atoi(e) : 256; if (v < 1) v = 1; }
+  if (v < 0) { const char* e = getenv("MT_PACK_BLOCKS"); v = e ? atoi(e) : 1024; if (v < 1) v = 1; }
   return (unsigned)v;
 }
 extern "C" int mt_pack_batched(const void* descs_device, int n, mt_stream_t stream) {

@@ -377,7 +377,10 @@ class ResAddOp(_Op):
         self.main.grad_init = True
         # residual branch: g itself (already masked) is added to / becomes the residual's gradient
         if self.res.grad is not None:
-            if self.res.grad_init:
+            if self.res.grad.data_ptr() == g.data_ptr():        # shared buffer (Engine._plan): g, masked in place, is already there
+                assert not self.res.grad_init, "gradient of %s was written before its residual add ran backward" % self.res.name
+                self.res.grad_init = True
+            elif self.res.grad_init:
                 self.res.grad.add_(g)
             else:
                 self.res.grad.copy_(g)
@@ -570,6 +573,12 @@ class Engine:
                     v.grad = None            # provided by the loss (dlogits)
                 else:
                     v.grad = self.buffer(v.name + '.grad', tuple(v.act.buf.shape[:4]) + (v.C,))
+            # out = lrelu(main + res): the masked gradient of `out` IS the first contribution to the gradient of `res` (ResAddOp is
+            # the last consumer of `res` in forward, so the first writer of its gradient in backward) — the two share one buffer and
+            # the residual path costs no copy; along a chain of blocks the gradient flows through ONE buffer, masked in place
+            for op in self.ops:
+                if isinstance(op, ResAddOp) and op.res.grad is not None and tuple(op.res.grad.shape) == tuple(op.out.grad.shape):
+                    op.out.grad = op.res.grad
         else:
             for op in self.ops:
                 op.out.grad = None

@@ -1,12 +1,18 @@
 #!/bin/bash
-# A/B of an environment switch over the bench workloads: tools/ab_env.sh VAR v1 v2 ...
+# A/B of an environment switch over the bench workloads: tools/ab_env.sh VAR v1 v2 ...   (WL="task009 resenc_bf16" restricts the workloads)
 var=$1; shift
+WL=${WL:-"task009 task100 resenc resenc_bf16"}
 run() { python bench.py "$@" --steps 8 --no-also --no-cpu-baseline --no-traffic --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
 for v in "$@"; do
   export $var=$v
   echo "== $var=$v"
-  echo -n "task009 fp32: "; run
-  echo -n "task100 fp32: "; run --workload task100
-  echo -n "resenc fp32: "; run --workload resenc
-  echo -n "resenc bf16: "; run --workload resenc --precision bf16
+  for w in $WL; do
+    case $w in
+      task009) echo -n "task009 fp32: "; run ;;
+      task100) echo -n "task100 fp32: "; run --workload task100 ;;
+      resenc) echo -n "resenc fp32: "; run --workload resenc ;;
+      resenc_bf16) echo -n "resenc bf16: "; run --workload resenc --precision bf16 ;;
+      task009_bf16) echo -n "task009 bf16: "; run --precision bf16 ;;
+    esac
+  done
 done
