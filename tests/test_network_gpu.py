@@ -178,3 +178,51 @@ def test_inference_mode_single_output(dev):
         out = net(x.to(dev))
     assert tuple(out.shape) == tuple(ref.shape)
     assert float((out.cpu() - ref).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("arch", ["plain", "resenc"])
+def test_weight_gradient_stream_changes_nothing(dev, arch):
+    """Engine.weight_stream: the backward-weight launches (and the backward-only weight packings) run on a side HIP stream beside the
+    backward-data chain.  Same kernels, same ordered reductions: logits and EVERY gradient must be bit-identical with the stream on
+    (default) and off, three iterations in a row (the second and third reuse the buffers while the side stream may still be busy)."""
+    from multitalent_amd.training.loss_functions.fused_losses import DC_and_CE_DS_loss
+    B, shape = 2, (8, 32, 32)
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn((B, 1) + shape, generator=g).to(dev) for _ in range(3)]
+
+    def run(streams):
+        if arch == "plain":
+            nc = 3
+            net, pools, _ = build_plain(nc)
+            scales = [[1, 1, 1], [.5, .5, .5], [.25, .25, .25]]
+        else:
+            from multitalent_amd.network_architecture.generic_modular_residual_UNet import FabiansUNet, get_default_network_config
+            from multitalent_amd.network_architecture.initialization import InitWeights_He
+            nc = 3
+            torch.manual_seed(0)
+            net = FabiansUNet(1, 8, [1, 2, 2, 2], 2, [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2]], [[1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+                              get_default_network_config(3, None, norm_type="in"), nc, [1, 1, 1], True, False, 24, InitWeights_He(1e-2))
+            scales = [[1, 1, 1], [1, .5, .5], [.5, .25, .25]]
+        net.train()
+        net.engine().bwdw_streams = streams
+        targets = [t.to(dev) for t in make_targets(shape, scales, nc, B, seed=4)]
+        loss = DC_and_CE_DS_loss([0.5, 0.3, 0.2])
+        outs = []
+        for x in xs:
+            for p in net.parameters():
+                p.grad = None
+            out = net(x)
+            l = loss(out, targets)
+            l.backward()
+            torch.cuda.synchronize()
+            outs.append([out[0].detach().clone()] + [p.grad.detach().clone() for p in net.parameters()])
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(p.grad, alpha=-0.05)            # the next iteration packs new weights (late packing on the side stream)
+            net.engine().mark_params_dirty()
+        return outs
+
+    on, off = run(1), run(0)
+    for it, (a, b) in enumerate(zip(on, off)):
+        for i, (u, v) in enumerate(zip(a, b)):
+            assert torch.equal(u, v), (it, i)
