@@ -409,6 +409,11 @@ def bench_infer(args, dev, rank, world, ddp, emit=True):
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    groups = None
+    if not args.no_roofline:          # every rank repeats one volume with per-launch events (the sharded run exchanges slabs)
+        with ConvTimer() as t:
+            run()
+            groups = t.groups()
     if rank == 0:
         steps = compute_steps_for_sliding_window(patch, tuple(args.volume), 0.5)
         ntiles = len(steps[0]) * len(steps[1]) * len(steps[2])
@@ -419,26 +424,28 @@ def bench_infer(args, dev, rank, world, ddp, emit=True):
             "config": {"workload": "predict_MultiTalent sliding window, Generic_UNet nc=47 sigmoid", "volume": list(args.volume),
                        "patch": list(patch), "tiles": ntiles, "step_size": 0.5, "gaussian": True, "mirror_tta": bool(args.mirror),
                        "parallelism": "tile-shard%d" % world}}
-        if world == 1 and not args.no_roofline:
-            with ConvTimer() as t:
-                run()
-                groups = t.groups()
+        if groups is not None:
             line["roofline"] = roofline_from_groups(groups, 1, args.precision)
-            if not args.no_traffic:
+            line["roofline"]["launches"] = "in step (forward only: one stream)"
+            if world == 1 and not args.no_traffic:
                 line["roofline"].update(measure_traffic(line["roofline"]["kernel"], child_argv(args)))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_infer(patch, ntiles, bool(args.mirror))
         stats = getattr(net, '_slab_exchange_stats', None)
         if stats is not None:
             line["comm"] = stats
-        if emit:
-            print(json.dumps(line), flush=True)
     else:
         line = None
     del net
-    if emit and ddp:
-        dist.barrier()
-        dist.destroy_process_group()
+    if emit:
+        if ddp:
+            flush_c_stdio()
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if ddp:
+            dist.barrier()
+            dist.destroy_process_group()
     return line
 
 
@@ -535,13 +542,14 @@ def measure_also(args, dev, rank, world, ddp):
     todo = [('task100', 'fp32'), ('resenc', 'fp32'), ('resenc', 'bf16')] if world == 1 else [('task100', 'fp32'), ('resenc', 'bf16')]
     for workload, precision in todo:
         B = DEFAULT_BATCH[workload]
-        r = time_training(workload, precision, patch, B, args.also_steps, 2, dev, rank, world, ddp)
+        r = time_training(workload, precision, patch, B, args.also_steps, 3, dev, rank, world, ddp)
+        rf = None if args.no_roofline else measure_roofline(r['step'], r['x'], r['largs'], precision, nrep=2)     # all ranks (collectives inside)
         if rank == 0:
-            e = training_line(r, workload, precision, patch, B, args.also_steps, 2, world)
+            e = training_line(r, workload, precision, patch, B, args.also_steps, 3, world)
             e = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "algorithmic_tflop_per_step",
                                    "step_frac_of_fp32_mfma_roofline", "comm") if k in e}
-            if world == 1 and not args.no_roofline:
-                e["roofline"] = measure_roofline(r['step'], r['x'], r['largs'], precision, nrep=2)
+            if rf is not None:
+                e["roofline"] = rf
             also[workload + ('' if precision == 'fp32' else '_bf16')] = e
         del r
         torch.cuda.empty_cache()
@@ -601,24 +609,40 @@ def main():
     line = None
     if rank == 0:
         line = training_line(r, workload, args.precision, patch, B, args.steps, args.warmup, world)
-    if rank == 0 and world == 1:
-        if not args.no_roofline:
-            line["roofline"] = measure_roofline(r['step'], r['x'], r['largs'], args.precision)
-            if not args.no_traffic:
+    if not args.no_roofline:
+        # every rank runs the per-launch pass (the step contains the gradient all-reduce); rank 0 reports its own launches
+        rf = measure_roofline(r['step'], r['x'], r['largs'], args.precision)
+        if rank == 0:
+            line["roofline"] = rf
+            if world == 1 and not args.no_traffic:
                 line["roofline"].update(measure_traffic(line["roofline"]["kernel"], child_argv(args)))
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(workload, patch)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(workload, patch)
     del r
     torch.cuda.empty_cache()
     if args.workload is None and not args.no_also:
         also = measure_also(args, dev, rank, world, ddp)
         if rank == 0:
             line["also"] = also
+    if ddp:
+        flush_c_stdio()
+        dist.barrier()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if ddp:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def flush_c_stdio():
+    """RCCL writes its version banner to stdout through C stdio, which a pipe buffers until exit — it would land AFTER the JSON line.
+    Every rank flushes C stdio before the barrier that precedes rank 0's print, so the JSON line is the last line of the job."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
 
 
 if __name__ == '__main__':
