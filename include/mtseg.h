@@ -243,7 +243,17 @@ int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* 
 int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale, const float* shift,
                  float slope, const float* y2, int y2cs, const float* scale2, const float* shift2,
                  float slope2, float* gcopy, int gcopycs, int N, long V, int C, mt_stream_t stream);
+/* mt_lrelu_bwd on dense tensors (channel stride == C) that also emits the first pass of the NEXT InstanceNorm backward: in a residual
+ * block out = lrelu(IN(y) + residual) (conv_blocks.py:201-213) the masked gradient g' is the gradient of IN(y), so
+ * part[n][blk][c] = (sum g', sum g' * (y - mean) * rstd) over the block's voxels — mt_inorm_lrelu_bwd(part, part_nblk =
+ * mt_lrelu_bwd_stats_blocks(V, C), part_cs = C, part_c0 = 0) then skips its own reduction over (g', y).  mean / rstd: [N][C] of that
+ * norm.  mt_lrelu_bwd_stats_blocks returns 0 for shapes this path does not take (C % 4 != 0, C > 1024). */
+int mt_lrelu_bwd_stats_blocks(long V, int C);
+int mt_lrelu_bwd_stats(float* g, const float* y, const float* scale, const float* shift, float slope,
+                       const float* y2, const float* scale2, const float* shift2, float slope2, float* gcopy,
+                       const float* mean, const float* rstd, float* part, int N, long V, int C, mt_stream_t stream);
 /* per-channel sum over all voxels: out[C] (+)= sum_{n,v} x[n,v,c]  (bias gradients of heads) */
+size_t mt_channel_sum_workspace(int N, long V, int C);
 int mt_channel_sum(const float* x, int xcs, int N, long V, int C, float* out, int accumulate,
                    void* ws, size_t ws_bytes, mt_stream_t stream);
 

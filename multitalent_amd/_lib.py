@@ -93,6 +93,9 @@ SIGNATURES = {
     'mt_inorm_bwd_workspace': (_sz, [_i, _l, _i]),
     'mt_inorm_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _i, _l, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     'mt_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _vp]),
+    'mt_lrelu_bwd_stats_blocks': (_i, [_l, _i]),
+    'mt_lrelu_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _l, _i, _vp]),
+    'mt_channel_sum_workspace': (_sz, [_i, _l, _i]),
     'mt_channel_sum': (_i, [_vp, _i, _i, _l, _i, _vp, _i, _vp, _sz, _vp]),
     'mt_multitalent_loss_fwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'mt_loss_workspace': (_sz, [_i, _l, _i]),

@@ -54,8 +54,16 @@ extern "C" int mt_inorm_finalize(const float* part, int N, int nsb, int C, doubl
 
 // ---- generic voxel-block geometry for channel-lane kernels -------------------------------------
 // grid = (nvb, N); block 256 = 8 voxel rows x 32 channel lanes; block covers VB voxels.
-#define NB_VB 2048
-static inline int nb_blocks(long V) { return mt_cdiv(V, NB_VB); }
+// Voxels per workgroup of the streaming kernels below (one definition for host and device: the partial-sum buffers are indexed by
+// it).  2048 at full resolution (1 728 workgroups for 2 x 48 x 192 x 192); a fixed 2048 left the mid-resolution layers with ~200
+// workgroups of 256 threads on 256 CUs — 2.9 TB/s where the full-resolution launches reach 5.4 — so smaller tensors get
+// proportionally smaller blocks (>= 128 voxels, about 512 blocks per sample).
+__host__ __device__ static inline int mt_vb(long V) {
+  if (V >= 2048L * 512) return 2048;
+  long vb = ((V + 511) / 512 + 63) / 64 * 64;
+  return vb < 128 ? 128 : (int)vb;
+}
+static inline int nb_blocks(long V) { return mt_cdiv(V, (long)mt_vb(V)); }
 
 // ---- materialise a = lrelu(y*sc+sh [+ residual]) ----------------------------------------------
 struct ApplyParams {
@@ -66,8 +74,9 @@ struct ApplyParams {
 __global__ __launch_bounds__(256) void inorm_apply_kernel(const ApplyParams P) {
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
-  const long v0 = (long)blockIdx.x * NB_VB;
-  const long v1 = (v0 + NB_VB < P.V) ? v0 + NB_VB : P.V;
+  const int vb = mt_vb(P.V);
+  const long v0 = (long)blockIdx.x * vb;
+  const long v1 = (v0 + vb < P.V) ? v0 + vb : P.V;
   for (int cb = 0; cb < P.C; cb += 32) {
     const int c = cb + cl;
     if (c >= P.C) continue;
@@ -112,8 +121,9 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const InBwdParams
   __shared__ float red[8][32][2];
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
-  const long v0 = (long)blockIdx.x * NB_VB;
-  const long v1 = (v0 + NB_VB < P.V) ? v0 + NB_VB : P.V;
+  const int vb = mt_vb(P.V);
+  const long v0 = (long)blockIdx.x * vb;
+  const long v1 = (v0 + vb < P.V) ? v0 + vb : P.V;
   for (int cb = 0; cb < P.C; cb += 32) {
     const int c = cb + cl;
     float a = 0.f, b = 0.f;
@@ -178,8 +188,9 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const InBwdParams 
   __shared__ float red[8][32];
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
-  const long v0 = (long)blockIdx.x * NB_VB;
-  const long v1 = (v0 + NB_VB < P.V) ? v0 + NB_VB : P.V;
+  const int vb = mt_vb(P.V);
+  const long v0 = (long)blockIdx.x * vb;
+  const long v1 = (v0 + vb < P.V) ? v0 + vb : P.V;
   for (int cb = 0; cb < P.C; cb += 32) {
     const int c = cb + cl;
     float sdy = 0.f;
@@ -380,8 +391,9 @@ struct LBwdParams {
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const LBwdParams P) {
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
-  const long v0 = (long)blockIdx.x * NB_VB;
-  const long v1 = (v0 + NB_VB < P.V) ? v0 + NB_VB : P.V;
+  const int vb = mt_vb(P.V);
+  const long v0 = (long)blockIdx.x * vb;
+  const long v1 = (v0 + vb < P.V) ? v0 + vb : P.V;
   for (int cb = 0; cb < P.C; cb += 32) {
     const int c = cb + cl;
     if (c >= P.C) continue;
@@ -492,13 +504,116 @@ extern "C" int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const fl
   return MT_OK;
 }
 
+// ---- the same with the first pass of the NEXT InstanceNorm backward fused in (residual blocks) ------------------------------------
+// out = lrelu(IN(y) + residual): the masked gradient g' = g * lrelu'(t) is the gradient of IN(y) (norm2 of the block, no nonlinearity
+// of its own), so the sums its norm backward needs, A = sum g' and B = sum g' * zhat with zhat = (y - mean) * rstd, can be taken
+// while g' is being produced — mt_inorm_lrelu_bwd(part = ...) then skips its own reduction over (g', y).  Dense tensors only (channel
+// stride == C); thread t keeps VEC constant channels (the mapping of inorm_bwd_fast_kernel), partials [N][nblk][C][2].
+struct LBwdStats {
+  float* g; const float* y; const float* y2; float* gcopy;
+  const float* scale; const float* shift; float slope;
+  const float* scale2; const float* shift2; float slope2;
+  const float* mean; const float* rstd;
+  long nvec; int C, G, A, nblk;
+  float* part;
+};
+template <int VEC>
+__global__ __launch_bounds__(256) void lrelu_bwd_stats_kernel(const LBwdStats P) {
+  typedef typename VecT<VEC>::T VT;
+  __shared__ float red[256 * VEC * 2];
+  const int n = blockIdx.y, t = threadIdx.x;
+  const bool act = t < P.A;
+  const int grp = t % P.G;
+  const bool has2 = P.y2 != nullptr;
+  float sc[VEC], sh[VEC], sc2[VEC], sh2[VEC], mu[VEC], rs[VEC], a0[VEC], a1[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const size_t k = (size_t)n * P.C + grp * VEC + e;
+    sc[e] = P.scale ? P.scale[k] : 1.f; sh[e] = P.scale ? P.shift[k] : 0.f;
+    sc2[e] = (has2 && P.scale2) ? P.scale2[k] : 1.f; sh2[e] = (has2 && P.scale2) ? P.shift2[k] : 0.f;
+    mu[e] = P.mean[k]; rs[e] = P.rstd[k];
+    a0[e] = 0.f; a1[e] = 0.f;
+  }
+  const long per = ((P.nvec + P.nblk - 1) / P.nblk + P.A - 1) / P.A * P.A;
+  const long lo = (long)blockIdx.x * per;
+  long hi = lo + per; if (hi > P.nvec) hi = P.nvec;
+  VT* gp = (VT*)(P.g + (size_t)n * P.nvec * VEC);
+  VT* cp = P.gcopy ? (VT*)(P.gcopy + (size_t)n * P.nvec * VEC) : nullptr;
+  const VT* yp = (const VT*)(P.y + (size_t)n * P.nvec * VEC);
+  const VT* y2p = has2 ? (const VT*)(P.y2 + (size_t)n * P.nvec * VEC) : nullptr;
+  if (act) {
+    for (long i0 = lo + t; i0 < hi; i0 += (long)P.A * NF_UNROLL) {
+      VT gv[NF_UNROLL], yv[NF_UNROLL], y2v[NF_UNROLL];
+#pragma unroll
+      for (int u = 0; u < NF_UNROLL; ++u) {
+        const long i = i0 + (long)u * P.A;
+        if (i < hi) { gv[u] = gp[i]; yv[u] = yp[i]; if (has2) y2v[u] = y2p[i]; }
+      }
+#pragma unroll
+      for (int u = 0; u < NF_UNROLL; ++u) {
+        const long i = i0 + (long)u * P.A;
+        if (i < hi) {
+          VT out;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float yy = vget<VEC>(yv[u], e);
+            float tt = fmaf(yy, sc[e], sh[e]);
+            if (has2) tt += mt_lrelu(fmaf(vget<VEC>(y2v[u], e), sc2[e], sh2[e]), P.slope2);
+            float gg = vget<VEC>(gv[u], e);
+            gg = tt > 0.f ? gg : gg * P.slope;
+            vset<VEC>(out, e, gg);
+            const float zh = (yy - mu[e]) * rs[e];
+            a0[e] += gg;
+            a1[e] = fmaf(gg, zh, a1[e]);
+          }
+          gp[i] = out;
+          if (cp) cp[i] = out;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { red[(t * VEC + e) * 2] = act ? a0[e] : 0.f; red[(t * VEC + e) * 2 + 1] = act ? a1[e] : 0.f; }
+  __syncthreads();
+  if (t < P.G) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int k = t; k < P.A; k += P.G) { s0 += red[(k * VEC + e) * 2]; s1 += red[(k * VEC + e) * 2 + 1]; }
+      float* o = P.part + (((size_t)n * P.nblk + blockIdx.x) * P.C + t * VEC + e) * 2;
+      o[0] = s0; o[1] = s1;
+    }
+  }
+}
+// blocks per sample of the partials (0: the tensors do not take the fused path — call mt_lrelu_bwd and let the norm backward reduce)
+extern "C" int mt_lrelu_bwd_stats_blocks(long V, int C) {
+  if (V <= 0 || C <= 0 || (C % 4) != 0 || C / 4 > 256 || (((long)V * C * 4) % 16) != 0) return 0;
+  return nb_blocks(V);
+}
+extern "C" int mt_lrelu_bwd_stats(float* g, const float* y, const float* scale, const float* shift, float slope,
+                                  const float* y2, const float* scale2, const float* shift2, float slope2, float* gcopy,
+                                  const float* mean, const float* rstd, float* part, int N, long V, int C, mt_stream_t stream) {
+  MT_REQUIRE(g && y && mean && rstd && part && N > 0, "lrelu_bwd_stats: bad args");
+  const int nblk = mt_lrelu_bwd_stats_blocks(V, C);
+  MT_REQUIRE(nblk > 0, "lrelu_bwd_stats: unsupported shape (V=%ld, C=%d): ask mt_lrelu_bwd_stats_blocks", V, C);
+  MT_REQUIRE(((((uintptr_t)g) | ((uintptr_t)y) | ((uintptr_t)y2) | ((uintptr_t)gcopy)) & 15) == 0, "lrelu_bwd_stats: tensors must be 16-byte aligned");
+  LBwdStats P;
+  P.g = g; P.y = y; P.y2 = y2; P.gcopy = gcopy; P.scale = scale; P.shift = shift; P.slope = slope;
+  P.scale2 = scale2; P.shift2 = shift2; P.slope2 = slope2; P.mean = mean; P.rstd = rstd;
+  P.nvec = (long)V * C / 4; P.C = C; P.G = C / 4; P.A = (256 / P.G) * P.G; P.nblk = nblk; P.part = part;
+  hipLaunchKernelGGL(lrelu_bwd_stats_kernel<4>, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, P);
+  MT_CHECK_LAUNCH("lrelu_bwd_stats");
+  return MT_OK;
+}
+
 // ---- per-channel sum -------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* x, int xcs, long V, int C, int nvb, float* part) {
   __shared__ float red[8][32];
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
-  const long v0 = (long)blockIdx.x * NB_VB;
-  const long v1 = (v0 + NB_VB < V) ? v0 + NB_VB : V;
+  const int vb = mt_vb(V);
+  const long v0 = (long)blockIdx.x * vb;
+  const long v1 = (v0 + vb < V) ? v0 + vb : V;
   for (int cb = 0; cb < C; cb += 32) {
     const int c = cb + cl;
     float a = 0.f;
@@ -515,6 +630,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* x, int xc
     __syncthreads();
   }
 }
+extern "C" size_t mt_channel_sum_workspace(int N, long V, int C) { return (size_t)N * nb_blocks(V) * C * sizeof(float); }
 extern "C" int mt_channel_sum(const float* x, int xcs, int N, long V, int C, float* out, int accumulate, void* ws,
                               size_t ws_bytes, mt_stream_t stream) {
   MT_REQUIRE(x && out && N > 0 && V > 0 && C > 0, "channel_sum: bad args");

@@ -198,7 +198,7 @@ class ConvNormOp(_Op):
             ops.inorm_lrelu_bwd(gact, a, self.norm.weight, self.norm.bias, eng.grad_of(self.norm.weight),
                                 eng.grad_of(self.norm.bias), dbias, ws, part=part, part_c0=part_c0)
         elif dbias is not None:
-            ws = eng.workspace(4 * gact.N * ((gact.V + 2047) // 2048) * gact.C)
+            ws = eng.workspace(ops.channel_sum_workspace(gact.N, gact.V, gact.C))
             ops.channel_sum(gact, dbias, False, ws)
         # backward-weight straight into the flat gradient buffer (torch parameter layout)
         acts = [s.act for s in self.srcs]
@@ -261,7 +261,7 @@ class ConvNormOp(_Op):
         """When this launch is the LAST writer of a source's gradient and that source is the output of a conv + InstanceNorm layer,
         the kernel also emits the first pass of that layer's norm backward (sum dz, sum dz zhat per block; mt_bwd_stats_t): the
         separate reduction over (g, y) — 45 % of the norm backward's time — disappears.  One source per launch."""
-        if not eng.fuse_norm_bwd:
+        if eng.fuse_norm_bwd not in (1, 2):
             return
         c0 = 0
         for s in self.srcs:
@@ -369,11 +369,24 @@ class ResAddOp(_Op):
         from . import _lib
         import ctypes as C
         gm = self.main.grad
-        # main branch gets its own buffer (it is transformed in place by the norm backward)
-        _lib.check(_lib.load().mt_lrelu_bwd(
-            C.c_void_p(g.data_ptr()), g.shape[4], C.c_void_p(m.data_ptr()), m.cs, ops._ptr(m.scale), ops._ptr(m.shift), self.slope,
-            C.c_void_p(r.data_ptr()), r.cs, ops._ptr(r.scale), ops._ptr(r.shift), r.slope,
-            C.c_void_p(gm.data_ptr()), gm.shape[4], m.N, m.V, m.C, ops._stream()), 'lrelu_bwd')
+        # main branch gets its own buffer (it is transformed in place by the norm backward).  When the main branch is conv -> norm
+        # (always, in the residual encoder) the kernel also takes the first pass of that norm's backward over the gradient it is
+        # producing (mt_lrelu_bwd_stats): the norm backward's own reduction over (g', y) disappears.
+        prod = eng.producer.get(id(self.main)) if eng.fuse_norm_bwd in (1, 3) else None
+        nblk = _lib.load().mt_lrelu_bwd_stats_blocks(m.V, m.C)
+        if (prod is not None and isinstance(prod, ConvNormOp) and prod.norm is not None and m.mean is not None and nblk > 0
+                and g.shape[4] == m.C and gm.shape[4] == m.C and m.cs == m.C and r.cs == m.C):
+            part = eng.buffer(self.name + '.bwdpart', (m.N, nblk, m.C, 2))
+            _lib.check(_lib.load().mt_lrelu_bwd_stats(
+                C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()), ops._ptr(m.scale), ops._ptr(m.shift), self.slope,
+                C.c_void_p(r.data_ptr()), ops._ptr(r.scale), ops._ptr(r.shift), r.slope, C.c_void_p(gm.data_ptr()),
+                ops._ptr(m.mean), ops._ptr(m.rstd), ops._ptr(part), m.N, m.V, m.C, ops._stream()), 'lrelu_bwd_stats')
+            prod.bwd_part = (part, 0)
+        else:
+            _lib.check(_lib.load().mt_lrelu_bwd(
+                C.c_void_p(g.data_ptr()), g.shape[4], C.c_void_p(m.data_ptr()), m.cs, ops._ptr(m.scale), ops._ptr(m.shift), self.slope,
+                C.c_void_p(r.data_ptr()), r.cs, ops._ptr(r.scale), ops._ptr(r.shift), r.slope,
+                C.c_void_p(gm.data_ptr()), gm.shape[4], m.N, m.V, m.C, ops._stream()), 'lrelu_bwd')
         self.main.grad_init = True
         # residual branch: g itself (already masked) is added to / becomes the residual's gradient
         if self.res.grad is not None:
@@ -413,7 +426,7 @@ class HeadOp(ConvNormOp):
         st = _strides(w)                                 # (s_ci, s_co, ...) of the [Cout, Cin, 1, 1, 1] weight
         done = ops.head_bwd(a, gact, self.wb, Act(s0.grad), s0.grad_init, eng.grad_of(w), st[0], st[1], dbias, False, ws)
         if dbias is not None and not done:
-            ws2 = eng.workspace(4 * gact.N * ((gact.V + 2047) // 2048) * gact.C)
+            ws2 = eng.workspace(ops.channel_sum_workspace(gact.N, gact.V, gact.C))
             ops.channel_sum(gact, dbias, False, ws2)
         s0.grad_init = True
 
@@ -443,7 +456,11 @@ class Engine:
         self.grad_ready_hook = None         # callable(lo, hi) on flat_grad element ranges, in completion order
         self.dummy = None
         self.mma = 0                        # matrix input type of the convolutions: 0 fp32, 1 bf16 (mixed precision)
-        self.fuse_norm_bwd = os.environ.get('MT_FUSE_NORM_BWD', '1') != '0'    # ConvNormOp._fuse_norm_bwd_stats
+        # first pass of a norm backward taken by the kernel that produces the gradient (ConvNormOp._fuse_norm_bwd_stats, ResAddOp.backward):
+        # 0 off, 1 on, 2 convolutions only, 3 residual adds only.  Default: on only when everything runs on ONE stream — beside the
+        # weight-gradient stream the separate (bandwidth-bound) reduction overlaps the (matrix-bound) backward-weight launches and
+        # fusing it into the matrix-bound kernel on the chain measured 0 ... +0.3 ms per step
+        self.fuse_norm_bwd = int(os.environ.get('MT_FUSE_NORM_BWD', '1' if self.bwdw_streams == 0 else '0'))
         self.producer, self.pending = {}, {}
 
     def set_precision(self, precision):

@@ -386,6 +386,10 @@ def set_bwd_stats(p, y_act, gamma, beta, c0):
     b.slope = float(y_act.slope)
 
 
+def channel_sum_workspace(N, V, Cn):
+    return _lib.load().mt_channel_sum_workspace(N, V, Cn)
+
+
 def channel_sum(x, out, accumulate, ws):
     _lib.check(_lib.load().mt_channel_sum(C.c_void_p(x.data_ptr()), x.cs, x.N, x.V, x.C, _ptr(out), int(accumulate), _ptr(ws),
                                           ws.numel() * ws.element_size(), _stream()), 'channel_sum')

@@ -226,3 +226,46 @@ def test_weight_gradient_stream_changes_nothing(dev, arch):
     for it, (a, b) in enumerate(zip(on, off)):
         for i, (u, v) in enumerate(zip(a, b)):
             assert torch.equal(u, v), (it, i)
+
+
+@pytest.mark.parametrize("arch", ["plain", "resenc"])
+def test_fused_norm_backward_statistics_through_the_engine(dev, arch):
+    """Engine.fuse_norm_bwd (default on only without the weight-gradient stream): the convolution / residual add that produces a norm
+    layer's output gradient also emits the first pass of that norm's backward (mt_bwd_stats_t, mt_lrelu_bwd_stats).  Same sums in a
+    different order: every gradient within 2e-5 of the unfused engine's, relative to the tensor's largest entry."""
+    from multitalent_amd.training.loss_functions.fused_losses import DC_and_CE_DS_loss
+    from multitalent_amd import ops
+    B, shape = 2, (8, 32, 64)
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn((B, 1) + shape, generator=g).to(dev)
+    ops.set_option('conv_wino', 2)                   # the Winograd kernels (the ones that fuse) also at this small size
+    try:
+        def run(fuse):
+            nc = 3
+            if arch == "plain":
+                net, pools, _ = build_plain(nc, base=16)
+                scales = [[1, 1, 1], [.5, .5, .5], [.25, .25, .25]]
+            else:
+                from multitalent_amd.network_architecture.generic_modular_residual_UNet import FabiansUNet, get_default_network_config
+                from multitalent_amd.network_architecture.initialization import InitWeights_He
+                torch.manual_seed(0)
+                net = FabiansUNet(1, 16, [1, 2, 2, 2], 2, [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2]], [[1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+                                  get_default_network_config(3, None, norm_type="in"), nc, [1, 1, 1], True, False, 48, InitWeights_He(1e-2))
+                scales = [[1, 1, 1], [1, .5, .5], [.5, .25, .25]]
+            net.train()
+            eng = net.engine()
+            eng.fuse_norm_bwd = fuse
+            targets = [t.to(dev) for t in make_targets(shape, scales, nc, B, seed=4)]
+            out = net(x)
+            DC_and_CE_DS_loss([0.5, 0.3, 0.2])(out, targets).backward()
+            torch.cuda.synchronize()
+            fused = sum(1 for k in eng._buffers if k.endswith('.bwdpart'))
+            return [p.grad.detach().clone() for p in net.parameters()], fused
+        on, n_on = run(1)
+        off, n_off = run(0)
+        assert n_on > 0 and n_off == 0, (n_on, n_off)          # the fused path really ran (its partial buffers exist) / did not
+        for i, (a, b) in enumerate(zip(on, off)):
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-3), i
+    finally:
+        ops.set_option('conv_wino', 1)
