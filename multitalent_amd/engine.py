@@ -451,6 +451,7 @@ class Engine:
         self.wstreams = []                  # side streams of the backward-weight launches (Engine.weight_stream)
         self._wnext = 0
         self._late_pack = None
+        self._mid_pack = None
         self._ws_side = {}
         self.bwdw_streams = int(os.environ.get('MT_BWDW_STREAMS', '1'))
         self.grad_ready_hook = None         # callable(lo, hi) on flat_grad element ranges, in completion order
@@ -615,28 +616,46 @@ class Engine:
         ops.set_mma(self.mma)
         if key not in self._pack_programs:   # record the ops' packing calls once; afterwards every step is one batched launch
             def record(bwd):
-                rec = []
+                rec, owner = [], []
                 ops._pack_recorder = rec
                 try:
-                    for op in self.ops:
+                    for i, op in enumerate(self.ops):
                         op.pack(self, bwd)
+                        owner += [i] * (len(rec) - len(owner))
                 finally:
                     ops._pack_recorder = None
-                return rec
-            rec = record(need_grad)
-            late = []
+                return rec, owner
+            rec, owner = record(need_grad)
+            late, mid, mid_op = [], [], None
             if need_grad and self.bwdw_streams > 0 and self.flat.is_cuda:
-                # the packings only backward reads (flipped / transposed weights of the backward-data launches) go to the side stream
-                # and overlap the forward pass; Engine.backward waits for them
-                fwd_dst = {r[1].data_ptr() for r in record(False)}
-                late = [r for r in rec if r[1].data_ptr() not in fwd_dst]
-                rec = [r for r in rec if r[1].data_ptr() in fwd_dst]
-            prog = (ops.PackProgram(rec, self.device) if rec else None, ops.PackProgram(late, self.device) if late else None)
+                # Off the chain, on the side stream: (a) the packings only backward reads (flipped / transposed weights of the
+                # backward-data launches) — Engine.backward waits for them; (b) the forward packings of the DEEP layers (almost all
+                # of the bytes: the 240..320-channel stages), which the forward pass only needs after the full-resolution layers
+                # have run for milliseconds — Engine.forward waits for them in front of op `mid_op`.  The main stream packs what the
+                # first layers need (2 MB) and starts.
+                fwd_dst = {r[1].data_ptr() for r in record(False)[0]}
+                is_fwd = [r[1].data_ptr() in fwd_dst for r in rec]
+                late = [r for r, f in zip(rec, is_fwd) if not f]
+                acc = 0
+                for r, f, o in zip(rec, is_fwd, owner):
+                    if f:
+                        acc += r[1].numel() * 4
+                        if acc > (2 << 20) and o > 0 and os.environ.get('MT_PACK_SPLIT', '1') != '0':
+                            mid_op = o
+                            break
+                if mid_op is not None:
+                    mid = [r for r, f, o in zip(rec, is_fwd, owner) if f and o >= mid_op]
+                    rec = [r for r, f, o in zip(rec, is_fwd, owner) if f and o < mid_op]
+                else:
+                    rec = [r for r, f in zip(rec, is_fwd) if f]
+            mk = lambda rr: ops.PackProgram(rr, self.device) if rr else None
+            prog = (mk(rec), mk(late), mk(mid), mid_op)
             self._pack_programs[key] = prog
         self._late_pack = None
+        self._mid_pack = None
         if prog[0] is not None:
             prog[0].run()
-        if prog[1] is not None:
+        if prog[1] is not None or prog[2] is not None:
             if not self.wstreams:
                 self.wstreams = [self._side_stream() for _ in range(self.bwdw_streams)]
             st = self.wstreams[0]
@@ -644,9 +663,14 @@ class Engine:
             ev.record(torch.cuda.current_stream())      # behind the optimizer step that wrote the weights
             st.wait_event(ev)
             with torch.cuda.stream(st):
-                prog[1].run()
-                self._late_pack = torch.cuda.Event()
-                self._late_pack.record(st)
+                if prog[2] is not None:
+                    prog[2].run()
+                    self._mid_pack = (prog[3], torch.cuda.Event())
+                    self._mid_pack[1].record(st)
+                if prog[1] is not None:
+                    prog[1].run()
+                    self._late_pack = torch.cuda.Event()
+                    self._late_pack.record(st)
         self._packed_version = ver
 
     # ---- execution --------------------------------------------------------------------------------
@@ -680,7 +704,10 @@ class Engine:
         skip_heads = set()
         if not all_heads:
             skip_heads = {id(self.heads[i]) for i in range(len(self.heads)) if i != self.final_head or _skip_final}
-        for op in self.ops:
+        for i, op in enumerate(self.ops):
+            if self._mid_pack is not None and i >= self._mid_pack[0]:      # the deep layers' packed weights (Engine._pack)
+                torch.cuda.current_stream().wait_event(self._mid_pack[1])
+                self._mid_pack = None
             if isinstance(op, HeadOp) and id(op.out) in skip_heads:
                 continue
             op.forward(self)

@@ -3,8 +3,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmcbench
 mkdir -p $O
 for prec in fp32 bf16; do
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${prec}_fetch -o b -- python $R/bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/${prec}_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${prec}_write -o b -- python $R/bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/${prec}_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${prec}_fetch -o b -- python $R/bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-also --no-traffic > $O/${prec}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${prec}_write -o b -- python $R/bench.py --precision $prec --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-also --no-traffic > $O/${prec}_write.log 2>&1
 done
 python - <<'PY'
 import csv, json, os, collections
