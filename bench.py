@@ -554,7 +554,7 @@ def measure_also(args, dev, rank, world, ddp):
         del r
         torch.cuda.empty_cache()
     ia = argparse.Namespace(**vars(args))
-    ia.workload, ia.mirror, ia.steps, ia.warmup, ia.no_cpu_baseline, ia.no_traffic, ia.precision = 'infer', 0, 1, 1, True, True, 'fp32'
+    ia.workload, ia.mirror, ia.steps, ia.warmup, ia.no_cpu_baseline, ia.no_traffic, ia.precision = 'infer', 0, 2, 1, True, True, 'fp32'
     e = bench_infer(ia, dev, rank, world, ddp, emit=False)
     if rank == 0:
         also['infer_512_nomirror'] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "scaling", "comm") if k in e}
