@@ -21,6 +21,16 @@ def _wrap(f):
         return f(p, *a)
     return g
 _ops.conv_kernel_name, _ops.conv_bwd_weight_kernel_name, _ops.conv_bwd_data_strided_kernel_name = [_wrap(f) for f in _names]
+pw_rows = []
+_pw = _ops.pointwise_fwd
+def _pw_timed(p):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); _pw(p); e1.record()
+    taps = p.soD * p.soH * p.soW
+    vb = p.N * p.Db * p.Hb * p.Wb
+    pw_rows.append(('pointwise base %dx%dx%d si %d%d%d so %d%d%d %d->%d acc%d' % (p.Db, p.Hb, p.Wb, p.siD, p.siH, p.siW, p.soD, p.soH, p.soW, p.Cin, p.Cout, p.accumulate),
+                    2.0 * vb * p.Cin * p.Cout * taps, 4.0 * vb * (p.Cin + p.Cout * taps * (2 if p.accumulate else 1)), e0, e1))
+_ops.pointwise_fwd = _pw_timed
 with bench.ConvTimer() as t:
     r['step'](r['x'], *r['largs'])
     torch.cuda.synchronize()
@@ -34,6 +44,8 @@ with bench.ConvTimer() as t:
     seq.sort(key=lambda q: first.elapsed_time(q[0]))
     for (q, sh) in zip(seq, shapes):
         rows.append((q[1] + ' ' + sh, q[2], q[3], q[4]))
+for (nm, fl, nb, e0, e1) in pw_rows:
+    rows.append((nm, fl, nb, e0.elapsed_time(e1)))
 rows.sort(key=lambda q: -q[3])
 tot = sum(q[3] for q in rows)
 print('%d conv launches, %.2f ms' % (len(rows), tot))
