@@ -637,6 +637,68 @@ __global__ __launch_bounds__(256) void pw_head_kernel(const PwKParams P) {
   }
 }
 
+// ---- narrow heads: 1x1x1 convolution to <= 4 output channels (the heads of the few-class single-dataset trainers: 2 logits for
+// Task009) from a dense CIN-channel tensor.  The MFMA forms spend a 32-wide output tile on 2 channels and fetch their A fragments as
+// 32-byte pieces of 120-byte rows (2.7 TB/s); here a thread owns a voxel: its row is one contiguous run (consecutive lanes = consecutive
+// rows: the wave reads 7.5 KiB linearly), the lazy InstanceNorm+LeakyReLU and CIN x Cout multiply-adds run on the vector ALU
+// (60 FMAs per 120 bytes: far below the bandwidth bound), W / scale / shift come from LDS as broadcast reads.
+template <int CIN>
+__global__ __launch_bounds__(256) void pw_narrow_kernel(const PwKParams P) {
+  const mt_pointwise_t& c = P.c;
+  __shared__ __attribute__((aligned(16))) float sw[4][CIN + 2], ssc[CIN + 2], ssh[CIN + 2];
+  const int tid = threadIdx.x;
+  const int nb = blockIdx.y;
+  const mt_src_t& S = c.src;
+  const bool aff = S.scale != nullptr;
+  for (int i = tid; i < 4 * CIN; i += 256) {
+    const int co = i / CIN, ci = i - co * CIN;
+    // packed layout 1 (ck = 16): channel ci = 16 ch + 8 half + 4 q + e of output co sits at [ch][q][lane = 32 half + co][e]
+    const int ch = ci >> 4, cl = ci & 15, half = cl >> 3, kp = cl & 7;
+    sw[co][ci] = co < c.Cout ? c.wpack[(size_t)ch * 512 + ((kp >> 2) * 64 + half * 32 + co) * 4 + (kp & 3)] : 0.f;
+  }
+  for (int i = tid; i < CIN; i += 256) {
+    ssc[i] = aff ? S.scale[(size_t)nb * S.C + i] : 1.f;
+    ssh[i] = aff ? S.shift[(size_t)nb * S.C + i] : 0.f;
+  }
+  __syncthreads();
+  const float slope = aff ? S.slope : 1.f;
+  float bias[4];
+#pragma unroll
+  for (int co = 0; co < 4; ++co) bias[co] = (c.bias != nullptr && co < c.Cout) ? c.bias[co] : 0.f;
+  const size_t in_sample = (size_t)P.Vb * CIN;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0, (int)(in_sample * 4), 0x00020000);
+  float* outp = c.out + (size_t)nb * P.Vb * c.Cout;
+  for (long v = (long)blockIdx.x * 256 + tid; v < P.Vb; v += (long)gridDim.x * 256) {
+    float x[CIN + 2];
+    const int o = (int)(v * (CIN * 4));
+#pragma unroll
+    for (int q = 0; q < CIN / 4; ++q) {
+      const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, o + q * 16, 0, 0));
+      x[4 * q] = t[0]; x[4 * q + 1] = t[1]; x[4 * q + 2] = t[2]; x[4 * q + 3] = t[3];
+    }
+    if constexpr ((CIN % 4) != 0) {
+      const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra, o + (CIN / 4) * 16, 0, 0));
+      x[CIN - 2] = t.x; x[CIN - 1] = t.y;
+    }
+    float y[4] = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const float t = fmaf(x[ci], ssc[ci], ssh[ci]);
+      const float a = fmaxf(t, t * slope);                   // LeakyReLU for slope in [0, 1]
+#pragma unroll
+      for (int co = 0; co < 4; ++co) y[co] = fmaf(a, sw[co][ci], y[co]);
+    }
+    float* q = outp + v * c.Cout;
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+      if (co < c.Cout) q[co] = y[co];
+  }
+}
+static bool pw_narrow_ok(const mt_pointwise_t* p, const PwKParams& P) {
+  return P.ntaps == 1 && p->siD == 1 && p->siH == 1 && p->siW == 1 && p->Cout <= 4 && (p->Cin == 30 || p->Cin == 32) && p->src.cs == p->Cin &&
+         p->ocs == p->Cout && !p->accumulate && p->stats_part == nullptr && p->Di == p->Db && p->Hi == p->Hb && p->Wi == p->Wb &&
+         (p->src.slope >= 0.f && p->src.slope <= 1.f) && ((((uintptr_t)p->out) & 15) == 0);
+}
 // the dense-output head form (pw_head_kernel): 1x1x1, unit strides, 33..64 output channels written densely, whole waves of voxels
 static bool pw_head_ok(const mt_pointwise_t* p, const PwKParams& P) {
   return P.ntaps == 1 && p->siD == 1 && p->siH == 1 && p->siW == 1 && p->Cout > 32 && p->Cout <= PWH_MAXCO && p->ocs == p->Cout &&
@@ -673,6 +735,13 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   {
     static int use_head = -1;
     if (use_head < 0) { const char* e = getenv("MT_PW_HEAD"); use_head = e ? atoi(e) : 1; }
+    if (use_head && pw_narrow_ok(p, P)) {
+      long blocks = (P.Vb + 255) / 256; if (blocks > 4096) blocks = 4096;
+      if (p->Cin == 30) hipLaunchKernelGGL(pw_narrow_kernel<30>, dim3((unsigned)blocks, (unsigned)p->N), dim3(256), 0, st, P);
+      else hipLaunchKernelGGL(pw_narrow_kernel<32>, dim3((unsigned)blocks, (unsigned)p->N), dim3(256), 0, st, P);
+      MT_CHECK_LAUNCH("pointwise_narrow");
+      return MT_OK;
+    }
     if (use_head && pw_head_ok(p, P)) {
       hipLaunchKernelGGL(pw_head_kernel, dim3((unsigned)(P.nsb * p->N)), dim3(256), 0, st, P);
       MT_CHECK_LAUNCH("pointwise_head");

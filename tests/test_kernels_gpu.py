@@ -901,10 +901,13 @@ def test_winograd_backward_data_emits_norm_backward_statistics(dev, split, acc):
 
 
 @pytest.mark.parametrize("Cin,Cout,shape,lazy,bias", [(30, 47, (4, 8, 16), True, True), (32, 64, (2, 8, 32), False, False),
-                                                       (30, 33, (3, 8, 12), True, False), (20, 47, (4, 4, 10), False, True)])
+                                                       (30, 33, (3, 8, 12), True, False), (20, 47, (4, 4, 10), False, True),
+                                                       (30, 2, (5, 9, 21), True, True), (32, 3, (3, 7, 11), False, True),
+                                                       (30, 4, (2, 8, 16), True, False), (30, 1, (3, 5, 7), True, True)])
 def test_dense_head_kernel(dev, Cin, Cout, shape, lazy, bias):
     """pw_head_kernel: the 1x1x1 head with 33..64 output channels written as one dense [V][Cout] run (both channel tiles from one
-    read of the input, transposed through LDS) vs F.conv3d; the (4,4,10) case has V % 32 != 0 and must fall back to pw_fast_kernel."""
+    read of the input, transposed through LDS) vs F.conv3d; the (4,4,10) case has V % 32 != 0 and must fall back to pw_fast_kernel.
+    Cout <= 4 from 30 / 32 dense channels: pw_narrow_kernel (one thread per voxel, vector ALU)."""
     ops = _ops()
     g = torch.Generator().manual_seed(15)
     N = 2
