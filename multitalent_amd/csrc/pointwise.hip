@@ -958,6 +958,122 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_b_kernel(const HeadBwdRed
   *o = R.accumulate ? *o + s : s;
 }
 
+// ---- narrow heads (Cout <= 4, 30 / 32 dense input channels; see pw_narrow_kernel): the same three results from one streaming pass
+// with a thread per voxel — dX[v][ci] (+)= sum_co dY[v][co] W[co][ci]; per-thread partial sums of dW[co][ci] = sum_v act(x)[v][ci]
+// dY[v][co] and dbias[co] = sum_v dY[v][co] in registers over the thread's voxels, reduced over the wave by DPP shuffles and over
+// the workgroup through LDS in a fixed order; one partial row per workgroup, summed in fp64 by head_narrow_reduce_kernel.
+#define HN_BLOCKS 1024
+template <int CIN, int NCO>
+__global__ __launch_bounds__(256) void head_bwd_narrow_kernel(const HeadBwdParams P) {
+  constexpr int NP = NCO * CIN + NCO;                       // partial sums per thread: dW rows, then dbias
+  __shared__ __attribute__((aligned(16))) float sw[NCO][CIN + 2], ssc[CIN + 2], ssh[CIN + 2];
+  __shared__ float red[4][NP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const mt_src_t& S = P.x;
+  const bool aff = S.scale != nullptr;
+  const float slope = aff ? S.slope : 1.f;
+  for (int i = tid; i < NCO * CIN; i += 256) {
+    const int co = i / CIN, ci = i - co * CIN;
+    sw[co][ci] = co < P.Cout ? P.wpack[ci * 4 + co] : 0.f;   // packed W^T (K = Cout in one chunk, co < 4: [lane = ci][e = co])
+  }
+  float part[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) part[k] = 0.f;
+  const long per_sample_blocks = HN_BLOCKS / P.N > 0 ? HN_BLOCKS / P.N : 1;
+  const int nb = (int)(blockIdx.x / per_sample_blocks);      // a workgroup stays inside one sample (its scale / shift)
+  if (nb < P.N) {
+    const long b = blockIdx.x - (long)nb * per_sample_blocks;
+    for (int i = tid; i < CIN; i += 256) {
+      ssc[i] = aff ? S.scale[(size_t)nb * S.C + i] : 1.f;
+      ssh[i] = aff ? S.shift[(size_t)nb * S.C + i] : 0.f;
+    }
+    __syncthreads();
+    const size_t xs = (size_t)P.V * CIN;
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * xs), 0, (int)(xs * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dx + (size_t)nb * xs), 0, (int)(xs * 4), 0x00020000);
+    const float* dyp = P.dy + (size_t)nb * P.V * P.dycs;
+    for (long v = b * 256 + tid; v < P.V; v += per_sample_blocks * 256) {
+      float x[CIN + 2], old[CIN + 2], dy[NCO];
+      const int o = (int)(v * (CIN * 4));
+#pragma unroll
+      for (int q = 0; q < CIN / 4; ++q) {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, o + q * 16, 0, 0));
+        x[4 * q] = t[0]; x[4 * q + 1] = t[1]; x[4 * q + 2] = t[2]; x[4 * q + 3] = t[3];
+      }
+      if constexpr ((CIN % 4) != 0) {
+        const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra, o + (CIN / 4) * 16, 0, 0));
+        x[CIN - 2] = t.x; x[CIN - 1] = t.y;
+      }
+      if (P.accumulate_dx) {
+#pragma unroll
+        for (int q = 0; q < CIN / 4; ++q) {
+          const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o + q * 16, 0, 0));
+          old[4 * q] = t[0]; old[4 * q + 1] = t[1]; old[4 * q + 2] = t[2]; old[4 * q + 3] = t[3];
+        }
+        if constexpr ((CIN % 4) != 0) {
+          const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rx, o + (CIN / 4) * 16, 0, 0));
+          old[CIN - 2] = t.x; old[CIN - 1] = t.y;
+        }
+      }
+#pragma unroll
+      for (int co = 0; co < NCO; ++co) dy[co] = co < P.Cout ? dyp[v * P.dycs + co] : 0.f;
+      float dx[CIN + 2];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        const float t = fmaf(x[ci], ssc[ci], ssh[ci]);
+        const float a = fmaxf(t, t * slope);
+        float g = P.accumulate_dx ? old[ci] : 0.f;
+#pragma unroll
+        for (int co = 0; co < NCO; ++co) {
+          g = fmaf(dy[co], sw[co][ci], g);
+          part[co * CIN + ci] = fmaf(a, dy[co], part[co * CIN + ci]);
+        }
+        dx[ci] = g;
+      }
+#pragma unroll
+      for (int co = 0; co < NCO; ++co) part[NCO * CIN + co] += dy[co];
+#pragma unroll
+      for (int q = 0; q < CIN / 4; ++q) {
+        f32x4 t; t[0] = dx[4 * q]; t[1] = dx[4 * q + 1]; t[2] = dx[4 * q + 2]; t[3] = dx[4 * q + 3];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, t), rx, o + q * 16, 0, 0);
+      }
+      if constexpr ((CIN % 4) != 0) {
+        float2 t; t.x = dx[CIN - 2]; t.y = dx[CIN - 1];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, t), rx, o + (CIN / 4) * 16, 0, 0);
+      }
+    }
+  }
+  // wave reduction (fixed butterfly), then the four waves through LDS in wave order
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    float s = part[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  for (int k = tid; k < NP; k += 256) P.part[(size_t)blockIdx.x * NP + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+}
+// dW[co][ci] / dbias[co] (+)= sum over the workgroups' partial rows, in block order, fp64
+__global__ __launch_bounds__(64) void head_narrow_reduce_kernel(const float* part, int nblocks, int np, int Cin, int Cout, int nco, float* dw, long s_ci,
+                                                               long s_co, float* dbias, int accumulate) {
+  const int k = blockIdx.x;                                 // one partial column per workgroup, 64 lanes over the rows
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 64) s += (double)part[(size_t)b * np + k];
+  s = mt_wave_sum_d(s);
+  if (threadIdx.x != 0) return;
+  const int co = k < nco * Cin ? k / Cin : k - nco * Cin, ci = k < nco * Cin ? k - co * Cin : -1;
+  if (co >= Cout) return;
+  if (ci >= 0) { float* o = dw + (long)ci * s_ci + (long)co * s_co; *o = accumulate ? *o + (float)s : (float)s; }
+  else if (dbias != nullptr) dbias[co] = accumulate ? dbias[co] + (float)s : (float)s;
+}
+static bool head_bwd_narrow_ok(const mt_src_t* x, int dycs, int dxcs, int Cin, int Cout, long V, int N, const float* dx) {
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_PW_HEAD"); use = e ? atoi(e) : 1; }
+  return use && Cout <= 4 && (Cin == 30 || Cin == 32) && x->cs == Cin && dxcs == Cin && N <= HN_BLOCKS &&
+         (x->scale == nullptr || (x->slope >= 0.f && x->slope <= 1.f)) && (double)V * Cin * 4.0 < 2147483648.0;
+}
+
 static inline int head_bwd_waves(int N, long V) {
   const long ntiles = (long)N * ((V + 31) / 32);
   long w = ntiles / 32;                                            // >= 32 tiles per wave: the 8 - 16 KiB partial of a wave is written once
@@ -975,7 +1091,9 @@ extern "C" int mt_head_bwd_supported(int Cin, int Cout) {
 extern "C" size_t mt_head_bwd_workspace(int N, long V, int Cin, int Cout) {
   if (!(Cin >= 1 && Cin <= 64 && Cout >= 1 && Cout <= 64)) return 0;
   const size_t per = (size_t)((Cin + 31) / 32) * 2 * 1024;
-  return (size_t)head_bwd_waves(N, V) * per * sizeof(float) + HB_SLICES * per * sizeof(double) + 64;
+  const size_t wide = (size_t)head_bwd_waves(N, V) * per * sizeof(float) + HB_SLICES * per * sizeof(double) + 64;
+  const size_t narrow = (Cout <= 4) ? (size_t)HN_BLOCKS * (4 * 32 + 4) * sizeof(float) : 0;      // head_bwd_narrow_kernel: one partial row per workgroup
+  return wide > narrow ? wide : narrow;
 }
 extern "C" int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, long V, int Cin, int Cout, const float* wpack_bwd,
                            float* dx, int dxcs, int accumulate_dx, float* dw, long s_ci, long s_co, float* dbias, int accumulate_dw,
@@ -988,6 +1106,20 @@ extern "C" int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, 
   HeadBwdParams P;
   P.x = *x; P.dy = dy; P.dycs = dycs; P.N = N; P.V = V; P.Cin = Cin; P.Cout = Cout; P.wpack = wpack_bwd;
   P.dx = dx; P.dxcs = dxcs; P.accumulate_dx = accumulate_dx; P.part = (float*)ws;
+  if (head_bwd_narrow_ok(x, dycs, dxcs, Cin, Cout, V, N, dx)) {
+    const int nco = Cout <= 2 ? 2 : 4, np = nco * Cin + nco;
+    const int per_sample = HN_BLOCKS / N > 0 ? HN_BLOCKS / N : 1, nblocks = per_sample * N;
+    MT_REQUIRE((size_t)nblocks * np * sizeof(float) <= ws_bytes, "head_bwd: workspace too small for the narrow form");
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin == 30 && nco == 2) hipLaunchKernelGGL((head_bwd_narrow_kernel<30, 2>), dim3(nblocks), dim3(256), 0, st, P);
+    else if (Cin == 30) hipLaunchKernelGGL((head_bwd_narrow_kernel<30, 4>), dim3(nblocks), dim3(256), 0, st, P);
+    else if (nco == 2) hipLaunchKernelGGL((head_bwd_narrow_kernel<32, 2>), dim3(nblocks), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((head_bwd_narrow_kernel<32, 4>), dim3(nblocks), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(head_narrow_reduce_kernel, dim3(np), dim3(64), 0, st, (const float*)ws, nblocks, np, Cin, Cout, nco, dw, s_ci, s_co, dbias, accumulate_dw);
+    MT_CHECK_LAUNCH("head_bwd_narrow");
+    if (dbias_done != nullptr) *dbias_done = 1;
+    return MT_OK;
+  }
   P.nwaves = head_bwd_waves(N, V); P.ntiles = (long)N * ((V + 31) / 32);
   const int nci = (Cin + 31) / 32;
   hipStream_t st = (hipStream_t)stream;

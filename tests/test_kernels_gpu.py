@@ -759,7 +759,9 @@ def test_multitalent_loss_kernels_flat_and_strided(dev, B, C, V, wide):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,V,lazy,acc,bias", [(2, 30, 47, 48 * 20 * 21 + 5, True, False, True), (1, 30, 2, 1000, True, True, False),
-                                                        (2, 60, 47, 777, False, True, True), (1, 64, 5, 4096, True, False, True), (3, 8, 64, 33, True, False, True)])
+                                                        (2, 60, 47, 777, False, True, True), (1, 64, 5, 4096, True, False, True), (3, 8, 64, 33, True, False, True),
+                                                        (2, 30, 2, 48 * 20 * 21 + 5, True, False, True), (1, 32, 3, 1000, False, True, True),
+                                                        (2, 30, 4, 777, True, True, False), (3, 32, 1, 4099, True, False, True)])
 def test_head_bwd_fused(dev, N, Cin, Cout, V, lazy, acc, bias):
     """mt_head_bwd: dX, dW and dbias of a 1x1x1 head in one pass vs autograd of F.conv3d on the activated input (fp64)."""
     ops = _ops()
@@ -794,7 +796,7 @@ def test_head_bwd_fused(dev, N, Cin, Cout, V, lazy, acc, bias):
     ref_dw = (dyf.t() @ xa).reshape(Cout, Cin, 1, 1, 1)
     assert relerr(dxd.cpu().double(), ref_dx) < 1e-5
     assert relerr(dw.cpu().double(), ref_dw) < 1e-5
-    assert done == (Cin % 32 != 0)
+    assert done == (Cin % 32 != 0 or (Cout <= 4 and Cin in (30, 32)))          # the narrow form (head_bwd_narrow_kernel) always produces dbias
     if bias and done:
         assert relerr(db.cpu().double(), dyf.sum(0)) < 1e-5
 
