@@ -15,6 +15,7 @@ struct PwKParams {
   mt_pointwise_t c;
   int ntaps, nchunks, nsb;
   long Vb;
+  int wide;      // pw_fast_kernel: transposed-conv outputs leave through LDS as 16-byte stores (see the wide epilogue)
 };
 
 #define PW_MAXC 1024   // largest Cin (rounded up to a chunk) whose scale/shift fit the LDS copy
@@ -25,6 +26,9 @@ struct PwKParams {
 // chunk costs 8 MFMAs per tap with no LDS traffic at all; every tap of a transposed conv accumulates into its own
 // accumulator tile (NT*16 AGPRs) and the input is read exactly once.  Outputs leave through buffer stores whose per-row
 // offsets are computed once (out-of-range rows carry the hardware-masked offset).
+#ifndef PW_ABL
+#define PW_ABL 0      // timing ablations of pw_fast_kernel: 1 no stores, 2 no weight-fragment loads, 4 no MFMAs
+#endif
 template <int NT, int VEC>
 __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   const mt_pointwise_t& c = P.c;
@@ -120,17 +124,22 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+  // blockIdx.z: which NT of the P.ntaps taps this workgroup computes (8 taps as two workgroups of 4: half the accumulator
+  // registers, twice the resident workgroups — their store phases overlap the others' multiplications)
+  const int tap0 = (int)blockIdx.z * NT;
 
   float xa[8], xn[8];
   load_a(0, xa);
   for (int ch = 0; ch < P.nchunks; ++ch) {
     if (ch + 1 < P.nchunks) load_a(ch + 1, xn);
     finish_a(ch, xa);
-    const float* wq = c.wpack + (size_t)(ntile * P.nchunks + ch) * NT * 512 + lane * 4;
+    const float* wq = c.wpack + ((size_t)(ntile * P.nchunks + ch) * P.ntaps + tap0) * 512 + lane * 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const f32x4 b0 = *(const f32x4*)(wq + t * 512);
-      const f32x4 b1 = *(const f32x4*)(wq + t * 512 + 256);
+      f32x4 b0, b1;
+      if (PW_ABL & 2) { b0 = f32x4{xa[0], xa[1], xa[2], xa[3]}; b1 = f32x4{xa[4], xa[5], xa[6], xa[7]}; }
+      else { b0 = *(const f32x4*)(wq + t * 512); b1 = *(const f32x4*)(wq + t * 512 + 256); }
+      if (PW_ABL & 4) { acc[t][0] += xa[t & 7] * b0[0] + b1[1]; continue; }
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], b0[e], acc[t], 0, 0, 0);
 #pragma unroll
@@ -138,6 +147,15 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) xa[e] = xn[e];
+  }
+  if (PW_ABL & 1) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sacc += acc[t][j];
+    if (sacc == 1234.5678f) c.out[0] = sacc;
+    return;
   }
 
   // ---- epilogue
@@ -148,6 +166,60 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   const size_t out_sample = (size_t)Do * Ho * Wo * c.ocs;
   __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out + (size_t)nb * out_sample), 0,
                                                                 (int)(out_sample * 4), 0x00020000);
+  if constexpr (NT >= 4 && VEC == 4) {
+    // Wide epilogue of the transposed convolutions (soW == 2, the wave's 32 base voxels in one row, <= 32 even output channels):
+    // the two kw taps of a (kd, kh) pair are 64 CONSECUTIVE output voxels.  The dword stores of the plain epilogue (one per
+    // accumulator element: 128 store instructions per wave, each two 120-byte runs) were 300 of the 460 us of the 60 -> 30
+    // launch (PW_ABL=1); here the pair goes through a wave-private LDS tile [64 voxels][32] and leaves as 16-byte stores.
+    if (P.wide) {
+      __shared__ __attribute__((aligned(16))) float wst[4][64 * 32];
+      float* sg = wst[wave];
+      int wb0, hb0, db0;
+      row_dhw(0, db0, hb0, wb0);                             // the row of the wave's first voxel (the whole wave is in it)
+      const bool wok = m0 < P.Vb;
+      const int pv = lane >> 3, pc = (lane & 7) * 4;         // piece (lane & 7) of output voxel pv + 8 k
+#pragma unroll
+      for (int pr = 0; pr < NT / 2; ++pr) {                  // (kd, kh) pairs: taps 2 pr (kw = 0) and 2 pr + 1 (kw = 1)
+        const int prg = pr + tap0 / 2;
+        const int th = prg % c.soH, tdd = prg / c.soH;
+#pragma unroll
+        for (int tw = 0; tw < 2; ++tw)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+            sg[(2 * iv + tw) * 32 + li] = acc[2 * pr + tw][j] + bias;
+          }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (wok && P.wide == 2) {
+          // dense output (channel stride == Cout): the pair's 64 voxels are ONE run of 64 * Cout floats
+          const int rowbase = ((((db0 * c.soD + tdd) * Ho + hb0 * c.soH + th) * Wo + wb0 * 2) * c.Cout) * 4;
+          const int n2 = 32 * c.Cout;                        // 8-byte units
+          for (int u = lane; u < n2; u += 64) {
+            const int e = 2 * u, ov = e / c.Cout, cc = e - ov * c.Cout;      // (Cout even: a unit never straddles two voxels)
+            const float2 h = *(const float2*)(sg + ov * 32 + cc);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, h), ro, rowbase + u * 8, 0, 0);
+          }
+        } else if (wok) {
+          const int rowbase = ((((db0 * c.soD + tdd) * Ho + hb0 * c.soH + th) * Wo + wb0 * 2) * c.ocs) * 4;      // bytes
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int ov = pv + 8 * k;
+            const f32x4 v = *(const f32x4*)(sg + ov * 32 + pc);
+            const int o = rowbase + (ov * c.ocs + pc) * 4;
+            if (pc + 4 <= c.Cout)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ro, o, 0, 0);
+            else if (pc + 2 <= c.Cout) {
+              float2 h; h.x = v[0]; h.y = v[1];
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, h), ro, o, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();                     // the tile is rewritten by the next pair
+      }
+      return;
+    }
+  }
   int obase[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -161,7 +233,8 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int tw = t % c.soW, th = (t / c.soW) % c.soH, tdd = t / (c.soW * c.soH);
+    const int tg = tap0 + t;
+    const int tw = tg % c.soW, th = (tg / c.soW) % c.soH, tdd = tg / (c.soW * c.soH);
     const int toff = ((tdd * Ho + th) * Wo + tw) * c.ocs * 4;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -723,6 +796,15 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
              (double)P.Vb * P.ntaps * p->ocs * 4.0 < 2147483648.0, "pointwise: sample larger than 2 GiB");
   MT_REQUIRE(P.ntaps == 1 || P.ntaps == 2 || P.ntaps == 4 || P.ntaps == 8, "pointwise: unsupported tap count %d", P.ntaps);
   MT_REQUIRE(P.nchunks * PW_CK <= PW_MAXC, "pointwise: Cin = %d exceeds %d", p->Cin, PW_MAXC);
+  {
+    static int use_wide = -1;
+    if (use_wide < 0) { const char* e = getenv("MT_PW_WIDE"); use_wide = e ? atoi(e) : 1; }
+    const bool shape_ok = use_wide && P.ntaps >= 4 && p->soW == 2 && p->soH == 2 && (p->Wb % 32) == 0 && p->Cout <= 32 && (p->Cout % 2) == 0 &&
+                          !p->accumulate && p->stats_part == nullptr && p->siD == 1 && p->siH == 1 && p->siW == 1;
+    P.wide = 0;
+    if (shape_ok && p->ocs == p->Cout && ((((uintptr_t)p->out) & 7) == 0)) P.wide = 2;                       // dense output: linear 8-byte stores
+    else if (shape_ok && (p->ocs % 4) == 0 && ((((uintptr_t)p->out) & 15) == 0)) P.wide = 1;                 // concat slot: 16-byte pieces per voxel
+  }
   const mt_src_t& S = p->src;
   // 16-byte loads whatever the alignment: a raw buffer_load_dwordx4 only needs dword alignment and range-checks per dword
   // (tools/ubench/oob128.hip); the 47-channel gradient of the heads (188-byte rows) went through eight scalar loads per chunk before
@@ -759,7 +841,13 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
     case 1: PW_LAUNCH(1); break;
     case 2: PW_LAUNCH(2); break;
     case 4: PW_LAUNCH(4); break;
-    default: PW_LAUNCH(8); break;
+    default: {
+      static int split8 = -1;
+      if (split8 < 0) { const char* e = getenv("MT_PW_SPLIT8"); split8 = e ? atoi(e) : 1; }
+      if (split8 && p->stats_part == nullptr) { grid.z = 2; PW_LAUNCH(4); }      // two workgroups of four taps (see pw_fast_kernel)
+      else PW_LAUNCH(8);
+      break;
+    }
   }
 #undef PW_LAUNCH
   MT_CHECK_LAUNCH("pointwise");

@@ -417,12 +417,17 @@ def test_conv_bwd_weight_bf16_1x3x3(dev, Cin, Cout, shape):
     assert 1e-5 < err < 1e-2, err
 
 
-@pytest.mark.parametrize("Cin,Cout,base,so", [
-    (60, 30, (4, 6, 10), (2, 2, 2)),
-    (320, 320, (3, 6, 6), (1, 2, 2)),
-    (30, 47, (4, 8, 16), (1, 1, 1)),
+@pytest.mark.parametrize("Cin,Cout,base,so,extra", [
+    (60, 30, (4, 6, 10), (2, 2, 2), 3),
+    (320, 320, (3, 6, 6), (1, 2, 2), 3),
+    (30, 47, (4, 8, 16), (1, 1, 1), 3),
+    (60, 30, (3, 4, 32), (2, 2, 2), 30),     # rows of 32 base voxels, 16-byte aligned concat slot: the wide (LDS-transposed) epilogue
+    (20, 14, (2, 3, 64), (1, 2, 2), 14),
+    (24, 32, (2, 2, 32), (2, 2, 2), 0),
+    (60, 30, (3, 4, 32), (2, 2, 2), 0),      # dense output (the engine's transposed convs): one linear run per (kd, kh) pair
+    (20, 14, (2, 3, 64), (1, 2, 2), 0),
 ])
-def test_pointwise_tconv_and_heads(dev, Cin, Cout, base, so):
+def test_pointwise_tconv_and_heads(dev, Cin, Cout, base, so, extra):
     ops = _ops()
     g = torch.Generator().manual_seed(5)
     N = 2
@@ -440,7 +445,7 @@ def test_pointwise_tconv_and_heads(dev, Cin, Cout, base, so):
         strides = ops.conv_weight_strides(wd, transposed_layout=True)
     wp = ops.pack_conv_weights(wd, Cin, 0, Cout, so, strides, False, ops.POINTWISE_CK)
     outshape = tuple(b * s for b, s in zip(base, so))
-    out = torch.full((N,) + outshape + (Cout + 3,), float('nan'), device=dev)   # write into a wider buffer (concat slot)
+    out = torch.full((N,) + outshape + (Cout + extra,), float('nan'), device=dev)   # write into a wider buffer (concat slot)
     oa = ops.Act(out, c0=0, C=Cout)
     p = ops.fill_pointwise(xa, base, base, (1, 1, 1), so, Cout, wp, None, oa)
     ops.pointwise_fwd(p)
