@@ -155,7 +155,8 @@ int mt_set_option(const char* name, int value);
  *   MT_CONV_FAST133, MT_CONV_GATHER, MT_CONV_VEC1 (1: dword staging loads),
  *   MT_PW_VEC / MT_GATHER_VEC (1|2|4: floats per load instruction of pw_fast_kernel / conv_gather_kernel; default 4 = 16-byte
  *   buffer loads on dword-aligned addresses, see mt_probe_device), MT_PW_HEAD (0: the 33..64-channel 1x1x1 heads on pw_fast_kernel
- *   instead of pw_head_kernel), MT_WINO_DMA (1: conv_wino8d_kernel), MT_PACK_BLOCKS (workgroups per descriptor of mt_pack_batched,
+ *   instead of pw_head_kernel; also the narrow-head kernels), MT_PW_WIDE (0: dword stores in the transposed-conv epilogue), MT_PW_SPLIT8 (0: all
+ *   eight taps of a 2x2x2 transposed conv in one workgroup), MT_WINO_DMA (1: conv_wino8d_kernel), MT_PACK_BLOCKS (workgroups per descriptor of mt_pack_batched,
  *   default 1024), MT_HEAD_BWD_WIDE, MT_CONV_CFG / MT_BF16_CFG (force a tile configuration), MT_CONV_STAGGER, MT_CONV_DBG (debugging).
  * Which workgroup computes which tile (block id -> XCD -> tile order) is a compile-time choice (-DMT_TILE_ORDER=0 builds
  * the round-2 order for A/B measurements); results do not depend on it. */
