@@ -58,9 +58,12 @@ extern "C" int mt_inorm_finalize(const float* part, int N, int nsb, int C, doubl
 // it).  2048 at full resolution (1 728 workgroups for 2 x 48 x 192 x 192); a fixed 2048 left the mid-resolution layers with ~200
 // workgroups of 256 threads on 256 CUs — 2.9 TB/s where the full-resolution launches reach 5.4 — so smaller tensors get
 // proportionally smaller blocks (>= 128 voxels, about 512 blocks per sample).
+#ifndef MT_VB_BLOCKS
+#define MT_VB_BLOCKS 512      // target workgroups per sample below full resolution (256 / 1024 measured no better: tools/build_norm_variant.sh)
+#endif
 __host__ __device__ static inline int mt_vb(long V) {
-  if (V >= 2048L * 512) return 2048;
-  long vb = ((V + 511) / 512 + 63) / 64 * 64;
+  if (V >= 2048L * MT_VB_BLOCKS) return 2048;
+  long vb = ((V + MT_VB_BLOCKS - 1) / MT_VB_BLOCKS + 63) / 64 * 64;
   return vb < 128 ? 128 : (int)vb;
 }
 static inline int nb_blocks(long V) { return mt_cdiv(V, (long)mt_vb(V)); }
