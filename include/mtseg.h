@@ -10,8 +10,9 @@
  * re-entrant per stream and per device; the only mutable state are the process-wide kernel-selection knobs
  * of mt_set_option (atomics) and per-device one-time kernel attributes.
  *
- * Layout: activations are NDHWC fp32 ("channels last"), possibly a channel slice of a wider
- * buffer (channel stride `cs`, first channel folded into the pointer).  A "lazy activation" is a
+ * Layout: activations are NDHWC ("channels last"), fp32 or — in the mixed-precision mode, for the tensors the caller chooses —
+ * bf16 (`dtype` = MT_BF16: the pointer then addresses 2-byte elements although it is typed `float*`), possibly a channel slice of a
+ * wider buffer (channel stride `cs` in ELEMENTS, first channel folded into the pointer).  A "lazy activation" is a
  * raw conv output y plus per-(n,c) scale/shift and a LeakyReLU slope:
  *     a = lrelu_slope(y*scale + shift)         (InstanceNorm + LeakyReLU applied on load)
  * which is how `ConvDropoutNormNonlin.forward` (generic_UNet.py:66-70) is fused away.
@@ -34,8 +35,16 @@ extern "C" {
 #define MT_EHIP (-3)    /* HIP runtime error on launch */
 #define MT_EUNSUPPORTED (-4) /* the device is not the one this library is built for (gfx950) */
 
-#define MT_ABI_VERSION 1
+#define MT_ABI_VERSION 2   /* 2: storage dtypes (mt_src_t.dtype, odtype fields, dtype arguments of the streaming kernels, mt_cast) */
 #define MT_MAX_CHUNKS 64
+
+/* Storage type of an activation / gradient tensor in HBM.  fp32 is the parity path.  bf16 is the storage of the mixed-precision
+ * mode (the reference's autocast keeps conv inputs / outputs in half precision: MultiTalent_Trainer_DDP.py:340-354,
+ * network_trainer.py:400-402): values are rounded to nearest-even when stored and widened exactly when loaded; all arithmetic
+ * (normalisation, statistics, accumulation, loss, optimizer) stays fp32.  Not every kernel takes every combination: ask the
+ * *_io_supported queries and convert with mt_cast where the answer is 0. */
+#define MT_F32 0
+#define MT_BF16 1
 
 typedef void* mt_stream_t; /* hipStream_t */
 
@@ -49,7 +58,7 @@ typedef struct {
   const float* scale;
   const float* shift;
   float slope;
-  int32_t _pad;
+  int32_t dtype;  /* MT_F32 | MT_BF16: element type behind `ptr` (cs counts elements) */
 } mt_src_t;
 
 /* Fused statistics for the InstanceNorm + LeakyReLU backward that runs next (generic_UNet.py:63-64 in reverse).  A convolution that
@@ -96,6 +105,8 @@ typedef struct {
   int32_t OD, OH, OW, osD, osH, osW, ooD, ooH, ooW;
   int32_t mma;                /* matrix input type of the convolution: 0 fp32 (exact), 1 bf16 inputs with fp32 accumulation
                                  (mixed precision, the reference's autocast mode); packed weights must match (mt_conv3d_pack_layout) */
+  int32_t odtype;             /* MT_F32 | MT_BF16: element type of out0 / out1 (ocs0 / ocs1 count elements); statistics are taken from
+                                 the values as stored */
   mt_bwd_stats_t bstats;      /* bstats.y != NULL: fused first pass of the NEXT InstanceNorm backward (see mt_bwd_stats_t) */
 } mt_conv3d_t;
 
@@ -139,6 +150,11 @@ int mt_pack_batched(const void* descs_device, int n, mt_stream_t stream);
 int mt_conv3d_bwd_data_strided(const mt_conv3d_t* p, mt_stream_t stream);
 int mt_conv3d_bwd_data_strided_supported(const mt_conv3d_t* p);   /* 1 when the geometry is handled, else 0 */
 int mt_conv3d_bwd_data_strided_pack_layout(const mt_conv3d_t* p); /* `layout` of its packed weights: 1, or 3 (bf16) when p->mma == 1 */
+/* Storage types: 1 when the kernel that serves p takes p->src[*].dtype / p->odtype natively (all-fp32: always).  0: convert the
+ * operands with mt_cast (the launch itself refuses with MT_EINVAL).  Same question for the other convolution entry points. */
+int mt_conv3d_io_supported(const mt_conv3d_t* p);
+int mt_conv3d_bwd_data_strided_io_supported(const mt_conv3d_t* p);
+int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_src_t* ysrc);
 /* Runtime options (tests, A/B measurements): "conv_wino" = 0 direct kernels only, 1 Winograd where the grid fills the chip
  * (default, also MT_CONV_WINO), 2 Winograd wherever the geometry is eligible; "wino_waves" 8 | 4; "wino_persist" 1 | 0 | n (8-wave
  * kernel: persistent over spatial tiles (default; n > 1: at most n workers per output-channel tile) or one tile per workgroup); "bwdw_wino" 0 | 1;
@@ -203,6 +219,8 @@ typedef struct {
   float* out; int32_t ocs;
   int32_t accumulate;
   float* stats_part;   /* NULL or [N][nsb][Cout][2] */
+  int32_t odtype;      /* MT_F32 | MT_BF16: element type of `out` */
+  int32_t _pad;
 } mt_pointwise_t;
 int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream);
 int mt_pointwise_stats_blocks(const mt_pointwise_t* p);
@@ -229,7 +247,7 @@ int mt_inorm_finalize(const float* part, int N, int nsb, int C, double count, co
 /* materialise a = lrelu(y*scale+shift) (+ optional residual add BEFORE the lrelu: conv_blocks.py:201-213) */
 int mt_inorm_lrelu_apply(const float* y, int ycs, const float* scale, const float* shift, float slope,
                          const float* res, int rcs, const float* rscale, const float* rshift, float rslope,
-                         float* out, int ocs, int N, long V, int C, mt_stream_t stream);
+                         float* out, int ocs, int N, long V, int C, int dtype /* storage type of y, res and out */, mt_stream_t stream);
 /* Backward of out = lrelu(IN(y)): given g = dL/dout (in place), produce dy in place, plus
  * dgamma[C] += , dbeta[C] +=, dbias[C] (= sum dy, may be NULL).  ws: mt_inorm_bwd_workspace bytes.
  * part != NULL: the first pass (sum dz, sum dz zhat per block) was fused into the convolution that produced g
@@ -239,11 +257,11 @@ size_t mt_inorm_bwd_workspace(int N, long V, int C);
 int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, float slope, int N, long V, int C,
                        float* dgamma, float* dbeta, float* dbias, const float* part, int part_nblk, int part_cs, int part_c0,
-                       void* ws, size_t ws_bytes, mt_stream_t stream);
+                       void* ws, size_t ws_bytes, int dtype /* storage type of g and y */, mt_stream_t stream);
 /* g *= lrelu'(y*scale+shift) in place, optionally also writes a copy (residual branch gradient) */
 int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale, const float* shift,
                  float slope, const float* y2, int y2cs, const float* scale2, const float* shift2,
-                 float slope2, float* gcopy, int gcopycs, int N, long V, int C, mt_stream_t stream);
+                 float slope2, float* gcopy, int gcopycs, int N, long V, int C, int dtype /* of g, y, y2, gcopy */, mt_stream_t stream);
 /* mt_lrelu_bwd on dense tensors (channel stride == C) that also emits the first pass of the NEXT InstanceNorm backward: in a residual
  * block out = lrelu(IN(y) + residual) (conv_blocks.py:201-213) the masked gradient g' is the gradient of IN(y), so
  * part[n][blk][c] = (sum g', sum g' * (y - mean) * rstd) over the block's voxels — mt_inorm_lrelu_bwd(part, part_nblk =
@@ -252,11 +270,17 @@ int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale,
 int mt_lrelu_bwd_stats_blocks(long V, int C);
 int mt_lrelu_bwd_stats(float* g, const float* y, const float* scale, const float* shift, float slope,
                        const float* y2, const float* scale2, const float* shift2, float slope2, float* gcopy,
-                       const float* mean, const float* rstd, float* part, int N, long V, int C, mt_stream_t stream);
+                       const float* mean, const float* rstd, float* part, int N, long V, int C, int dtype /* of g, y, y2, gcopy */,
+                       mt_stream_t stream);
 /* per-channel sum over all voxels: out[C] (+)= sum_{n,v} x[n,v,c]  (bias gradients of heads) */
 size_t mt_channel_sum_workspace(int N, long V, int C);
 int mt_channel_sum(const float* x, int xcs, int N, long V, int C, float* out, int accumulate,
-                   void* ws, size_t ws_bytes, mt_stream_t stream);
+                   void* ws, size_t ws_bytes, int dtype /* storage type of x */, mt_stream_t stream);
+/* Storage-type conversion, the boundary op of the mixed-precision mode: dst[r][c] (+)= src[r][c] for `rows` voxels (all samples) of
+ * C channels, each side with its own storage type (MT_F32 | MT_BF16) and channel stride in elements.  accumulate adds in fp32 and
+ * rounds once.  A kernel that does not take a tensor's storage type (the *_io_supported queries) works on such a copy. */
+int mt_cast(const void* src, int scs, int sdtype, void* dst, int dcs, int ddtype, long rows, int C, int accumulate,
+            mt_stream_t stream);
 
 /* ---- losses --------------------------------------------------------------------------------- */
 /* MultiTalent loss for one deep-supervision level (MultiTalent_Trainer_DDP.py:544-623):

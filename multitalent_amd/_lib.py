@@ -16,7 +16,7 @@ c_float_p = C.POINTER(C.c_float)
 
 class mt_src_t(C.Structure):
     _fields_ = [('ptr', C.c_void_p), ('cs', C.c_int32), ('C', C.c_int32), ('scale', C.c_void_p),
-                ('shift', C.c_void_p), ('slope', C.c_float), ('_pad', C.c_int32)]
+                ('shift', C.c_void_p), ('slope', C.c_float), ('dtype', C.c_int32)]
 
 
 class mt_bwd_stats_t(C.Structure):
@@ -40,7 +40,8 @@ class mt_conv3d_t(C.Structure):
                 ('stats_part', C.c_void_p),
                 ('OD', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
                 ('osD', C.c_int32), ('osH', C.c_int32), ('osW', C.c_int32),
-                ('ooD', C.c_int32), ('ooH', C.c_int32), ('ooW', C.c_int32), ('mma', C.c_int32), ('bstats', mt_bwd_stats_t)]
+                ('ooD', C.c_int32), ('ooH', C.c_int32), ('ooW', C.c_int32), ('mma', C.c_int32), ('odtype', C.c_int32),
+                ('bstats', mt_bwd_stats_t)]
 
 
 class mt_pointwise_t(C.Structure):
@@ -52,8 +53,11 @@ class mt_pointwise_t(C.Structure):
                 ('Cin', C.c_int32), ('Cout', C.c_int32),
                 ('wpack', C.c_void_p), ('bias', C.c_void_p),
                 ('out', C.c_void_p), ('ocs', C.c_int32), ('accumulate', C.c_int32),
-                ('stats_part', C.c_void_p)]
+                ('stats_part', C.c_void_p), ('odtype', C.c_int32), ('_pad', C.c_int32)]
 
+
+MT_F32, MT_BF16 = 0, 1
+MT_ABI_VERSION = 2
 
 _vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
 _P = C.POINTER
@@ -89,14 +93,18 @@ SIGNATURES = {
     'mt_head_bwd_workspace': (_sz, [_i, _l, _i, _i]),
     'mt_head_bwd': (_i, [_P(mt_src_t), _vp, _i, _i, _l, _i, _i, _vp, _vp, _i, _i, _vp, _l, _l, _vp, _i, _P(C.c_int), _vp, _sz, _vp]),
     'mt_inorm_finalize': (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
-    'mt_inorm_lrelu_apply': (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _vp]),
+    'mt_inorm_lrelu_apply': (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _i, _vp]),
     'mt_inorm_bwd_workspace': (_sz, [_i, _l, _i]),
-    'mt_inorm_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _i, _l, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    'mt_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _vp]),
+    'mt_inorm_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _i, _l, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _vp]),
+    'mt_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _i, _vp]),
     'mt_lrelu_bwd_stats_blocks': (_i, [_l, _i]),
-    'mt_lrelu_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _l, _i, _vp]),
+    'mt_lrelu_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _vp]),
     'mt_channel_sum_workspace': (_sz, [_i, _l, _i]),
-    'mt_channel_sum': (_i, [_vp, _i, _i, _l, _i, _vp, _i, _vp, _sz, _vp]),
+    'mt_channel_sum': (_i, [_vp, _i, _i, _l, _i, _vp, _i, _vp, _sz, _i, _vp]),
+    'mt_cast': (_i, [_vp, _i, _i, _vp, _i, _i, _l, _i, _i, _vp]),
+    'mt_conv3d_io_supported': (_i, [_P(mt_conv3d_t)]),
+    'mt_conv3d_bwd_data_strided_io_supported': (_i, [_P(mt_conv3d_t)]),
+    'mt_conv3d_bwd_weight_io_supported': (_i, [_P(mt_conv3d_t), _P(mt_src_t)]),
     'mt_multitalent_loss_fwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'mt_loss_workspace': (_sz, [_i, _l, _i]),
     'mt_multitalent_loss_bwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -140,8 +148,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.mt_abi_version() != 1:
-        raise RuntimeError("libmtseg_hip.so ABI version mismatch")
+    if lib.mt_abi_version() != MT_ABI_VERSION:
+        raise RuntimeError("libmtseg_hip.so ABI version %d, this binding needs %d: rebuild it (make -C multitalent_amd/csrc)"
+                           % (lib.mt_abi_version(), MT_ABI_VERSION))
     _lib = lib
     probe_device()          # fail loudly on a device the vector-load kernels are not valid for (no-op without a GPU)
     return lib

@@ -921,8 +921,10 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
 // the haloed input tile ((TD-1)*SD+3) x 9 x 17 voxels x 16 channels stays under 64 KiB so two workgroups share a CU; the four
 // waves are 2 M tiles (one output plane each) x 2 N tiles, so every staged voxel feeds 64 output channels.
 // BF = true (mixed precision, mt_conv3d_t.mma == 1): bf16 LDS image and v_mfma_f32_32x32x16_bf16 through mt_stage_bf16 / bf16_chunk.
-template <int SD, int SH, int SW, int VEC, bool BF = false>
+// XB / OB (BF only): source / destination stored as bf16 (mt_src_t.dtype, mt_conv3d_t.odtype).
+template <int SD, int SH, int SW, int VEC, bool BF = false, bool XB = false, bool OB = false>
 __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParams P) {
+  static_assert(BF || !(XB || OB), "bf16 storage is served by the bf16 matrix path");
   constexpr int TD = 2, TH = 4, TW = 8;
   constexpr int LD = (TD - 1) * SD + 3, LH = (TH - 1) * SH + 3, LW = (TW - 1) * SW + 3;
   constexpr int LWP = BF ? bstage_lwp<LD, LH, LW, VEC, 4>() : stage_lwp<LD, LH, LW, VEC>();
@@ -953,7 +955,7 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
     __syncthreads();
     if constexpr (BF) {
       const unsigned* wlane = (const unsigned*)c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 256) + lane * 4;
-      mt_stage_bf16<LD, LH, LW, VEC, 4>((unsigned*)lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
+      mt_stage_bf16<LD, LH, LW, VEC, 4, XB>((unsigned*)lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
       __syncthreads();
       bf16_chunk<1, 1, LH, LWP>((const unsigned*)lds, abase, wlane, 0, accb);
     } else {
@@ -969,10 +971,35 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
   const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
   const int ocs = c.ocs0;
   const size_t out_sample = (size_t)c.Do * c.Ho * c.Wo;
-  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
-                                                                (int)(out_sample * ocs * 4), 0x00020000);
+  constexpr int OEB = OB ? 2 : 4;
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)nb * out_sample * ocs * OEB), 0,
+                                                                (int)(out_sample * ocs * OEB), 0x00020000);
   const int od = od0 + dm;
   float s1 = 0.f, s2 = 0.f;
+  if constexpr (OB) {                  // channel-pair dwords (mt_pair_exchange): even lanes store row j, odd lanes row j + 1
+    const bool odd = li & 1;
+    const int coe = co & ~1;
+    const bool pvalid = nt_ok && coe + 1 < c.Cout;
+    float q1[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+      const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf + (odd ? 1 : 0);
+      const int oh = oh0 + (iv >> 3), ow = ow0 + (iv & 7);
+      const bool ok = pvalid && (od < c.Do) && (oh < c.Ho) && (ow < c.Wo);
+      const int off = ok ? (((od * c.Ho + oh) * c.Wo + ow) * ocs + coe) * 2 : (int)0x80000000;
+      float a, b;
+      mt_pair_exchange(acc[0][j] + bv, acc[0][j + 1] + bv, odd, a, b);
+      if (c.accumulate) { const unsigned pv = __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0); a += mt_bf16_lo(pv); b += mt_bf16_hi(pv); }
+      const unsigned pk = mt_pk_bf16(a, b);
+      __builtin_amdgcn_raw_buffer_store_b32(pk, rd, off, 0, 0);
+      if (ok) {
+        const float ar = mt_bf16_lo(pk), br = mt_bf16_hi(pk);
+        q1[0] += ar; q2[0] = fmaf(ar, ar, q2[0]); q1[1] += br; q2[1] = fmaf(br, br, q2[1]);
+      }
+    }
+    s1 = mt_pair_combine(q1[0], q1[1], odd);
+    s2 = mt_pair_combine(q2[0], q2[1], odd);
+  } else {
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf;
@@ -983,6 +1010,7 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
     if (c.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0));
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off, 0, 0);
     if (ok) { s1 += v; s2 = fmaf(v, v, s2); }
+  }
   }
   if (c.stats_part != nullptr) {
     s1 += __shfl_xor(s1, 32, 64);
@@ -1576,8 +1604,9 @@ template <int S> __host__ __device__ constexpr int bd_off(int k) { return S == 2
 #ifndef BDS_ABL
 #define BDS_ABL 0      // timing ablations: 1 skip the dY staging, 2 skip the weight-fragment loads, 4 skip the epilogue, 8 skip the MFMAs
 #endif
-template <int SD, int SH, int SW, int VEC, bool BF = false>
+template <int SD, int SH, int SW, int VEC, bool BF = false, bool XB = false, bool OB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_bwdd_strided_kernel(const ConvKParams P) {
+  static_assert(BF || !(XB || OB), "bf16 storage is served by the bf16 matrix path");
   constexpr int TD = 2, TH = 4, TW = 16;                       // dY positions per workgroup: 4 waves x 32
   constexpr int LD = TD + (SD == 2 ? 1 : 2), LH = TH + (SH == 2 ? 1 : 2), LW = TW + (SW == 2 ? 1 : 2);
   constexpr int NC = SD * SH * SW, LWP = BF ? bstage_lwp<LD, LH, LW, VEC, 4>() : stage_lwp<LD, LH, LW, VEC>();
@@ -1606,7 +1635,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
     __syncthreads();
     if constexpr (BF) {
-      mt_stage_bf16<LD, LH, LW, VEC, 4>((unsigned*)lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
+      mt_stage_bf16<LD, LH, LW, VEC, 4, XB>((unsigned*)lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
       __syncthreads();
       const unsigned* ldsu = (const unsigned*)lds;
       const unsigned* wl = (const unsigned*)c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 256) + lane * 4;
@@ -1682,10 +1711,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   const bool covalid = co < c.Cout;
   const int ocs = c.ocs0;
   const size_t out_sample = (size_t)c.OD * c.OH * c.OW;
-  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
-                                                                (int)(out_sample * ocs * 4), 0x00020000);
+  constexpr int OEB = OB ? 2 : 4;
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)nb * out_sample * ocs * OEB), 0,
+                                                                (int)(out_sample * ocs * OEB), 0x00020000);
   const int md = md0 + dm;
   if (BDS_ABL & 4) { float t = 0.f; for (int q = 0; q < NC; ++q) t += acc[q][3] + acc[q][9]; if (t == 1234.5f) c.out0[0] = t; return; }
+  if constexpr (OB) {
+    // bf16 dX: channel-pair dwords (mt_pair_exchange) — even lanes own accumulator row j, odd lanes row j + 1; the read-modify-write of
+    // an accumulating launch is pipelined one row pair ahead like the fp32 form below
+    const bool odd = li & 1;
+    const int coe = co & ~1;
+    const bool pvalid = coe + 1 < c.Cout;
+    auto pair_off = [&](int j, int (&off)[NC]) {
+      const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf + (odd ? 1 : 0);
+      const int mh = mh0 + rbase + (iv >> 4), mw = mw0 + (iv & 15);
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int pd = q / (SH * SW), ph = (q / SW) % SH, pw = q % SW;
+        const int xd = md * SD + pd, xh = mh * SH + ph, xw = mw * SW + pw;
+        const bool ok = pvalid && xd < c.OD && xh < c.OH && xw < c.OW;
+        off[q] = ok ? (((xd * c.OH + xh) * c.OW + xw) * ocs + coe) * 2 : (int)0x80000000;
+      }
+    };
+    int poff[2][NC];
+    unsigned pprev[2][NC];
+    pair_off(0, poff[0]);
+    if (c.accumulate) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) pprev[0][q] = __builtin_amdgcn_raw_buffer_load_b32(rd, poff[0][q], 0, 0);
+    }
+#pragma unroll
+    for (int jp = 0; jp < 8; ++jp) {
+      const int j = 2 * jp;
+      if (jp + 1 < 8) {
+        pair_off(j + 2, poff[(jp + 1) & 1]);
+        if (c.accumulate) {
+#pragma unroll
+          for (int q = 0; q < NC; ++q) pprev[(jp + 1) & 1][q] = __builtin_amdgcn_raw_buffer_load_b32(rd, poff[(jp + 1) & 1][q], 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        float a, b;
+        mt_pair_exchange(acc[q][j], acc[q][j + 1], odd, a, b);
+        if (c.accumulate) { a += mt_bf16_lo(pprev[jp & 1][q]); b += mt_bf16_hi(pprev[jp & 1][q]); }
+        __builtin_amdgcn_raw_buffer_store_b32(mt_pk_bf16(a, b), rd, poff[jp & 1][q], 0, 0);
+      }
+    }
+    return;
+  }
   // Accumulating into dX (the skip connection wrote it first) is a read-modify-write of 16 x NC scattered dwords per lane: the
   // NC loads of accumulator row j+1 are requested before the NC stores of row j go out, so a row's round trip hides behind the
   // previous row's stores (one load -> add -> store chain per element cost 0.26 of 0.81 ms on 30 <- 60 @ 48x192x192)
@@ -1874,9 +1948,21 @@ static int conv_fast_vec(const mt_conv3d_t* p) {
   if (force1) return 1;
   for (int i = 0; i < p->nsrc; ++i) {
     const mt_src_t& s = p->src[i];
-    if ((s.cs & 1) || (s.C & 1) || (((uintptr_t)s.ptr) & 7)) return 1;
+    if ((s.cs & 1) || (s.C & 1) || (((uintptr_t)s.ptr) & (s.dtype == MT_BF16 ? 3 : 7))) return 1;   // a channel pair = one 8 / 4-byte load
   }
   return 2;
+}
+// storage types of a problem: the common type of the sources (-1: mixed), and whether the destination(s) can be written as bf16
+// dwords (channel pairs: even channel counts / strides / split, dword-aligned bases)
+static int conv_src_dtype(const mt_conv3d_t* p) {
+  const int d = p->src[0].dtype;
+  if (p->nsrc == 2 && p->src[1].dtype != d) return -1;
+  return (d == MT_F32 || d == MT_BF16) ? d : -1;
+}
+static bool conv_out_pairs_ok(const mt_conv3d_t* p) {
+  if ((p->Cout & 1) || (p->ocs0 & 1) || (((uintptr_t)p->out0) & 3)) return false;
+  if (p->csplit < p->Cout && ((p->csplit & 1) || (p->ocs1 & 1) || (((uintptr_t)p->out1) & 3))) return false;
+  return true;
 }
 
 template <int MW, int RH, int TD, int VEC, int KD = 3>
@@ -1926,7 +2012,13 @@ static int launch_fast_strided_t(const mt_conv3d_t* p, hipStream_t st) {
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 64), 1);
   if (strided_use_bf16(p)) {
-    hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
+    const int sd = conv_src_dtype(p);
+    if (sd == MT_BF16 && p->odtype == MT_BF16)
+      hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 4, true, true, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 4, 4>()), st, P);
+    else if (sd == MT_BF16)              // the level below the storage threshold stays fp32
+      hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 4, true, true, false>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 4, 4>()), st, P);
+    else
+      hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
   } else if (conv_fast_vec(p) == 2) {
     hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 2>()), st, P);
   } else {
@@ -2028,7 +2120,7 @@ static bool strided_use_bf16(const mt_conv3d_t* p) {      // forward strided sta
   return use && g_bf16_mode && p->mma == 1 && p->Cin >= 16 && conv_fast_vec(p) == 2;
 }
 static int conv_bf16_vec(const mt_conv3d_t*) { return 2; }    // 16-byte staging loads measured slower (0.409 vs 0.372 ms on 32->32)
-template <int MW, int RH, int TD, int VEC, int NT, int NW, int KD = 3>
+template <int MW, int RH, int TD, int VEC, int NT, int NW, int KD = 3, bool XB = false, bool OB = false>
 static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   ConvKParams P;
   P.c = *p;
@@ -2041,7 +2133,7 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
   const size_t ldsb = bstage_lds_bytes<TD + KD - 1, TH + 2, TW + 2, VEC, NW>();
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(mt_cdiv(p->Cout, 32), NT), 1);
-  auto kfn = conv_bf16_kernel<MW, RH, TD, VEC, NT, NW, KD>;
+  auto kfn = conv_bf16_kernel<MW, RH, TD, VEC, NT, NW, KD, XB, OB>;
   if (ldsb > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
@@ -2052,8 +2144,14 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
 }
 static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
   // NT = 2 (64 output channels per workgroup) measured slower: 0.197 vs 0.179 ms on 64->64 @ 24x96x96; 8 waves: no gain
+  // storage: all fp32, or all bf16 (sources read as 8-byte groups of four channels, destination written as channel-pair dwords)
+  const bool sb = conv_src_dtype(p) == MT_BF16 && p->odtype == MT_BF16;
+  MT_REQUIRE(sb || (conv_src_dtype(p) == MT_F32 && p->odtype == MT_F32), "conv3d: conv_bf16_kernel takes fp32 or bf16 storage on ALL operands (ask mt_conv3d_io_supported)");
 #define MT_BF_CASE(I_, MW_, RH_, TD_, NW_)                                                   \
-  if (cfg == I_) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 2, 1, NW_, 1>(p, st) : launch_bf16_t<MW_, RH_, TD_, 2, 1, NW_>(p, st);
+  if (cfg == I_) {                                                                           \
+    if (sb) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 1, true, true>(p, st) : launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 3, true, true>(p, st); \
+    return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 2, 1, NW_, 1>(p, st) : launch_bf16_t<MW_, RH_, TD_, 2, 1, NW_>(p, st); \
+  }
   MT_BF_CASE(0, 32, 4, 4, 4)
   MT_BF_CASE(1, 32, 4, 2, 4)
   MT_BF_CASE(2, 16, 4, 2, 4)
@@ -2343,12 +2441,30 @@ extern "C" int mt_conv3d_bwd_stats_supported(const mt_conv3d_t* p) {
   return (pl.cfg >= 0 && pl.kind == CONV_WINO && wino_serves_bwd_stats(p)) ? 1 : 0;
 }
 
+// Storage types (mt_src_t.dtype, mt_conv3d_t.odtype): 1 when the kernel that serves p reads / writes them natively.  All-fp32 is
+// always supported; bf16 storage is taken by the bf16 matrix kernels (p->mma == 1): conv_bf16_kernel with bf16 on ALL operands,
+// the strided stage kernel with bf16 sources (destination bf16 or fp32).  Elsewhere the caller converts with mt_cast.
+extern "C" int mt_conv3d_io_supported(const mt_conv3d_t* p) {
+  if (p == nullptr) return 0;
+  const int sd = conv_src_dtype(p);
+  if (sd < 0 || !mt_dtype_ok(p->odtype)) return 0;
+  if (sd == MT_F32 && p->odtype == MT_F32) return 1;
+  if (p->bstats.y != nullptr) return 0;
+  const ConvPlan pl = conv_plan(p);
+  if (pl.cfg < 0) return 0;
+  if (pl.kind == CONV_BF16) return (sd == MT_BF16 && p->odtype == MT_BF16 && conv_out_pairs_ok(p)) ? 1 : 0;
+  if (pl.kind == CONV_FAST_STRIDED && strided_use_bf16(p)) return (sd == MT_BF16 && (p->odtype == MT_F32 || conv_out_pairs_ok(p))) ? 1 : 0;
+  return 0;
+}
+
 extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
   int rc = conv_validate(p);
   if (rc != MT_OK) return rc;
   const ConvPlan pl = conv_plan(p);
   const int i = pl.cfg;
   MT_REQUIRE(i >= 0, "conv3d: no tile configuration fits LDS");
+  MT_REQUIRE(mt_conv3d_io_supported(p), "conv3d: storage types (src %d/%d, out %d) not taken by the kernel that serves this problem "
+             "(ask mt_conv3d_io_supported, convert with mt_cast)", p->src[0].dtype, p->nsrc == 2 ? p->src[1].dtype : -1, p->odtype);
   MT_REQUIRE(p->bstats.y == nullptr || pl.kind == CONV_WINO, "conv3d: bstats set on a problem whose kernel does not compute them "
              "(ask mt_conv3d_bwd_stats_supported)");
   if (pl.kind == CONV_BF16) return launch_bf16(p, i, (hipStream_t)stream);
@@ -2410,9 +2526,16 @@ static bool bwdd_strided_use_bf16(const mt_conv3d_t* p) {          // p = FORWAR
   static int use = -1;
   if (use < 0) { const char* e = getenv("MT_STRIDED_BF16"); use = e ? atoi(e) : 1; }
   const mt_src_t& s0 = p->src[0];
-  return use && g_bf16_mode && p->mma == 1 && p->Cout >= 16 && !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7));
+  return use && g_bf16_mode && p->mma == 1 && p->Cout >= 16 && !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & (s0.dtype == MT_BF16 ? 3 : 7)));
 }
 extern "C" int mt_conv3d_bwd_data_strided_pack_layout(const mt_conv3d_t* p) { return (p != nullptr && bwdd_strided_use_bf16(p)) ? 3 : 1; }
+extern "C" int mt_conv3d_bwd_data_strided_io_supported(const mt_conv3d_t* p) {
+  if (p == nullptr || !mt_dtype_ok(p->src[0].dtype) || !mt_dtype_ok(p->odtype)) return 0;
+  if (p->src[0].dtype == MT_F32 && p->odtype == MT_F32) return 1;
+  if (!bwdd_strided_use_bf16(p)) return 0;
+  // dX bf16 (channel-pair dwords: even Cin / stride, dword-aligned base) from dY bf16 or fp32
+  return (p->odtype == MT_BF16 && !(p->Cin & 1) && !(p->ocs0 & 1) && !(((uintptr_t)p->out0) & 3)) ? 1 : 0;
+}
 template <int SD, int SH, int SW>
 static int launch_bwdd_strided(const mt_conv3d_t* p, hipStream_t st) {
   constexpr int TD = 2, TH = 4, TW = 16;
@@ -2433,7 +2556,15 @@ static int launch_bwdd_strided(const mt_conv3d_t* p, hipStream_t st) {
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cin, 32), 1);
   const mt_src_t& s0 = p->src[0];
   const bool v2 = !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7));
-  if (bwdd_strided_use_bf16(p)) hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
+  MT_REQUIRE(mt_conv3d_bwd_data_strided_io_supported(p), "bwd_data_strided: storage types not taken by the kernel that serves this problem (ask mt_conv3d_bwd_data_strided_io_supported)");
+  if (bwdd_strided_use_bf16(p)) {
+    if (s0.dtype == MT_BF16 && p->odtype == MT_BF16)
+      hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 4, true, true, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 4, 4>()), st, P);
+    else if (p->odtype == MT_BF16)       // dY of the fp32 level below the storage threshold, dX bf16
+      hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2, true, false, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
+    else
+      hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
+  }
   else if (v2) hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 2>()), st, P);
   else    hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 1>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 1>()), st, P);
   MT_CHECK_LAUNCH("conv_bwdd_strided");
@@ -3596,10 +3727,29 @@ extern "C" int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_s
   return MT_OK;
 }
 
+// storage types of a backward-weight problem: X = p->src (common type), dY = ysrc.  The bf16 Winograd marching kernels take any
+// combination; every other kernel is fp32-only (convert with mt_cast).
+extern "C" int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_src_t* ysrc) {
+  if (p == nullptr || ysrc == nullptr) return 0;
+  const int xdt = conv_src_dtype(p);
+  if (xdt < 0 || !mt_dtype_ok(ysrc->dtype)) return 0;
+  if (xdt == MT_F32 && ysrc->dtype == MT_F32) return 1;
+  static int use_fast_q = -1;
+  if (use_fast_q < 0) { const char* e = getenv("MT_BWDW_FAST"); use_fast_q = e ? atoi(e) : 1; }
+  if (!use_fast_q || bwdw_is_stem(p, ysrc)) return 0;
+  const int geo = bwdw_fast_geo(p, ysrc);
+  if (geo == 0 && bwdw_use_bf16(p)) return 1;
+  if (geo == 6 && bwdw_use_bf16_133(p)) return 1;
+  return 0;
+}
+
 extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, float* dw, long s_ci, long s_co,
                                     long s_kd, long s_kh, long s_kw, int accumulate, void* workspace,
                                     size_t workspace_bytes, mt_stream_t stream) {
   MT_REQUIRE(p != nullptr && ysrc != nullptr && dw != nullptr, "bwd_weight: null argument");
+  MT_REQUIRE(mt_conv3d_bwd_weight_io_supported(p, ysrc), "bwd_weight: storage types (X %d/%d, dY %d) not taken by the kernel that serves this problem "
+             "(ask mt_conv3d_bwd_weight_io_supported, convert with mt_cast)", p->src[0].dtype, p->nsrc == 2 ? p->src[1].dtype : -1, ysrc->dtype);
+  const int xdt = conv_src_dtype(p);
   MT_REQUIRE(p->nsrc == 1 || p->nsrc == 2, "bwd_weight: nsrc must be 1 or 2");
   MT_REQUIRE(p->KD >= 1 && p->KD <= 3 && p->KH >= 1 && p->KH <= 3 && p->KW >= 1 && p->KW <= 3, "bwd_weight: kernel size must be 1..3");
   MT_REQUIRE(p->dilD == 1 && p->dilH == 1 && p->dilW == 1, "bwd_weight: dilation unsupported");
@@ -3646,7 +3796,11 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     switch (geo) {
       case 0: {
         if (bwdw_use_bf16(p)) {
-          hipLaunchKernelGGL(conv_bwdw_wino_bf16_kernel<3>, dim3(P.nsg, P.ncot, P.nchunks), dim3(256), BWB_LDS_BYTES, st, P);
+          const dim3 g3(P.nsg, P.ncot, P.nchunks);
+          if (xdt == MT_BF16 && ysrc->dtype == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, true, true>), g3, dim3(256), BWB_LDS_BYTES, st, P);
+          else if (xdt == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, true, false>), g3, dim3(256), BWB_LDS_BYTES, st, P);
+          else if (ysrc->dtype == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, false, true>), g3, dim3(256), BWB_LDS_BYTES, st, P);
+          else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3>), g3, dim3(256), BWB_LDS_BYTES, st, P);
           MT_CHECK_LAUNCH("conv_bwdw_wino_bf16");
           rc = MT_OK;
           break;
@@ -3678,7 +3832,11 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
       case 8: rc = launch_bwdw_fast<1, 1, 1, 1, 2, 2>(P, vec, st); break;
       case 6:
         if (bwdw_use_bf16_133(p)) {
-          hipLaunchKernelGGL(conv_bwdw_wino_bf16_kernel<1>, dim3(P.nsg, P.ncot, P.nchunks), dim3(256), BWB_LDS_BYTES, st, P);
+          const dim3 g3(P.nsg, P.ncot, P.nchunks);
+          if (xdt == MT_BF16 && ysrc->dtype == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, true, true>), g3, dim3(256), BWB_LDS_BYTES, st, P);
+          else if (xdt == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, true, false>), g3, dim3(256), BWB_LDS_BYTES, st, P);
+          else if (ysrc->dtype == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, false, true>), g3, dim3(256), BWB_LDS_BYTES, st, P);
+          else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1>), g3, dim3(256), BWB_LDS_BYTES, st, P);
           MT_CHECK_LAUNCH("conv_bwdw_wino_bf16<1>");
           rc = MT_OK;
           break;

@@ -41,6 +41,58 @@ __device__ __forceinline__ int mt_xcd_remap(int bid, int nblk) {
 
 __device__ __forceinline__ float mt_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// ---- bf16 storage (MT_BF16): widening is exact (a shift), narrowing rounds to nearest-even (v_cvt_pk_bf16_f32) ----------------
+typedef __bf16 mt_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned mt_pk_bf16(float a, float b) {          // dword = (bf16(a) low half, bf16(b) high half)
+  typedef float mt_f32x2 __attribute__((ext_vector_type(2)));
+  mt_f32x2 v; v[0] = a; v[1] = b;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mt_bf16x2));
+}
+__device__ __forceinline__ float mt_bf16_lo(unsigned d) { return __builtin_bit_cast(float, d << 16); }
+__device__ __forceinline__ float mt_bf16_hi(unsigned d) { return __builtin_bit_cast(float, d & 0xffff0000u); }
+__device__ __forceinline__ float mt_round_bf16(float a) { return mt_bf16_lo(mt_pk_bf16(a, a)); }     // the value a bf16 store keeps
+// scalar element access with a compile-time storage type (generic, strided kernels)
+template <bool BF> __device__ __forceinline__ float mt_ld(const void* p, size_t i) {
+  if constexpr (BF) return __builtin_bit_cast(float, (unsigned)((const unsigned short*)p)[i] << 16);
+  else return ((const float*)p)[i];
+}
+template <bool BF> __device__ __forceinline__ void mt_st(void* p, size_t i, float v) {
+  if constexpr (BF) ((unsigned short*)p)[i] = (unsigned short)(mt_pk_bf16(v, v) & 0xffffu);
+  else ((float*)p)[i] = v;
+}
+// VEC consecutive elements as one 4 / 8 / 16-byte access (fp32: VEC 1, 2, 4; bf16: VEC 2, 4, 8); idx counts vectors
+template <int VEC, bool BF> __device__ __forceinline__ void mt_ldv(const void* p, size_t idx, float (&v)[VEC]) {
+  if constexpr (!BF) {
+    if constexpr (VEC == 1) v[0] = ((const float*)p)[idx];
+    else if constexpr (VEC == 2) { const float2 t = ((const float2*)p)[idx]; v[0] = t.x; v[1] = t.y; }
+    else { static_assert(VEC == 4, "fp32 vectors: 1, 2, 4"); const float4 t = ((const float4*)p)[idx]; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  } else {
+    static_assert(VEC == 2 || VEC == 4 || VEC == 8, "bf16 vectors: 2, 4, 8");
+    unsigned d[VEC / 2];
+    if constexpr (VEC == 2) d[0] = ((const unsigned*)p)[idx];
+    else if constexpr (VEC == 4) { const uint2 t = ((const uint2*)p)[idx]; d[0] = t.x; d[1] = t.y; }
+    else { const uint4 t = ((const uint4*)p)[idx]; d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
+#pragma unroll
+    for (int k = 0; k < VEC / 2; ++k) { v[2 * k] = mt_bf16_lo(d[k]); v[2 * k + 1] = mt_bf16_hi(d[k]); }
+  }
+}
+template <int VEC, bool BF> __device__ __forceinline__ void mt_stv(void* p, size_t idx, const float (&v)[VEC]) {
+  if constexpr (!BF) {
+    if constexpr (VEC == 1) ((float*)p)[idx] = v[0];
+    else if constexpr (VEC == 2) { float2 t; t.x = v[0]; t.y = v[1]; ((float2*)p)[idx] = t; }
+    else { float4 t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; ((float4*)p)[idx] = t; }
+  } else {
+    unsigned d[VEC / 2];
+#pragma unroll
+    for (int k = 0; k < VEC / 2; ++k) d[k] = mt_pk_bf16(v[2 * k], v[2 * k + 1]);
+    if constexpr (VEC == 2) ((unsigned*)p)[idx] = d[0];
+    else if constexpr (VEC == 4) { uint2 t; t.x = d[0]; t.y = d[1]; ((uint2*)p)[idx] = t; }
+    else { uint4 t; t.x = d[0]; t.y = d[1]; t.z = d[2]; t.w = d[3]; ((uint4*)p)[idx] = t; }
+  }
+}
+static inline size_t mt_esize(int dtype) { return dtype == MT_BF16 ? 2 : 4; }
+static inline bool mt_dtype_ok(int dtype) { return dtype == MT_F32 || dtype == MT_BF16; }
+
 __device__ __forceinline__ float mt_wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

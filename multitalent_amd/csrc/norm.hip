@@ -68,12 +68,29 @@ __host__ __device__ static inline int mt_vb(long V) {
 }
 static inline int nb_blocks(long V) { return mt_cdiv(V, (long)mt_vb(V)); }
 
+// ---- storage types ---------------------------------------------------------------------------------
+// Every streaming kernel below is templated on the storage type of its activation / gradient operands (BF = bf16, mt_common.h):
+// all tensor operands of one call share it (the engine chooses the type per resolution level, so the operands of a normalisation
+// or a residual add always agree; mt_cast converts where they do not).  Arithmetic and partial sums are fp32 / fp64 either way.
+#define MT_DT_SWITCH(dtype_, CALL_) do { if ((dtype_) == MT_BF16) { constexpr bool BF = true; CALL_; } else { constexpr bool BF = false; CALL_; } } while (0)
+// widest vector (elements) the dense fast paths may use: divides C, keeps every sample base aligned, <= 16 bytes
+static int dense_vec(int C, long per_sample, int dtype, std::initializer_list<const void*> ptrs) {
+  const int es = (int)mt_esize(dtype);
+  int v = 16 / es;                                   // 4 (fp32) or 8 (bf16)
+  while (v > 1 && (C % v || per_sample % v)) v >>= 1;
+  for (const void* q : ptrs)
+    if (q != nullptr) { while (v > 1 && (((uintptr_t)q) & (size_t)(v * es - 1))) v >>= 1; }
+  if (dtype == MT_BF16 && v < 2) return 0;           // bf16 vectors are at least one dword
+  return v;
+}
+
 // ---- materialise a = lrelu(y*sc+sh [+ residual]) ----------------------------------------------
 struct ApplyParams {
-  const float* y; int ycs; const float* scale; const float* shift; float slope;
-  const float* res; int rcs; const float* rscale; const float* rshift; float rslope;
-  float* out; int ocs; long V; int C;
+  const void* y; int ycs; const float* scale; const float* shift; float slope;
+  const void* res; int rcs; const float* rscale; const float* rshift; float rslope;
+  void* out; int ocs; long V; int C;
 };
+template <bool BF>
 __global__ __launch_bounds__(256) void inorm_apply_kernel(const ApplyParams P) {
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
@@ -88,21 +105,23 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const ApplyParams P) {
     const float rsh = (P.res && P.rscale) ? P.rshift[(size_t)n * P.C + c] : 0.f;
     for (long v = v0 + vr; v < v1; v += 8) {
       const size_t e = (size_t)n * P.V + v;
-      float t = fmaf(P.y[e * P.ycs + c], sc, sh);
-      if (P.res) t += mt_lrelu(fmaf(P.res[e * P.rcs + c], rsc, rsh), P.rslope);
-      P.out[e * P.ocs + c] = mt_lrelu(t, P.slope);
+      float t = fmaf(mt_ld<BF>(P.y, e * P.ycs + c), sc, sh);
+      if (P.res) t += mt_lrelu(fmaf(mt_ld<BF>(P.res, e * P.rcs + c), rsc, rsh), P.rslope);
+      mt_st<BF>(P.out, e * P.ocs + c, mt_lrelu(t, P.slope));
     }
   }
 }
-struct ApplyParams;
-static int launch_apply_fast(const ApplyParams& P, int N, mt_stream_t stream, const float* res_or_y);
+static int launch_apply_fast(const ApplyParams& P, int N, int dtype, int vec, mt_stream_t stream);
 extern "C" int mt_inorm_lrelu_apply(const float* y, int ycs, const float* scale, const float* shift, float slope,
                                     const float* res, int rcs, const float* rscale, const float* rshift, float rslope,
-                                    float* out, int ocs, int N, long V, int C, mt_stream_t stream) {
-  MT_REQUIRE(y && out && N > 0 && V > 0 && C > 0, "inorm_lrelu_apply: bad args");
+                                    float* out, int ocs, int N, long V, int C, int dtype, mt_stream_t stream) {
+  MT_REQUIRE(y && out && N > 0 && V > 0 && C > 0 && mt_dtype_ok(dtype), "inorm_lrelu_apply: bad args");
   ApplyParams P{y, ycs, scale, shift, slope, res, rcs, rscale, rshift, rslope, out, ocs, V, C};
-  if (ycs == C && ocs == C && (res == nullptr || rcs == C)) return launch_apply_fast(P, N, stream, res != nullptr ? res : y);
-  hipLaunchKernelGGL(inorm_apply_kernel, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P);
+  if (ycs == C && ocs == C && (res == nullptr || rcs == C)) {
+    const int vec = dense_vec(C, V * C, dtype, {y, out, res});
+    if (vec > 0) return launch_apply_fast(P, N, dtype, vec, stream);
+  }
+  MT_DT_SWITCH(dtype, hipLaunchKernelGGL(inorm_apply_kernel<BF>, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P));
   MT_CHECK_LAUNCH("inorm_lrelu_apply");
   return MT_OK;
 }
@@ -110,7 +129,7 @@ extern "C" int mt_inorm_lrelu_apply(const float* y, int ycs, const float* scale,
 // ---- backward of out = lrelu(IN(y)) -------------------------------------------------------------
 // pass 1: per (n,c) A = sum dz, B = sum dz*zhat   (dz = g * lrelu'(z)); pass 2: dy in place.
 struct InBwdParams {
-  float* g; int gcs; const float* y; int ycs;
+  void* g; int gcs; const void* y; int ycs;
   const float* mean; const float* rstd; const float* gamma; const float* beta; float slope;
   long V; int C; int nvb;
   float* part1;  // [N][nvb][C][2]
@@ -120,6 +139,7 @@ struct InBwdParams {
   // pass: part1, nvb, C, 0; fused into the producing convolution: its stats_part, its nsb, its Cout, bstats.c0)
   const float* p1; int p1_nblk, p1_cs, p1_c0;
 };
+template <bool BF>
 __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const InBwdParams P) {
   __shared__ float red[8][32][2];
   const int n = blockIdx.y;
@@ -135,9 +155,9 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const InBwdParams
       const float ga = P.gamma ? P.gamma[c] : 1.f, be = P.beta ? P.beta[c] : 0.f;
       for (long v = v0 + vr; v < v1; v += 8) {
         const size_t e = (size_t)n * P.V + v;
-        const float zh = (P.y[e * P.ycs + c] - mu) * rs;
+        const float zh = (mt_ld<BF>(P.y, e * P.ycs + c) - mu) * rs;
         const float z = fmaf(zh, ga, be);
-        float dz = P.g[e * P.gcs + c];
+        float dz = mt_ld<BF>(P.g, e * P.gcs + c);
         dz = z > 0.f ? dz : dz * P.slope;
         a += dz;
         b += dz * zh;
@@ -187,6 +207,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_finalize_kernel(const InBwdPara
     if (dbeta) dbeta[c] += (float)ta;
   }
 }
+template <bool BF>
 __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const InBwdParams P) {
   __shared__ float red[8][32];
   const int n = blockIdx.y;
@@ -204,12 +225,13 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const InBwdParams 
       const float k = ga * rs;
       for (long v = v0 + vr; v < v1; v += 8) {
         const size_t e = (size_t)n * P.V + v;
-        const float zh = (P.y[e * P.ycs + c] - mu) * rs;
+        const float zh = (mt_ld<BF>(P.y, e * P.ycs + c) - mu) * rs;
         const float z = fmaf(zh, ga, be);
-        float dz = P.g[e * P.gcs + c];
+        float dz = mt_ld<BF>(P.g, e * P.gcs + c);
         dz = z > 0.f ? dz : dz * P.slope;
-        const float dy = k * (dz - m1 - zh * m2);
-        P.g[e * P.gcs + c] = dy;
+        float dy = k * (dz - m1 - zh * m2);
+        if constexpr (BF) dy = mt_round_bf16(dy);       // the bias gradient sums what the next kernel reads
+        mt_st<BF>(P.g, e * P.gcs + c, dy);
         sdy += dy;
       }
     }
@@ -241,21 +263,9 @@ __global__ __launch_bounds__(64) void colsum_kernel(const float* part, long rows
 // base + t + k*A, whose channel group is (t mod G) for every k (A is a multiple of G) -> per-channel constants live in
 // registers, consecutive lanes read consecutive vectors (fully coalesced), 4 independent loads in flight per tensor.
 #define NF_UNROLL 4
-template <int VEC> struct VecT;
-template <> struct VecT<1> { typedef float T; };
-template <> struct VecT<2> { typedef float2 T; };
-template <> struct VecT<4> { typedef float4 T; };
-template <int VEC> __device__ __forceinline__ float vget(const typename VecT<VEC>::T& v, int e);
-template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
-template <> __device__ __forceinline__ float vget<2>(const float2& v, int e) { return e ? v.y : v.x; }
-template <> __device__ __forceinline__ float vget<4>(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
-template <int VEC> __device__ __forceinline__ void vset(typename VecT<VEC>::T& v, int e, float x);
-template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v = x; }
-template <> __device__ __forceinline__ void vset<2>(float2& v, int e, float x) { if (e) v.y = x; else v.x = x; }
-template <> __device__ __forceinline__ void vset<4>(float4& v, int e, float x) { if (e == 0) v.x = x; else if (e == 1) v.y = x; else if (e == 2) v.z = x; else v.w = x; }
 
 struct InBwdFast {
-  float* g; const float* y;
+  void* g; const void* y;
   const float* mean; const float* rstd; const float* gamma; const float* beta; float slope;
   long nvec;      // vectors per sample = V*C/VEC
   int C, G, A, nblk;
@@ -264,9 +274,8 @@ struct InBwdFast {
   float* part2;   // [N][nblk][C] or null
 };
 
-template <int VEC, bool APPLY>
+template <int VEC, bool APPLY, bool BF>
 __global__ __launch_bounds__(256) void inorm_bwd_fast_kernel(const InBwdFast P) {
-  typedef typename VecT<VEC>::T VT;
   __shared__ float red[256 * VEC * 2];
   const int n = blockIdx.y, t = threadIdx.x;
   const bool act = t < P.A;
@@ -284,37 +293,39 @@ __global__ __launch_bounds__(256) void inorm_bwd_fast_kernel(const InBwdFast P) 
   const long per = ((P.nvec + P.nblk - 1) / P.nblk + P.A - 1) / P.A * P.A;
   const long lo = (long)blockIdx.x * per;
   long hi = lo + per; if (hi > P.nvec) hi = P.nvec;
-  VT* gp = (VT*)(P.g + (size_t)n * P.nvec * VEC);
-  const VT* yp = (const VT*)(P.y + (size_t)n * P.nvec * VEC);
+  const size_t sbytes = (size_t)n * P.nvec * VEC * (BF ? 2 : 4);
+  char* gp = (char*)P.g + sbytes;
+  const char* yp = (const char*)P.y + sbytes;
   if (act) {
     for (long i0 = lo + t; i0 < hi; i0 += (long)P.A * NF_UNROLL) {
-      VT gv[NF_UNROLL], yv[NF_UNROLL];
+      float gv[NF_UNROLL][VEC], yv[NF_UNROLL][VEC];
 #pragma unroll
       for (int u = 0; u < NF_UNROLL; ++u) {
         const long i = i0 + (long)u * P.A;
-        if (i < hi) { gv[u] = gp[i]; yv[u] = yp[i]; }
+        if (i < hi) { mt_ldv<VEC, BF>(gp, (size_t)i, gv[u]); mt_ldv<VEC, BF>(yp, (size_t)i, yv[u]); }
       }
 #pragma unroll
       for (int u = 0; u < NF_UNROLL; ++u) {
         const long i = i0 + (long)u * P.A;
         if (i < hi) {
-          VT out;
+          float out[VEC];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
-            const float zh = (vget<VEC>(yv[u], e) - mu[e]) * rs[e];
+            const float zh = (yv[u][e] - mu[e]) * rs[e];
             const float z = fmaf(zh, ga[e], be[e]);
-            float dz = vget<VEC>(gv[u], e);
+            float dz = gv[u][e];
             dz = z > 0.f ? dz : dz * P.slope;
             if (APPLY) {
-              const float dy = ga[e] * rs[e] * (dz - m1[e] - zh * m2[e]);
-              vset<VEC>(out, e, dy);
+              float dy = ga[e] * rs[e] * (dz - m1[e] - zh * m2[e]);
+              if constexpr (BF) dy = mt_round_bf16(dy);
+              out[e] = dy;
               a0[e] += dy;
             } else {
               a0[e] += dz;
               a1[e] = fmaf(dz, zh, a1[e]);
             }
           }
-          if (APPLY) gp[i] = out;
+          if (APPLY) mt_stv<VEC, BF>(gp, (size_t)i, out);
         }
       }
     }
@@ -340,11 +351,27 @@ extern "C" size_t mt_inorm_bwd_workspace(int N, long V, int C) {
   const size_t nvb = (size_t)nb_blocks(V);
   return ((size_t)N * nvb * C * 3 + (size_t)N * C * 2) * sizeof(float);
 }
+template <int VEC, bool BF>
+static void launch_inorm_bwd_fast(const InBwdFast& F, dim3 grid, bool reduce, hipStream_t st) {
+  if (reduce) hipLaunchKernelGGL((inorm_bwd_fast_kernel<VEC, false, BF>), grid, dim3(256), 0, st, F);
+  else hipLaunchKernelGGL((inorm_bwd_fast_kernel<VEC, true, BF>), grid, dim3(256), 0, st, F);
+}
+static void inorm_bwd_fast_dispatch(const InBwdFast& F, dim3 grid, int vec, int dtype, bool reduce, hipStream_t st) {
+  if (dtype == MT_BF16) {
+    if (vec == 8) launch_inorm_bwd_fast<8, true>(F, grid, reduce, st);
+    else if (vec == 4) launch_inorm_bwd_fast<4, true>(F, grid, reduce, st);
+    else launch_inorm_bwd_fast<2, true>(F, grid, reduce, st);
+  } else {
+    if (vec == 4) launch_inorm_bwd_fast<4, false>(F, grid, reduce, st);
+    else if (vec == 2) launch_inorm_bwd_fast<2, false>(F, grid, reduce, st);
+    else launch_inorm_bwd_fast<1, false>(F, grid, reduce, st);
+  }
+}
 extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, float slope, int N, long V, int C,
                                   float* dgamma, float* dbeta, float* dbias, const float* part, int part_nblk, int part_cs, int part_c0,
-                                  void* ws, size_t ws_bytes, mt_stream_t stream) {
-  MT_REQUIRE(g && y && mean && rstd && N > 0 && V > 0 && C > 0, "inorm_lrelu_bwd: bad args");
+                                  void* ws, size_t ws_bytes, int dtype, mt_stream_t stream) {
+  MT_REQUIRE(g && y && mean && rstd && N > 0 && V > 0 && C > 0 && mt_dtype_ok(dtype), "inorm_lrelu_bwd: bad args");
   MT_REQUIRE(part == nullptr || (part_nblk > 0 && part_cs >= part_c0 + C && part_c0 >= 0), "inorm_lrelu_bwd: bad external partials");
   if (ws == nullptr || ws_bytes < mt_inorm_bwd_workspace(N, V, C)) { mt_set_error("inorm_lrelu_bwd: workspace too small"); return MT_EWORKSPACE; }
   InBwdParams P;
@@ -357,28 +384,21 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
   P.p1 = part ? part : P.part1; P.p1_nblk = part ? part_nblk : P.nvb; P.p1_cs = part ? part_cs : C; P.p1_c0 = part ? part_c0 : 0;
   hipStream_t st = (hipStream_t)stream;
   // contiguous tensors take the vectorised lane-constant-channel path
-  const int vec = (C % 4 == 0) ? 4 : (C % 2 == 0) ? 2 : 1;
-  const bool contig = (gcs == C) && (ycs == C) && (C / vec <= 256) && ((((uintptr_t)g) | ((uintptr_t)y)) & 15) == 0 &&
-                      (((long)V * C) % vec == 0) && ((((long)V * C) * 4) % 16 == 0);
+  const int vec = (gcs == C && ycs == C) ? dense_vec(C, V * C, dtype, {g, y}) : 0;
+  const bool contig = vec > 0 && (C / vec <= 256);
   if (contig) {
     InBwdFast F;
     F.g = g; F.y = y; F.mean = mean; F.rstd = rstd; F.gamma = gamma; F.beta = beta; F.slope = slope;
     F.nvec = (long)V * C / vec; F.C = C; F.G = C / vec; F.A = (256 / F.G) * F.G; F.nblk = P.nvb;
     F.part1 = P.part1; F.m = P.m; F.part2 = P.part2;
     dim3 grid(P.nvb, N);
-    if (part == nullptr) {           // (the first pass was not fused into the kernel that produced g)
-      if (vec == 4) hipLaunchKernelGGL((inorm_bwd_fast_kernel<4, false>), grid, dim3(256), 0, st, F);
-      else if (vec == 2) hipLaunchKernelGGL((inorm_bwd_fast_kernel<2, false>), grid, dim3(256), 0, st, F);
-      else hipLaunchKernelGGL((inorm_bwd_fast_kernel<1, false>), grid, dim3(256), 0, st, F);
-    }
+    if (part == nullptr) inorm_bwd_fast_dispatch(F, grid, vec, dtype, true, st);   // (the first pass was not fused into the kernel that produced g)
     hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, P, N, dgamma, dbeta);
-    if (vec == 4) hipLaunchKernelGGL((inorm_bwd_fast_kernel<4, true>), grid, dim3(256), 0, st, F);
-    else if (vec == 2) hipLaunchKernelGGL((inorm_bwd_fast_kernel<2, true>), grid, dim3(256), 0, st, F);
-    else hipLaunchKernelGGL((inorm_bwd_fast_kernel<1, true>), grid, dim3(256), 0, st, F);
+    inorm_bwd_fast_dispatch(F, grid, vec, dtype, false, st);
   } else {
-    if (part == nullptr) hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
+    if (part == nullptr) MT_DT_SWITCH(dtype, hipLaunchKernelGGL(inorm_bwd_reduce_kernel<BF>, dim3(P.nvb, N), dim3(256), 0, st, P));
     hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, P, N, dgamma, dbeta);
-    hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
+    MT_DT_SWITCH(dtype, hipLaunchKernelGGL(inorm_bwd_apply_kernel<BF>, dim3(P.nvb, N), dim3(256), 0, st, P));
   }
   if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(64), 0, st, (const float*)P.part2, (long)N * P.nvb, C, dbias, 0);
   MT_CHECK_LAUNCH("inorm_lrelu_bwd");
@@ -387,10 +407,11 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
 
 // ---- g *= lrelu'(t), t = y*sc+sh (+ second term) ; optional copy --------------------------------
 struct LBwdParams {
-  float* g; int gcs; const float* y; int ycs; const float* scale; const float* shift; float slope;
-  const float* y2; int y2cs; const float* scale2; const float* shift2; float slope2;
-  float* gcopy; int gcopycs; long V; int C;
+  void* g; int gcs; const void* y; int ycs; const float* scale; const float* shift; float slope;
+  const void* y2; int y2cs; const float* scale2; const float* shift2; float slope2;
+  void* gcopy; int gcopycs; long V; int C;
 };
+template <bool BF>
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const LBwdParams P) {
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
@@ -405,12 +426,12 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const LBwdParams P) {
     const float sh2 = (P.y2 && P.scale2) ? P.shift2[(size_t)n * P.C + c] : 0.f;
     for (long v = v0 + vr; v < v1; v += 8) {
       const size_t e = (size_t)n * P.V + v;
-      float t = fmaf(P.y[e * P.ycs + c], sc, sh);
-      if (P.y2) t += mt_lrelu(fmaf(P.y2[e * P.y2cs + c], sc2, sh2), P.slope2);
-      float gv = P.g[e * P.gcs + c];
+      float t = fmaf(mt_ld<BF>(P.y, e * P.ycs + c), sc, sh);
+      if (P.y2) t += mt_lrelu(fmaf(mt_ld<BF>(P.y2, e * P.y2cs + c), sc2, sh2), P.slope2);
+      float gv = mt_ld<BF>(P.g, e * P.gcs + c);
       gv = t > 0.f ? gv : gv * P.slope;
-      P.g[e * P.gcs + c] = gv;
-      if (P.gcopy) P.gcopy[e * P.gcopycs + c] = gv;
+      mt_st<BF>(P.g, e * P.gcs + c, gv);
+      if (P.gcopy) mt_st<BF>(P.gcopy, e * P.gcopycs + c, gv);
     }
   }
 }
@@ -418,17 +439,19 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const LBwdParams P) {
 // ---- dense fast paths of the two element-wise kernels above (every operand contiguous, cs == C, C % VEC == 0): one thread
 // moves VEC consecutive channels of a voxel per iteration with 16/8-byte accesses; the per-(n, c) scale/shift come from a
 // small table read through the cache.  HBM-bound: apply = 2-3 streams, lrelu_bwd = 3-5 streams.
-template <int VEC>
+template <int VEC, bool BF>
 __global__ __launch_bounds__(256) void inorm_apply_fast_kernel(const ApplyParams P, long per_sample) {
-  typedef typename VecT<VEC>::T V;
   const int n = blockIdx.y;
-  const size_t base = (size_t)n * per_sample;                    // elements
+  const size_t sb = (size_t)n * per_sample * (BF ? 2 : 4);         // bytes
+  const char* yp = (const char*)P.y + sb;
+  const char* rp = P.res ? (const char*)P.res + sb : nullptr;
+  char* op = (char*)P.out + sb;
   const bool has_res = P.res != nullptr;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC; i < per_sample; i += (long)gridDim.x * 256 * VEC) {
     const int c = (int)(i % P.C);
     float y[VEC], r[VEC], o[VEC];
-    *(V*)y = *(const V*)(P.y + base + i);
-    if (has_res) *(V*)r = *(const V*)(P.res + base + i);
+    mt_ldv<VEC, BF>(yp, (size_t)(i / VEC), y);
+    if (has_res) mt_ldv<VEC, BF>(rp, (size_t)(i / VEC), r);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float sc = P.scale ? P.scale[(size_t)n * P.C + c + e] : 1.f, sh = P.scale ? P.shift[(size_t)n * P.C + c + e] : 0.f;
@@ -439,22 +462,25 @@ __global__ __launch_bounds__(256) void inorm_apply_fast_kernel(const ApplyParams
       }
       o[e] = mt_lrelu(t, P.slope);
     }
-    *(V*)(P.out + base + i) = *(V*)o;
+    mt_stv<VEC, BF>(op, (size_t)(i / VEC), o);
   }
 }
 
-template <int VEC>
+template <int VEC, bool BF>
 __global__ __launch_bounds__(256) void lrelu_bwd_fast_kernel(const LBwdParams P, long per_sample) {
-  typedef typename VecT<VEC>::T V;
   const int n = blockIdx.y;
-  const size_t base = (size_t)n * per_sample;
+  const size_t sb = (size_t)n * per_sample * (BF ? 2 : 4);
+  const char* yp = (const char*)P.y + sb;
+  const char* y2p = P.y2 ? (const char*)P.y2 + sb : nullptr;
+  char* gp = (char*)P.g + sb;
+  char* cp = P.gcopy ? (char*)P.gcopy + sb : nullptr;
   const bool has2 = P.y2 != nullptr;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC; i < per_sample; i += (long)gridDim.x * 256 * VEC) {
     const int c = (int)(i % P.C);
     float y[VEC], y2[VEC], g[VEC];
-    *(V*)y = *(const V*)(P.y + base + i);
-    *(V*)g = *(const V*)(P.g + base + i);
-    if (has2) *(V*)y2 = *(const V*)(P.y2 + base + i);
+    mt_ldv<VEC, BF>(yp, (size_t)(i / VEC), y);
+    mt_ldv<VEC, BF>(gp, (size_t)(i / VEC), g);
+    if (has2) mt_ldv<VEC, BF>(y2p, (size_t)(i / VEC), y2);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float sc = P.scale ? P.scale[(size_t)n * P.C + c + e] : 1.f, sh = P.scale ? P.shift[(size_t)n * P.C + c + e] : 0.f;
@@ -465,44 +491,49 @@ __global__ __launch_bounds__(256) void lrelu_bwd_fast_kernel(const LBwdParams P,
       }
       g[e] = t > 0.f ? g[e] : g[e] * P.slope;
     }
-    *(V*)(P.g + base + i) = *(V*)g;
-    if (P.gcopy) *(V*)(P.gcopy + base + i) = *(V*)g;
+    mt_stv<VEC, BF>(gp, (size_t)(i / VEC), g);
+    if (cp) mt_stv<VEC, BF>(cp, (size_t)(i / VEC), g);
   }
 }
-static int dense_vec(int C, std::initializer_list<const void*> ptrs) {
-  int v = (C % 4 == 0) ? 4 : ((C % 2 == 0) ? 2 : 1);
-  for (const void* q : ptrs)
-    if (q != nullptr) { while (v > 1 && (((uintptr_t)q) & (v * 4 - 1))) v >>= 1; }
-  return v;
-}
 
-static int launch_apply_fast(const ApplyParams& P, int N, mt_stream_t stream, const float* res_or_y) {
+// kernels of the dense element-wise paths, by (storage type, vector width)
+#define MT_DENSE_DISPATCH(KERNEL_, dtype_, vec_, ...)                                                            \
+  do {                                                                                                           \
+    if ((dtype_) == MT_BF16) {                                                                                   \
+      if ((vec_) == 8) hipLaunchKernelGGL((KERNEL_<8, true>), __VA_ARGS__);                                      \
+      else if ((vec_) == 4) hipLaunchKernelGGL((KERNEL_<4, true>), __VA_ARGS__);                                 \
+      else hipLaunchKernelGGL((KERNEL_<2, true>), __VA_ARGS__);                                                  \
+    } else {                                                                                                     \
+      if ((vec_) == 4) hipLaunchKernelGGL((KERNEL_<4, false>), __VA_ARGS__);                                     \
+      else if ((vec_) == 2) hipLaunchKernelGGL((KERNEL_<2, false>), __VA_ARGS__);                                \
+      else hipLaunchKernelGGL((KERNEL_<1, false>), __VA_ARGS__);                                                 \
+    }                                                                                                            \
+  } while (0)
+
+static int launch_apply_fast(const ApplyParams& P, int N, int dtype, int vec, mt_stream_t stream) {
   const long per = P.V * P.C;
-  const int vec = dense_vec(P.C, {P.y, P.out, res_or_y});
   int blocks = (int)((per / vec + 255) / 256); if (blocks > 8192) blocks = 8192;
-  if (vec == 4) hipLaunchKernelGGL(inorm_apply_fast_kernel<4>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
-  else if (vec == 2) hipLaunchKernelGGL(inorm_apply_fast_kernel<2>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
-  else hipLaunchKernelGGL(inorm_apply_fast_kernel<1>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
+  MT_DENSE_DISPATCH(inorm_apply_fast_kernel, dtype, vec, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
   MT_CHECK_LAUNCH("inorm_apply_fast");
   return MT_OK;
 }
 
 extern "C" int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale, const float* shift, float slope,
                             const float* y2, int y2cs, const float* scale2, const float* shift2, float slope2,
-                            float* gcopy, int gcopycs, int N, long V, int C, mt_stream_t stream) {
-  MT_REQUIRE(g && y && N > 0 && V > 0 && C > 0, "lrelu_bwd: bad args");
+                            float* gcopy, int gcopycs, int N, long V, int C, int dtype, mt_stream_t stream) {
+  MT_REQUIRE(g && y && N > 0 && V > 0 && C > 0 && mt_dtype_ok(dtype), "lrelu_bwd: bad args");
   LBwdParams P{g, gcs, y, ycs, scale, shift, slope, y2, y2cs, scale2, shift2, slope2, gcopy, gcopycs, V, C};
   if (gcs == C && ycs == C && (y2 == nullptr || y2cs == C) && (gcopy == nullptr || gcopycs == C) && V * C < (1L << 40)) {
     const long per = V * C;
-    const int vec = dense_vec(C, {g, y, y2, gcopy});
-    int blocks = (int)((per / vec + 255) / 256); if (blocks > 8192) blocks = 8192;
-    if (vec == 4) hipLaunchKernelGGL(lrelu_bwd_fast_kernel<4>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
-    else if (vec == 2) hipLaunchKernelGGL(lrelu_bwd_fast_kernel<2>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
-    else hipLaunchKernelGGL(lrelu_bwd_fast_kernel<1>, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
-    MT_CHECK_LAUNCH("lrelu_bwd_fast");
-    return MT_OK;
+    const int vec = dense_vec(C, per, dtype, {g, y, y2, gcopy});
+    if (vec > 0) {
+      int blocks = (int)((per / vec + 255) / 256); if (blocks > 8192) blocks = 8192;
+      MT_DENSE_DISPATCH(lrelu_bwd_fast_kernel, dtype, vec, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
+      MT_CHECK_LAUNCH("lrelu_bwd_fast");
+      return MT_OK;
+    }
   }
-  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P);
+  MT_DT_SWITCH(dtype, hipLaunchKernelGGL(lrelu_bwd_kernel<BF>, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P));
   MT_CHECK_LAUNCH("lrelu_bwd");
   return MT_OK;
 }
@@ -513,16 +544,15 @@ extern "C" int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const fl
 // while g' is being produced — mt_inorm_lrelu_bwd(part = ...) then skips its own reduction over (g', y).  Dense tensors only (channel
 // stride == C); thread t keeps VEC constant channels (the mapping of inorm_bwd_fast_kernel), partials [N][nblk][C][2].
 struct LBwdStats {
-  float* g; const float* y; const float* y2; float* gcopy;
+  void* g; const void* y; const void* y2; void* gcopy;
   const float* scale; const float* shift; float slope;
   const float* scale2; const float* shift2; float slope2;
   const float* mean; const float* rstd;
   long nvec; int C, G, A, nblk;
   float* part;
 };
-template <int VEC>
+template <int VEC, bool BF>
 __global__ __launch_bounds__(256) void lrelu_bwd_stats_kernel(const LBwdStats P) {
-  typedef typename VecT<VEC>::T VT;
   __shared__ float red[256 * VEC * 2];
   const int n = blockIdx.y, t = threadIdx.x;
   const bool act = t < P.A;
@@ -540,37 +570,39 @@ __global__ __launch_bounds__(256) void lrelu_bwd_stats_kernel(const LBwdStats P)
   const long per = ((P.nvec + P.nblk - 1) / P.nblk + P.A - 1) / P.A * P.A;
   const long lo = (long)blockIdx.x * per;
   long hi = lo + per; if (hi > P.nvec) hi = P.nvec;
-  VT* gp = (VT*)(P.g + (size_t)n * P.nvec * VEC);
-  VT* cp = P.gcopy ? (VT*)(P.gcopy + (size_t)n * P.nvec * VEC) : nullptr;
-  const VT* yp = (const VT*)(P.y + (size_t)n * P.nvec * VEC);
-  const VT* y2p = has2 ? (const VT*)(P.y2 + (size_t)n * P.nvec * VEC) : nullptr;
+  const size_t sb = (size_t)n * P.nvec * VEC * (BF ? 2 : 4);
+  char* gp = (char*)P.g + sb;
+  char* cp = P.gcopy ? (char*)P.gcopy + sb : nullptr;
+  const char* yp = (const char*)P.y + sb;
+  const char* y2p = has2 ? (const char*)P.y2 + sb : nullptr;
   if (act) {
     for (long i0 = lo + t; i0 < hi; i0 += (long)P.A * NF_UNROLL) {
-      VT gv[NF_UNROLL], yv[NF_UNROLL], y2v[NF_UNROLL];
+      float gv[NF_UNROLL][VEC], yv[NF_UNROLL][VEC], y2v[NF_UNROLL][VEC];
 #pragma unroll
       for (int u = 0; u < NF_UNROLL; ++u) {
         const long i = i0 + (long)u * P.A;
-        if (i < hi) { gv[u] = gp[i]; yv[u] = yp[i]; if (has2) y2v[u] = y2p[i]; }
+        if (i < hi) { mt_ldv<VEC, BF>(gp, (size_t)i, gv[u]); mt_ldv<VEC, BF>(yp, (size_t)i, yv[u]); if (has2) mt_ldv<VEC, BF>(y2p, (size_t)i, y2v[u]); }
       }
 #pragma unroll
       for (int u = 0; u < NF_UNROLL; ++u) {
         const long i = i0 + (long)u * P.A;
         if (i < hi) {
-          VT out;
+          float out[VEC];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
-            const float yy = vget<VEC>(yv[u], e);
+            const float yy = yv[u][e];
             float tt = fmaf(yy, sc[e], sh[e]);
-            if (has2) tt += mt_lrelu(fmaf(vget<VEC>(y2v[u], e), sc2[e], sh2[e]), P.slope2);
-            float gg = vget<VEC>(gv[u], e);
+            if (has2) tt += mt_lrelu(fmaf(y2v[u][e], sc2[e], sh2[e]), P.slope2);
+            float gg = gv[u][e];
             gg = tt > 0.f ? gg : gg * P.slope;
-            vset<VEC>(out, e, gg);
+            if constexpr (BF) gg = mt_round_bf16(gg);
+            out[e] = gg;
             const float zh = (yy - mu[e]) * rs[e];
             a0[e] += gg;
             a1[e] = fmaf(gg, zh, a1[e]);
           }
-          gp[i] = out;
-          if (cp) cp[i] = out;
+          mt_stv<VEC, BF>(gp, (size_t)i, out);
+          if (cp) mt_stv<VEC, BF>(cp, (size_t)i, out);
         }
       }
     }
@@ -595,8 +627,8 @@ extern "C" int mt_lrelu_bwd_stats_blocks(long V, int C) {
 }
 extern "C" int mt_lrelu_bwd_stats(float* g, const float* y, const float* scale, const float* shift, float slope,
                                   const float* y2, const float* scale2, const float* shift2, float slope2, float* gcopy,
-                                  const float* mean, const float* rstd, float* part, int N, long V, int C, mt_stream_t stream) {
-  MT_REQUIRE(g && y && mean && rstd && part && N > 0, "lrelu_bwd_stats: bad args");
+                                  const float* mean, const float* rstd, float* part, int N, long V, int C, int dtype, mt_stream_t stream) {
+  MT_REQUIRE(g && y && mean && rstd && part && N > 0 && mt_dtype_ok(dtype), "lrelu_bwd_stats: bad args");
   const int nblk = mt_lrelu_bwd_stats_blocks(V, C);
   MT_REQUIRE(nblk > 0, "lrelu_bwd_stats: unsupported shape (V=%ld, C=%d): ask mt_lrelu_bwd_stats_blocks", V, C);
   MT_REQUIRE(((((uintptr_t)g) | ((uintptr_t)y) | ((uintptr_t)y2) | ((uintptr_t)gcopy)) & 15) == 0, "lrelu_bwd_stats: tensors must be 16-byte aligned");
@@ -604,13 +636,15 @@ extern "C" int mt_lrelu_bwd_stats(float* g, const float* y, const float* scale, 
   P.g = g; P.y = y; P.y2 = y2; P.gcopy = gcopy; P.scale = scale; P.shift = shift; P.slope = slope;
   P.scale2 = scale2; P.shift2 = shift2; P.slope2 = slope2; P.mean = mean; P.rstd = rstd;
   P.nvec = (long)V * C / 4; P.C = C; P.G = C / 4; P.A = (256 / P.G) * P.G; P.nblk = nblk; P.part = part;
-  hipLaunchKernelGGL(lrelu_bwd_stats_kernel<4>, dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, P);
+  if (dtype == MT_BF16) hipLaunchKernelGGL((lrelu_bwd_stats_kernel<4, true>), dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, P);
+  else hipLaunchKernelGGL((lrelu_bwd_stats_kernel<4, false>), dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, P);
   MT_CHECK_LAUNCH("lrelu_bwd_stats");
   return MT_OK;
 }
 
 // ---- per-channel sum -------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* x, int xcs, long V, int C, int nvb, float* part) {
+template <bool BF>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const void* x, int xcs, long V, int C, int nvb, float* part) {
   __shared__ float red[8][32];
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
@@ -621,7 +655,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* x, int xc
     const int c = cb + cl;
     float a = 0.f;
     if (c < C)
-      for (long v = v0 + vr; v < v1; v += 8) a += x[((size_t)n * V + v) * xcs + c];
+      for (long v = v0 + vr; v < v1; v += 8) a += mt_ld<BF>(x, ((size_t)n * V + v) * xcs + c);
     red[vr][cl] = a;
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -635,14 +669,68 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* x, int xc
 }
 extern "C" size_t mt_channel_sum_workspace(int N, long V, int C) { return (size_t)N * nb_blocks(V) * C * sizeof(float); }
 extern "C" int mt_channel_sum(const float* x, int xcs, int N, long V, int C, float* out, int accumulate, void* ws,
-                              size_t ws_bytes, mt_stream_t stream) {
-  MT_REQUIRE(x && out && N > 0 && V > 0 && C > 0, "channel_sum: bad args");
+                              size_t ws_bytes, int dtype, mt_stream_t stream) {
+  MT_REQUIRE(x && out && N > 0 && V > 0 && C > 0 && mt_dtype_ok(dtype), "channel_sum: bad args");
   const int nvb = nb_blocks(V);
   if (ws == nullptr || ws_bytes < (size_t)N * nvb * C * sizeof(float)) { mt_set_error("channel_sum: workspace too small"); return MT_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(nvb, N), dim3(256), 0, st, x, xcs, V, C, nvb, (float*)ws);
+  MT_DT_SWITCH(dtype, hipLaunchKernelGGL(channel_sum_kernel<BF>, dim3(nvb, N), dim3(256), 0, st, (const void*)x, xcs, V, C, nvb, (float*)ws));
   hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(64), 0, st, (const float*)ws, (long)N * nvb, C, out, accumulate);
   MT_CHECK_LAUNCH("channel_sum");
+  return MT_OK;
+}
+
+// ---- storage-type conversion ---------------------------------------------------------------------------
+// dst[r][c] (+)= src[r][c] for rows r < rows (voxels of all samples) and c < C, each side with its own storage type and channel
+// stride.  The boundary op of the mixed-precision mode: a kernel that does not take a tensor's storage type reads / writes an
+// fp32 (or bf16) copy instead (see the *_io_supported queries); accumulate adds in fp32 and rounds once.
+struct CastParams { const void* src; void* dst; long rows; int C, scs, dcs, accumulate; };
+template <bool SB, bool DB, int VEC>
+__global__ __launch_bounds__(256) void cast_dense_kernel(const CastParams P, long nvec) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    float v[VEC];
+    mt_ldv<VEC, SB>(P.src, (size_t)i, v);
+    if (P.accumulate) {
+      float o[VEC];
+      mt_ldv<VEC, DB>(P.dst, (size_t)i, o);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] += o[e];
+    }
+    mt_stv<VEC, DB>(P.dst, (size_t)i, v);
+  }
+}
+template <bool SB, bool DB>
+__global__ __launch_bounds__(256) void cast_strided_kernel(const CastParams P) {
+  const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
+  for (long r = (long)blockIdx.x * 8 + vr; r < P.rows; r += (long)gridDim.x * 8)
+    for (int c = cl; c < P.C; c += 32) {
+      float v = mt_ld<SB>(P.src, (size_t)r * P.scs + c);
+      if (P.accumulate) v += mt_ld<DB>(P.dst, (size_t)r * P.dcs + c);
+      mt_st<DB>(P.dst, (size_t)r * P.dcs + c, v);
+    }
+}
+extern "C" int mt_cast(const void* src, int scs, int sdtype, void* dst, int dcs, int ddtype, long rows, int C, int accumulate,
+                       mt_stream_t stream) {
+  MT_REQUIRE(src && dst && rows > 0 && C > 0 && scs >= C && dcs >= C && mt_dtype_ok(sdtype) && mt_dtype_ok(ddtype), "cast: bad args");
+  CastParams P{src, dst, rows, C, scs, dcs, accumulate};
+  hipStream_t st = (hipStream_t)stream;
+  const long n = rows * C;
+  const bool dense = scs == C && dcs == C && (n % 4) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+  if (dense) {
+    const long nvec = n / 4;
+    int blocks = (int)((nvec + 255) / 256); if (blocks > 16384) blocks = 16384;
+    if (sdtype == MT_BF16 && ddtype == MT_BF16) hipLaunchKernelGGL((cast_dense_kernel<true, true, 4>), dim3(blocks), dim3(256), 0, st, P, nvec);
+    else if (sdtype == MT_BF16) hipLaunchKernelGGL((cast_dense_kernel<true, false, 4>), dim3(blocks), dim3(256), 0, st, P, nvec);
+    else if (ddtype == MT_BF16) hipLaunchKernelGGL((cast_dense_kernel<false, true, 4>), dim3(blocks), dim3(256), 0, st, P, nvec);
+    else hipLaunchKernelGGL((cast_dense_kernel<false, false, 4>), dim3(blocks), dim3(256), 0, st, P, nvec);
+  } else {
+    int blocks = (int)((rows + 7) / 8); if (blocks > 16384) blocks = 16384;
+    if (sdtype == MT_BF16 && ddtype == MT_BF16) hipLaunchKernelGGL((cast_strided_kernel<true, true>), dim3(blocks), dim3(256), 0, st, P);
+    else if (sdtype == MT_BF16) hipLaunchKernelGGL((cast_strided_kernel<true, false>), dim3(blocks), dim3(256), 0, st, P);
+    else if (ddtype == MT_BF16) hipLaunchKernelGGL((cast_strided_kernel<false, true>), dim3(blocks), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((cast_strided_kernel<false, false>), dim3(blocks), dim3(256), 0, st, P);
+  }
+  MT_CHECK_LAUNCH("cast");
   return MT_OK;
 }
 

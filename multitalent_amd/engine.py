@@ -82,7 +82,8 @@ class ConvNormOp(_Op):
         self.geom = ConvGeom(sp, self.kernel, self.stride, self.pad)
         self.out.spatial = self.geom.out
         Cout = self.conv.out_channels
-        buf = eng.buffer(self.name + '.y', (N,) + self.geom.out + (Cout,))
+        self.mma = eng.op_mma(self.geom.out)          # bf16 matrix inputs for this layer (forward, backward-data and backward-weight)
+        buf = eng.buffer(self.name + '.y', (N,) + self.geom.out + (Cout,), self._out_dtype(eng))
         if self.norm is not None:
             st = eng.buffer(self.name + '.stats', (4, N, Cout))
             self.out.act = Act(buf, scale=st[2], shift=st[3], slope=self.slope if self.lrelu else 1.0, mean=st[0], rstd=st[1])
@@ -91,18 +92,28 @@ class ConvNormOp(_Op):
         self.part = None
         self.wf = self.wb = None
 
-    def _fwd_params(self, eng):
+    def _out_dtype(self, eng):
+        return eng.val_dtype(self.geom.out)
+
+    def _fwd_io(self, eng):
+        """storage types of the forward launch: the operands as they are where the kernel takes them, fp32 copies elsewhere (Engine.io)"""
         Cout = self.conv.out_channels
         acts = [s.act for s in self.srcs]
         if self.pointwise:
-            a = acts[0]
-            p = ops.fill_pointwise(a, self.geom.out, a.spatial, self.stride, (1, 1, 1), Cout, eng.dummy, self.conv.bias, self.out.act)
-            if self.norm is not None and self.part is None:
-                self.part = eng.buffer(self.name + '.part', (a.N, ops.pointwise_stats_blocks(p), Cout, 2))
-        else:
-            p = ops.fill_conv(acts, self.geom, Cout, bias=self.conv.bias, out0=self.out.act)
-            if self.norm is not None and self.part is None:
-                self.part = eng.buffer(self.name + '.part', (acts[0].N, ops.conv_stats_blocks(p), Cout, 2))
+            def build(ins, outs):
+                a = ins[0]
+                return ops.fill_pointwise(a, self.geom.out, a.spatial, self.stride, (1, 1, 1), Cout, eng.dummy, self.conv.bias, outs[0])
+            return eng.io(self.name + '.fwd', acts, [self.out.act], build, ops.pointwise_io_supported)
+        build = lambda ins, outs: ops.fill_conv(ins, self.geom, Cout, bias=self.conv.bias, out0=outs[0], mma=self.mma)
+        return eng.io(self.name + '.fwd', acts, [self.out.act], build, ops.conv_io_supported)
+
+    def _fwd_params(self, eng, io=None):
+        Cout = self.conv.out_channels
+        io = io if io is not None else self._fwd_io(eng)
+        p = io.build()
+        if self.norm is not None and self.part is None:
+            nsb = ops.pointwise_stats_blocks(p) if self.pointwise else ops.conv_stats_blocks(p)
+            self.part = eng.buffer(self.name + '.part', (io.ins[0].N, nsb, Cout, 2))
         if self.part is not None:
             p.stats_part = self.part.data_ptr()
         return p
@@ -124,39 +135,46 @@ class ConvNormOp(_Op):
         if need_bwd and any(s.grad is not None for s in self.srcs):
             if self._use_strided_bwd(eng):
                 self.wb = ops.pack_conv_weights(w, Cout, 0, C0, self.kernel, _strides(w, as_bwd_data=True), False, 16, out=self.wb,
-                                                layout=ops.conv_bwd_data_strided_pack_layout(self._strided_bwd_params(None)))
+                                                layout=ops.conv_bwd_data_strided_pack_layout(self._strided_bwd_io(eng, None).build()))
                 return
             if self._use_parity_classes():
                 cls = self._parity_classes()
                 if self.wb is None:
                     self.wb = [None] * len(cls)
                 for i, (geomc, place, tapmap) in enumerate(cls):
-                    pb = ops.fill_conv([Act(self.out.act.buf)], geomc, C0, place=place)
+                    pb = ops.fill_conv([eng.as_fp32(Act(self.out.act.buf), geometry_only=True)], geomc, C0, place=place, mma=self.mma)
                     self.wb[i] = ops.pack_conv_weights(w, Cout, 0, C0, geomc.k, _strides(w, as_bwd_data=True), False,
                                                        ops.conv_ck(pb), out=self.wb[i], tapmap=tapmap)
                 return
-            pb = self._bwd_data_params(eng, None)
-            pb.ocs0 = C0                      # the kernel choice (and with it the packed layout) must match the launch in backward()
-            if C1:
-                pb.csplit = C0
-                pb.ocs1 = C1
+            pb = self._bwd_data_io(eng, None).build()     # the kernel choice (and with it the packed layout) must match the launch in backward()
             self.ck_b = ops.conv_ck(pb)
             self.wb = ops.pack_conv_weights(w, Cout, 0, C0 + C1, self.kernel, _strides(w, as_bwd_data=True), True, self.ck_b, out=self.wb,
                                             layout=ops.conv_pack_layout(pb))
 
-    def _strided_bwd_params(self, g):
+    def _strided_bwd_io(self, eng, g):
         """mt_conv3d_bwd_data_strided takes the FORWARD geometry with src[0] = dY and out0 = dX."""
-        gact = Act(g) if g is not None else Act(self.out.act.buf)
-        p = ops.fill_conv([gact], self.geom, self.conv.out_channels)
-        p.Cin = self.srcs[0].C
-        return p
+        s0 = self.srcs[0]
+        gact = Act(g) if g is not None else Act(self._grad_like(eng, self.out))
+        dx = Act(s0.grad) if s0.grad is not None else Act(self._grad_like(eng, s0))
+
+        def build(ins, outs):
+            p = ops.fill_conv(ins, self.geom, self.conv.out_channels, out0=outs[0], mma=self.mma)
+            p.Cin = s0.C
+            return p
+        return eng.io(self.name + '.bwdd', [gact], [dx], build, ops.conv_bwd_data_strided_io_supported, grad_ins=True)
+
+    def _strided_bwd_params(self, g, eng=None):
+        return self._strided_bwd_io(eng if eng is not None else self._eng, g).build()
+
+    @staticmethod
+    def _grad_like(eng, val):
+        """a tensor with the shape and storage type of val's gradient (geometry / kernel-choice queries before the buffers exist)"""
+        return val.act.buf if val.grad is None else val.grad      # (a gradient has its activation's shape and storage type)
 
     def _use_strided_bwd(self, eng):
         if self.stride == (1, 1, 1) or len(self.srcs) != 1 or self.pointwise:
             return False
-        p = self._strided_bwd_params(None)
-        p.ocs0 = self.srcs[0].C
-        return ops.conv3d_bwd_data_strided_supported(p)
+        return ops.conv3d_bwd_data_strided_supported(self._strided_bwd_io(eng, None).build())
 
     def _use_parity_classes(self):
         return self.stride != (1, 1, 1) and len(self.srcs) == 1 and not self.pointwise
@@ -165,25 +183,33 @@ class ConvNormOp(_Op):
         return ops.bwd_data_parity_classes(self.geom)
 
     def forward(self, eng):
-        p = self._fwd_params(eng)
+        io = self._fwd_io(eng)
+        p = self._fwd_params(eng, io)
         p.wpack = self.wf.data_ptr()
+        io.pre()
         if self.pointwise:
             ops.pointwise_fwd(p)
         else:
             ops.conv3d_fwd(p)
+        io.post()
         if self.norm is not None:
             a = self.out.act
             nsb = self.part.shape[1]
             ops.inorm_finalize(self.part, a.N, nsb, a.C, a.V, self.norm.weight, self.norm.bias, self.norm.eps,
                                a.mean, a.rstd, a.scale, a.shift)
 
-    def _bwd_data_params(self, eng, g):
+    def _bwd_data_io(self, eng, g):
+        """backward-data as a stride-1 convolution of dY with the flipped weights; destinations = the sources' gradient buffers"""
         Cin = sum(s.C for s in self.srcs)
         geomT = ConvGeom(self.geom.out, self.kernel, (1, 1, 1), tuple(k - 1 - p for k, p in zip(self.kernel, self.pad)),
                          dil=self.stride, out_spatial=self.geom.inp)
-        gact = Act(g) if g is not None else Act(self.out.act.buf)  # geometry-only when g is None
-        p = ops.fill_conv([gact], geomT, Cin)
-        return p
+        gact = Act(g) if g is not None else Act(self._grad_like(eng, self.out))  # geometry-only when g is None
+        outs = [Act(self._grad_like(eng, s)) for s in self.srcs]
+
+        def build(ins, outs_):
+            return ops.fill_conv(ins, geomT, Cin, out0=outs_[0], out1=outs_[1] if len(outs_) > 1 else None,
+                                 csplit=self.srcs[0].C if len(outs_) > 1 else None, mma=self.mma)
+        return eng.io(self.name + '.bwdd', [gact], outs, build, ops.conv_io_supported, grad_ins=True)
 
     def backward(self, eng):
         g = self.out.grad
@@ -201,12 +227,15 @@ class ConvNormOp(_Op):
             ws = eng.workspace(ops.channel_sum_workspace(gact.N, gact.V, gact.C))
             ops.channel_sum(gact, dbias, False, ws)
         # backward-weight straight into the flat gradient buffer (torch parameter layout)
-        acts = [s.act for s in self.srcs]
-        pw = ops.fill_conv(acts, self.geom, self.conv.out_channels)
         dw = eng.grad_of(self.conv.weight)
         with eng.weight_stream() as side:
+            iow = eng.io(self.name + '.bwdw', [s.act for s in self.srcs] + [gact], [],
+                         lambda ins, outs: (ops.fill_conv(ins[:-1], self.geom, self.conv.out_channels, mma=self.mma), ins[-1]),
+                         lambda py: ops.conv_bwd_weight_io_supported(py[0], py[1]), grad_ins=[False] * len(self.srcs) + [True])
+            pw, yact = iow.build()
+            iow.pre()
             ws = eng.workspace(ops.conv3d_bwd_weight_workspace(pw), side=side)
-            ops.conv3d_bwd_weight(pw, gact, dw, _strides(self.conv.weight), False, ws)
+            ops.conv3d_bwd_weight(pw, yact, dw, _strides(self.conv.weight), False, ws)
         # backward-data into the sources' gradient buffers
         dsts = [s for s in self.srcs if s.grad is not None]
         if not dsts:
@@ -219,17 +248,22 @@ class ConvNormOp(_Op):
             if self.stride != (1, 1, 1):
                 raise NotImplementedError("backward-data of a strided pointwise conv is handled by ResBlockOp")
             s0 = self.srcs[0]
-            p = ops.fill_pointwise(gact, self.geom.out, self.geom.out, (1, 1, 1), (1, 1, 1), s0.C, self.wb, None,
-                                   Act(s0.grad), accumulate=acc)
+            io = eng.io(self.name + '.bwdd', [gact], [Act(s0.grad)],
+                        lambda ins, outs: ops.fill_pointwise(ins[0], self.geom.out, self.geom.out, (1, 1, 1), (1, 1, 1), s0.C, self.wb, None, outs[0]),
+                        ops.pointwise_io_supported, grad_ins=True)
+            p = io.build()
+            p.accumulate = io.accumulate(acc)
+            io.pre()
             ops.pointwise_fwd(p)
+            io.post(acc)
         elif self._use_strided_bwd(eng):
-            s0 = self.srcs[0]
-            p = self._strided_bwd_params(g)
+            io = self._strided_bwd_io(eng, g)
+            p = io.build()
             p.wpack = self.wb.data_ptr()
-            p.out0 = s0.grad.data_ptr()
-            p.ocs0 = s0.C
-            p.accumulate = 1 if acc else 0
+            p.accumulate = io.accumulate(acc)
+            io.pre()
             ops.conv3d_bwd_data_strided(p)
+            io.post(acc)
         elif self._use_parity_classes():
             s0 = self.srcs[0]
             cls = self._parity_classes()
@@ -239,21 +273,26 @@ class ConvNormOp(_Op):
             if len(cls) < full and not acc:      # some input positions receive no gradient from this conv
                 s0.grad.zero_()
                 acc = True
+            # (runtime-geometry kernel with strided output placement: fp32 operands; other storage types through fp32 copies)
+            gin = eng.as_fp32(gact, reuse=False)
+            dx = Act(s0.grad) if s0.grad.dtype == torch.float32 else Act(eng.buffer(self.name + '.bwdd.out0', tuple(s0.grad.shape)))
+            if dx.buf is not s0.grad and acc:
+                ops.cast(Act(s0.grad), dx)
             for (geomc, place, _), wb in zip(cls, self.wb):
-                p = ops.fill_conv([gact], geomc, s0.C, wpack=wb, out0=Act(s0.grad), accumulate=acc, place=place)
+                p = ops.fill_conv([gin], geomc, s0.C, wpack=wb, out0=dx, accumulate=acc, place=place, mma=self.mma)
                 ops.conv3d_fwd(p)
+            if dx.buf is not s0.grad:
+                ops.cast(dx, Act(s0.grad))
         else:
-            p = self._bwd_data_params(eng, g)
+            io = self._bwd_data_io(eng, g)
+            p = io.build()
             p.wpack = self.wb.data_ptr()
-            p.out0 = self.srcs[0].grad.data_ptr()
-            p.ocs0 = self.srcs[0].C
-            if len(self.srcs) > 1:
-                p.out1 = self.srcs[1].grad.data_ptr()
-                p.ocs1 = self.srcs[1].C
-                p.csplit = self.srcs[0].C
-            p.accumulate = 1 if acc else 0
-            self._fuse_norm_bwd_stats(eng, p)
+            p.accumulate = io.accumulate(acc)
+            if io.native:
+                self._fuse_norm_bwd_stats(eng, p)
+            io.pre()
             ops.conv3d_fwd(p)
+            io.post(acc)
         for s in self.srcs:
             s.grad_init = True
 
@@ -295,7 +334,7 @@ class TConvOp(_Op):
         sp = self.src.spatial
         self.out.spatial = tuple(a * b for a, b in zip(sp, self.k))
         Cout = self.tu.out_channels
-        self.out.act = Act(eng.buffer(self.name + '.y', (N,) + self.out.spatial + (Cout,)))
+        self.out.act = Act(eng.buffer(self.name + '.y', (N,) + self.out.spatial + (Cout,), eng.val_dtype(self.out.spatial)))
         self.wf = self.wb = None
 
     def pack(self, eng, need_bwd):
@@ -303,38 +342,54 @@ class TConvOp(_Op):
         Cin, Cout = self.tu.in_channels, self.tu.out_channels
         self.wf = ops.pack_conv_weights(w, Cin, 0, Cout, self.k, _strides(w, transposed_layout=True), False, ops.POINTWISE_CK, out=self.wf)
         if need_bwd and self.src.grad is not None:
-            p = self._bwd_params()
+            p = self._bwd_io(eng).build()
             self.ck_b = ops.conv_ck(p)
             self.wb = ops.pack_conv_weights(w, Cout, 0, Cin, self.k, _strides(w, transposed_layout=True, as_bwd_data=True),
                                             False, self.ck_b, out=self.wb)
 
     def forward(self, eng):
-        a = self.src.act
-        p = ops.fill_pointwise(a, a.spatial, a.spatial, (1, 1, 1), self.k, self.tu.out_channels, self.wf, None, self.out.act)
+        io = eng.io(self.name + '.fwd', [self.src.act], [self.out.act],
+                    lambda ins, outs: ops.fill_pointwise(ins[0], ins[0].spatial, ins[0].spatial, (1, 1, 1), self.k, self.tu.out_channels, self.wf, None, outs[0]),
+                    ops.pointwise_io_supported)
+        p = io.build()
+        io.pre()
         ops.pointwise_fwd(p)
+        io.post()
 
-    def _bwd_params(self):
-        # dX = conv(k = stride = pool kernel, pad 0) of dOut
-        geom = ConvGeom(self.out.spatial, self.k, self.k, (0, 0, 0))
+    def _geom(self):
+        return ConvGeom(self.out.spatial, self.k, self.k, (0, 0, 0))   # dX = conv(k = stride = pool kernel, pad 0) of dOut
+
+    def _bwd_io(self, eng):
         g = self.out.grad if self.out.grad is not None else self.out.act.buf
-        return ops.fill_conv([Act(g)], geom, self.tu.in_channels)
+        dx = self.src.grad if self.src.grad is not None else self.src.act.buf
+
+        def build(ins, outs):
+            p = ops.fill_conv(ins, self._geom(), self.tu.in_channels, out0=outs[0])
+            p.csplit = self.tu.in_channels
+            return p
+        return eng.io(self.name + '.bwdd', [Act(g)], [Act(dx)], build, ops.conv_io_supported, grad_ins=True)
 
     def backward(self, eng):
         g = self.out.grad
         assert g is not None and self.out.grad_init
         w = self.tu.weight
-        p = self._bwd_params()
         # backward-weight: X = dOut (channels = Cout_t), Y = tconv input (lazy act, channels = Cin_t)
         with eng.weight_stream() as side:
-            ws = eng.workspace(ops.conv3d_bwd_weight_workspace(p), side=side)
-            ops.conv3d_bwd_weight(p, self.src.act, eng.grad_of(w), _strides(w, transposed_layout=True, as_bwd_data=True), False, ws)
+            iow = eng.io(self.name + '.bwdw', [Act(g), self.src.act], [],
+                         lambda ins, outs: (ops.fill_conv(ins[:1], self._geom(), self.tu.in_channels), ins[1]),
+                         lambda py: ops.conv_bwd_weight_io_supported(py[0], py[1]), grad_ins=[True, False])
+            pw, yact = iow.build()
+            iow.pre()
+            ws = eng.workspace(ops.conv3d_bwd_weight_workspace(pw), side=side)
+            ops.conv3d_bwd_weight(pw, yact, eng.grad_of(w), _strides(w, transposed_layout=True, as_bwd_data=True), False, ws)
         if self.src.grad is not None:
+            io = self._bwd_io(eng)
+            p = io.build()
             p.wpack = self.wb.data_ptr()
-            p.out0 = self.src.grad.data_ptr()
-            p.ocs0 = self.src.C
-            p.csplit = self.tu.in_channels
-            p.accumulate = 1 if self.src.grad_init else 0
+            p.accumulate = io.accumulate(self.src.grad_init)
+            io.pre()
             ops.conv3d_fwd(p)
+            io.post(self.src.grad_init)
             self.src.grad_init = True
 
 
@@ -351,7 +406,7 @@ class ResAddOp(_Op):
 
     def plan(self, eng, N):
         self.out.spatial = self.main.spatial
-        self.out.act = Act(eng.buffer(self.name + '.a', (N,) + self.main.spatial + (self.main.C,)))
+        self.out.act = Act(eng.buffer(self.name + '.a', (N,) + self.main.spatial + (self.main.C,), eng.val_dtype(self.main.spatial)))
 
     def pack(self, eng, need_bwd):
         pass
@@ -374,19 +429,20 @@ class ResAddOp(_Op):
         # producing (mt_lrelu_bwd_stats): the norm backward's own reduction over (g', y) disappears.
         prod = eng.producer.get(id(self.main)) if eng.fuse_norm_bwd in (1, 3) else None
         nblk = _lib.load().mt_lrelu_bwd_stats_blocks(m.V, m.C)
+        dt = ops._same_dt(Act(g), m, r, Act(gm))          # one resolution level: one storage type
         if (prod is not None and isinstance(prod, ConvNormOp) and prod.norm is not None and m.mean is not None and nblk > 0
                 and g.shape[4] == m.C and gm.shape[4] == m.C and m.cs == m.C and r.cs == m.C):
             part = eng.buffer(self.name + '.bwdpart', (m.N, nblk, m.C, 2))
             _lib.check(_lib.load().mt_lrelu_bwd_stats(
                 C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()), ops._ptr(m.scale), ops._ptr(m.shift), self.slope,
                 C.c_void_p(r.data_ptr()), ops._ptr(r.scale), ops._ptr(r.shift), r.slope, C.c_void_p(gm.data_ptr()),
-                ops._ptr(m.mean), ops._ptr(m.rstd), ops._ptr(part), m.N, m.V, m.C, ops._stream()), 'lrelu_bwd_stats')
+                ops._ptr(m.mean), ops._ptr(m.rstd), ops._ptr(part), m.N, m.V, m.C, dt, ops._stream()), 'lrelu_bwd_stats')
             prod.bwd_part = (part, 0)
         else:
             _lib.check(_lib.load().mt_lrelu_bwd(
                 C.c_void_p(g.data_ptr()), g.shape[4], C.c_void_p(m.data_ptr()), m.cs, ops._ptr(m.scale), ops._ptr(m.shift), self.slope,
                 C.c_void_p(r.data_ptr()), r.cs, ops._ptr(r.scale), ops._ptr(r.shift), r.slope,
-                C.c_void_p(gm.data_ptr()), gm.shape[4], m.N, m.V, m.C, ops._stream()), 'lrelu_bwd')
+                C.c_void_p(gm.data_ptr()), gm.shape[4], m.N, m.V, m.C, dt, ops._stream()), 'lrelu_bwd')
         self.main.grad_init = True
         # residual branch: g itself (already masked) is added to / becomes the residual's gradient
         if self.res.grad is not None:
@@ -406,6 +462,9 @@ class HeadOp(ConvNormOp):
     def __init__(self, name, src, out, conv):
         super().__init__(name, [src], out, conv, None, lrelu=False, pointwise=True)
 
+    def _out_dtype(self, eng):
+        return torch.float32            # logits and their gradient stay fp32 (the losses are fp32 in the reference's autocast mode too)
+
     def backward(self, eng):
         """dX, dW and dbias of the head in ONE pass over (x, dlogits) (mt_head_bwd) when the head is narrow enough (<= 64 channels
         in and out: the full-resolution heads, where 47 logit channels make the separate kernels cost 3 ms of a Task100 step);
@@ -419,16 +478,58 @@ class HeadOp(ConvNormOp):
         g = self.out.grad
         assert g is not None and self.out.grad_init, "gradient of %s was never produced" % self.name
         gact = Act(g)
-        a = s0.act
         dbias = eng.grad_of(self.conv.bias) if self.conv.bias is not None else None
-        ws = eng.workspace(ops.head_bwd_workspace(a.N, a.V, s0.C, Cout))
         w = self.conv.weight
         st = _strides(w)                                 # (s_ci, s_co, ...) of the [Cout, Cin, 1, 1, 1] weight
-        done = ops.head_bwd(a, gact, self.wb, Act(s0.grad), s0.grad_init, eng.grad_of(w), st[0], st[1], dbias, False, ws)
+        io = eng.io(self.name + '.hbwd', [s0.act], [Act(s0.grad)], lambda ins, outs: (ins[0], outs[0]),
+                    lambda xo: ops.head_bwd_io_supported(xo[0], xo[1], Cout))
+        a, dx = io.build()
+        io.pre()
+        ws = eng.workspace(ops.head_bwd_workspace(a.N, a.V, s0.C, Cout))
+        done = ops.head_bwd(a, gact, self.wb, dx, bool(io.accumulate(s0.grad_init)), eng.grad_of(w), st[0], st[1], dbias, False, ws)
+        io.post(s0.grad_init)
         if dbias is not None and not done:
             ws2 = eng.workspace(ops.channel_sum_workspace(gact.N, gact.V, gact.C))
             ops.channel_sum(gact, dbias, False, ws2)
         s0.grad_init = True
+
+
+class _IO:
+    """Storage types of ONE launch (Engine.io): the operands as the graph has them where the kernel that serves the launch takes them,
+    fp32 copies (mt_cast) elsewhere.  ins / outs are the EFFECTIVE operands the launch is built with; pre() fills the input copies,
+    post() writes (or accumulates) the output copies back in the tensor's own storage type."""
+
+    def __init__(self, eng, key, ins, outs, build, flags, grad_ins):
+        self.eng, self._build = eng, build
+        cast_in, cast_out = flags
+        self.native = not (cast_in or cast_out)
+        self._cin = [(a, g) for a, g in zip(ins, grad_ins) if cast_in and a.dtype != torch.float32]
+        self.ins = [eng.as_fp32(a, geometry_only=True) if (cast_in and a.dtype != torch.float32) else a for a in ins]
+        self._cout = []
+        self.outs = []
+        for i, o in enumerate(outs):
+            if cast_out and o.dtype != torch.float32:
+                t = Act(eng.buffer('%s.out%d' % (key, i), tuple(o.buf.shape[:4]) + (o.C,)))
+                self._cout.append((t, o))
+                self.outs.append(t)
+            else:
+                self.outs.append(o)
+
+    def build(self):
+        return self._build(self.ins, self.outs)
+
+    def pre(self):
+        for a, is_grad in self._cin:
+            self.eng.as_fp32(a, reuse=not is_grad)
+
+    def accumulate(self, acc):
+        """accumulate flag of the launch: an output that goes through an fp32 copy is written fresh and accumulated by post()"""
+        return 0 if self._cout else int(bool(acc))
+
+    def post(self, acc=False):
+        for t, o in self._cout:
+            ops.cast(t, o, accumulate=bool(acc))
+            self.eng.io_cast_bytes += t.buf.numel() * 4
 
 
 class Engine:
@@ -457,6 +558,16 @@ class Engine:
         self.grad_ready_hook = None         # callable(lo, hi) on flat_grad element ranges, in completion order
         self.dummy = None
         self.mma = 0                        # matrix input type of the convolutions: 0 fp32, 1 bf16 (mixed precision)
+        # mixed precision: activations and gradients of the levels with at least bf16_min_voxels voxels per sample are STORED as bf16
+        # (MT_BF16_STORAGE=0: fp32 storage, bf16 matrix inputs only = the mode of rounds 1-3); smaller levels (<= 6x12x12 in the residual
+        # encoder) are latency-bound, gain nothing from bf16 and carry the fewest voxels to average its rounding over: they stay fp32
+        # in storage AND arithmetic
+        self.storage_bf16 = os.environ.get('MT_BF16_STORAGE', '1') != '0'
+        self.bf16_min_voxels = int(os.environ.get('MT_BF16_MIN_VOXELS', '2048'))
+        self._io_cache = {}
+        self._fp32_copies = {}
+        self._iter = 0
+        self.io_cast_bytes = 0              # bytes moved by storage-type conversions (diagnostic: 0 when every kernel takes its operands natively)
         # first pass of a norm backward taken by the kernel that produces the gradient (ConvNormOp._fuse_norm_bwd_stats, ResAddOp.backward):
         # 0 off, 1 on, 2 convolutions only, 3 residual adds only.  Default: on only when everything runs on ONE stream — beside the
         # weight-gradient stream the separate (bandwidth-bound) reduction overlaps the (matrix-bound) backward-weight launches and
@@ -471,15 +582,76 @@ class Engine:
         mma = {'fp32': 0, 'bf16': 1, 0: 0, 1: 1, False: 0, True: 1}[precision]
         if mma != self.mma:
             self.mma = mma
-            self._planned = None            # packed layouts and statistics tilings depend on the kernel choice
-            self._packed_version = None
-            self._pack_programs = {}
+            self._replan()
+
+    def _replan(self):
+        self._planned = None                # packed layouts, statistics tilings and storage types depend on the kernel choice
+        self._packed_version = None
+        self._pack_programs = {}
+        self._io_cache = {}
+
+    # ---- mixed precision: which level computes / stores what ------------------------------------------
+    def op_mma(self, out_spatial):
+        """matrix input type of a layer whose output has this spatial size"""
+        v = out_spatial[0] * out_spatial[1] * out_spatial[2]
+        return 1 if (self.mma and v >= self.bf16_min_voxels) else 0
+
+    def val_dtype(self, spatial):
+        """storage type of an activation (and of its gradient) at this spatial size"""
+        v = spatial[0] * spatial[1] * spatial[2]
+        return torch.bfloat16 if (self.mma and self.storage_bf16 and v >= self.bf16_min_voxels) else torch.float32
+
+    def io(self, key, ins, outs, build, supported, grad_ins=False):
+        """Resolve the storage types of one launch.  ins / outs: Acts as the graph has them; build(ins', outs') -> launch parameters;
+        supported(params) -> does the kernel that serves them take these storage types (the *_io_supported queries of the C ABI).
+        Preference: as they are; fp32 copies of the bf16 inputs; an fp32 copy of the output; both (all-fp32 is always supported)."""
+        gi = list(grad_ins) if isinstance(grad_ins, (list, tuple)) else [bool(grad_ins)] * len(ins)
+        sig = (key, tuple(a.dt for a in ins), tuple(o.dt for o in outs))
+        flags = self._io_cache.get(sig)
+        if flags is None:
+            if all(a.dtype == torch.float32 for a in list(ins) + list(outs)):
+                flags = (False, False)
+            else:
+                flags = (True, True)
+                for cand in ((False, False), (True, False), (False, True)):
+                    if cand[0] and all(a.dtype == torch.float32 for a in ins):
+                        continue
+                    if cand[1] and all(o.dtype == torch.float32 for o in outs):
+                        continue
+                    t = _IO(self, key, ins, outs, build, cand, gi)
+                    if supported(t.build()):
+                        flags = cand
+                        break
+                if os.environ.get('MT_IO_DEBUG') and flags != (False, False):
+                    print("[mt io] %s: %s copies (in %s, out %s)" % (key, 'input' if flags == (True, False) else 'output' if flags == (False, True) else 'input+output',
+                                                                     [str(a.dtype) for a in ins], [str(o.dtype) for o in outs]))
+            self._io_cache[sig] = flags
+        return _IO(self, key, ins, outs, build, flags, gi)
+
+    def as_fp32(self, a, reuse=True, geometry_only=False):
+        """fp32 copy of the raw values of a bf16 activation / gradient (the lazy scale / shift stay with it).  reuse: a copy made
+        earlier in this iteration ON THIS STREAM is still valid (activations; never gradients, which change in place)."""
+        if a.dtype == torch.float32:
+            return a
+        stream = torch.cuda.current_stream().cuda_stream if a.buf.is_cuda else 0
+        key = (a.buf.data_ptr(), a.c0, a.C, tuple(a.buf.shape[:4]), stream)
+        ent = self._fp32_copies.get(key)
+        if ent is None:
+            ent = self._fp32_copies[key] = [torch.empty(tuple(a.buf.shape[:4]) + (a.C,), dtype=torch.float32, device=a.buf.device), -1]
+        t = a.with_buf(ent[0])
+        if geometry_only:
+            return t
+        if not (reuse and ent[1] == self._iter):
+            ops.cast(Act(a.buf, a.c0, a.C), Act(ent[0]))
+            ent[1] = self._iter if reuse else -1
+            self.io_cast_bytes += ent[0].numel() * 4
+        return t
 
     # ---- memory -----------------------------------------------------------------------------------
-    def buffer(self, name, shape):
+    def buffer(self, name, shape, dtype=torch.float32):
         t = self._buffers.get(name)
-        if t is None or tuple(t.shape) != tuple(shape):
-            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
             self._buffers[name] = t
         return t
 
@@ -565,9 +737,8 @@ class Engine:
                 self._op_ranges.append((op, lo, hi))
         self.dummy = torch.zeros(64, dtype=torch.float32, device=device)
         self._buffers.clear()
-        self._planned = None
-        self._packed_version = None
-        self._pack_programs = {}
+        self._fp32_copies.clear()
+        self._replan()
         self.params_version += 1
 
     def grad_of(self, p):
@@ -590,7 +761,7 @@ class Engine:
                 if isinstance(op, HeadOp):
                     v.grad = None            # provided by the loss (dlogits)
                 else:
-                    v.grad = self.buffer(v.name + '.grad', tuple(v.act.buf.shape[:4]) + (v.C,))
+                    v.grad = self.buffer(v.name + '.grad', tuple(v.act.buf.shape[:4]) + (v.C,), v.act.buf.dtype)
             # out = lrelu(main + res): the masked gradient of `out` IS the first contribution to the gradient of `res` (ResAddOp is
             # the last consumer of `res` in forward, so the first writer of its gradient in backward) — the two share one buffer and
             # the residual path costs no copy; along a chain of blocks the gradient flows through ONE buffer, masked in place
@@ -604,6 +775,7 @@ class Engine:
         self._planned = key
         self._packed_version = None
         self._pack_programs = {}
+        self._io_cache = {}
 
     def _pack(self, need_grad):
         ver = (self.params_version, self.flat._version, need_grad)
@@ -680,9 +852,9 @@ class Engine:
         nonlinearity, the un-flip and the accumulation of the sliding window (the logits are never stored)."""
         self.forward(x, need_grad=False, all_heads=False, _skip_final=True)
         op = next(o for o in self.ops if isinstance(o, HeadOp) and o.out is self.heads[self.final_head])
-        a = op.srcs[0].act
+        a = self.as_fp32(op.srcs[0].act)        # (the fused inference head reads fp32)
         p = ops.fill_pointwise(a, op.geom.out, a.spatial, (1, 1, 1), (1, 1, 1), op.conv.out_channels, op.wf, op.conv.bias, op.out.act)
-        p._keep = (op.wf, op.conv.bias)         # the struct only holds raw pointers
+        p._keep = (op.wf, op.conv.bias, a.buf)  # the struct only holds raw pointers
         return p
 
     def forward(self, x, need_grad=True, all_heads=True, _skip_final=False):
@@ -691,6 +863,7 @@ class Engine:
             raise RuntimeError("multitalent_amd: the network runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
         self.attach(x.device)
         ops.set_mma(self.mma)
+        self._iter += 1
         N, Cin = x.shape[0], x.shape[1]
         spatial = tuple(x.shape[2:])
         self._plan(N, spatial, need_grad)
@@ -893,7 +1066,7 @@ class _MaterialiseOp(_Op):
 
     def plan(self, eng, N):
         self.out.spatial = self.src.spatial
-        self.out.act = Act(eng.buffer(self.name, (N,) + self.src.spatial + (self.src.C,)))
+        self.out.act = Act(eng.buffer(self.name, (N,) + self.src.spatial + (self.src.C,), eng.val_dtype(self.src.spatial)))
 
     def pack(self, eng, need_bwd):
         pass

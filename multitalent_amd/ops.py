@@ -1,8 +1,8 @@
 """Thin torch-tensor wrappers over the C ABI (include/mtseg.h).
 
 Everything here is plumbing: torch owns device memory and streams, the arithmetic happens in
-libmtseg_hip.so.  Activations are NDHWC float32 tensors [N, D, H, W, C] (possibly channel slices of a
-wider buffer).  There is NO CPU fallback: tensors must live on a HIP device.
+libmtseg_hip.so.  Activations are NDHWC tensors [N, D, H, W, C] (possibly channel slices of a wider buffer), float32 or — the
+storage of the mixed-precision mode — bfloat16 (mt_src_t.dtype / odtype).  There is NO CPU fallback: tensors must live on a HIP device.
 """
 import ctypes as C
 
@@ -33,7 +33,7 @@ class Act:
     __slots__ = ('buf', 'c0', 'C', 'scale', 'shift', 'slope', 'mean', 'rstd')
 
     def __init__(self, buf, c0=0, C=None, scale=None, shift=None, slope=1.0, mean=None, rstd=None):
-        assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype == torch.float32
+        assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype in (torch.float32, torch.bfloat16)
         self.buf, self.c0 = buf, c0
         self.C = buf.shape[4] - c0 if C is None else C
         self.scale, self.shift, self.slope = scale, shift, float(slope)
@@ -51,14 +51,27 @@ class Act:
     @property
     def V(self): return self.buf.shape[1] * self.buf.shape[2] * self.buf.shape[3]
 
+    @property
+    def dtype(self): return self.buf.dtype
+
+    @property
+    def dt(self):
+        """storage type code of the C ABI (MT_F32 | MT_BF16)"""
+        return _lib.MT_BF16 if self.buf.dtype == torch.bfloat16 else _lib.MT_F32
+
     def data_ptr(self):
-        return self.buf.data_ptr() + 4 * self.c0
+        return self.buf.data_ptr() + self.buf.element_size() * self.c0
+
+    def with_buf(self, buf, c0=0):
+        """the same lazy activation over another buffer (a storage-type copy of the raw values)"""
+        return Act(buf, c0=c0, C=self.C, scale=self.scale, shift=self.shift, slope=self.slope, mean=self.mean, rstd=self.rstd)
 
     def src(self):
         s = mt_src_t()
         s.ptr = self.data_ptr()
         s.cs = self.cs
         s.C = self.C
+        s.dtype = self.dt
         s.scale = self.scale.data_ptr() if self.scale is not None else None
         s.shift = self.shift.data_ptr() if self.shift is not None else None
         s.slope = self.slope
@@ -66,7 +79,7 @@ class Act:
 
     def dense(self):
         """Materialise to a plain [N,D,H,W,C] tensor with torch ops (test/debug helper only)."""
-        x = self.buf[..., self.c0:self.c0 + self.C]
+        x = self.buf[..., self.c0:self.c0 + self.C].float()
         if self.scale is not None:
             x = x * self.scale[:, None, None, None, :] + self.shift[:, None, None, None, :]
             x = torch.where(x > 0, x, x * self.slope)
@@ -125,7 +138,9 @@ def fill_conv(srcs, geom, Cout, wpack=None, bias=None, out0=None, out1=None, csp
     if out0 is not None:
         p.out0 = out0.data_ptr()
         p.ocs0 = out0.cs
+        p.odtype = out0.dt
     if out1 is not None:
+        assert out0 is not None and out1.dt == out0.dt, "the two destinations of a convolution share one storage type"
         p.out1 = out1.data_ptr()
         p.ocs1 = out1.cs
     p.csplit = Cout if csplit is None else csplit
@@ -271,6 +286,31 @@ def conv3d_fwd(p):
     _lib.check(_lib.load().mt_conv3d_fwd(C.byref(p), _stream()), 'conv3d_fwd')
 
 
+def conv_io_supported(p):
+    return bool(_lib.load().mt_conv3d_io_supported(C.byref(p)))
+
+
+def conv_bwd_data_strided_io_supported(p):
+    return bool(_lib.load().mt_conv3d_bwd_data_strided_io_supported(C.byref(p)))
+
+
+def conv_bwd_weight_io_supported(p, y):
+    ys = y.src()
+    return bool(_lib.load().mt_conv3d_bwd_weight_io_supported(C.byref(p), C.byref(ys)))
+
+
+def pointwise_io_supported(p):
+    """mt_pointwise_fwd reads and writes fp32 only (for now): bf16 operands go through cast()."""
+    return p.src.dtype == _lib.MT_F32 and p.odtype == _lib.MT_F32
+
+
+def cast(src, dst, accumulate=False):
+    """dst (+)= src between storage types (mt_cast); src / dst: Act over the raw values (channel slices allowed)."""
+    assert src.N == dst.N and src.V == dst.V and src.C == dst.C
+    _lib.check(_lib.load().mt_cast(C.c_void_p(src.data_ptr()), src.cs, src.dt, C.c_void_p(dst.data_ptr()), dst.cs, dst.dt,
+                                   src.N * src.V, src.C, int(accumulate), _stream()), 'cast')
+
+
 def conv3d_bwd_data_strided_supported(p):
     return bool(_lib.load().mt_conv3d_bwd_data_strided_supported(C.byref(p)))
 
@@ -307,6 +347,7 @@ def fill_pointwise(src, base, in_spatial, si, so, Cout, wpack, bias, out, accumu
     p.bias = bias.data_ptr() if bias is not None else None
     p.out = out.data_ptr()
     p.ocs = out.cs
+    p.odtype = out.dt
     p.accumulate = 1 if accumulate else 0
     p.stats_part = stats_part.data_ptr() if stats_part is not None else None
     return p
@@ -324,12 +365,18 @@ def head_bwd(x, dy, wpack_bwd, dx, accumulate_dx, dw, s_ci, s_co, dbias, accumul
     """Fused backward of a 1x1x1 head: x = Act (head input, lazy), dy = Act over the dense gradient of the logits, dx = Act over the
     gradient buffer of the head's input.  Returns True when dbias was produced (see mt_head_bwd)."""
     lib = _lib.load()
+    assert x.dt == dy.dt == dx.dt == _lib.MT_F32, "mt_head_bwd reads and writes fp32 (convert with cast())"
     xs = x.src()
     done = C.c_int(0)
     _lib.check(lib.mt_head_bwd(C.byref(xs), C.c_void_p(dy.data_ptr()), dy.cs, x.N, x.V, x.C, dy.C, _ptr(wpack_bwd),
                                C.c_void_p(dx.data_ptr()), dx.cs, int(accumulate_dx), _ptr(dw), int(s_ci), int(s_co), _ptr(dbias),
                                int(accumulate_dw), C.byref(done), _ptr(ws), ws.numel() * ws.element_size(), _stream()), 'head_bwd')
     return bool(done.value)
+
+
+def head_bwd_io_supported(x, dx, Cout):
+    """mt_head_bwd reads and writes fp32 only (for now)"""
+    return x.dt == _lib.MT_F32 and dx.dt == _lib.MT_F32
 
 
 def head_bwd_workspace(N, V, Cin, Cout):
@@ -352,7 +399,15 @@ def inorm_lrelu_apply(y, out, res=None):
         C.c_void_p(res.data_ptr()) if res is not None else None, res.cs if res is not None else 0,
         _ptr(res.scale) if res is not None else None, _ptr(res.shift) if res is not None else None,
         res.slope if res is not None else 1.0,
-        C.c_void_p(out.data_ptr()), out.cs, y.N, y.V, y.C, _stream()), 'inorm_lrelu_apply')
+        C.c_void_p(out.data_ptr()), out.cs, y.N, y.V, y.C, _same_dt(y, out, res), _stream()), 'inorm_lrelu_apply')
+
+
+def _same_dt(*acts):
+    """the streaming kernels take ONE storage type for all their tensor operands (the engine chooses it per resolution level)"""
+    dts = {a.dt for a in acts if a is not None}
+    if len(dts) != 1:
+        raise RuntimeError("operands of a streaming kernel must share one storage type (got %s): convert with ops.cast" % sorted(dts))
+    return dts.pop()
 
 
 def inorm_bwd_workspace(N, V, Cn):
@@ -367,7 +422,7 @@ def inorm_lrelu_bwd(g, y, gamma, beta, dgamma, dbeta, dbias, ws, part=None, part
     _lib.check(_lib.load().mt_inorm_lrelu_bwd(
         C.c_void_p(g.data_ptr()), g.cs, C.c_void_p(y.data_ptr()), y.cs, _ptr(y.mean), _ptr(y.rstd), _ptr(gamma), _ptr(beta),
         y.slope, y.N, y.V, y.C, _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(part), int(part.shape[1]) if part is not None else 0,
-        int(part.shape[2]) if part is not None else 0, int(part_c0), _ptr(ws), ws.numel() * ws.element_size(), _stream()),
+        int(part.shape[2]) if part is not None else 0, int(part_c0), _ptr(ws), ws.numel() * ws.element_size(), _same_dt(g, y), _stream()),
         'inorm_lrelu_bwd')
 
 
@@ -378,6 +433,7 @@ def conv_bwd_stats_supported(p):
 def set_bwd_stats(p, y_act, gamma, beta, c0):
     """fused first pass of the InstanceNorm backward of `y_act`'s layer in the epilogue of the convolution p (the last writer of that
     layer's output gradient): see mt_bwd_stats_t.  The caller keeps the tensors alive and provides p.stats_part."""
+    assert y_act.dt == _lib.MT_F32, "the fused norm-backward statistics read an fp32 y"
     b = p.bstats
     b.y, b.ycs, b.c0, b.C = y_act.buf.data_ptr() + 4 * y_act.c0, y_act.cs, int(c0), y_act.C
     b.mean, b.rstd = y_act.mean.data_ptr(), y_act.rstd.data_ptr()
@@ -392,7 +448,7 @@ def channel_sum_workspace(N, V, Cn):
 
 def channel_sum(x, out, accumulate, ws):
     _lib.check(_lib.load().mt_channel_sum(C.c_void_p(x.data_ptr()), x.cs, x.N, x.V, x.C, _ptr(out), int(accumulate), _ptr(ws),
-                                          ws.numel() * ws.element_size(), _stream()), 'channel_sum')
+                                          ws.numel() * ws.element_size(), x.dt, _stream()), 'channel_sum')
 
 
 def loss_workspace(B, V, Cn):

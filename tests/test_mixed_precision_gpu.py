@@ -60,7 +60,12 @@ def test_bf16_mode_uses_the_bf16_kernel_and_tracks_fp32(dev):
             assert float((a - b).abs().max()) < 3e-2 * float(b.abs().max())
         assert abs(res['bf16'][1] - res['fp32'][1]) < 1e-2
         ga, gb = res['bf16'][2], res['fp32'][2]
-        assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.995
+        # bf16 STORAGE of the two upper levels (round 4) rounds every activation and gradient of those levels once more than the
+        # bf16-operand mode did (measured 0.9941; MT_BF16_STORAGE=0 keeps the round-3 arithmetic and its 0.995)
+        import os
+        cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+        print("bf16 vs fp32 gradient cosine: %.5f" % cos)
+        assert cos > (0.995 if os.environ.get('MT_BF16_STORAGE', '1') == '0' else 0.99), cos
         for la, lb in zip(res['bf16'][3], res['fp32'][3]):
             assert np.isfinite(la) and abs(la - lb) < 2e-2, (res['bf16'][3], res['fp32'][3])
         assert res['bf16'][3][-1] < res['bf16'][3][0]                   # it trains
