@@ -38,13 +38,16 @@ extern "C" {
 #define MT_ABI_VERSION 2   /* 2: storage dtypes (mt_src_t.dtype, odtype fields, dtype arguments of the streaming kernels, mt_cast) */
 #define MT_MAX_CHUNKS 64
 
-/* Storage type of an activation / gradient tensor in HBM.  fp32 is the parity path.  bf16 is the storage of the mixed-precision
- * mode (the reference's autocast keeps conv inputs / outputs in half precision: MultiTalent_Trainer_DDP.py:340-354,
- * network_trainer.py:400-402): values are rounded to nearest-even when stored and widened exactly when loaded; all arithmetic
- * (normalisation, statistics, accumulation, loss, optimizer) stays fp32.  Not every kernel takes every combination: ask the
+/* Storage type of an activation / gradient tensor in HBM.  fp32 is the parity path.  The mixed-precision mode (the reference's
+ * autocast keeps conv inputs / outputs in half precision: MultiTalent_Trainer_DDP.py:340-354, network_trainer.py:400-402) stores
+ * ACTIVATIONS as fp16 — the reference's own type: 11 significand bits, and the forward convolutions then multiply fp16 operands
+ * (v_mfma_f32_32x32x16_f16) — and GRADIENTS as bf16 (fp32's exponent range: no loss scaling; the backward convolutions multiply
+ * bf16 operands).  Values are rounded to nearest-even when stored and widened exactly when loaded; all arithmetic in between
+ * (normalisation, statistics, accumulation, loss, optimizer) is fp32.  Not every kernel takes every combination: ask the
  * *_io_supported queries and convert with mt_cast where the answer is 0. */
 #define MT_F32 0
 #define MT_BF16 1
+#define MT_F16 2
 
 typedef void* mt_stream_t; /* hipStream_t */
 
@@ -58,7 +61,7 @@ typedef struct {
   const float* scale;
   const float* shift;
   float slope;
-  int32_t dtype;  /* MT_F32 | MT_BF16: element type behind `ptr` (cs counts elements) */
+  int32_t dtype;  /* MT_F32 | MT_BF16 | MT_F16: element type behind `ptr` (cs counts elements) */
 } mt_src_t;
 
 /* Fused statistics for the InstanceNorm + LeakyReLU backward that runs next (generic_UNet.py:63-64 in reverse).  A convolution that
@@ -105,7 +108,7 @@ typedef struct {
   int32_t OD, OH, OW, osD, osH, osW, ooD, ooH, ooW;
   int32_t mma;                /* matrix input type of the convolution: 0 fp32 (exact), 1 bf16 inputs with fp32 accumulation
                                  (mixed precision, the reference's autocast mode); packed weights must match (mt_conv3d_pack_layout) */
-  int32_t odtype;             /* MT_F32 | MT_BF16: element type of out0 / out1 (ocs0 / ocs1 count elements); statistics are taken from
+  int32_t odtype;             /* MT_F32 | MT_BF16 | MT_F16: element type of out0 / out1 (ocs0 / ocs1 count elements); statistics are taken from
                                  the values as stored */
   mt_bwd_stats_t bstats;      /* bstats.y != NULL: fused first pass of the NEXT InstanceNorm backward (see mt_bwd_stats_t) */
 } mt_conv3d_t;
@@ -219,7 +222,7 @@ typedef struct {
   float* out; int32_t ocs;
   int32_t accumulate;
   float* stats_part;   /* NULL or [N][nsb][Cout][2] */
-  int32_t odtype;      /* MT_F32 | MT_BF16: element type of `out` */
+  int32_t odtype;      /* MT_F32 | MT_BF16 | MT_F16: element type of `out` */
   int32_t _pad;
 } mt_pointwise_t;
 int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream);
@@ -257,11 +260,12 @@ size_t mt_inorm_bwd_workspace(int N, long V, int C);
 int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, float slope, int N, long V, int C,
                        float* dgamma, float* dbeta, float* dbias, const float* part, int part_nblk, int part_cs, int part_c0,
-                       void* ws, size_t ws_bytes, int dtype /* storage type of g and y */, mt_stream_t stream);
+                       void* ws, size_t ws_bytes, int gdtype, int ydtype /* storage types of g and of y */, mt_stream_t stream);
 /* g *= lrelu'(y*scale+shift) in place, optionally also writes a copy (residual branch gradient) */
 int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale, const float* shift,
                  float slope, const float* y2, int y2cs, const float* scale2, const float* shift2,
-                 float slope2, float* gcopy, int gcopycs, int N, long V, int C, int dtype /* of g, y, y2, gcopy */, mt_stream_t stream);
+                 float slope2, float* gcopy, int gcopycs, int N, long V, int C, int gdtype /* of g, gcopy */, int ydtype /* of y, y2 */,
+                 mt_stream_t stream);
 /* mt_lrelu_bwd on dense tensors (channel stride == C) that also emits the first pass of the NEXT InstanceNorm backward: in a residual
  * block out = lrelu(IN(y) + residual) (conv_blocks.py:201-213) the masked gradient g' is the gradient of IN(y), so
  * part[n][blk][c] = (sum g', sum g' * (y - mean) * rstd) over the block's voxels — mt_inorm_lrelu_bwd(part, part_nblk =
@@ -270,14 +274,14 @@ int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale,
 int mt_lrelu_bwd_stats_blocks(long V, int C);
 int mt_lrelu_bwd_stats(float* g, const float* y, const float* scale, const float* shift, float slope,
                        const float* y2, const float* scale2, const float* shift2, float slope2, float* gcopy,
-                       const float* mean, const float* rstd, float* part, int N, long V, int C, int dtype /* of g, y, y2, gcopy */,
-                       mt_stream_t stream);
+                       const float* mean, const float* rstd, float* part, int N, long V, int C, int gdtype /* of g, gcopy */,
+                       int ydtype /* of y, y2 */, mt_stream_t stream);
 /* per-channel sum over all voxels: out[C] (+)= sum_{n,v} x[n,v,c]  (bias gradients of heads) */
 size_t mt_channel_sum_workspace(int N, long V, int C);
 int mt_channel_sum(const float* x, int xcs, int N, long V, int C, float* out, int accumulate,
                    void* ws, size_t ws_bytes, int dtype /* storage type of x */, mt_stream_t stream);
 /* Storage-type conversion, the boundary op of the mixed-precision mode: dst[r][c] (+)= src[r][c] for `rows` voxels (all samples) of
- * C channels, each side with its own storage type (MT_F32 | MT_BF16) and channel stride in elements.  accumulate adds in fp32 and
+ * C channels, each side with its own storage type (MT_F32 | MT_BF16 | MT_F16) and channel stride in elements.  accumulate adds in fp32 and
  * rounds once.  A kernel that does not take a tensor's storage type (the *_io_supported queries) works on such a copy. */
 int mt_cast(const void* src, int scs, int sdtype, void* dst, int dcs, int ddtype, long rows, int C, int accumulate,
             mt_stream_t stream);

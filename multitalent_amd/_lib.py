@@ -56,7 +56,7 @@ class mt_pointwise_t(C.Structure):
                 ('stats_part', C.c_void_p), ('odtype', C.c_int32), ('_pad', C.c_int32)]
 
 
-MT_F32, MT_BF16 = 0, 1
+MT_F32, MT_BF16, MT_F16 = 0, 1, 2
 MT_ABI_VERSION = 2
 
 _vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
@@ -95,10 +95,10 @@ SIGNATURES = {
     'mt_inorm_finalize': (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     'mt_inorm_lrelu_apply': (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _i, _vp]),
     'mt_inorm_bwd_workspace': (_sz, [_i, _l, _i]),
-    'mt_inorm_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _i, _l, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _vp]),
-    'mt_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _i, _vp]),
+    'mt_inorm_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _i, _l, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _i, _i, _vp]),
+    'mt_lrelu_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _i, _i, _vp]),
     'mt_lrelu_bwd_stats_blocks': (_i, [_l, _i]),
-    'mt_lrelu_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _vp]),
+    'mt_lrelu_bwd_stats': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _vp]),
     'mt_channel_sum_workspace': (_sz, [_i, _l, _i]),
     'mt_channel_sum': (_i, [_vp, _i, _i, _l, _i, _vp, _i, _vp, _sz, _i, _vp]),
     'mt_cast': (_i, [_vp, _i, _i, _vp, _i, _i, _l, _i, _i, _vp]),

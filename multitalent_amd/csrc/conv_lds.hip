@@ -921,10 +921,11 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
 // the haloed input tile ((TD-1)*SD+3) x 9 x 17 voxels x 16 channels stays under 64 KiB so two workgroups share a CU; the four
 // waves are 2 M tiles (one output plane each) x 2 N tiles, so every staged voxel feeds 64 output channels.
 // BF = true (mixed precision, mt_conv3d_t.mma == 1): bf16 LDS image and v_mfma_f32_32x32x16_bf16 through mt_stage_bf16 / bf16_chunk.
-// XB / OB (BF only): source / destination stored as bf16 (mt_src_t.dtype, mt_conv3d_t.odtype).
-template <int SD, int SH, int SW, int VEC, bool BF = false, bool XB = false, bool OB = false>
+// XS / OS (BF only): storage types of the source / destination (mt_src_t.dtype, mt_conv3d_t.odtype); MTY: matrix type (mt_stage_bf16).
+template <int SD, int SH, int SW, int VEC, bool BF = false, int XS = MT_F32, int OS = MT_F32, int MTY = MT_BF16>
 __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParams P) {
-  static_assert(BF || !(XB || OB), "bf16 storage is served by the bf16 matrix path");
+  static_assert(BF || (XS == MT_F32 && OS == MT_F32), "16-bit storage is served by the 16-bit matrix path");
+  constexpr bool OB = OS != MT_F32;
   constexpr int TD = 2, TH = 4, TW = 8;
   constexpr int LD = (TD - 1) * SD + 3, LH = (TH - 1) * SH + 3, LW = (TW - 1) * SW + 3;
   constexpr int LWP = BF ? bstage_lwp<LD, LH, LW, VEC, 4>() : stage_lwp<LD, LH, LW, VEC>();
@@ -955,9 +956,9 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
     __syncthreads();
     if constexpr (BF) {
       const unsigned* wlane = (const unsigned*)c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 256) + lane * 4;
-      mt_stage_bf16<LD, LH, LW, VEC, 4, XB>((unsigned*)lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
+      mt_stage_bf16<LD, LH, LW, VEC, 4, XS, MTY>((unsigned*)lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
       __syncthreads();
-      bf16_chunk<1, 1, LH, LWP>((const unsigned*)lds, abase, wlane, 0, accb);
+      bf16_chunk<1, 1, LH, LWP, 3, MTY>((const unsigned*)lds, abase, wlane, 0, accb);
     } else {
       const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
       mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
   const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
   const int ocs = c.ocs0;
   const size_t out_sample = (size_t)c.Do * c.Ho * c.Wo;
-  constexpr int OEB = OB ? 2 : 4;
+  constexpr int OEB = mt_ebytes<OS>();
   __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)nb * out_sample * ocs * OEB), 0,
                                                                 (int)(out_sample * ocs * OEB), 0x00020000);
   const int od = od0 + dm;
@@ -989,11 +990,11 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
       const int off = ok ? (((od * c.Ho + oh) * c.Wo + ow) * ocs + coe) * 2 : (int)0x80000000;
       float a, b;
       mt_pair_exchange(acc[0][j] + bv, acc[0][j + 1] + bv, odd, a, b);
-      if (c.accumulate) { const unsigned pv = __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0); a += mt_bf16_lo(pv); b += mt_bf16_hi(pv); }
-      const unsigned pk = mt_pk_bf16(a, b);
+      if (c.accumulate) { const unsigned pv = __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0); a += mt_lo16<OS>(pv); b += mt_hi16<OS>(pv); }
+      const unsigned pk = mt_pk16<OS>(a, b);
       __builtin_amdgcn_raw_buffer_store_b32(pk, rd, off, 0, 0);
       if (ok) {
-        const float ar = mt_bf16_lo(pk), br = mt_bf16_hi(pk);
+        const float ar = mt_lo16<OS>(pk), br = mt_hi16<OS>(pk);
         q1[0] += ar; q2[0] = fmaf(ar, ar, q2[0]); q1[1] += br; q2[1] = fmaf(br, br, q2[1]);
       }
     }
@@ -1037,8 +1038,10 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
 // M tile (2x4x4) x 32 output channels and its four waves split the 27 TAPS (t = wave, wave+4, ...), so the serial chain per wave
 // is 4x shorter and the grid 4x larger; the four accumulator tiles are summed through LDS in a fixed order (deterministic).
 // BF = true (mixed precision): bf16 LDS image and one v_mfma_f32_32x32x16_bf16 per tap instead of eight fp32 MFMAs.
-template <int VEC, bool BF = false>
+// XS / OS / MTY (BF only): storage types of the source / destination and the matrix type, as in conv_bf16_kernel.
+template <int VEC, bool BF = false, int XS = MT_F32, int OS = MT_F32, int MTY = MT_BF16>
 __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P) {
+  static_assert(BF || (XS == MT_F32 && OS == MT_F32), "16-bit storage is served by the 16-bit matrix path");
   constexpr int TD = 2, TH = 4, TW = 4, LD = TD + 2, LH = TH + 2, LW = TW + 2;
   constexpr int LWP = BF ? bstage_lwp<LD, LH, LW, VEC, 4>() : stage_lwp<LD, LH, LW, VEC>();
   constexpr int PITCH = BF ? BFP : FCKP;
@@ -1062,7 +1065,7 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
     const ConvChunk cc = P.chunk[ch];
     __syncthreads();
     if constexpr (BF) {
-      mt_stage_bf16<LD, LH, LW, VEC, 4>((unsigned*)lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+      mt_stage_bf16<LD, LH, LW, VEC, 4, XS, MTY>((unsigned*)lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
       __syncthreads();
       const unsigned* ldsu = (const unsigned*)lds;
       const unsigned* wl = (const unsigned*)c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 256) + lane * 4;
@@ -1075,7 +1078,7 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
       }
 #pragma unroll
       for (int i = 0; i < 7; ++i)
-        if (i < 6 || wave < 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[i], acc, 0, 0, 0);
+        if (i < 6 || wave < 3) acc = mt_mfma16<MTY>(fa[i], fb[i], acc);
       continue;
     }
     const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
@@ -1123,9 +1126,34 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
   const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
   const int ocs = c.ocs0;
   const size_t out_sample = (size_t)c.Do * c.Ho * c.Wo;
-  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
-                                                                (int)(out_sample * ocs * 4), 0x00020000);
+  constexpr int OEB = mt_ebytes<OS>();
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)nb * out_sample * ocs * OEB), 0,
+                                                                (int)(out_sample * ocs * OEB), 0x00020000);
   float s1 = 0.f, s2 = 0.f;
+  if constexpr (OS != MT_F32) {        // channel-pair dwords (mt_pair_exchange): even lanes store row jj, odd lanes row jj + 1
+    const bool odd = li & 1;
+    const int coe = co & ~1;
+    const bool pvalid = coe + 1 < c.Cout;
+    float q1[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 4; jj += 2) {
+      const int iv = jj + 8 * wave + 4 * lhalf + (odd ? 1 : 0);
+      const int od = od0 + (iv >> 4), oh = oh0 + ((iv >> 2) & 3), ow = ow0 + (iv & 3);
+      const bool ok = pvalid && od < c.Do && oh < c.Ho && ow < c.Wo;
+      const int off = ok ? (((od * c.Ho + oh) * c.Wo + ow) * ocs + coe) * 2 : (int)0x80000000;
+      float a, b;
+      mt_pair_exchange(v[jj] + bv, v[jj + 1] + bv, odd, a, b);
+      if (c.accumulate) { const unsigned pv = __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0); a += mt_lo16<OS>(pv); b += mt_hi16<OS>(pv); }
+      const unsigned pk = mt_pk16<OS>(a, b);
+      __builtin_amdgcn_raw_buffer_store_b32(pk, rd, off, 0, 0);
+      if (ok) {
+        const float ar = mt_lo16<OS>(pk), br = mt_hi16<OS>(pk);
+        q1[0] += ar; q2[0] = fmaf(ar, ar, q2[0]); q1[1] += br; q2[1] = fmaf(br, br, q2[1]);
+      }
+    }
+    s1 = mt_pair_combine(q1[0], q1[1], odd);
+    s2 = mt_pair_combine(q2[0], q2[1], odd);
+  } else
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
     // accumulator register j = 4*wave + jj holds M row (j&3) + 8*(j>>2) + 4*lhalf = jj + 8*wave + 4*lhalf
@@ -1604,9 +1632,10 @@ template <int S> __host__ __device__ constexpr int bd_off(int k) { return S == 2
 #ifndef BDS_ABL
 #define BDS_ABL 0      // timing ablations: 1 skip the dY staging, 2 skip the weight-fragment loads, 4 skip the epilogue, 8 skip the MFMAs
 #endif
-template <int SD, int SH, int SW, int VEC, bool BF = false, bool XB = false, bool OB = false>
+template <int SD, int SH, int SW, int VEC, bool BF = false, int XS = MT_F32, int OS = MT_F32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_bwdd_strided_kernel(const ConvKParams P) {
-  static_assert(BF || !(XB || OB), "bf16 storage is served by the bf16 matrix path");
+  static_assert(BF || (XS == MT_F32 && OS == MT_F32), "16-bit storage is served by the bf16 matrix path");
+  constexpr bool OB = OS != MT_F32;
   constexpr int TD = 2, TH = 4, TW = 16;                       // dY positions per workgroup: 4 waves x 32
   constexpr int LD = TD + (SD == 2 ? 1 : 2), LH = TH + (SH == 2 ? 1 : 2), LW = TW + (SW == 2 ? 1 : 2);
   constexpr int NC = SD * SH * SW, LWP = BF ? bstage_lwp<LD, LH, LW, VEC, 4>() : stage_lwp<LD, LH, LW, VEC>();
@@ -1635,7 +1664,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
     __syncthreads();
     if constexpr (BF) {
-      mt_stage_bf16<LD, LH, LW, VEC, 4, XB>((unsigned*)lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
+      mt_stage_bf16<LD, LH, LW, VEC, 4, XS, MT_BF16>((unsigned*)lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
       __syncthreads();
       const unsigned* ldsu = (const unsigned*)lds;
       const unsigned* wl = (const unsigned*)c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 256) + lane * 4;
@@ -1711,7 +1740,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   const bool covalid = co < c.Cout;
   const int ocs = c.ocs0;
   const size_t out_sample = (size_t)c.OD * c.OH * c.OW;
-  constexpr int OEB = OB ? 2 : 4;
+  constexpr int OEB = mt_ebytes<OS>();
   __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)nb * out_sample * ocs * OEB), 0,
                                                                 (int)(out_sample * ocs * OEB), 0x00020000);
   const int md = md0 + dm;
@@ -1754,8 +1783,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       for (int q = 0; q < NC; ++q) {
         float a, b;
         mt_pair_exchange(acc[q][j], acc[q][j + 1], odd, a, b);
-        if (c.accumulate) { a += mt_bf16_lo(pprev[jp & 1][q]); b += mt_bf16_hi(pprev[jp & 1][q]); }
-        __builtin_amdgcn_raw_buffer_store_b32(mt_pk_bf16(a, b), rd, poff[jp & 1][q], 0, 0);
+        if (c.accumulate) { a += mt_lo16<OS>(pprev[jp & 1][q]); b += mt_hi16<OS>(pprev[jp & 1][q]); }
+        __builtin_amdgcn_raw_buffer_store_b32(mt_pk16<OS>(a, b), rd, poff[jp & 1][q], 0, 0);
       }
     }
     return;
@@ -1853,6 +1882,7 @@ static int launch_gather(const mt_conv3d_t* p, hipStream_t st);
 static bool conv_is_133(const mt_conv3d_t* p);
 static int conv_bf16_cfg(const mt_conv3d_t* p);
 static bool strided_use_bf16(const mt_conv3d_t* p);
+static int conv_matrix_type(const mt_conv3d_t* p);
 static ConvPlan conv_plan(const mt_conv3d_t* p) {
   static int use_v2 = -1, use_rt = -1;
   if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
@@ -1899,8 +1929,9 @@ extern "C" int mt_conv3d_ck(const mt_conv3d_t* p) {
 }
 extern "C" int mt_conv3d_pack_layout(const mt_conv3d_t* p) {      // layout argument of mt_pack_conv_weights for this problem
   const int k = conv_plan(p).kind;
-  if ((k == CONV_FAST_STRIDED || k == CONV_TAPSPLIT) && strided_use_bf16(p)) return 3;
-  return k == CONV_WINO ? 2 : k == CONV_BF16 ? 3 : 1;
+  const int l16 = conv_matrix_type(p) == MT_F16 ? 4 : 3;
+  if ((k == CONV_FAST_STRIDED || k == CONV_TAPSPLIT) && strided_use_bf16(p)) return l16;
+  return k == CONV_WINO ? 2 : k == CONV_BF16 ? l16 : 1;
 }
 extern "C" int mt_conv3d_stats_blocks(const mt_conv3d_t* p) {
   const ConvPlan pl = conv_plan(p);
@@ -1948,7 +1979,7 @@ static int conv_fast_vec(const mt_conv3d_t* p) {
   if (force1) return 1;
   for (int i = 0; i < p->nsrc; ++i) {
     const mt_src_t& s = p->src[i];
-    if ((s.cs & 1) || (s.C & 1) || (((uintptr_t)s.ptr) & (s.dtype == MT_BF16 ? 3 : 7))) return 1;   // a channel pair = one 8 / 4-byte load
+    if ((s.cs & 1) || (s.C & 1) || (((uintptr_t)s.ptr) & (mt_is16(s.dtype) ? 3 : 7))) return 1;   // a channel pair = one 8 / 4-byte load
   }
   return 2;
 }
@@ -1957,8 +1988,11 @@ static int conv_fast_vec(const mt_conv3d_t* p) {
 static int conv_src_dtype(const mt_conv3d_t* p) {
   const int d = p->src[0].dtype;
   if (p->nsrc == 2 && p->src[1].dtype != d) return -1;
-  return (d == MT_F32 || d == MT_BF16) ? d : -1;
+  return mt_dtype_ok(d) ? d : -1;
 }
+// matrix type of a problem served by the 16-bit matrix kernels (p->mma == 1): fp16 sources multiply as fp16 (forward over fp16
+// activations), everything else as bf16.  The packed weights must match: layout 4 (fp16) / 3 (bf16).
+static int conv_matrix_type(const mt_conv3d_t* p) { return conv_src_dtype(p) == MT_F16 ? MT_F16 : MT_BF16; }
 static bool conv_out_pairs_ok(const mt_conv3d_t* p) {
   if ((p->Cout & 1) || (p->ocs0 & 1) || (((uintptr_t)p->out0) & 3)) return false;
   if (p->csplit < p->Cout && ((p->csplit & 1) || (p->ocs1 & 1) || (((uintptr_t)p->out1) & 3))) return false;
@@ -2013,12 +2047,15 @@ static int launch_fast_strided_t(const mt_conv3d_t* p, hipStream_t st) {
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 64), 1);
   if (strided_use_bf16(p)) {
     const int sd = conv_src_dtype(p);
-    if (sd == MT_BF16 && p->odtype == MT_BF16)
-      hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 4, true, true, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 4, 4>()), st, P);
-    else if (sd == MT_BF16)              // the level below the storage threshold stays fp32
-      hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 4, true, true, false>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 4, 4>()), st, P);
-    else
-      hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
+    // 16-bit source: fp16 activations multiply as fp16 (the forward pass), bf16 sources as bf16; the destination has the source's
+    // type, or fp32 (a level the engine keeps in fp32)
+#define MT_FS_LAUNCH(XS_, OS_, MTY_, VEC_) hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, VEC_, true, XS_, OS_, MTY_>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, VEC_, 4>()), st, P)
+    if (sd == MT_F16 && p->odtype == MT_F16) MT_FS_LAUNCH(MT_F16, MT_F16, MT_F16, 4);
+    else if (sd == MT_F16) MT_FS_LAUNCH(MT_F16, MT_F32, MT_F16, 4);
+    else if (sd == MT_BF16 && p->odtype == MT_BF16) MT_FS_LAUNCH(MT_BF16, MT_BF16, MT_BF16, 4);
+    else if (sd == MT_BF16) MT_FS_LAUNCH(MT_BF16, MT_F32, MT_BF16, 4);
+    else MT_FS_LAUNCH(MT_F32, MT_F32, MT_BF16, 2);
+#undef MT_FS_LAUNCH
   } else if (conv_fast_vec(p) == 2) {
     hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 2>()), st, P);
   } else {
@@ -2048,9 +2085,18 @@ static int launch_tapsplit(const mt_conv3d_t* p, hipStream_t st) {
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
   const size_t red = (size_t)4 * 16 * 64 * sizeof(float);
-  if (strided_use_bf16(p)) {               // same eligibility: mma == 1, >= 16 even channels, 8-byte aligned sources
-    size_t l = bstage_lds_bytes<4, 6, 6, 2, 4>(); if (l < red) l = red;
-    hipLaunchKernelGGL((conv_tapsplit_kernel<2, true>), grid, dim3(256), l, st, P);
+  if (strided_use_bf16(p)) {               // same eligibility: mma == 1, >= 16 even channels, aligned sources
+    const int sd = conv_src_dtype(p);
+    if (sd == MT_F32) {
+      size_t l = bstage_lds_bytes<4, 6, 6, 2, 4>(); if (l < red) l = red;
+      hipLaunchKernelGGL((conv_tapsplit_kernel<2, true>), grid, dim3(256), l, st, P);
+    } else {
+      size_t l = bstage_lds_bytes<4, 6, 6, 4, 4>(); if (l < red) l = red;
+      if (sd == MT_F16 && p->odtype == MT_F16) hipLaunchKernelGGL((conv_tapsplit_kernel<4, true, MT_F16, MT_F16, MT_F16>), grid, dim3(256), l, st, P);
+      else if (sd == MT_F16) hipLaunchKernelGGL((conv_tapsplit_kernel<4, true, MT_F16, MT_F32, MT_F16>), grid, dim3(256), l, st, P);
+      else if (p->odtype == MT_BF16) hipLaunchKernelGGL((conv_tapsplit_kernel<4, true, MT_BF16, MT_BF16, MT_BF16>), grid, dim3(256), l, st, P);
+      else hipLaunchKernelGGL((conv_tapsplit_kernel<4, true, MT_BF16, MT_F32, MT_BF16>), grid, dim3(256), l, st, P);
+    }
   } else if (conv_fast_vec(p) == 2) {
     size_t l = stage_lds_bytes<4, 6, 6, 2>(); if (l < red) l = red;
     hipLaunchKernelGGL((conv_tapsplit_kernel<2>), grid, dim3(256), l, st, P);
@@ -2120,7 +2166,7 @@ static bool strided_use_bf16(const mt_conv3d_t* p) {      // forward strided sta
   return use && g_bf16_mode && p->mma == 1 && p->Cin >= 16 && conv_fast_vec(p) == 2;
 }
 static int conv_bf16_vec(const mt_conv3d_t*) { return 2; }    // 16-byte staging loads measured slower (0.409 vs 0.372 ms on 32->32)
-template <int MW, int RH, int TD, int VEC, int NT, int NW, int KD = 3, bool XB = false, bool OB = false>
+template <int MW, int RH, int TD, int VEC, int NT, int NW, int KD = 3, int XS = MT_F32, int OS = MT_F32, int MTY = MT_BF16>
 static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   ConvKParams P;
   P.c = *p;
@@ -2133,7 +2179,7 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
   const size_t ldsb = bstage_lds_bytes<TD + KD - 1, TH + 2, TW + 2, VEC, NW>();
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(mt_cdiv(p->Cout, 32), NT), 1);
-  auto kfn = conv_bf16_kernel<MW, RH, TD, VEC, NT, NW, KD, XB, OB>;
+  auto kfn = conv_bf16_kernel<MW, RH, TD, VEC, NT, NW, KD, XS, OS, MTY>;
   if (ldsb > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
@@ -2144,12 +2190,14 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
 }
 static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
   // NT = 2 (64 output channels per workgroup) measured slower: 0.197 vs 0.179 ms on 64->64 @ 24x96x96; 8 waves: no gain
-  // storage: all fp32, or all bf16 (sources read as 8-byte groups of four channels, destination written as channel-pair dwords)
-  const bool sb = conv_src_dtype(p) == MT_BF16 && p->odtype == MT_BF16;
-  MT_REQUIRE(sb || (conv_src_dtype(p) == MT_F32 && p->odtype == MT_F32), "conv3d: conv_bf16_kernel takes fp32 or bf16 storage on ALL operands (ask mt_conv3d_io_supported)");
+  // storage: all fp32 (bf16 matrix type), all bf16 (backward-data over gradients) or all fp16 (forward over activations: fp16 matrix
+  // type); 16-bit sources are read as 8-byte groups of four channels, 16-bit destinations written as channel-pair dwords
+  const int sd = conv_src_dtype(p);
+  MT_REQUIRE(sd >= 0 && sd == p->odtype, "conv3d: conv_bf16_kernel takes ONE storage type on all operands (ask mt_conv3d_io_supported)");
 #define MT_BF_CASE(I_, MW_, RH_, TD_, NW_)                                                   \
   if (cfg == I_) {                                                                           \
-    if (sb) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 1, true, true>(p, st) : launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 3, true, true>(p, st); \
+    if (sd == MT_F16) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 1, MT_F16, MT_F16, MT_F16>(p, st) : launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 3, MT_F16, MT_F16, MT_F16>(p, st); \
+    if (sd == MT_BF16) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 1, MT_BF16, MT_BF16, MT_BF16>(p, st) : launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 3, MT_BF16, MT_BF16, MT_BF16>(p, st); \
     return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 2, 1, NW_, 1>(p, st) : launch_bf16_t<MW_, RH_, TD_, 2, 1, NW_>(p, st); \
   }
   MT_BF_CASE(0, 32, 4, 4, 4)
@@ -2418,7 +2466,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   if (pl.kind == CONV_FAST)
     snprintf(buf, n, "conv_fast_kernel<%d, %d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p), p->KD);
   else if (pl.kind == CONV_TAPSPLIT)
-    snprintf(buf, n, strided_use_bf16(p) ? "conv_tapsplit_kernel<%d, true>" : "conv_tapsplit_kernel<%d, false>", conv_fast_vec(p));
+    snprintf(buf, n, strided_use_bf16(p) ? "conv_tapsplit_kernel<%d, true>" : "conv_tapsplit_kernel<%d, false>", (strided_use_bf16(p) && conv_src_dtype(p) != MT_F32) ? 4 : conv_fast_vec(p));
   else if (pl.kind == CONV_STEM)
     snprintf(buf, n, "conv_stem_kernel");
   else if (pl.kind == CONV_WINO)
@@ -2442,8 +2490,9 @@ extern "C" int mt_conv3d_bwd_stats_supported(const mt_conv3d_t* p) {
 }
 
 // Storage types (mt_src_t.dtype, mt_conv3d_t.odtype): 1 when the kernel that serves p reads / writes them natively.  All-fp32 is
-// always supported; bf16 storage is taken by the bf16 matrix kernels (p->mma == 1): conv_bf16_kernel with bf16 on ALL operands,
-// the strided stage kernel with bf16 sources (destination bf16 or fp32).  Elsewhere the caller converts with mt_cast.
+// always supported; 16-bit storage is taken by the 16-bit matrix kernels (p->mma == 1): conv_bf16_kernel with ONE 16-bit type on all
+// operands (fp16: the forward pass, fp16 products; bf16: backward-data, bf16 products), the strided stage kernel with 16-bit sources
+// (destination of the same type, or fp32).  Elsewhere the caller converts with mt_cast.
 extern "C" int mt_conv3d_io_supported(const mt_conv3d_t* p) {
   if (p == nullptr) return 0;
   const int sd = conv_src_dtype(p);
@@ -2452,8 +2501,9 @@ extern "C" int mt_conv3d_io_supported(const mt_conv3d_t* p) {
   if (p->bstats.y != nullptr) return 0;
   const ConvPlan pl = conv_plan(p);
   if (pl.cfg < 0) return 0;
-  if (pl.kind == CONV_BF16) return (sd == MT_BF16 && p->odtype == MT_BF16 && conv_out_pairs_ok(p)) ? 1 : 0;
-  if (pl.kind == CONV_FAST_STRIDED && strided_use_bf16(p)) return (sd == MT_BF16 && (p->odtype == MT_F32 || conv_out_pairs_ok(p))) ? 1 : 0;
+  if (pl.kind == CONV_BF16) return (mt_is16(sd) && p->odtype == sd && conv_out_pairs_ok(p)) ? 1 : 0;
+  if ((pl.kind == CONV_FAST_STRIDED || pl.kind == CONV_TAPSPLIT) && strided_use_bf16(p))
+    return (mt_is16(sd) && (p->odtype == MT_F32 || (p->odtype == sd && conv_out_pairs_ok(p)))) ? 1 : 0;
   return 0;
 }
 
@@ -2526,13 +2576,13 @@ static bool bwdd_strided_use_bf16(const mt_conv3d_t* p) {          // p = FORWAR
   static int use = -1;
   if (use < 0) { const char* e = getenv("MT_STRIDED_BF16"); use = e ? atoi(e) : 1; }
   const mt_src_t& s0 = p->src[0];
-  return use && g_bf16_mode && p->mma == 1 && p->Cout >= 16 && !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & (s0.dtype == MT_BF16 ? 3 : 7)));
+  return use && g_bf16_mode && p->mma == 1 && p->Cout >= 16 && !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & (mt_is16(s0.dtype) ? 3 : 7)));
 }
 extern "C" int mt_conv3d_bwd_data_strided_pack_layout(const mt_conv3d_t* p) { return (p != nullptr && bwdd_strided_use_bf16(p)) ? 3 : 1; }
 extern "C" int mt_conv3d_bwd_data_strided_io_supported(const mt_conv3d_t* p) {
   if (p == nullptr || !mt_dtype_ok(p->src[0].dtype) || !mt_dtype_ok(p->odtype)) return 0;
   if (p->src[0].dtype == MT_F32 && p->odtype == MT_F32) return 1;
-  if (!bwdd_strided_use_bf16(p)) return 0;
+  if (!bwdd_strided_use_bf16(p) || p->src[0].dtype == MT_F16) return 0;        // gradients are fp32 or bf16
   // dX bf16 (channel-pair dwords: even Cin / stride, dword-aligned base) from dY bf16 or fp32
   return (p->odtype == MT_BF16 && !(p->Cin & 1) && !(p->ocs0 & 1) && !(((uintptr_t)p->out0) & 3)) ? 1 : 0;
 }
@@ -2559,9 +2609,9 @@ static int launch_bwdd_strided(const mt_conv3d_t* p, hipStream_t st) {
   MT_REQUIRE(mt_conv3d_bwd_data_strided_io_supported(p), "bwd_data_strided: storage types not taken by the kernel that serves this problem (ask mt_conv3d_bwd_data_strided_io_supported)");
   if (bwdd_strided_use_bf16(p)) {
     if (s0.dtype == MT_BF16 && p->odtype == MT_BF16)
-      hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 4, true, true, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 4, 4>()), st, P);
-    else if (p->odtype == MT_BF16)       // dY of the fp32 level below the storage threshold, dX bf16
-      hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2, true, false, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
+      hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 4, true, MT_BF16, MT_BF16>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 4, 4>()), st, P);
+    else if (p->odtype == MT_BF16)       // dY of an fp32 level, dX bf16
+      hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2, true, MT_F32, MT_BF16>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
     else
       hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 2, true>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 2, 4>()), st, P);
   }
@@ -2672,12 +2722,12 @@ __device__ __forceinline__ void pack_weights_body(const PackParams& P, long firs
     }
     return;
   }
-  if (P.layout == 1 || P.layout == 3) {
+  if (P.layout == 1 || P.layout == 3 || P.layout == 4) {
     // One work item per (lane slot, channel group) of a fragment, looping over the taps: the K taps of a (cin, cout) pair are
     // contiguous in the torch weight (one 108-byte run, read once), and for a fixed tap consecutive work items write consecutive
     // dwords.  (The previous one-item-per-element mapping fetched 837 MB for 117 MB of weights: profiles/r01_pmc_per_kernel.json.)
     //   layout 1: [ntile][chunk][tap][kp/4][lane][4]: lane half h owns channels h*nkp .. h*nkp+nkp-1, float4 = 4 consecutive
-    //   layout 3: [ntile][chunk][tap][lane][4 dwords]: lane half h owns channels 8h .. 8h+7 as bf16 pairs (RNE)
+    //   layout 3: [ntile][chunk][tap][lane][4 dwords]: lane half h owns channels 8h .. 8h+7 as bf16 pairs (RNE); layout 4: as fp16 pairs
     const int K3 = P.KD * P.KH * P.KW;
     const int nq = P.layout == 1 ? P.nkp / 4 : 1;
     const int per_tap = nq * 256;
@@ -2692,7 +2742,7 @@ __device__ __forceinline__ void pack_weights_body(const PackParams& P, long firs
       const ConvChunk cc = P.chunk[ch];
       const int co = nt * 32 + (l & 31);
       const int c0 = P.layout == 1 ? (l >> 5) * P.nkp + q * 4 + e : (l >> 5) * 8 + 2 * e;
-      const bool v0 = c0 < cc.ck && co < P.Cout, v1 = P.layout == 3 && (c0 + 1) < cc.ck && co < P.Cout;
+      const bool v0 = c0 < cc.ck && co < P.Cout, v1 = P.layout >= 3 && (c0 + 1) < cc.ck && co < P.Cout;
       const float* w0 = P.w + (long)(cc.cglob + c0) * P.s_ci + (long)co * P.s_co;
       float* dp = P.dst + ((size_t)(nt * P.nchunks + ch) * K3) * per_tap + (q * 64 + l) * 4 + e;
       int tap = 0;
@@ -2704,7 +2754,8 @@ __device__ __forceinline__ void pack_weights_body(const PackParams& P, long firs
             const long o = zd * P.s_kd + zh * P.s_kh + zw * P.s_kw;
             const float a0 = v0 ? w0[o] : 0.f;
             if (P.layout == 1) dp[(size_t)tap * per_tap] = a0;
-            else ((unsigned*)dp)[(size_t)tap * per_tap] = mt_pack_bf16(a0, v1 ? w0[o + P.s_ci] : 0.f);
+            else if (P.layout == 3) ((unsigned*)dp)[(size_t)tap * per_tap] = mt_pk16<MT_BF16>(a0, v1 ? w0[o + P.s_ci] : 0.f);
+            else ((unsigned*)dp)[(size_t)tap * per_tap] = mt_pk16<MT_F16>(a0, v1 ? w0[o + P.s_ci] : 0.f);
           }
     }
     return;
@@ -2755,15 +2806,15 @@ static int pack_fill(PackParams& P, size_t* packed_floats, const float* w, float
                      const int32_t* tapmap) {
   MT_REQUIRE(ck >= 2 && (ck % 2) == 0, "pack: ck must be even (got %d)", ck);
   MT_REQUIRE(layout == 0 || (layout == 1 && (ck % 8) == 0) || (layout == 2 && ck == 8 && KD == 3 && KH == 3 && KW == 3 && tapmap == nullptr) ||
-             (layout == 3 && ck == 16),
-             "pack: layout 1 needs ck %% 8 == 0; layout 2 (Winograd) needs ck == 8 and a 3x3x3 kernel; layout 3 (bf16) needs ck == 16");
+             ((layout == 3 || layout == 4) && ck == 16),
+             "pack: layout 1 needs ck %% 8 == 0; layout 2 (Winograd) needs ck == 8 and a 3x3x3 kernel; layouts 3 / 4 (bf16 / fp16) need ck == 16");
   std::memset((void*)&P, 0, sizeof(P));
   P.nchunks = mt_build_chunks(C0, C1, ck, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "pack: too many chunks");
   P.ntiles = mt_cdiv(Cout, 32);
   P.nkp = ck / 2;
   if (packed_floats) *packed_floats = layout == 2 ? (size_t)P.ntiles * P.nchunks * 64 * 256
-                                    : layout == 3 ? (size_t)P.ntiles * P.nchunks * KD * KH * KW * 256
+                                    : layout >= 3 ? (size_t)P.ntiles * P.nchunks * KD * KH * KW * 256
                                                   : (size_t)P.ntiles * P.nchunks * KD * KH * KW * P.nkp * 64;
   P.w = w; P.dst = dst; P.Cout = Cout; P.KD = KD; P.KH = KH; P.KW = KW; P.flip = flip; P.layout = layout;
   P.has_tm = tapmap != nullptr;
@@ -3734,6 +3785,7 @@ extern "C" int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_
   const int xdt = conv_src_dtype(p);
   if (xdt < 0 || !mt_dtype_ok(ysrc->dtype)) return 0;
   if (xdt == MT_F32 && ysrc->dtype == MT_F32) return 1;
+  if (ysrc->dtype == MT_F16) return 0;                        // gradients are fp32 or bf16
   static int use_fast_q = -1;
   if (use_fast_q < 0) { const char* e = getenv("MT_BWDW_FAST"); use_fast_q = e ? atoi(e) : 1; }
   if (!use_fast_q || bwdw_is_stem(p, ysrc)) return 0;
@@ -3797,9 +3849,13 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
       case 0: {
         if (bwdw_use_bf16(p)) {
           const dim3 g3(P.nsg, P.ncot, P.nchunks);
-          if (xdt == MT_BF16 && ysrc->dtype == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, true, true>), g3, dim3(256), BWB_LDS_BYTES, st, P);
-          else if (xdt == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, true, false>), g3, dim3(256), BWB_LDS_BYTES, st, P);
-          else if (ysrc->dtype == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, false, true>), g3, dim3(256), BWB_LDS_BYTES, st, P);
+          const bool yb = ysrc->dtype == MT_BF16;
+#define MT_BWB(XS_) do { if (yb) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, XS_, MT_BF16>), g3, dim3(256), BWB_LDS_BYTES, st, P); \
+                         else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, XS_, MT_F32>), g3, dim3(256), BWB_LDS_BYTES, st, P); } while (0)
+          if (xdt == MT_F16) MT_BWB(MT_F16);
+          else if (xdt == MT_BF16) MT_BWB(MT_BF16);
+          else if (yb) MT_BWB(MT_F32);
+#undef MT_BWB
           else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3>), g3, dim3(256), BWB_LDS_BYTES, st, P);
           MT_CHECK_LAUNCH("conv_bwdw_wino_bf16");
           rc = MT_OK;
@@ -3833,9 +3889,13 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
       case 6:
         if (bwdw_use_bf16_133(p)) {
           const dim3 g3(P.nsg, P.ncot, P.nchunks);
-          if (xdt == MT_BF16 && ysrc->dtype == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, true, true>), g3, dim3(256), BWB_LDS_BYTES, st, P);
-          else if (xdt == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, true, false>), g3, dim3(256), BWB_LDS_BYTES, st, P);
-          else if (ysrc->dtype == MT_BF16) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, false, true>), g3, dim3(256), BWB_LDS_BYTES, st, P);
+          const bool yb = ysrc->dtype == MT_BF16;
+#define MT_BWB(XS_) do { if (yb) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, XS_, MT_BF16>), g3, dim3(256), BWB_LDS_BYTES, st, P); \
+                         else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, XS_, MT_F32>), g3, dim3(256), BWB_LDS_BYTES, st, P); } while (0)
+          if (xdt == MT_F16) MT_BWB(MT_F16);
+          else if (xdt == MT_BF16) MT_BWB(MT_BF16);
+          else if (yb) MT_BWB(MT_F32);
+#undef MT_BWB
           else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1>), g3, dim3(256), BWB_LDS_BYTES, st, P);
           MT_CHECK_LAUNCH("conv_bwdw_wino_bf16<1>");
           rc = MT_OK;

@@ -69,10 +69,23 @@ __host__ __device__ static inline int mt_vb(long V) {
 static inline int nb_blocks(long V) { return mt_cdiv(V, (long)mt_vb(V)); }
 
 // ---- storage types ---------------------------------------------------------------------------------
-// Every streaming kernel below is templated on the storage type of its activation / gradient operands (BF = bf16, mt_common.h):
-// all tensor operands of one call share it (the engine chooses the type per resolution level, so the operands of a normalisation
-// or a residual add always agree; mt_cast converts where they do not).  Arithmetic and partial sums are fp32 / fp64 either way.
-#define MT_DT_SWITCH(dtype_, CALL_) do { if ((dtype_) == MT_BF16) { constexpr bool BF = true; CALL_; } else { constexpr bool BF = false; CALL_; } } while (0)
+// Every streaming kernel below takes the storage type of its ACTIVATION operands (AT: y, residual, materialised output) and of its
+// GRADIENT operands (GT: g, copies of g) — mt_common.h.  The dense fast paths are compiled for the combinations the engine produces
+// (fp32 / fp32, fp16 activations with bf16 gradients, bf16 / bf16); anything else takes the strided kernels, which read the type at
+// run time.  Arithmetic and partial sums are fp32 / fp64 either way.
+#define MT_AG_SWITCH(at_, gt_, CALL_, ELSE_)                                                                                  \
+  do {                                                                                                                        \
+    if ((at_) == MT_F32 && (gt_) == MT_F32) { constexpr int AT = MT_F32, GT = MT_F32; CALL_; }                                \
+    else if ((at_) == MT_F16 && (gt_) == MT_BF16) { constexpr int AT = MT_F16, GT = MT_BF16; CALL_; }                         \
+    else if ((at_) == MT_BF16 && (gt_) == MT_BF16) { constexpr int AT = MT_BF16, GT = MT_BF16; CALL_; }                       \
+    else { ELSE_; }                                                                                                           \
+  } while (0)
+#define MT_A_SWITCH(at_, CALL_)                                                                                               \
+  do {                                                                                                                        \
+    if ((at_) == MT_F32) { constexpr int AT = MT_F32; CALL_; }                                                                \
+    else if ((at_) == MT_F16) { constexpr int AT = MT_F16; CALL_; }                                                           \
+    else { constexpr int AT = MT_BF16; CALL_; }                                                                               \
+  } while (0)
 // widest vector (elements) the dense fast paths may use: divides C, keeps every sample base aligned, <= 16 bytes
 static int dense_vec(int C, long per_sample, int dtype, std::initializer_list<const void*> ptrs) {
   const int es = (int)mt_esize(dtype);
@@ -80,7 +93,7 @@ static int dense_vec(int C, long per_sample, int dtype, std::initializer_list<co
   while (v > 1 && (C % v || per_sample % v)) v >>= 1;
   for (const void* q : ptrs)
     if (q != nullptr) { while (v > 1 && (((uintptr_t)q) & (size_t)(v * es - 1))) v >>= 1; }
-  if (dtype == MT_BF16 && v < 2) return 0;           // bf16 vectors are at least one dword
+  if (mt_is16(dtype) && v < 2) return 0;             // 16-bit vectors are at least one dword
   return v;
 }
 
@@ -90,8 +103,7 @@ struct ApplyParams {
   const void* res; int rcs; const float* rscale; const float* rshift; float rslope;
   void* out; int ocs; long V; int C;
 };
-template <bool BF>
-__global__ __launch_bounds__(256) void inorm_apply_kernel(const ApplyParams P) {
+__global__ __launch_bounds__(256) void inorm_apply_kernel(const ApplyParams P, int at) {
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
   const int vb = mt_vb(P.V);
@@ -105,9 +117,9 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const ApplyParams P) {
     const float rsh = (P.res && P.rscale) ? P.rshift[(size_t)n * P.C + c] : 0.f;
     for (long v = v0 + vr; v < v1; v += 8) {
       const size_t e = (size_t)n * P.V + v;
-      float t = fmaf(mt_ld<BF>(P.y, e * P.ycs + c), sc, sh);
-      if (P.res) t += mt_lrelu(fmaf(mt_ld<BF>(P.res, e * P.rcs + c), rsc, rsh), P.rslope);
-      mt_st<BF>(P.out, e * P.ocs + c, mt_lrelu(t, P.slope));
+      float t = fmaf(mt_ld_rt(P.y, e * P.ycs + c, at), sc, sh);
+      if (P.res) t += mt_lrelu(fmaf(mt_ld_rt(P.res, e * P.rcs + c, at), rsc, rsh), P.rslope);
+      mt_st_rt(P.out, e * P.ocs + c, mt_lrelu(t, P.slope), at);
     }
   }
 }
@@ -121,7 +133,7 @@ extern "C" int mt_inorm_lrelu_apply(const float* y, int ycs, const float* scale,
     const int vec = dense_vec(C, V * C, dtype, {y, out, res});
     if (vec > 0) return launch_apply_fast(P, N, dtype, vec, stream);
   }
-  MT_DT_SWITCH(dtype, hipLaunchKernelGGL(inorm_apply_kernel<BF>, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P));
+  hipLaunchKernelGGL(inorm_apply_kernel, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P, dtype);
   MT_CHECK_LAUNCH("inorm_lrelu_apply");
   return MT_OK;
 }
@@ -138,8 +150,8 @@ struct InBwdParams {
   // first-pass partials as the finalize kernel reads them: [N][p1_nblk][p1_cs][2], channel c at column p1_c0 + c (own reduce
   // pass: part1, nvb, C, 0; fused into the producing convolution: its stats_part, its nsb, its Cout, bstats.c0)
   const float* p1; int p1_nblk, p1_cs, p1_c0;
+  int gt, at;    // storage types of g and y
 };
-template <bool BF>
 __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const InBwdParams P) {
   __shared__ float red[8][32][2];
   const int n = blockIdx.y;
@@ -155,9 +167,9 @@ __global__ __launch_bounds__(256) void inorm_bwd_reduce_kernel(const InBwdParams
       const float ga = P.gamma ? P.gamma[c] : 1.f, be = P.beta ? P.beta[c] : 0.f;
       for (long v = v0 + vr; v < v1; v += 8) {
         const size_t e = (size_t)n * P.V + v;
-        const float zh = (mt_ld<BF>(P.y, e * P.ycs + c) - mu) * rs;
+        const float zh = (mt_ld_rt(P.y, e * P.ycs + c, P.at) - mu) * rs;
         const float z = fmaf(zh, ga, be);
-        float dz = mt_ld<BF>(P.g, e * P.gcs + c);
+        float dz = mt_ld_rt(P.g, e * P.gcs + c, P.gt);
         dz = z > 0.f ? dz : dz * P.slope;
         a += dz;
         b += dz * zh;
@@ -207,7 +219,6 @@ __global__ __launch_bounds__(256) void inorm_bwd_finalize_kernel(const InBwdPara
     if (dbeta) dbeta[c] += (float)ta;
   }
 }
-template <bool BF>
 __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const InBwdParams P) {
   __shared__ float red[8][32];
   const int n = blockIdx.y;
@@ -225,13 +236,12 @@ __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const InBwdParams 
       const float k = ga * rs;
       for (long v = v0 + vr; v < v1; v += 8) {
         const size_t e = (size_t)n * P.V + v;
-        const float zh = (mt_ld<BF>(P.y, e * P.ycs + c) - mu) * rs;
+        const float zh = (mt_ld_rt(P.y, e * P.ycs + c, P.at) - mu) * rs;
         const float z = fmaf(zh, ga, be);
-        float dz = mt_ld<BF>(P.g, e * P.gcs + c);
+        float dz = mt_ld_rt(P.g, e * P.gcs + c, P.gt);
         dz = z > 0.f ? dz : dz * P.slope;
-        float dy = k * (dz - m1 - zh * m2);
-        if constexpr (BF) dy = mt_round_bf16(dy);       // the bias gradient sums what the next kernel reads
-        mt_st<BF>(P.g, e * P.gcs + c, dy);
+        const float dy = mt_round_rt(k * (dz - m1 - zh * m2), P.gt);       // the bias gradient sums what the next kernel reads
+        mt_st_rt(P.g, e * P.gcs + c, dy, P.gt);
         sdy += dy;
       }
     }
@@ -274,8 +284,9 @@ struct InBwdFast {
   float* part2;   // [N][nblk][C] or null
 };
 
-template <int VEC, bool APPLY, bool BF>
+template <int VEC, bool APPLY, int AT, int GT>
 __global__ __launch_bounds__(256) void inorm_bwd_fast_kernel(const InBwdFast P) {
+  static_assert(mt_ebytes<AT>() == mt_ebytes<GT>(), "one vector index addresses both tensors");
   __shared__ float red[256 * VEC * 2];
   const int n = blockIdx.y, t = threadIdx.x;
   const bool act = t < P.A;
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_fast_kernel(const InBwdFast P) 
   const long per = ((P.nvec + P.nblk - 1) / P.nblk + P.A - 1) / P.A * P.A;
   const long lo = (long)blockIdx.x * per;
   long hi = lo + per; if (hi > P.nvec) hi = P.nvec;
-  const size_t sbytes = (size_t)n * P.nvec * VEC * (BF ? 2 : 4);
+  const size_t sbytes = (size_t)n * P.nvec * VEC * mt_ebytes<GT>();
   char* gp = (char*)P.g + sbytes;
   const char* yp = (const char*)P.y + sbytes;
   if (act) {
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_fast_kernel(const InBwdFast P) 
 #pragma unroll
       for (int u = 0; u < NF_UNROLL; ++u) {
         const long i = i0 + (long)u * P.A;
-        if (i < hi) { mt_ldv<VEC, BF>(gp, (size_t)i, gv[u]); mt_ldv<VEC, BF>(yp, (size_t)i, yv[u]); }
+        if (i < hi) { mt_ldv<VEC, GT>(gp, (size_t)i, gv[u]); mt_ldv<VEC, AT>(yp, (size_t)i, yv[u]); }
       }
 #pragma unroll
       for (int u = 0; u < NF_UNROLL; ++u) {
@@ -316,8 +327,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_fast_kernel(const InBwdFast P) 
             float dz = gv[u][e];
             dz = z > 0.f ? dz : dz * P.slope;
             if (APPLY) {
-              float dy = ga[e] * rs[e] * (dz - m1[e] - zh * m2[e]);
-              if constexpr (BF) dy = mt_round_bf16(dy);
+              const float dy = mt_round_st<GT>(ga[e] * rs[e] * (dz - m1[e] - zh * m2[e]));
               out[e] = dy;
               a0[e] += dy;
             } else {
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_fast_kernel(const InBwdFast P) 
               a1[e] = fmaf(dz, zh, a1[e]);
             }
           }
-          if (APPLY) mt_stv<VEC, BF>(gp, (size_t)i, out);
+          if (APPLY) mt_stv<VEC, GT>(gp, (size_t)i, out);
         }
       }
     }
@@ -351,27 +361,32 @@ extern "C" size_t mt_inorm_bwd_workspace(int N, long V, int C) {
   const size_t nvb = (size_t)nb_blocks(V);
   return ((size_t)N * nvb * C * 3 + (size_t)N * C * 2) * sizeof(float);
 }
-template <int VEC, bool BF>
+template <int VEC, int AT, int GT>
 static void launch_inorm_bwd_fast(const InBwdFast& F, dim3 grid, bool reduce, hipStream_t st) {
-  if (reduce) hipLaunchKernelGGL((inorm_bwd_fast_kernel<VEC, false, BF>), grid, dim3(256), 0, st, F);
-  else hipLaunchKernelGGL((inorm_bwd_fast_kernel<VEC, true, BF>), grid, dim3(256), 0, st, F);
+  if (reduce) hipLaunchKernelGGL((inorm_bwd_fast_kernel<VEC, false, AT, GT>), grid, dim3(256), 0, st, F);
+  else hipLaunchKernelGGL((inorm_bwd_fast_kernel<VEC, true, AT, GT>), grid, dim3(256), 0, st, F);
 }
-static void inorm_bwd_fast_dispatch(const InBwdFast& F, dim3 grid, int vec, int dtype, bool reduce, hipStream_t st) {
-  if (dtype == MT_BF16) {
-    if (vec == 8) launch_inorm_bwd_fast<8, true>(F, grid, reduce, st);
-    else if (vec == 4) launch_inorm_bwd_fast<4, true>(F, grid, reduce, st);
-    else launch_inorm_bwd_fast<2, true>(F, grid, reduce, st);
+static bool ag_fast(int at, int gt) { return (at == MT_F32 && gt == MT_F32) || (at == MT_F16 && gt == MT_BF16) || (at == MT_BF16 && gt == MT_BF16); }
+static void inorm_bwd_fast_dispatch(const InBwdFast& F, dim3 grid, int vec, int at, int gt, bool reduce, hipStream_t st) {
+  if (at == MT_F32) {
+    if (vec == 4) launch_inorm_bwd_fast<4, MT_F32, MT_F32>(F, grid, reduce, st);
+    else if (vec == 2) launch_inorm_bwd_fast<2, MT_F32, MT_F32>(F, grid, reduce, st);
+    else launch_inorm_bwd_fast<1, MT_F32, MT_F32>(F, grid, reduce, st);
+  } else if (at == MT_F16) {
+    if (vec == 8) launch_inorm_bwd_fast<8, MT_F16, MT_BF16>(F, grid, reduce, st);
+    else if (vec == 4) launch_inorm_bwd_fast<4, MT_F16, MT_BF16>(F, grid, reduce, st);
+    else launch_inorm_bwd_fast<2, MT_F16, MT_BF16>(F, grid, reduce, st);
   } else {
-    if (vec == 4) launch_inorm_bwd_fast<4, false>(F, grid, reduce, st);
-    else if (vec == 2) launch_inorm_bwd_fast<2, false>(F, grid, reduce, st);
-    else launch_inorm_bwd_fast<1, false>(F, grid, reduce, st);
+    if (vec == 8) launch_inorm_bwd_fast<8, MT_BF16, MT_BF16>(F, grid, reduce, st);
+    else if (vec == 4) launch_inorm_bwd_fast<4, MT_BF16, MT_BF16>(F, grid, reduce, st);
+    else launch_inorm_bwd_fast<2, MT_BF16, MT_BF16>(F, grid, reduce, st);
   }
 }
 extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, float slope, int N, long V, int C,
                                   float* dgamma, float* dbeta, float* dbias, const float* part, int part_nblk, int part_cs, int part_c0,
-                                  void* ws, size_t ws_bytes, int dtype, mt_stream_t stream) {
-  MT_REQUIRE(g && y && mean && rstd && N > 0 && V > 0 && C > 0 && mt_dtype_ok(dtype), "inorm_lrelu_bwd: bad args");
+                                  void* ws, size_t ws_bytes, int gdtype, int ydtype, mt_stream_t stream) {
+  MT_REQUIRE(g && y && mean && rstd && N > 0 && V > 0 && C > 0 && mt_dtype_ok(gdtype) && mt_dtype_ok(ydtype), "inorm_lrelu_bwd: bad args");
   MT_REQUIRE(part == nullptr || (part_nblk > 0 && part_cs >= part_c0 + C && part_c0 >= 0), "inorm_lrelu_bwd: bad external partials");
   if (ws == nullptr || ws_bytes < mt_inorm_bwd_workspace(N, V, C)) { mt_set_error("inorm_lrelu_bwd: workspace too small"); return MT_EWORKSPACE; }
   InBwdParams P;
@@ -382,9 +397,10 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
   P.m = w; w += (size_t)N * C * 2;
   P.part2 = dbias ? w : nullptr;
   P.p1 = part ? part : P.part1; P.p1_nblk = part ? part_nblk : P.nvb; P.p1_cs = part ? part_cs : C; P.p1_c0 = part ? part_c0 : 0;
+  P.gt = gdtype; P.at = ydtype;
   hipStream_t st = (hipStream_t)stream;
   // contiguous tensors take the vectorised lane-constant-channel path
-  const int vec = (gcs == C && ycs == C) ? dense_vec(C, V * C, dtype, {g, y}) : 0;
+  const int vec = (gcs == C && ycs == C && ag_fast(ydtype, gdtype)) ? dense_vec(C, V * C, gdtype, {g, y}) : 0;
   const bool contig = vec > 0 && (C / vec <= 256);
   if (contig) {
     InBwdFast F;
@@ -392,13 +408,13 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
     F.nvec = (long)V * C / vec; F.C = C; F.G = C / vec; F.A = (256 / F.G) * F.G; F.nblk = P.nvb;
     F.part1 = P.part1; F.m = P.m; F.part2 = P.part2;
     dim3 grid(P.nvb, N);
-    if (part == nullptr) inorm_bwd_fast_dispatch(F, grid, vec, dtype, true, st);   // (the first pass was not fused into the kernel that produced g)
+    if (part == nullptr) inorm_bwd_fast_dispatch(F, grid, vec, ydtype, gdtype, true, st);   // (the first pass was not fused into the kernel that produced g)
     hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, P, N, dgamma, dbeta);
-    inorm_bwd_fast_dispatch(F, grid, vec, dtype, false, st);
+    inorm_bwd_fast_dispatch(F, grid, vec, ydtype, gdtype, false, st);
   } else {
-    if (part == nullptr) MT_DT_SWITCH(dtype, hipLaunchKernelGGL(inorm_bwd_reduce_kernel<BF>, dim3(P.nvb, N), dim3(256), 0, st, P));
+    if (part == nullptr) hipLaunchKernelGGL(inorm_bwd_reduce_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
     hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, P, N, dgamma, dbeta);
-    MT_DT_SWITCH(dtype, hipLaunchKernelGGL(inorm_bwd_apply_kernel<BF>, dim3(P.nvb, N), dim3(256), 0, st, P));
+    hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3(P.nvb, N), dim3(256), 0, st, P);
   }
   if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(64), 0, st, (const float*)P.part2, (long)N * P.nvb, C, dbias, 0);
   MT_CHECK_LAUNCH("inorm_lrelu_bwd");
@@ -410,8 +426,8 @@ struct LBwdParams {
   void* g; int gcs; const void* y; int ycs; const float* scale; const float* shift; float slope;
   const void* y2; int y2cs; const float* scale2; const float* shift2; float slope2;
   void* gcopy; int gcopycs; long V; int C;
+  int gt, at;   // storage types of (g, gcopy) and of (y, y2)
 };
-template <bool BF>
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const LBwdParams P) {
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
@@ -426,12 +442,12 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const LBwdParams P) {
     const float sh2 = (P.y2 && P.scale2) ? P.shift2[(size_t)n * P.C + c] : 0.f;
     for (long v = v0 + vr; v < v1; v += 8) {
       const size_t e = (size_t)n * P.V + v;
-      float t = fmaf(mt_ld<BF>(P.y, e * P.ycs + c), sc, sh);
-      if (P.y2) t += mt_lrelu(fmaf(mt_ld<BF>(P.y2, e * P.y2cs + c), sc2, sh2), P.slope2);
-      float gv = mt_ld<BF>(P.g, e * P.gcs + c);
+      float t = fmaf(mt_ld_rt(P.y, e * P.ycs + c, P.at), sc, sh);
+      if (P.y2) t += mt_lrelu(fmaf(mt_ld_rt(P.y2, e * P.y2cs + c, P.at), sc2, sh2), P.slope2);
+      float gv = mt_ld_rt(P.g, e * P.gcs + c, P.gt);
       gv = t > 0.f ? gv : gv * P.slope;
-      mt_st<BF>(P.g, e * P.gcs + c, gv);
-      if (P.gcopy) mt_st<BF>(P.gcopy, e * P.gcopycs + c, gv);
+      mt_st_rt(P.g, e * P.gcs + c, gv, P.gt);
+      if (P.gcopy) mt_st_rt(P.gcopy, e * P.gcopycs + c, gv, P.gt);
     }
   }
 }
@@ -439,10 +455,10 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const LBwdParams P) {
 // ---- dense fast paths of the two element-wise kernels above (every operand contiguous, cs == C, C % VEC == 0): one thread
 // moves VEC consecutive channels of a voxel per iteration with 16/8-byte accesses; the per-(n, c) scale/shift come from a
 // small table read through the cache.  HBM-bound: apply = 2-3 streams, lrelu_bwd = 3-5 streams.
-template <int VEC, bool BF>
+template <int VEC, int AT>
 __global__ __launch_bounds__(256) void inorm_apply_fast_kernel(const ApplyParams P, long per_sample) {
   const int n = blockIdx.y;
-  const size_t sb = (size_t)n * per_sample * (BF ? 2 : 4);         // bytes
+  const size_t sb = (size_t)n * per_sample * mt_ebytes<AT>();         // bytes
   const char* yp = (const char*)P.y + sb;
   const char* rp = P.res ? (const char*)P.res + sb : nullptr;
   char* op = (char*)P.out + sb;
@@ -450,8 +466,8 @@ __global__ __launch_bounds__(256) void inorm_apply_fast_kernel(const ApplyParams
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC; i < per_sample; i += (long)gridDim.x * 256 * VEC) {
     const int c = (int)(i % P.C);
     float y[VEC], r[VEC], o[VEC];
-    mt_ldv<VEC, BF>(yp, (size_t)(i / VEC), y);
-    if (has_res) mt_ldv<VEC, BF>(rp, (size_t)(i / VEC), r);
+    mt_ldv<VEC, AT>(yp, (size_t)(i / VEC), y);
+    if (has_res) mt_ldv<VEC, AT>(rp, (size_t)(i / VEC), r);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float sc = P.scale ? P.scale[(size_t)n * P.C + c + e] : 1.f, sh = P.scale ? P.shift[(size_t)n * P.C + c + e] : 0.f;
@@ -462,14 +478,15 @@ __global__ __launch_bounds__(256) void inorm_apply_fast_kernel(const ApplyParams
       }
       o[e] = mt_lrelu(t, P.slope);
     }
-    mt_stv<VEC, BF>(op, (size_t)(i / VEC), o);
+    mt_stv<VEC, AT>(op, (size_t)(i / VEC), o);
   }
 }
 
-template <int VEC, bool BF>
+template <int VEC, int AT, int GT>
 __global__ __launch_bounds__(256) void lrelu_bwd_fast_kernel(const LBwdParams P, long per_sample) {
+  static_assert(mt_ebytes<AT>() == mt_ebytes<GT>(), "one vector index addresses all tensors");
   const int n = blockIdx.y;
-  const size_t sb = (size_t)n * per_sample * (BF ? 2 : 4);
+  const size_t sb = (size_t)n * per_sample * mt_ebytes<GT>();
   const char* yp = (const char*)P.y + sb;
   const char* y2p = P.y2 ? (const char*)P.y2 + sb : nullptr;
   char* gp = (char*)P.g + sb;
@@ -478,9 +495,9 @@ __global__ __launch_bounds__(256) void lrelu_bwd_fast_kernel(const LBwdParams P,
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC; i < per_sample; i += (long)gridDim.x * 256 * VEC) {
     const int c = (int)(i % P.C);
     float y[VEC], y2[VEC], g[VEC];
-    mt_ldv<VEC, BF>(yp, (size_t)(i / VEC), y);
-    mt_ldv<VEC, BF>(gp, (size_t)(i / VEC), g);
-    if (has2) mt_ldv<VEC, BF>(y2p, (size_t)(i / VEC), y2);
+    mt_ldv<VEC, AT>(yp, (size_t)(i / VEC), y);
+    mt_ldv<VEC, GT>(gp, (size_t)(i / VEC), g);
+    if (has2) mt_ldv<VEC, AT>(y2p, (size_t)(i / VEC), y2);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const float sc = P.scale ? P.scale[(size_t)n * P.C + c + e] : 1.f, sh = P.scale ? P.shift[(size_t)n * P.C + c + e] : 0.f;
@@ -491,49 +508,61 @@ __global__ __launch_bounds__(256) void lrelu_bwd_fast_kernel(const LBwdParams P,
       }
       g[e] = t > 0.f ? g[e] : g[e] * P.slope;
     }
-    mt_stv<VEC, BF>(gp, (size_t)(i / VEC), g);
-    if (cp) mt_stv<VEC, BF>(cp, (size_t)(i / VEC), g);
+    mt_stv<VEC, GT>(gp, (size_t)(i / VEC), g);
+    if (cp) mt_stv<VEC, GT>(cp, (size_t)(i / VEC), g);
   }
 }
-
-// kernels of the dense element-wise paths, by (storage type, vector width)
-#define MT_DENSE_DISPATCH(KERNEL_, dtype_, vec_, ...)                                                            \
-  do {                                                                                                           \
-    if ((dtype_) == MT_BF16) {                                                                                   \
-      if ((vec_) == 8) hipLaunchKernelGGL((KERNEL_<8, true>), __VA_ARGS__);                                      \
-      else if ((vec_) == 4) hipLaunchKernelGGL((KERNEL_<4, true>), __VA_ARGS__);                                 \
-      else hipLaunchKernelGGL((KERNEL_<2, true>), __VA_ARGS__);                                                  \
-    } else {                                                                                                     \
-      if ((vec_) == 4) hipLaunchKernelGGL((KERNEL_<4, false>), __VA_ARGS__);                                     \
-      else if ((vec_) == 2) hipLaunchKernelGGL((KERNEL_<2, false>), __VA_ARGS__);                                \
-      else hipLaunchKernelGGL((KERNEL_<1, false>), __VA_ARGS__);                                                 \
-    }                                                                                                            \
-  } while (0)
 
 static int launch_apply_fast(const ApplyParams& P, int N, int dtype, int vec, mt_stream_t stream) {
   const long per = P.V * P.C;
   int blocks = (int)((per / vec + 255) / 256); if (blocks > 8192) blocks = 8192;
-  MT_DENSE_DISPATCH(inorm_apply_fast_kernel, dtype, vec, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
+  const dim3 grid(blocks, N);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MT_F32) {
+    if (vec == 4) hipLaunchKernelGGL((inorm_apply_fast_kernel<4, MT_F32>), grid, dim3(256), 0, st, P, per);
+    else if (vec == 2) hipLaunchKernelGGL((inorm_apply_fast_kernel<2, MT_F32>), grid, dim3(256), 0, st, P, per);
+    else hipLaunchKernelGGL((inorm_apply_fast_kernel<1, MT_F32>), grid, dim3(256), 0, st, P, per);
+  } else if (dtype == MT_F16) {
+    if (vec == 8) hipLaunchKernelGGL((inorm_apply_fast_kernel<8, MT_F16>), grid, dim3(256), 0, st, P, per);
+    else if (vec == 4) hipLaunchKernelGGL((inorm_apply_fast_kernel<4, MT_F16>), grid, dim3(256), 0, st, P, per);
+    else hipLaunchKernelGGL((inorm_apply_fast_kernel<2, MT_F16>), grid, dim3(256), 0, st, P, per);
+  } else {
+    if (vec == 8) hipLaunchKernelGGL((inorm_apply_fast_kernel<8, MT_BF16>), grid, dim3(256), 0, st, P, per);
+    else if (vec == 4) hipLaunchKernelGGL((inorm_apply_fast_kernel<4, MT_BF16>), grid, dim3(256), 0, st, P, per);
+    else hipLaunchKernelGGL((inorm_apply_fast_kernel<2, MT_BF16>), grid, dim3(256), 0, st, P, per);
+  }
   MT_CHECK_LAUNCH("inorm_apply_fast");
   return MT_OK;
+}
+template <int AT, int GT>
+static void launch_lrelu_bwd_fast(const LBwdParams& P, dim3 grid, int vec, long per, hipStream_t st) {
+  if constexpr (AT == MT_F32) {
+    if (vec == 4) hipLaunchKernelGGL((lrelu_bwd_fast_kernel<4, AT, GT>), grid, dim3(256), 0, st, P, per);
+    else if (vec == 2) hipLaunchKernelGGL((lrelu_bwd_fast_kernel<2, AT, GT>), grid, dim3(256), 0, st, P, per);
+    else hipLaunchKernelGGL((lrelu_bwd_fast_kernel<1, AT, GT>), grid, dim3(256), 0, st, P, per);
+  } else {
+    if (vec == 8) hipLaunchKernelGGL((lrelu_bwd_fast_kernel<8, AT, GT>), grid, dim3(256), 0, st, P, per);
+    else if (vec == 4) hipLaunchKernelGGL((lrelu_bwd_fast_kernel<4, AT, GT>), grid, dim3(256), 0, st, P, per);
+    else hipLaunchKernelGGL((lrelu_bwd_fast_kernel<2, AT, GT>), grid, dim3(256), 0, st, P, per);
+  }
 }
 
 extern "C" int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const float* scale, const float* shift, float slope,
                             const float* y2, int y2cs, const float* scale2, const float* shift2, float slope2,
-                            float* gcopy, int gcopycs, int N, long V, int C, int dtype, mt_stream_t stream) {
-  MT_REQUIRE(g && y && N > 0 && V > 0 && C > 0 && mt_dtype_ok(dtype), "lrelu_bwd: bad args");
-  LBwdParams P{g, gcs, y, ycs, scale, shift, slope, y2, y2cs, scale2, shift2, slope2, gcopy, gcopycs, V, C};
-  if (gcs == C && ycs == C && (y2 == nullptr || y2cs == C) && (gcopy == nullptr || gcopycs == C) && V * C < (1L << 40)) {
+                            float* gcopy, int gcopycs, int N, long V, int C, int gdtype, int ydtype, mt_stream_t stream) {
+  MT_REQUIRE(g && y && N > 0 && V > 0 && C > 0 && mt_dtype_ok(gdtype) && mt_dtype_ok(ydtype), "lrelu_bwd: bad args");
+  LBwdParams P{g, gcs, y, ycs, scale, shift, slope, y2, y2cs, scale2, shift2, slope2, gcopy, gcopycs, V, C, gdtype, ydtype};
+  if (gcs == C && ycs == C && (y2 == nullptr || y2cs == C) && (gcopy == nullptr || gcopycs == C) && V * C < (1L << 40) && ag_fast(ydtype, gdtype)) {
     const long per = V * C;
-    const int vec = dense_vec(C, per, dtype, {g, y, y2, gcopy});
+    const int vec = dense_vec(C, per, gdtype, {g, y, y2, gcopy});
     if (vec > 0) {
       int blocks = (int)((per / vec + 255) / 256); if (blocks > 8192) blocks = 8192;
-      MT_DENSE_DISPATCH(lrelu_bwd_fast_kernel, dtype, vec, dim3(blocks, N), dim3(256), 0, (hipStream_t)stream, P, per);
+      MT_AG_SWITCH(ydtype, gdtype, (launch_lrelu_bwd_fast<AT, GT>(P, dim3(blocks, N), vec, per, (hipStream_t)stream)), (void)0);
       MT_CHECK_LAUNCH("lrelu_bwd_fast");
       return MT_OK;
     }
   }
-  MT_DT_SWITCH(dtype, hipLaunchKernelGGL(lrelu_bwd_kernel<BF>, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P));
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P);
   MT_CHECK_LAUNCH("lrelu_bwd");
   return MT_OK;
 }
@@ -551,8 +580,9 @@ struct LBwdStats {
   long nvec; int C, G, A, nblk;
   float* part;
 };
-template <int VEC, bool BF>
+template <int VEC, int AT, int GT>
 __global__ __launch_bounds__(256) void lrelu_bwd_stats_kernel(const LBwdStats P) {
+  static_assert(mt_ebytes<AT>() == mt_ebytes<GT>(), "one vector index addresses all tensors");
   __shared__ float red[256 * VEC * 2];
   const int n = blockIdx.y, t = threadIdx.x;
   const bool act = t < P.A;
@@ -570,7 +600,7 @@ __global__ __launch_bounds__(256) void lrelu_bwd_stats_kernel(const LBwdStats P)
   const long per = ((P.nvec + P.nblk - 1) / P.nblk + P.A - 1) / P.A * P.A;
   const long lo = (long)blockIdx.x * per;
   long hi = lo + per; if (hi > P.nvec) hi = P.nvec;
-  const size_t sb = (size_t)n * P.nvec * VEC * (BF ? 2 : 4);
+  const size_t sb = (size_t)n * P.nvec * VEC * mt_ebytes<GT>();
   char* gp = (char*)P.g + sb;
   char* cp = P.gcopy ? (char*)P.gcopy + sb : nullptr;
   const char* yp = (const char*)P.y + sb;
@@ -581,7 +611,7 @@ __global__ __launch_bounds__(256) void lrelu_bwd_stats_kernel(const LBwdStats P)
 #pragma unroll
       for (int u = 0; u < NF_UNROLL; ++u) {
         const long i = i0 + (long)u * P.A;
-        if (i < hi) { mt_ldv<VEC, BF>(gp, (size_t)i, gv[u]); mt_ldv<VEC, BF>(yp, (size_t)i, yv[u]); if (has2) mt_ldv<VEC, BF>(y2p, (size_t)i, y2v[u]); }
+        if (i < hi) { mt_ldv<VEC, GT>(gp, (size_t)i, gv[u]); mt_ldv<VEC, AT>(yp, (size_t)i, yv[u]); if (has2) mt_ldv<VEC, AT>(y2p, (size_t)i, y2v[u]); }
       }
 #pragma unroll
       for (int u = 0; u < NF_UNROLL; ++u) {
@@ -595,14 +625,14 @@ __global__ __launch_bounds__(256) void lrelu_bwd_stats_kernel(const LBwdStats P)
             if (has2) tt += mt_lrelu(fmaf(y2v[u][e], sc2[e], sh2[e]), P.slope2);
             float gg = gv[u][e];
             gg = tt > 0.f ? gg : gg * P.slope;
-            if constexpr (BF) gg = mt_round_bf16(gg);
+            gg = mt_round_st<GT>(gg);
             out[e] = gg;
             const float zh = (yy - mu[e]) * rs[e];
             a0[e] += gg;
             a1[e] = fmaf(gg, zh, a1[e]);
           }
-          mt_stv<VEC, BF>(gp, (size_t)i, out);
-          if (cp) mt_stv<VEC, BF>(cp, (size_t)i, out);
+          mt_stv<VEC, GT>(gp, (size_t)i, out);
+          if (cp) mt_stv<VEC, GT>(cp, (size_t)i, out);
         }
       }
     }
@@ -627,8 +657,8 @@ extern "C" int mt_lrelu_bwd_stats_blocks(long V, int C) {
 }
 extern "C" int mt_lrelu_bwd_stats(float* g, const float* y, const float* scale, const float* shift, float slope,
                                   const float* y2, const float* scale2, const float* shift2, float slope2, float* gcopy,
-                                  const float* mean, const float* rstd, float* part, int N, long V, int C, int dtype, mt_stream_t stream) {
-  MT_REQUIRE(g && y && mean && rstd && part && N > 0 && mt_dtype_ok(dtype), "lrelu_bwd_stats: bad args");
+                                  const float* mean, const float* rstd, float* part, int N, long V, int C, int gdtype, int ydtype, mt_stream_t stream) {
+  MT_REQUIRE(g && y && mean && rstd && part && N > 0 && ag_fast(ydtype, gdtype), "lrelu_bwd_stats: storage types (g %d, y %d) not taken (fp32/fp32, bf16/fp16, bf16/bf16)", gdtype, ydtype);
   const int nblk = mt_lrelu_bwd_stats_blocks(V, C);
   MT_REQUIRE(nblk > 0, "lrelu_bwd_stats: unsupported shape (V=%ld, C=%d): ask mt_lrelu_bwd_stats_blocks", V, C);
   MT_REQUIRE(((((uintptr_t)g) | ((uintptr_t)y) | ((uintptr_t)y2) | ((uintptr_t)gcopy)) & 15) == 0, "lrelu_bwd_stats: tensors must be 16-byte aligned");
@@ -636,15 +666,13 @@ extern "C" int mt_lrelu_bwd_stats(float* g, const float* y, const float* scale, 
   P.g = g; P.y = y; P.y2 = y2; P.gcopy = gcopy; P.scale = scale; P.shift = shift; P.slope = slope;
   P.scale2 = scale2; P.shift2 = shift2; P.slope2 = slope2; P.mean = mean; P.rstd = rstd;
   P.nvec = (long)V * C / 4; P.C = C; P.G = C / 4; P.A = (256 / P.G) * P.G; P.nblk = nblk; P.part = part;
-  if (dtype == MT_BF16) hipLaunchKernelGGL((lrelu_bwd_stats_kernel<4, true>), dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, P);
-  else hipLaunchKernelGGL((lrelu_bwd_stats_kernel<4, false>), dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, P);
+  MT_AG_SWITCH(ydtype, gdtype, hipLaunchKernelGGL((lrelu_bwd_stats_kernel<4, AT, GT>), dim3(nblk, N), dim3(256), 0, (hipStream_t)stream, P), (void)0);
   MT_CHECK_LAUNCH("lrelu_bwd_stats");
   return MT_OK;
 }
 
 // ---- per-channel sum -------------------------------------------------------------------------------
-template <bool BF>
-__global__ __launch_bounds__(256) void channel_sum_kernel(const void* x, int xcs, long V, int C, int nvb, float* part) {
+__global__ __launch_bounds__(256) void channel_sum_kernel(const void* x, int xcs, long V, int C, int nvb, float* part, int st) {
   __shared__ float red[8][32];
   const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
@@ -655,7 +683,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const void* x, int xcs
     const int c = cb + cl;
     float a = 0.f;
     if (c < C)
-      for (long v = v0 + vr; v < v1; v += 8) a += mt_ld<BF>(x, ((size_t)n * V + v) * xcs + c);
+      for (long v = v0 + vr; v < v1; v += 8) a += mt_ld_rt(x, ((size_t)n * V + v) * xcs + c, st);
     red[vr][cl] = a;
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -674,7 +702,7 @@ extern "C" int mt_channel_sum(const float* x, int xcs, int N, long V, int C, flo
   const int nvb = nb_blocks(V);
   if (ws == nullptr || ws_bytes < (size_t)N * nvb * C * sizeof(float)) { mt_set_error("channel_sum: workspace too small"); return MT_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
-  MT_DT_SWITCH(dtype, hipLaunchKernelGGL(channel_sum_kernel<BF>, dim3(nvb, N), dim3(256), 0, st, (const void*)x, xcs, V, C, nvb, (float*)ws));
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(nvb, N), dim3(256), 0, st, (const void*)x, xcs, V, C, nvb, (float*)ws, dtype);
   hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(64), 0, st, (const float*)ws, (long)N * nvb, C, out, accumulate);
   MT_CHECK_LAUNCH("channel_sum");
   return MT_OK;
@@ -685,7 +713,7 @@ extern "C" int mt_channel_sum(const float* x, int xcs, int N, long V, int C, flo
 // stride.  The boundary op of the mixed-precision mode: a kernel that does not take a tensor's storage type reads / writes an
 // fp32 (or bf16) copy instead (see the *_io_supported queries); accumulate adds in fp32 and rounds once.
 struct CastParams { const void* src; void* dst; long rows; int C, scs, dcs, accumulate; };
-template <bool SB, bool DB, int VEC>
+template <int SB, int DB, int VEC>
 __global__ __launch_bounds__(256) void cast_dense_kernel(const CastParams P, long nvec) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
     float v[VEC];
@@ -699,14 +727,13 @@ __global__ __launch_bounds__(256) void cast_dense_kernel(const CastParams P, lon
     mt_stv<VEC, DB>(P.dst, (size_t)i, v);
   }
 }
-template <bool SB, bool DB>
-__global__ __launch_bounds__(256) void cast_strided_kernel(const CastParams P) {
+__global__ __launch_bounds__(256) void cast_strided_kernel(const CastParams P, int sb, int db) {
   const int cl = threadIdx.x & 31, vr = threadIdx.x >> 5;
   for (long r = (long)blockIdx.x * 8 + vr; r < P.rows; r += (long)gridDim.x * 8)
     for (int c = cl; c < P.C; c += 32) {
-      float v = mt_ld<SB>(P.src, (size_t)r * P.scs + c);
-      if (P.accumulate) v += mt_ld<DB>(P.dst, (size_t)r * P.dcs + c);
-      mt_st<DB>(P.dst, (size_t)r * P.dcs + c, v);
+      float v = mt_ld_rt(P.src, (size_t)r * P.scs + c, sb);
+      if (P.accumulate) v += mt_ld_rt(P.dst, (size_t)r * P.dcs + c, db);
+      mt_st_rt(P.dst, (size_t)r * P.dcs + c, v, db);
     }
 }
 extern "C" int mt_cast(const void* src, int scs, int sdtype, void* dst, int dcs, int ddtype, long rows, int C, int accumulate,
@@ -719,16 +746,15 @@ extern "C" int mt_cast(const void* src, int scs, int sdtype, void* dst, int dcs,
   if (dense) {
     const long nvec = n / 4;
     int blocks = (int)((nvec + 255) / 256); if (blocks > 16384) blocks = 16384;
-    if (sdtype == MT_BF16 && ddtype == MT_BF16) hipLaunchKernelGGL((cast_dense_kernel<true, true, 4>), dim3(blocks), dim3(256), 0, st, P, nvec);
-    else if (sdtype == MT_BF16) hipLaunchKernelGGL((cast_dense_kernel<true, false, 4>), dim3(blocks), dim3(256), 0, st, P, nvec);
-    else if (ddtype == MT_BF16) hipLaunchKernelGGL((cast_dense_kernel<false, true, 4>), dim3(blocks), dim3(256), 0, st, P, nvec);
-    else hipLaunchKernelGGL((cast_dense_kernel<false, false, 4>), dim3(blocks), dim3(256), 0, st, P, nvec);
+    const dim3 grid(blocks);
+#define MT_CAST_CASE(S_, D_) if (sdtype == S_ && ddtype == D_) hipLaunchKernelGGL((cast_dense_kernel<S_, D_, 4>), grid, dim3(256), 0, st, P, nvec);
+    MT_CAST_CASE(MT_F32, MT_F32) else MT_CAST_CASE(MT_F32, MT_BF16) else MT_CAST_CASE(MT_F32, MT_F16)
+    else MT_CAST_CASE(MT_BF16, MT_F32) else MT_CAST_CASE(MT_BF16, MT_BF16) else MT_CAST_CASE(MT_BF16, MT_F16)
+    else MT_CAST_CASE(MT_F16, MT_F32) else MT_CAST_CASE(MT_F16, MT_BF16) else MT_CAST_CASE(MT_F16, MT_F16)
+#undef MT_CAST_CASE
   } else {
     int blocks = (int)((rows + 7) / 8); if (blocks > 16384) blocks = 16384;
-    if (sdtype == MT_BF16 && ddtype == MT_BF16) hipLaunchKernelGGL((cast_strided_kernel<true, true>), dim3(blocks), dim3(256), 0, st, P);
-    else if (sdtype == MT_BF16) hipLaunchKernelGGL((cast_strided_kernel<true, false>), dim3(blocks), dim3(256), 0, st, P);
-    else if (ddtype == MT_BF16) hipLaunchKernelGGL((cast_strided_kernel<false, true>), dim3(blocks), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((cast_strided_kernel<false, false>), dim3(blocks), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(cast_strided_kernel, dim3(blocks), dim3(256), 0, st, P, sdtype, ddtype);
   }
   MT_CHECK_LAUNCH("cast");
   return MT_OK;

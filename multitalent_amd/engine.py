@@ -169,7 +169,9 @@ class ConvNormOp(_Op):
     @staticmethod
     def _grad_like(eng, val):
         """a tensor with the shape and storage type of val's gradient (geometry / kernel-choice queries before the buffers exist)"""
-        return val.act.buf if val.grad is None else val.grad      # (a gradient has its activation's shape and storage type)
+        if val.grad is not None:
+            return val.grad
+        return eng.buffer(val.name + '.grad', tuple(val.act.buf.shape[:4]) + (val.C,), eng.grad_dtype(val.spatial))
 
     def _use_strided_bwd(self, eng):
         if self.stride == (1, 1, 1) or len(self.srcs) != 1 or self.pointwise:
@@ -360,8 +362,8 @@ class TConvOp(_Op):
         return ConvGeom(self.out.spatial, self.k, self.k, (0, 0, 0))   # dX = conv(k = stride = pool kernel, pad 0) of dOut
 
     def _bwd_io(self, eng):
-        g = self.out.grad if self.out.grad is not None else self.out.act.buf
-        dx = self.src.grad if self.src.grad is not None else self.src.act.buf
+        g = ConvNormOp._grad_like(eng, self.out)
+        dx = ConvNormOp._grad_like(eng, self.src)
 
         def build(ins, outs):
             p = ops.fill_conv(ins, self._geom(), self.tu.in_channels, out0=outs[0])
@@ -429,20 +431,20 @@ class ResAddOp(_Op):
         # producing (mt_lrelu_bwd_stats): the norm backward's own reduction over (g', y) disappears.
         prod = eng.producer.get(id(self.main)) if eng.fuse_norm_bwd in (1, 3) else None
         nblk = _lib.load().mt_lrelu_bwd_stats_blocks(m.V, m.C)
-        dt = ops._same_dt(Act(g), m, r, Act(gm))          # one resolution level: one storage type
+        gdt, ydt = ops._same_dt(Act(g), Act(gm)), ops._same_dt(m, r)      # one resolution level: one gradient type, one activation type
         if (prod is not None and isinstance(prod, ConvNormOp) and prod.norm is not None and m.mean is not None and nblk > 0
                 and g.shape[4] == m.C and gm.shape[4] == m.C and m.cs == m.C and r.cs == m.C):
             part = eng.buffer(self.name + '.bwdpart', (m.N, nblk, m.C, 2))
             _lib.check(_lib.load().mt_lrelu_bwd_stats(
                 C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()), ops._ptr(m.scale), ops._ptr(m.shift), self.slope,
                 C.c_void_p(r.data_ptr()), ops._ptr(r.scale), ops._ptr(r.shift), r.slope, C.c_void_p(gm.data_ptr()),
-                ops._ptr(m.mean), ops._ptr(m.rstd), ops._ptr(part), m.N, m.V, m.C, dt, ops._stream()), 'lrelu_bwd_stats')
+                ops._ptr(m.mean), ops._ptr(m.rstd), ops._ptr(part), m.N, m.V, m.C, gdt, ydt, ops._stream()), 'lrelu_bwd_stats')
             prod.bwd_part = (part, 0)
         else:
             _lib.check(_lib.load().mt_lrelu_bwd(
                 C.c_void_p(g.data_ptr()), g.shape[4], C.c_void_p(m.data_ptr()), m.cs, ops._ptr(m.scale), ops._ptr(m.shift), self.slope,
                 C.c_void_p(r.data_ptr()), r.cs, ops._ptr(r.scale), ops._ptr(r.shift), r.slope,
-                C.c_void_p(gm.data_ptr()), gm.shape[4], m.N, m.V, m.C, dt, ops._stream()), 'lrelu_bwd')
+                C.c_void_p(gm.data_ptr()), gm.shape[4], m.N, m.V, m.C, gdt, ydt, ops._stream()), 'lrelu_bwd')
         self.main.grad_init = True
         # residual branch: g itself (already masked) is added to / becomes the residual's gradient
         if self.res.grad is not None:
@@ -558,12 +560,16 @@ class Engine:
         self.grad_ready_hook = None         # callable(lo, hi) on flat_grad element ranges, in completion order
         self.dummy = None
         self.mma = 0                        # matrix input type of the convolutions: 0 fp32, 1 bf16 (mixed precision)
-        # mixed precision: activations and gradients of the levels with at least bf16_min_voxels voxels per sample are STORED as bf16
-        # (MT_BF16_STORAGE=0: fp32 storage, bf16 matrix inputs only = the mode of rounds 1-3); smaller levels (<= 6x12x12 in the residual
-        # encoder) are latency-bound, gain nothing from bf16 and carry the fewest voxels to average its rounding over: they stay fp32
-        # in storage AND arithmetic
+        # mixed precision: ACTIVATIONS are stored as fp16 and the forward convolutions multiply fp16 operands (the reference's autocast
+        # arithmetic: 11 significand bits keep the LeakyReLU decisions of the forward pass — which is what the gradient's direction
+        # hangs on, DESIGN.md 3.3 — four times closer to the exact ones than bf16 does); GRADIENTS are stored as bf16 and the backward
+        # convolutions multiply bf16 operands (fp32's exponent range: no loss scaling).  MT_BF16_STORAGE=0: fp32 storage with bf16
+        # matrix inputs only (the mode of rounds 1-3); MT_ACT_STORAGE=bf16: bf16 activations (measured: gradient cosine 0.86 instead of
+        # 0.98 on the full-size residual encoder).  bf16_min_voxels > 0 keeps the levels with fewer voxels per sample in fp32, storage
+        # and arithmetic (measured: no gain in accuracy, +2.5 ms per step: default 0).
         self.storage_bf16 = os.environ.get('MT_BF16_STORAGE', '1') != '0'
-        self.bf16_min_voxels = int(os.environ.get('MT_BF16_MIN_VOXELS', '2048'))
+        self.act_storage = {'fp16': torch.float16, 'bf16': torch.bfloat16}[os.environ.get('MT_ACT_STORAGE', 'fp16')]
+        self.bf16_min_voxels = int(os.environ.get('MT_BF16_MIN_VOXELS', '0'))
         self._io_cache = {}
         self._fp32_copies = {}
         self._iter = 0
@@ -597,9 +603,13 @@ class Engine:
         return 1 if (self.mma and v >= self.bf16_min_voxels) else 0
 
     def val_dtype(self, spatial):
-        """storage type of an activation (and of its gradient) at this spatial size"""
+        """storage type of an activation at this spatial size"""
         v = spatial[0] * spatial[1] * spatial[2]
-        return torch.bfloat16 if (self.mma and self.storage_bf16 and v >= self.bf16_min_voxels) else torch.float32
+        return self.act_storage if (self.mma and self.storage_bf16 and v >= self.bf16_min_voxels) else torch.float32
+
+    def grad_dtype(self, spatial):
+        """storage type of the gradient of an activation at this spatial size"""
+        return torch.bfloat16 if self.val_dtype(spatial) != torch.float32 else torch.float32
 
     def io(self, key, ins, outs, build, supported, grad_ins=False):
         """Resolve the storage types of one launch.  ins / outs: Acts as the graph has them; build(ins', outs') -> launch parameters;
@@ -761,7 +771,7 @@ class Engine:
                 if isinstance(op, HeadOp):
                     v.grad = None            # provided by the loss (dlogits)
                 else:
-                    v.grad = self.buffer(v.name + '.grad', tuple(v.act.buf.shape[:4]) + (v.C,), v.act.buf.dtype)
+                    v.grad = self.buffer(v.name + '.grad', tuple(v.act.buf.shape[:4]) + (v.C,), self.grad_dtype(v.spatial))
             # out = lrelu(main + res): the masked gradient of `out` IS the first contribution to the gradient of `res` (ResAddOp is
             # the last consumer of `res` in forward, so the first writer of its gradient in backward) — the two share one buffer and
             # the residual path costs no copy; along a chain of blocks the gradient flows through ONE buffer, masked in place

@@ -2,7 +2,7 @@
 
 Everything here is plumbing: torch owns device memory and streams, the arithmetic happens in
 libmtseg_hip.so.  Activations are NDHWC tensors [N, D, H, W, C] (possibly channel slices of a wider buffer), float32 or — the
-storage of the mixed-precision mode — bfloat16 (mt_src_t.dtype / odtype).  There is NO CPU fallback: tensors must live on a HIP device.
+storage of the mixed-precision mode — float16 (activations) / bfloat16 (gradients) (mt_src_t.dtype / odtype).  There is NO CPU fallback: tensors must live on a HIP device.
 """
 import ctypes as C
 
@@ -26,6 +26,9 @@ def _check_dev(*ts):
             raise RuntimeError("multitalent_amd ops require HIP device tensors (no CPU fallback)")
 
 
+_DT_CODES = {torch.float32: _lib.MT_F32, torch.bfloat16: _lib.MT_BF16, torch.float16: _lib.MT_F16}
+
+
 class Act:
     """A (lazy) activation: channel slice [c0, c0+C) of an NDHWC buffer `buf` [N,D,H,W,cs], read as
     lrelu_slope(buf*scale + shift) when scale is not None (InstanceNorm+LeakyReLU applied on load)."""
@@ -33,7 +36,7 @@ class Act:
     __slots__ = ('buf', 'c0', 'C', 'scale', 'shift', 'slope', 'mean', 'rstd')
 
     def __init__(self, buf, c0=0, C=None, scale=None, shift=None, slope=1.0, mean=None, rstd=None):
-        assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype in (torch.float32, torch.bfloat16)
+        assert buf.dim() == 5 and buf.is_contiguous() and buf.dtype in _DT_CODES
         self.buf, self.c0 = buf, c0
         self.C = buf.shape[4] - c0 if C is None else C
         self.scale, self.shift, self.slope = scale, shift, float(slope)
@@ -56,8 +59,8 @@ class Act:
 
     @property
     def dt(self):
-        """storage type code of the C ABI (MT_F32 | MT_BF16)"""
-        return _lib.MT_BF16 if self.buf.dtype == torch.bfloat16 else _lib.MT_F32
+        """storage type code of the C ABI (MT_F32 | MT_BF16 | MT_F16)"""
+        return _DT_CODES[self.buf.dtype]
 
     def data_ptr(self):
         return self.buf.data_ptr() + self.buf.element_size() * self.c0
@@ -403,7 +406,8 @@ def inorm_lrelu_apply(y, out, res=None):
 
 
 def _same_dt(*acts):
-    """the streaming kernels take ONE storage type for all their tensor operands (the engine chooses it per resolution level)"""
+    """the streaming kernels take ONE storage type for all their activation operands and one for all their gradient operands (the
+    engine chooses them per resolution level)"""
     dts = {a.dt for a in acts if a is not None}
     if len(dts) != 1:
         raise RuntimeError("operands of a streaming kernel must share one storage type (got %s): convert with ops.cast" % sorted(dts))
@@ -422,7 +426,7 @@ def inorm_lrelu_bwd(g, y, gamma, beta, dgamma, dbeta, dbias, ws, part=None, part
     _lib.check(_lib.load().mt_inorm_lrelu_bwd(
         C.c_void_p(g.data_ptr()), g.cs, C.c_void_p(y.data_ptr()), y.cs, _ptr(y.mean), _ptr(y.rstd), _ptr(gamma), _ptr(beta),
         y.slope, y.N, y.V, y.C, _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(part), int(part.shape[1]) if part is not None else 0,
-        int(part.shape[2]) if part is not None else 0, int(part_c0), _ptr(ws), ws.numel() * ws.element_size(), _same_dt(g, y), _stream()),
+        int(part.shape[2]) if part is not None else 0, int(part_c0), _ptr(ws), ws.numel() * ws.element_size(), g.dt, y.dt, _stream()),
         'inorm_lrelu_bwd')
 
 

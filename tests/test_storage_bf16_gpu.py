@@ -1,9 +1,11 @@
-"""bf16 STORAGE of activations and gradients (the mixed-precision mode's HBM format; reference: autocast keeps conv inputs / outputs in
-half precision, MultiTalent_Trainer_DDP.py:340-354, network_trainer.py:400-402).
+"""16-bit STORAGE of activations (fp16) and gradients (bf16): the mixed-precision mode's HBM format (reference: autocast keeps conv
+inputs / outputs in half precision, MultiTalent_Trainer_DDP.py:340-354, network_trainer.py:400-402).
 
-A kernel that reads bf16 widens exactly and a kernel that writes bf16 rounds its fp32 result once (RNE), so on inputs that ARE
-bf16-representable every bf16-storage kernel must agree with its fp32-storage form (validated against the oracle elsewhere)
-BIT FOR BIT after rounding: out_bf16 == bf16(out_fp32).  The streaming kernels are checked against the same formulas in torch."""
+A kernel that reads a 16-bit tensor widens exactly and a kernel that writes one rounds its fp32 result once (RNE).  Where the
+matrix type does not change with the storage type (bf16 products: backward-data, backward-weight) every 16-bit-storage kernel must
+therefore agree with its fp32-storage form (validated against the oracle elsewhere) BIT FOR BIT after rounding on inputs that are
+representable: out_16 == round(out_fp32).  The fp16 forward kernels (fp16 products) are checked against the same arithmetic restated
+on the host (operands rounded to fp16, exact products, fp32-level sums); the streaming kernels against their formulas in torch."""
 import numpy as np
 import pytest
 import torch
@@ -16,8 +18,8 @@ def _ops():
     return ops
 
 
-def rbf(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+def rbf(x, dt=torch.bfloat16):
+    return x.to(dt).to(torch.float32)
 
 
 def nd(x):
@@ -46,11 +48,23 @@ def test_cast_roundtrip_strided_accumulate(dev):
     b2 = torch.empty_like(x2, dtype=torch.bfloat16)
     ops.cast(ops.Act(x2), ops.Act(b2))
     assert torch.equal(b2, x2.to(torch.bfloat16))
+    # fp16 <-> fp32 <-> bf16
+    h = torch.empty_like(x, dtype=torch.float16)
+    ops.cast(ops.Act(x), ops.Act(h))
+    assert torch.equal(h, x.to(torch.float16))
+    hb = torch.empty_like(x, dtype=torch.bfloat16)
+    ops.cast(ops.Act(h), ops.Act(hb))
+    assert torch.equal(hb, h.float().to(torch.bfloat16))
+    h2 = torch.empty_like(x2, dtype=torch.float16)
+    ops.cast(ops.Act(b2), ops.Act(h2))
+    assert torch.equal(h2, b2.float().to(torch.float16))
 
 
+@pytest.mark.parametrize("adt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("C,shape", [(30, (6, 10, 12)), (32, (4, 8, 16)), (60, (5, 7, 9)), (120, (3, 4, 8)), (7, (3, 5, 5))])
-def test_streaming_kernels_bf16(dev, C, shape):
-    """inorm_lrelu_apply (+ residual), inorm_lrelu_bwd, lrelu_bwd (+ copy), lrelu_bwd_stats, channel_sum on bf16 tensors."""
+def test_streaming_kernels_16bit(dev, C, shape, adt):
+    """inorm_lrelu_apply (+ residual), inorm_lrelu_bwd, lrelu_bwd (+ copy), lrelu_bwd_stats, channel_sum: activations of type adt
+    (fp16 = the engine's choice, bf16), gradients bf16."""
     from multitalent_amd import _lib
     import ctypes as Ct
     ops = _ops()
@@ -58,8 +72,11 @@ def test_streaming_kernels_bf16(dev, C, shape):
     N = 2
     V = int(np.prod(shape))
     bf = lambda t: t.to(dev).to(torch.bfloat16)
-    y = bf(torch.randn((N,) + shape + (C,), generator=g) * 2 + 0.5)
-    r = bf(torch.randn((N,) + shape + (C,), generator=g))
+    af = lambda t: t.to(dev).to(adt)
+    ulp = 2.0 ** -7 if adt == torch.bfloat16 else 2.0 ** -10
+    ADT = _lib.MT_BF16 if adt == torch.bfloat16 else _lib.MT_F16
+    y = af(torch.randn((N,) + shape + (C,), generator=g) * 2 + 0.5)
+    r = af(torch.randn((N,) + shape + (C,), generator=g))
     sc = (torch.rand((N, C), generator=g) + 0.5).to(dev)
     sh = torch.randn((N, C), generator=g).to(dev)
     rsc = (torch.rand((N, C), generator=g) + 0.5).to(dev)
@@ -71,9 +88,9 @@ def test_streaming_kernels_bf16(dev, C, shape):
     ops.inorm_lrelu_apply(ops.Act(y, scale=sc, shift=sh, slope=0.01), ops.Act(out), res=ops.Act(r, scale=rsc, shift=rsh, slope=1.0))
     t = torch.addcmul(bc(sh), y.float(), bc(sc))        # fma
     ref = lre(t + lre(torch.addcmul(bc(rsh), r.float(), bc(rsc)), 1.0), 0.01)
-    d = (out.float() - rbf(ref)).abs().max()
-    assert float(d) <= float(ref.abs().max()) * 2 ** -7, float(d)         # at most one bf16 ulp (fma vs mul+add before the rounding)
-    assert float((out.float() != rbf(ref)).float().mean()) < 0.01
+    d = (out.float() - rbf(ref, adt)).abs().max()
+    assert float(d) <= float(ref.abs().max()) * ulp, float(d)         # at most one ulp (fma vs mul+add before the rounding)
+    assert float((out.float() != rbf(ref, adt)).float().mean()) < 0.01
     # ---- norm backward
     mean = y.float().mean((1, 2, 3))
     var = y.float().var((1, 2, 3), unbiased=False)
@@ -106,7 +123,7 @@ def test_streaming_kernels_bf16(dev, C, shape):
     want = torch.where(tt > 0, g1ref.float(), g1ref.float() * 0.01)
     _lib.check(lib.mt_lrelu_bwd(Ct.c_void_p(g1.data_ptr()), C, Ct.c_void_p(y.data_ptr()), C, ops._ptr(sc), ops._ptr(sh), 0.01,
                                 Ct.c_void_p(r.data_ptr()), C, ops._ptr(rsc), ops._ptr(rsh), 1.0, Ct.c_void_p(cp.data_ptr()), C, N, V, C,
-                                _lib.MT_BF16, ops._stream()), 'lrelu_bwd')
+                                _lib.MT_BF16, ADT, ops._stream()), 'lrelu_bwd')
     assert float((g1.float() != rbf(want)).float().mean()) < 1e-3 and torch.equal(cp, g1)     # (fma vs mul+add can flip the sign of a t ~ 0)
     nblk = lib.mt_lrelu_bwd_stats_blocks(V, C)
     if nblk > 0:
@@ -114,7 +131,7 @@ def test_streaming_kernels_bf16(dev, C, shape):
         part = torch.zeros((N, nblk, C, 2), device=dev)
         _lib.check(lib.mt_lrelu_bwd_stats(Ct.c_void_p(g2.data_ptr()), Ct.c_void_p(y.data_ptr()), ops._ptr(sc), ops._ptr(sh), 0.01,
                                           Ct.c_void_p(r.data_ptr()), ops._ptr(rsc), ops._ptr(rsh), 1.0, None, ops._ptr(mean), ops._ptr(rstd),
-                                          ops._ptr(part), N, V, C, _lib.MT_BF16, ops._stream()), 'lrelu_bwd_stats')
+                                          ops._ptr(part), N, V, C, _lib.MT_BF16, ADT, ops._stream()), 'lrelu_bwd_stats')
         assert torch.equal(g2, g1)
         s = part.sum(1)
         assert torch.allclose(s[..., 0], g2.float().sum((1, 2, 3)), rtol=1e-3, atol=1e-3 * V ** 0.5)
@@ -208,6 +225,93 @@ def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, s
         ops.set_option('conv_bf16', 1)
 
 
+def _host_conv_16(srcs, lazy, w, b, stride, pad, dt):
+    """what a 16-bit matrix kernel computes, on the host: the lazily activated input rounded to dt, the weights rounded to dt, exact
+    products, double sums"""
+    import torch.nn.functional as F
+    xs = []
+    for s, lz in zip(srcs, lazy):
+        t = s.permute(0, 4, 1, 2, 3)
+        if lz is not None:
+            sc, sh, sl = lz
+            t = torch.addcmul(sh[:, :, None, None, None], t, sc[:, :, None, None, None])
+            t = torch.maximum(t, t * sl)
+        xs.append(rbf(t, dt))
+    x = torch.cat(xs, 1)
+    y = F.conv3d(x.double(), rbf(w, dt).double(), b.double() if b is not None else None, stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 4, 1).float()
+
+
+@pytest.mark.parametrize("Cin,Cout,shape,k,stride,two,odt", [
+    (32, 32, (8, 16, 64), (3, 3, 3), (1, 1, 1), False, torch.float16),       # conv_bf16_kernel, fp16 products
+    (30, 60, (9, 14, 70), (3, 3, 3), (1, 1, 1), False, torch.float16),
+    (30, 30, (6, 20, 40), (1, 3, 3), (1, 1, 1), False, torch.float16),
+    (60, 30, (8, 16, 64), (3, 3, 3), (1, 1, 1), True, torch.float16),
+    (30, 60, (8, 18, 34), (3, 3, 3), (2, 2, 2), False, torch.float16),       # strided stage conv
+    (32, 64, (6, 16, 32), (3, 3, 3), (1, 2, 2), False, torch.float32),       # ... into a level kept in fp32
+    (64, 64, (3, 6, 6), (3, 3, 3), (1, 1, 1), False, torch.float16),         # tap-split kernel (low-resolution stages)
+    (320, 320, (6, 12, 12), (3, 3, 3), (1, 1, 1), False, torch.float16),
+])
+def test_forward_convs_fp16_storage(dev, Cin, Cout, shape, k, stride, two, odt):
+    """forward convolutions over fp16 activations: fp16 products (v_mfma_f32_32x32x16_f16), fp32 sums, fp16 (or fp32) output, statistics
+    of the stored values — against the host restatement."""
+    ops = _ops()
+    tapsplit = k == (3, 3, 3) and stride == (1, 1, 1) and shape[2] <= 12
+    ops.set_option('conv_bf16', 1 if tapsplit else 2)          # 2: the 16-bit matrix kernel also on the small grids of this test
+    try:
+        _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit)
+    finally:
+        ops.set_option('conv_bf16', 1)
+
+
+def _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit):
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    N = 2
+    pad = tuple((kk - 1) // 2 for kk in k)
+    geom = ops.ConvGeom(shape, k, stride, pad)
+    H = torch.float16
+    if two:
+        srcs = [rbf(torch.randn((N,) + shape + (Cin // 2,), generator=g), H), rbf(torch.randn((N,) + shape + (Cin // 2,), generator=g), H)]
+        lazy = [None, (torch.rand((N, Cin // 2), generator=g) + 0.5, torch.randn((N, Cin // 2), generator=g), 0.01)]
+    else:
+        srcs = [rbf(torch.randn((N,) + shape + (Cin,), generator=g), H)]
+        lazy = [(torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)]
+    w = torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))
+    b = torch.randn(Cout, generator=g)
+    acts, keep = [], []
+    for sx, lz in zip(srcs, lazy):
+        buf = sx.to(dev).to(H)
+        keep.append(buf)
+        acts.append(ops.Act(buf) if lz is None else ops.Act(buf, scale=lz[0].to(dev), shift=lz[1].to(dev), slope=lz[2]))
+    out = torch.full((N,) + tuple(geom.out) + (Cout,), float('nan'), device=dev).to(odt)
+    bd = b.to(dev)
+    p = ops.fill_conv(acts, geom, Cout, out0=ops.Act(out), bias=bd, mma=1)
+    name = ops.conv_kernel_name(p)
+    assert ops.conv_io_supported(p), name
+    assert ops.conv_pack_layout(p) == 4, (name, ops.conv_pack_layout(p))                 # fp16 weight fragments
+    wd = w.to(dev).contiguous()
+    wp = ops.pack_conv_weights(wd, acts[0].C, acts[1].C if two else 0, Cout, k, ops.conv_weight_strides(wd), False, ops.conv_ck(p), layout=4)
+    p.wpack = wp.data_ptr()
+    part = torch.zeros((N, ops.conv_stats_blocks(p), Cout, 2), device=dev)
+    p.stats_part = part.data_ptr()
+    ops.conv3d_fwd(p)
+    torch.cuda.synchronize()
+    ref = _host_conv_16(srcs, lazy, w, b, stride, pad, H)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    tol = (2.0 ** -10 if odt == H else 1e-4) * float(ref.abs().max())
+    # (the activation t = x * scale + shift is an fma on the device: an fp16 rounding boundary crossed by it shows as one input ulp)
+    assert float((got - ref).abs().max()) < 4 * tol + 2e-3, (name, float((got - ref).abs().max()), tol)
+    assert float(((got - ref).abs() > tol).float().mean()) < 2e-3, name
+    o = out.float().double()
+    sm = part.double().sum(1)
+    assert torch.allclose(sm[..., 0], o.sum((1, 2, 3)), rtol=1e-4, atol=1e-3 * o[0, ..., 0].numel() ** 0.5)
+    assert torch.allclose(sm[..., 1], (o * o).sum((1, 2, 3)), rtol=1e-4)
+    if tapsplit:
+        assert name.startswith('conv_tapsplit_kernel'), name
+
+
 @pytest.mark.parametrize("Cin,Cout,shape,stride", [(30, 60, (8, 18, 34), (2, 2, 2)), (32, 64, (6, 16, 32), (1, 2, 2))])
 @pytest.mark.parametrize("out_bf16", [True, False])
 def test_strided_stage_conv_bf16_storage_bitexact(dev, Cin, Cout, shape, stride, out_bf16):
@@ -280,18 +384,18 @@ def test_strided_stage_conv_bf16_storage_bitexact(dev, Cin, Cout, shape, stride,
 
 
 @pytest.mark.parametrize("Cin,Cout,shape,k", [(32, 32, (6, 12, 64), (3, 3, 3)), (30, 60, (5, 10, 40), (3, 3, 3)), (30, 30, (4, 12, 64), (1, 3, 3))])
-@pytest.mark.parametrize("xb,yb", [(True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("xb,yb", [(torch.float16, True), (torch.bfloat16, True), (torch.float16, False), (None, True)])
 def test_bwdw_wino_bf16_storage_bitexact(dev, Cin, Cout, shape, k, xb, yb):
     ops = _ops()
     g = torch.Generator().manual_seed(8)
     N = 2
     pad = tuple((kk - 1) // 2 for kk in k)
     geom = ops.ConvGeom(shape, k, (1, 1, 1), pad)
-    x = rbf(torch.randn((N,) + shape + (Cin,), generator=g))
+    x = rbf(torch.randn((N,) + shape + (Cin,), generator=g), xb if xb is not None else torch.bfloat16)
     sc, sh = torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g)
     dy = rbf(torch.randn((N,) + shape + (Cout,), generator=g))
     res = []
-    for xdt, ydt in ((torch.float32, torch.float32), (torch.bfloat16 if xb else torch.float32, torch.bfloat16 if yb else torch.float32)):
+    for xdt, ydt in ((torch.float32, torch.float32), (xb if xb is not None else torch.float32, torch.bfloat16 if yb else torch.float32)):
         a = ops.Act(x.to(dev).to(xdt), scale=sc.to(dev), shift=sh.to(dev), slope=0.01)
         y = ops.Act(dy.to(dev).to(ydt))
         p = ops.fill_conv([a], geom, Cout, mma=1)

@@ -1,5 +1,5 @@
 """Gradient / logit accuracy of the mixed-precision mode on the full-size residual-encoder network (BASELINE configs[3]) against the
-fp64 oracle, for several (storage, compute-threshold) settings.  usage: python tools/bf16_accuracy.py "storage,minvox" ..."""
+fp64 oracle, for several (storage, compute-threshold) settings.  usage: python tools/bf16_accuracy.py "storage,minvox,act" ...   (storage 0|1, act fp16|bf16)"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 def main():
     import test_fullsize_oracle_gpu as T
     dev = torch.device('cuda:0')
-    settings = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(0, 0), (0, 2048), (1, 2048), (1, 0)]
+    settings = [tuple(a.split(',')) for a in sys.argv[1:]] or [('0', '0', 'fp16'), ('1', '0', 'fp16'), ('1', '0', 'bf16')]
     os.environ['MT_BF16_STORAGE'] = '0'
     sd0, x, tg, valid, w, logits, loss, grads, names = T._resenc(dev, 'fp32')
     o32, o64 = T._resenc_oracle(sd0, x, tg, valid, w)
@@ -31,12 +31,13 @@ def main():
             tag, cos, float((ga - gr).norm() / gr.norm()), lrel, worst[0], worst[1]), flush=True)
     report('fp32', logits, grads)
     del logits, grads
-    for st, mv in settings:
+    for st, mv, act in settings:
         os.environ['MT_BF16_STORAGE'] = str(st)
         os.environ['MT_BF16_MIN_VOXELS'] = str(mv)
+        os.environ['MT_ACT_STORAGE'] = act
         torch.cuda.empty_cache()
         _, _, _, _, _, lb, lossb, gb, nb = T._resenc(dev, 'bf16')
-        report('bf16 storage=%d minvox=%d' % (st, mv), lb, gb)
+        report('mixed storage=%s minvox=%s act=%s' % (st, mv, act), lb, gb)
         del lb, gb
 
 
