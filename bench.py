@@ -122,7 +122,7 @@ class ConvTimer:
         from multitalent_amd import ops
         self.ops = ops
         self.orig = (ops.conv3d_fwd, ops.conv3d_bwd_weight, ops.conv3d_bwd_data_strided)
-        esz = lambda p: 4.0          # activations and gradients are fp32 in HBM in both precisions
+        eb = lambda dt: 4.0 if dt == 0 else 2.0          # bytes per stored element (MT_F32 | MT_BF16 / MT_F16: mixed-precision storage)
 
         def timed(name, flops, nbytes, call):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -136,19 +136,19 @@ class ConvTimer:
             # dilated-input conv) only carries 1/prod(dil) non-structural-zero taps.  Bytes: the input read once,
             # the output written once (read + written when accumulating)
             fl = 2.0 * p.N * p.Do * p.Ho * p.Wo * p.Cin * p.Cout * p.KD * p.KH * p.KW / (p.dilD * p.dilH * p.dilW)
-            nb = esz(p) * p.N * (p.Di * p.Hi * p.Wi * p.Cin / (p.dilD * p.dilH * p.dilW) + p.Do * p.Ho * p.Wo * p.Cout * (2 if p.accumulate else 1))
+            nb = p.N * (eb(p.src[0].dtype) * p.Di * p.Hi * p.Wi * p.Cin / (p.dilD * p.dilH * p.dilW) + eb(p.odtype) * p.Do * p.Ho * p.Wo * p.Cout * (2 if p.accumulate else 1))
             timed(ops.conv_kernel_name(p), fl, nb, lambda: self.orig[0](p))
 
         def bwdw(p, y, *a):
             # dW = X (*) dY: both activations read once; the weight gradient itself is negligible
             fl = 2.0 * p.N * p.Do * p.Ho * p.Wo * p.Cin * p.Cout * p.KD * p.KH * p.KW
-            nb = esz(p) * p.N * (p.Di * p.Hi * p.Wi * p.Cin + p.Do * p.Ho * p.Wo * p.Cout)
+            nb = p.N * (eb(p.src[0].dtype) * p.Di * p.Hi * p.Wi * p.Cin + eb(y.dt) * p.Do * p.Ho * p.Wo * p.Cout)
             timed(ops.conv_bwd_weight_kernel_name(p, y), fl, nb, lambda: self.orig[1](p, y, *a))
 
         def bwdd(p):
             # p = FORWARD geometry with src = dY [Do..] x Cout and out = dX [Di..] x Cin
             fl = 2.0 * p.N * p.Do * p.Ho * p.Wo * p.Cin * p.Cout * p.KD * p.KH * p.KW
-            nb = esz(p) * p.N * (p.Do * p.Ho * p.Wo * p.Cout + p.Di * p.Hi * p.Wi * p.Cin * (2 if p.accumulate else 1))
+            nb = p.N * (eb(p.src[0].dtype) * p.Do * p.Ho * p.Wo * p.Cout + eb(p.odtype) * p.Di * p.Hi * p.Wi * p.Cin * (2 if p.accumulate else 1))
             timed(ops.conv_bwd_data_strided_kernel_name(p), fl, nb, lambda: self.orig[2](p))
 
         ops.conv3d_fwd, ops.conv3d_bwd_weight, ops.conv3d_bwd_data_strided = fwd, bwdw, bwdd
@@ -522,7 +522,7 @@ def training_line(r, workload, precision, patch, B, steps, warmup, world):
         "config": {"workload": WORKLOAD_NAMES[workload], "patch": list(patch), "batch_per_gpu": B, "global_batch": B * world,
                    "parallelism": "dp%d" % world, "step": "fwd+loss+bwd+clip12+SGD-nesterov",
                    "precision": "fp32" if precision == 'fp32' else
-                   "bf16 matrix inputs + fp32 accumulation in the convolutions (fwd, bwd-data, bwd-weight); fp32 master weights, norm statistics, loss, optimizer",
+                   "mixed: fp16 activations (storage + forward products), bf16 gradients (storage + backward products), fp32 accumulation, master weights, norm statistics, loss, optimizer",
                    "final_loss": round(r['loss'], 5)},
         "algorithmic_tflop_per_step": round(fl / 1e12, 3),
         "step_frac_of_fp32_mfma_roofline": round(fl / (r['ms'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),

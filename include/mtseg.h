@@ -223,10 +223,13 @@ typedef struct {
   int32_t accumulate;
   float* stats_part;   /* NULL or [N][nsb][Cout][2] */
   int32_t odtype;      /* MT_F32 | MT_BF16 | MT_F16: element type of `out` */
-  int32_t _pad;
+  int32_t scatter;     /* 0: all prod(so) taps (transposed convolution).  1: ONLY tap (0,0,0) — out[base*so] (+)= W x in[base], one packed
+                          tap: the backward-data of a strided 1x1x1 convolution (conv_blocks.py:159-165); the other output positions are
+                          not touched (the caller zero-fills or accumulates) */
 } mt_pointwise_t;
 int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream);
 int mt_pointwise_stats_blocks(const mt_pointwise_t* p);
+int mt_pointwise_io_supported(const mt_pointwise_t* p);   /* 1 when p->src.dtype / p->odtype are read / written natively (see MT_F16) */
 /* Backward of a 1x1x1 segmentation head (generic_UNet.py:349-351, generic_modular_UNet.py:244,251: seg_outputs / deep_supervision_outputs)
  * in ONE pass over (x, dY):  dX[n,v,ci] (+)= sum_co dY[n,v,co] W[co,ci] (gradient w.r.t. the lazily ACTIVATED head input),
  * dW[co*s_co + ci*s_ci] (+)= sum_{n,v} act(x)[n,v,ci] dY[n,v,co], dbias[co] (+)= sum dY.  Cin, Cout <= 64; mt_head_bwd_supported says
@@ -238,8 +241,9 @@ int mt_pointwise_stats_blocks(const mt_pointwise_t* p);
 int mt_head_bwd_supported(int Cin, int Cout);
 size_t mt_head_bwd_workspace(int N, long V, int Cin, int Cout);
 int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, long V, int Cin, int Cout, const float* wpack_bwd,
-                float* dx, int dxcs, int accumulate_dx, float* dw, long s_ci, long s_co, float* dbias, int accumulate_dw,
-                int* dbias_done, void* ws, size_t ws_bytes, mt_stream_t stream);
+                float* dx, int dxcs, int dxdtype /* storage type of dx: fp32, or bf16 with a 16-bit x */, int accumulate_dx, float* dw,
+                long s_ci, long s_co, float* dbias, int accumulate_dw, int* dbias_done, void* ws, size_t ws_bytes, mt_stream_t stream);
+int mt_head_bwd_io_supported(int xdtype, int xcs, int dxdtype, int dxcs, int Cin, int Cout);
 
 
 /* ---- InstanceNorm3d(eps, affine) + LeakyReLU (generic_UNet.py:63-64,69-70) ------------------- */

@@ -622,18 +622,22 @@ struct Stage2Regs {
   bool nosel;
 };
 
-template <int LD, int LH, int LW, int VEC>
+// XS: storage type of the source.  A 16-bit source (VEC == 2 only) leaves the RAW dword — two elements — in v[r][i][0]; stage2_store
+// widens it (a conversion right behind the load would put a wait between the loads and drain the prefetch).
+template <int LD, int LH, int LW, int VEC, int XS = MT_F32>
 __device__ __forceinline__ void stage2_load(Stage2Regs<LD, LH, LW, VEC>& g, const mt_conv3d_t& c, const ConvChunk ch, int nb,
                                             int ud0, int uh0, int uw0, int lane, int wave) {
   typedef Stage2Regs<LD, LH, LW, VEC> RG_;
   constexpr int LPV = RG_::LPV, VPS = RG_::VPS, NI = RG_::NI, R = RG_::R, RPW = RG_::RPW;
+  constexpr int XE = mt_ebytes<XS>();
+  static_assert(XS == MT_F32 || VEC == 2, "16-bit sources are staged as channel pairs");
   const mt_src_t& S = c.src[ch.src];
   const int cl = (lane % LPV) * VEC, vl = lane / LPV;
   const bool cval0 = cl < ch.ck;
   const int cs = S.cs;
   const size_t sample_elems = (size_t)c.Di * c.Hi * c.Wi * cs;
   __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * sample_elems), 0, (int)(sample_elems * 4), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (size_t)nb * sample_elems * XE), 0, (int)(sample_elems * XE), 0x00020000);
   g.nb = nb;
   g.nosel = (ud0 >= 0) && (uh0 >= 0) && (uw0 >= 0) && (ud0 + LD <= c.Di) && (uh0 + LH <= c.Hi) && (uw0 + LW <= c.Wi) &&
             (S.slope >= 0.f) && (S.slope <= 1.f);
@@ -642,7 +646,7 @@ __device__ __forceinline__ void stage2_load(Stage2Regs<LD, LH, LW, VEC>& g, cons
     const int lw = vl + i * VPS;
     const int uw = uw0 + lw;
     const bool ok = cval0 && (lw < LW) && ((unsigned)uw < (unsigned)c.Wi);
-    g.voff[i] = ok ? (uw * cs + ch.c0 + cl) * 4 : (int)0x80000000;
+    g.voff[i] = ok ? (uw * cs + ch.c0 + cl) * XE : (int)0x80000000;
   }
   g.rvmask = 0;
 #pragma unroll
@@ -653,10 +657,13 @@ __device__ __forceinline__ void stage2_load(Stage2Regs<LD, LH, LW, VEC>& g, cons
     const bool rv = (row < R) && ((unsigned)ud < (unsigned)c.Di) && ((unsigned)uh < (unsigned)c.Hi);
     if (rv) {
       g.rvmask |= 1u << r;
-      const int srow = (ud * c.Hi + uh) * c.Wi * cs * 4;
+      const int srow = (ud * c.Hi + uh) * c.Wi * cs * XE;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        if constexpr (VEC == 2) {
+        if constexpr (XS != MT_F32) {
+          g.v[r][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, g.voff[i] + srow, 0, 0));
+          g.v[r][i][1] = 0.f;
+        } else if constexpr (VEC == 2) {
           const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, g.voff[i] + srow, 0, 0));
           g.v[r][i][0] = t.x; g.v[r][i][1] = t.y;
         } else {
@@ -672,7 +679,7 @@ __device__ __forceinline__ void stage2_load(Stage2Regs<LD, LH, LW, VEC>& g, cons
   }
 }
 
-template <int LD, int LH, int LW, int VEC, int PITCH = FCKP>
+template <int LD, int LH, int LW, int VEC, int PITCH = FCKP, int XS = MT_F32>
 __device__ __forceinline__ void stage2_store(const Stage2Regs<LD, LH, LW, VEC>& g, float* __restrict__ lds, const mt_conv3d_t& c,
                                              const ConvChunk ch, int lane, int wave) {
   typedef Stage2Regs<LD, LH, LW, VEC> RG_;
@@ -707,7 +714,8 @@ __device__ __forceinline__ void stage2_store(const Stage2Regs<LD, LH, LW, VEC>& 
           const bool ok = rv && g.voff[i] >= 0;
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
-            x[e] = g.v[r][i][e];
+            if constexpr (XS != MT_F32) { const unsigned raw = __builtin_bit_cast(unsigned, g.v[r][i][0]); x[e] = e ? mt_hi16<XS>(raw) : mt_lo16<XS>(raw); }
+            else x[e] = g.v[r][i][e];
             if (has_aff) {
               const float t = fmaf(x[e], sc[e], sh[e]);
               const float a = fmaxf(t, t * slope);
@@ -1206,6 +1214,8 @@ __device__ __forceinline__ void stem_stage(float* __restrict__ xs, const mt_conv
   }
 }
 
+// OS: storage type of the output (the network input is fp32)
+template <int OS = MT_F32>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvKParams P) {
   constexpr int TD = 2, TH = 4, TW = 32, LH = TH + 2, LW = TW + 2, NJ = 14;      // 14 MFMAs x k=2 cover 27 taps (+1 zero)
   __shared__ float xs[(TD + 2) * LH * LW];
@@ -1247,10 +1257,38 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvKParams P) {
   const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
   const int ocs = c.ocs0;
   const size_t out_sample = (size_t)c.Do * c.Ho * c.Wo;
-  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0,
-                                                                (int)(out_sample * ocs * 4), 0x00020000);
+  constexpr int OEB = mt_ebytes<OS>();
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)nb * out_sample * ocs * OEB), 0,
+                                                                (int)(out_sample * ocs * OEB), 0x00020000);
   float s1 = 0.f, s2 = 0.f;
   const int od = od0 + (wave >> 1);
+  if constexpr (OS != MT_F32) {        // channel-pair dwords (mt_pair_exchange): even lanes store voxel q, odd lanes voxel q + 1
+    const bool odd = li & 1;
+    const int coe = co & ~1;
+    const bool pvalid = coe + 1 < c.Cout;
+    float q1[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int oh = oh0 + (wave & 1) * 2 + m;
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {
+        const int ow = ow0 + (q & 3) + 8 * (q >> 2) + 4 * lhalf + (odd ? 1 : 0);
+        const bool ok = pvalid && od < c.Do && oh < c.Ho && ow < c.Wo;
+        const int off = ok ? (((od * c.Ho + oh) * c.Wo + ow) * ocs + coe) * 2 : (int)0x80000000;
+        float a, b;
+        mt_pair_exchange(acc[m][q] + bv, acc[m][q + 1] + bv, odd, a, b);
+        if (c.accumulate) { const unsigned pv = __builtin_amdgcn_raw_buffer_load_b32(rd, off, 0, 0); a += mt_lo16<OS>(pv); b += mt_hi16<OS>(pv); }
+        const unsigned pk = mt_pk16<OS>(a, b);
+        __builtin_amdgcn_raw_buffer_store_b32(pk, rd, off, 0, 0);
+        if (ok) {
+          const float ar = mt_lo16<OS>(pk), br = mt_hi16<OS>(pk);
+          q1[0] += ar; q2[0] = fmaf(ar, ar, q2[0]); q1[1] += br; q2[1] = fmaf(br, br, q2[1]);
+        }
+      }
+    }
+    s1 = mt_pair_combine(q1[0], q1[1], odd);
+    s2 = mt_pair_combine(q2[0], q2[1], odd);
+  } else
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const int oh = oh0 + (wave & 1) * 2 + m;
@@ -1285,8 +1323,9 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvKParams P) {
 // (generic_UNet.py:335-336) — every output voxel reads its own kD*kH*kW block, nothing is shared between outputs, so there is
 // no halo to stage: A fragments come straight from global memory (32-byte per-lane vectors, lazy activation in registers) as in
 // the pointwise kernel, one accumulator tile per wave of 32 output voxels x 32 channels.
-template <int VEC>
+template <int VEC, int XS = MT_F32, int OS = MT_F32>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
+  constexpr int XE = mt_ebytes<XS>(), OE = mt_ebytes<OS>();
   const mt_conv3d_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1302,8 +1341,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
   const bool vok = mv < V;
   const int ow = (int)(mv % c.Wo), oh = (int)((mv / c.Wo) % c.Ho), od = (int)(mv / ((long)c.Wo * c.Ho));
   const size_t in_sample = (size_t)c.Di * c.Hi * c.Wi * S.cs;
-  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0, (int)(in_sample * 4), 0x00020000);
-  const int abase = vok ? ((((od * c.SD) * c.Hi + oh * c.SH) * c.Wi + ow * c.SW) * S.cs + 8 * lhalf) * 4 : (int)0x80000000;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (size_t)nb * in_sample * XE), 0, (int)(in_sample * XE), 0x00020000);
+  const int abase = vok ? ((((od * c.SD) * c.Hi + oh * c.SH) * c.Wi + ow * c.SW) * S.cs + 8 * lhalf) * XE : (int)0x80000000;
   const bool aff = S.scale != nullptr;
   const float slope = aff ? S.slope : 1.f;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(aff ? S.scale + (size_t)nb * S.C : S.ptr), 0, aff ? S.C * 4 : 0, 0x00020000);
@@ -1314,9 +1353,13 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
   // instructions each on this hardware (no integer divider), three of them per 8 MFMAs in the first version
   int l_ch = 0, l_kd = 0, l_kh = 0, l_kw = 0;
   auto load_a = [&](float (&x)[8]) {
-    const int so = __builtin_amdgcn_readfirstlane((((l_kd * c.Hi + l_kh) * c.Wi + l_kw) * S.cs + l_ch * FCK) * 4);
+    const int so = __builtin_amdgcn_readfirstlane((((l_kd * c.Hi + l_kh) * c.Wi + l_kw) * S.cs + l_ch * FCK) * XE);
     if (++l_kw == c.KW) { l_kw = 0; if (++l_kh == c.KH) { l_kh = 0; if (++l_kd == c.KD) { l_kd = 0; ++l_ch; } } }
-    if constexpr (VEC == 4) {
+    if constexpr (XS != MT_F32) {         // 8 channels of a 16-bit source: one 16-byte load
+      const uint4 t = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ra, abase, so, 0));
+      x[0] = mt_lo16<XS>(t.x); x[1] = mt_hi16<XS>(t.x); x[2] = mt_lo16<XS>(t.y); x[3] = mt_hi16<XS>(t.y);
+      x[4] = mt_lo16<XS>(t.z); x[5] = mt_hi16<XS>(t.z); x[6] = mt_lo16<XS>(t.w); x[7] = mt_hi16<XS>(t.w);
+    } else if constexpr (VEC == 4) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, abase + g * 16, so, 0));
@@ -1371,7 +1414,21 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
   const bool covalid = co < c.Cout;
   const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
   const size_t out_sample = (size_t)V * c.ocs0;
-  __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample), 0, (int)(out_sample * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)nb * out_sample * OE), 0, (int)(out_sample * OE), 0x00020000);
+  if constexpr (OS != MT_F32) {          // channel-pair dwords (mt_pair_exchange)
+    const bool odd = li & 1;
+    const int coe = co & ~1;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+      const long v = m0 + (j & 3) + 8 * (j >> 2) + 4 * lhalf + (odd ? 1 : 0);
+      const int off = (coe + 1 < c.Cout && v < V) ? (int)((v * c.ocs0 + coe) * 2) : (int)0x80000000;
+      float a, b;
+      mt_pair_exchange(acc[j] + bv, acc[j + 1] + bv, odd, a, b);
+      if (c.accumulate) { const unsigned pv = __builtin_amdgcn_raw_buffer_load_b32(ro, off, 0, 0); a += mt_lo16<OS>(pv); b += mt_hi16<OS>(pv); }
+      __builtin_amdgcn_raw_buffer_store_b32(mt_pk16<OS>(a, b), ro, off, 0, 0);
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const long v = m0 + (j & 3) + 8 * (j >> 2) + 4 * lhalf;
@@ -2117,7 +2174,9 @@ static int launch_stem(const mt_conv3d_t* p, hipStream_t st) {
   P.ntaps = 27; P.dbg = 0; P.stagger = 0;
   P.nchunks = mt_build_chunks(1, 0, FCK, P.chunk);
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
-  hipLaunchKernelGGL(conv_stem_kernel, grid, dim3(256), 0, st, P);
+  if (p->odtype == MT_F16) hipLaunchKernelGGL((conv_stem_kernel<MT_F16>), grid, dim3(256), 0, st, P);
+  else if (p->odtype == MT_BF16) hipLaunchKernelGGL((conv_stem_kernel<MT_BF16>), grid, dim3(256), 0, st, P);
+  else hipLaunchKernelGGL((conv_stem_kernel<MT_F32>), grid, dim3(256), 0, st, P);
   MT_CHECK_LAUNCH("conv3d_stem");
   return MT_OK;
 }
@@ -2360,7 +2419,11 @@ static int launch_gather(const mt_conv3d_t* p, hipStream_t st) {
   if (force_vec == 1 || force_vec == 2) vec = force_vec;
   if (vec == 2 && !((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0)) vec = 1;
   (void)S;
-  if (vec == 4) hipLaunchKernelGGL(conv_gather_kernel<4>, grid, dim3(256), 0, st, P);
+  // gradients: bf16 -> bf16 (backward-data of a transposed convolution between two 16-bit levels), bf16 -> fp32, fp32 -> bf16
+  if (S.dtype == MT_BF16 && p->odtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_BF16, MT_BF16>), grid, dim3(256), 0, st, P);
+  else if (S.dtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_BF16, MT_F32>), grid, dim3(256), 0, st, P);
+  else if (p->odtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_F32, MT_BF16>), grid, dim3(256), 0, st, P);
+  else if (vec == 4) hipLaunchKernelGGL(conv_gather_kernel<4>, grid, dim3(256), 0, st, P);
   else if (vec == 2) hipLaunchKernelGGL(conv_gather_kernel<2>, grid, dim3(256), 0, st, P);
   else hipLaunchKernelGGL(conv_gather_kernel<1>, grid, dim3(256), 0, st, P);
   MT_CHECK_LAUNCH("conv3d_gather");
@@ -2504,6 +2567,12 @@ extern "C" int mt_conv3d_io_supported(const mt_conv3d_t* p) {
   if (pl.kind == CONV_BF16) return (mt_is16(sd) && p->odtype == sd && conv_out_pairs_ok(p)) ? 1 : 0;
   if ((pl.kind == CONV_FAST_STRIDED || pl.kind == CONV_TAPSPLIT) && strided_use_bf16(p))
     return (mt_is16(sd) && (p->odtype == MT_F32 || (p->odtype == sd && conv_out_pairs_ok(p)))) ? 1 : 0;
+  if (pl.kind == CONV_STEM) return (sd == MT_F32 && conv_out_pairs_ok(p)) ? 1 : 0;          // fp32 network input, any output type
+  if (pl.kind == CONV_RT && conv_gather_ok(p)) {                                             // gradients: fp32 / bf16 on either side
+    if (sd == MT_F16 || p->odtype == MT_F16) return 0;
+    if (sd == MT_BF16 && ((p->src[0].cs & 1) || (((uintptr_t)p->src[0].ptr) & 3))) return 0;
+    return (p->odtype == MT_F32 || conv_out_pairs_ok(p)) ? 1 : 0;
+  }
   return 0;
 }
 
@@ -3130,8 +3199,10 @@ __device__ __forceinline__ void bwdw_wg_reduce_store(f32x4 (&acc)[NT][2], float*
 // X tile: LDS [voxel][20] (same staging as the forward kernel).  Y fragments are wave-private, so they bypass LDS:
 // buffer loads straight into registers in B-fragment order.  A workgroup walks a strided list of tiles and writes
 // one partial per WAVE; bwdw_reduce_kernel sums them deterministically.
-template <int KD, int KH, int KW, int SD, int SH, int SW, int TH, int TW, int VEC>
+// XS / YS: storage types of X (p->src) and dY (ysrc)
+template <int KD, int KH, int KW, int SD, int SH, int SW, int TH, int TW, int VEC, int XS = MT_F32, int YS = MT_F32>
 __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P) {
+  constexpr int YE = mt_ebytes<YS>();
   // compile-time geometry: kernel K, stride S, pad (K-1)/2 for odd K and 0 for K = 2 (transposed-conv weights); tile 1 x TH x TW
   constexpr int NT = KD * KH * KW;
   constexpr int PD = (KD == 3) ? 1 : 0, PH = (KH == 3) ? 1 : 0, PW = (KW == 3) ? 1 : 0;
@@ -3175,7 +3246,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
   // ISSUE ONLY: the optional lazy-activation transform is applied when the fragments are rotated in (finish_y), never
   // right behind the loads — otherwise hipcc parks an s_waitcnt vmcnt(0) after every load pair and drains the prefetch.
   auto issue_y = [&](float (&yb)[KS][2], unsigned& okmask, int nb, int od0, int oh0, int ow0) {
-    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(Y.ptr + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Y.ptr + (size_t)nb * ysample * YE), 0, (int)(ysample * YE), 0x00020000);
     okmask = 0;
 #pragma unroll
     for (int s2 = 0; s2 < KS; ++s2) {
@@ -3186,9 +3257,18 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
       const bool k0 = vok && co < c.Cout, k1 = vok && co + 16 < c.Cout;
       okmask |= (k0 ? 1u : 0u) << (2 * s2);
       okmask |= (k1 ? 1u : 0u) << (2 * s2 + 1);
-      yb[s2][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, k0 ? base * 4 : (int)0x80000000, 0, 0));
-      yb[s2][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, k1 ? (base + 16) * 4 : (int)0x80000000, 0, 0));
+      if constexpr (YS == MT_F32) {
+        yb[s2][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, k0 ? base * 4 : (int)0x80000000, 0, 0));
+        yb[s2][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, k1 ? (base + 16) * 4 : (int)0x80000000, 0, 0));
+      } else {         // raw 16-bit elements; widened in finish_y
+        yb[s2][0] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(yr, k0 ? base * 2 : (int)0x80000000, 0, 0));
+        yb[s2][1] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(yr, k1 ? (base + 16) * 2 : (int)0x80000000, 0, 0));
+      }
     }
+  };
+  auto widen_y = [&](float raw) -> float {
+    if constexpr (YS == MT_F32) return raw;
+    else return mt_from16<YS>((unsigned short)__builtin_bit_cast(unsigned, raw));
   };
   auto finish_y = [&](float (&dst)[KS][2], const float (&src)[KS][2], unsigned okmask, int nb) {
     if (yaff) {
@@ -3197,12 +3277,12 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
       if (co + 16 < c.Cout) { ysc1 = Y.scale[(size_t)nb * Y.C + co + 16]; ysh1 = Y.shift[(size_t)nb * Y.C + co + 16]; }
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) {
-        dst[s2][0] = ((okmask >> (2 * s2)) & 1u) ? mt_lrelu(fmaf(src[s2][0], ysc0, ysh0), Y.slope) : 0.f;
-        dst[s2][1] = ((okmask >> (2 * s2 + 1)) & 1u) ? mt_lrelu(fmaf(src[s2][1], ysc1, ysh1), Y.slope) : 0.f;
+        dst[s2][0] = ((okmask >> (2 * s2)) & 1u) ? mt_lrelu(fmaf(widen_y(src[s2][0]), ysc0, ysh0), Y.slope) : 0.f;
+        dst[s2][1] = ((okmask >> (2 * s2 + 1)) & 1u) ? mt_lrelu(fmaf(widen_y(src[s2][1]), ysc1, ysh1), Y.slope) : 0.f;
       }
     } else {
 #pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) { dst[s2][0] = src[s2][0]; dst[s2][1] = src[s2][1]; }
+      for (int s2 = 0; s2 < KS; ++s2) { dst[s2][0] = widen_y(src[s2][0]); dst[s2][1] = widen_y(src[s2][1]); }
     }
   };
 
@@ -3215,19 +3295,19 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
   int tile = sg;
   if (tile < P.ntiles_total) {
     int nb, od0, oh0, ow0; tile_coords(tile, nb, od0, oh0, ow0);
-    stage2_load<LD, LH, LW, VEC>(xr, c, cc, nb, od0 * SD - PD, oh0 * SH - PH, ow0 * SW - PW, lane, wave);
+    stage2_load<LD, LH, LW, VEC, XS>(xr, c, cc, nb, od0 * SD - PD, oh0 * SH - PH, ow0 * SW - PW, lane, wave);
     issue_y(ynxt, yok, nb, od0, oh0, ow0);
     ynb = nb;
   }
   for (; tile < P.ntiles_total; tile += P.nsg) {
     __syncthreads();     // previous tile's X reads are done
-    if (!(BW_ABL & 1)) stage2_store<LD, LH, LW, VEC>(xr, lds, c, cc, lane, wave);
+    if (!(BW_ABL & 1)) stage2_store<LD, LH, LW, VEC, FCKP, XS>(xr, lds, c, cc, lane, wave);
     if (!(BW_ABL & 2)) finish_y(ycur, ynxt, yok, ynb);
     __syncthreads();
     const int tnext = tile + P.nsg;
     if (tnext < P.ntiles_total) {
       int nb, od0, oh0, ow0; tile_coords(tnext, nb, od0, oh0, ow0);
-      if (!(BW_ABL & 1)) stage2_load<LD, LH, LW, VEC>(xr, c, cc, nb, od0 * SD - PD, oh0 * SH - PH, ow0 * SW - PW, lane, wave);
+      if (!(BW_ABL & 1)) stage2_load<LD, LH, LW, VEC, XS>(xr, c, cc, nb, od0 * SD - PD, oh0 * SH - PH, ow0 * SW - PW, lane, wave);
       if (!(BW_ABL & 2)) issue_y(ynxt, yok, nb, od0, oh0, ow0);
       ynb = nb;
     }
@@ -3482,8 +3562,10 @@ __global__ __launch_bounds__(256) void conv_bwdw_march_kernel(const BwdWParams P
 // Stem backward-weight (Cin = 1): dW[tap][cout] = sum over voxels of x[voxel + tap] * dY[voxel][cout] as a GEMM with
 // M = taps (27 of 32 rows), N = cout, K = voxels: per MFMA one scalar LDS read (lane = tap, voxel parity) and one coalesced
 // dY load (lane = cout, voxel parity).  dY is streamed exactly once; persistent workgroups, fixed-order reduction.
+// YS: storage type of dY (fp32 | bf16)
+template <int YS = MT_F32>
 __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P) {
-  constexpr int TD = 2, TH = 4, TW = 32, LH = TH + 2, LW = TW + 2;
+  constexpr int TD = 2, TH = 4, TW = 32, LH = TH + 2, LW = TW + 2, YE = mt_ebytes<YS>();
   __shared__ float xs[(TD + 2) * LH * LW];
   __shared__ float red[3 * 16 * 64];
   const mt_conv3d_t& c = P.c;
@@ -3496,7 +3578,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P)
   const int tap = li < 27 ? li : 26;
   const int dm = wave >> 1, r0 = (wave & 1) * 2;
   const int xlane = ((dm + tap / 9) * LH + r0 + (tap / 3) % 3) * LW + tap % 3 + lhalf;
-  const int ylane = (co < c.Cout) ? (lhalf * Y.cs + co) * 4 : (int)0x80000000;
+  const int ylane = (co < c.Cout) ? (lhalf * Y.cs + co) * YE : (int)0x80000000;
   const size_t ysample = (size_t)c.Do * c.Ho * c.Wo * Y.cs;
   f32x16 acc;
 #pragma unroll
@@ -3511,18 +3593,19 @@ __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P)
     __syncthreads();
     stem_stage<TD, TH, TW>(xs, c, nb, od0, oh0, ow0, tid);
     __syncthreads();
-    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(Y.ptr + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Y.ptr + (size_t)nb * ysample * YE), 0, (int)(ysample * YE), 0x00020000);
     const int od = od0 + dm;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int oh = oh0 + r0 + m;
       const bool rowok = od < c.Do && oh < c.Ho;                         // wave-uniform
-      const int rowoff = rowok ? ((od * c.Ho + oh) * c.Wo + ow0) * Y.cs * 4 : 0;
+      const int rowoff = rowok ? ((od * c.Ho + oh) * c.Wo + ow0) * Y.cs * YE : 0;
       float b[16];
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const bool ok = rowok && (ow0 + 2 * v + lhalf < c.Wo);
-        b[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ok ? ylane : (int)0x80000000, rowoff + v * 2 * Y.cs * 4, 0));
+        if constexpr (YS == MT_F32) b[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, ok ? ylane : (int)0x80000000, rowoff + v * 2 * Y.cs * 4, 0));
+        else b[v] = mt_from16<YS>(__builtin_amdgcn_raw_buffer_load_b16(yr, ok ? ylane : (int)0x80000000, rowoff + v * 2 * Y.cs * YE, 0));
       }
 #pragma unroll
       for (int v = 0; v < 16; ++v)
@@ -3695,18 +3778,30 @@ static int launch_bwdw_fast(const BwdWParams& P, int vec, hipStream_t st) {
   if (ldsb < BW_RED_LDS(KD * KH * KW)) ldsb = BW_RED_LDS(KD * KH * KW);
   MT_REQUIRE(ldsb <= 160 * 1024, "bwd_weight: LDS tile too large (%zu)", ldsb);
   dim3 grid(P.nsg, P.ncot, P.nchunks);
-#define MT_BW_LAUNCH(TH_, TW_, VEC_)                                                                          \
+#define MT_BW_LAUNCH_K(KFN_)                                                                                  \
   do {                                                                                                        \
-    auto kfn = conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, TH_, TW_, VEC_>;                                 \
+    auto kfn = KFN_;                                                                                          \
     if (ldsb > 64 * 1024) {                                                                                   \
       hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); \
       if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; } \
     }                                                                                                         \
     hipLaunchKernelGGL(kfn, grid, dim3(256), ldsb, st, P);                                                    \
   } while (0)
+  // storage types: X fp32 | fp16 | bf16 (16-bit: channel pairs, vec == 2), dY fp32 | bf16 — the combinations the engine produces
+  const int xs = P.c.src[0].dtype, ys = P.y.dtype;
+#define MT_BW_LAUNCH(TH_, TW_, VEC_)                                                                          \
+  do {                                                                                                        \
+    if (xs == MT_F32 && ys == MT_F32) MT_BW_LAUNCH_K((conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, TH_, TW_, VEC_>)); \
+    else if (VEC_ == 2 && xs == MT_F16 && ys == MT_BF16) MT_BW_LAUNCH_K((conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, TH_, TW_, 2, MT_F16, MT_BF16>)); \
+    else if (VEC_ == 2 && xs == MT_F16 && ys == MT_F32) MT_BW_LAUNCH_K((conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, TH_, TW_, 2, MT_F16, MT_F32>)); \
+    else if (VEC_ == 2 && xs == MT_BF16 && ys == MT_F16) MT_BW_LAUNCH_K((conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, TH_, TW_, 2, MT_BF16, MT_F16>)); \
+    else if (VEC_ == 2 && xs == MT_BF16 && ys == MT_BF16) MT_BW_LAUNCH_K((conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, TH_, TW_, 2, MT_BF16, MT_BF16>)); \
+    else { mt_set_error("bwd_weight: storage types (X %d, dY %d) not compiled into conv_bwdw_fast_kernel", xs, ys); return MT_EINVAL; } \
+  } while (0)
   if (P.TW == 32) { if (vec == 2) MT_BW_LAUNCH(4, 32, 2); else MT_BW_LAUNCH(4, 32, 1); }
   else            { if (vec == 2) MT_BW_LAUNCH(8, 16, 2); else MT_BW_LAUNCH(8, 16, 1); }
 #undef MT_BW_LAUNCH
+#undef MT_BW_LAUNCH_K
   MT_CHECK_LAUNCH("conv_bwdw_fast");
   return MT_OK;
 }
@@ -3785,14 +3880,18 @@ extern "C" int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_
   const int xdt = conv_src_dtype(p);
   if (xdt < 0 || !mt_dtype_ok(ysrc->dtype)) return 0;
   if (xdt == MT_F32 && ysrc->dtype == MT_F32) return 1;
-  if (ysrc->dtype == MT_F16) return 0;                        // gradients are fp32 or bf16
   static int use_fast_q = -1;
   if (use_fast_q < 0) { const char* e = getenv("MT_BWDW_FAST"); use_fast_q = e ? atoi(e) : 1; }
-  if (!use_fast_q || bwdw_is_stem(p, ysrc)) return 0;
+  if (!use_fast_q) return 0;
+  const int ydt = ysrc->dtype;
+  if (bwdw_is_stem(p, ysrc)) return (xdt == MT_F32 && ydt != MT_F16) ? 1 : 0;       // fp32 network input, fp32 | bf16 gradient
   const int geo = bwdw_fast_geo(p, ysrc);
-  if (geo == 0 && bwdw_use_bf16(p)) return 1;
-  if (geo == 6 && bwdw_use_bf16_133(p)) return 1;
-  return 0;
+  if (geo < 0) return 0;
+  if ((geo == 0 && bwdw_use_bf16(p)) || (geo == 6 && bwdw_use_bf16_133(p))) return ydt != MT_F16 ? 1 : 0;   // bf16 Winograd marching kernels
+  if (geo == 0) return 0;                                     // fp32 Winograd / marching kernels: fp32 storage only
+  // conv_bwdw_fast_kernel (strided 3x3x3, transposed-conv weights, 1x1x1, 1x3x3): 16-bit X as channel pairs
+  if (conv_fast_vec(p) != 2) return 0;
+  return ((xdt == MT_F16 && (ydt == MT_BF16 || ydt == MT_F32)) || (xdt == MT_BF16 && (ydt == MT_F16 || ydt == MT_BF16))) ? 1 : 0;
 }
 
 extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, float* dw, long s_ci, long s_co,
@@ -3823,7 +3922,8 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     if (workspace == nullptr || workspace_bytes < need) { mt_set_error("bwd_weight: workspace %zu < %zu", workspace_bytes, need); return MT_EWORKSPACE; }
     P.part = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_bwdw_stem_kernel, dim3(P.nsg, P.ncot, 1), dim3(256), 0, st, P);
+    if (ysrc->dtype == MT_BF16) hipLaunchKernelGGL((conv_bwdw_stem_kernel<MT_BF16>), dim3(P.nsg, P.ncot, 1), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((conv_bwdw_stem_kernel<MT_F32>), dim3(P.nsg, P.ncot, 1), dim3(256), 0, st, P);
     MT_CHECK_LAUNCH("conv_bwdw_stem");
     BwdWReduceParams R;
     R.part = P.part; R.dw = dw; R.Cin = p->Cin; R.Cout = p->Cout; R.KD = 3; R.KH = 3; R.KW = 3;

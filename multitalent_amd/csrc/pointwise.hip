@@ -21,6 +21,37 @@ struct PwKParams {
 #define PW_MAXC 1024   // largest Cin (rounded up to a chunk) whose scale/shift fit the LDS copy
 #define PW_CK 16   // channels per K chunk (packed weight layout 1, ck = 16 — the conv kernels' layout)
 
+// ---- storage types (mt_src_t.dtype, odtype; mt_common.h).  The matrix arithmetic of this file is fp32 either way: a 16-bit source
+// is widened on load (8 channels = ONE 16-byte load instead of two), a 16-bit destination rounded on store.
+// 16-bit output of a 32x32 accumulator tile as channel-pair dwords: the lanes of a channel pair (li even, li odd) trade one value per
+// two accumulator rows, so the EVEN lane holds both channels of voxel row j and the ODD lane both channels of row j + 1.
+__device__ __forceinline__ void pw_pair_exchange(float vj, float vj1, bool odd, float& a, float& b) {
+  const float send = odd ? vj : vj1;
+  const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+  a = odd ? recv : vj;
+  b = odd ? vj1 : recv;
+}
+__device__ __forceinline__ float pw_pair_combine(float s0, float s1, bool odd) {       // per-channel total of sums kept per pair member
+  const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+  const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+  return odd ? s1 + t1 : s0 + t0;
+}
+// 8 consecutive channels of one voxel (byte offset o inside the buffer): two 16-byte loads (fp32) or one (16-bit)
+template <int XS>
+__device__ __forceinline__ void pw_load8(__amdgpu_buffer_rsrc_t r, int o, float (&x)[8]) {
+  if constexpr (XS == MT_F32) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, o + g * 16, 0, 0));
+      x[4 * g] = t[0]; x[4 * g + 1] = t[1]; x[4 * g + 2] = t[2]; x[4 * g + 3] = t[3];
+    }
+  } else {
+    const uint4 t = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 0));
+    x[0] = mt_lo16<XS>(t.x); x[1] = mt_hi16<XS>(t.x); x[2] = mt_lo16<XS>(t.y); x[3] = mt_hi16<XS>(t.y);
+    x[4] = mt_lo16<XS>(t.z); x[5] = mt_hi16<XS>(t.z); x[6] = mt_lo16<XS>(t.w); x[7] = mt_hi16<XS>(t.w);
+  }
+}
+
 // One wave = 32 base voxels x 32 output channels x NT taps.  Lane (i, h) holds channels 8h..8h+7 of voxel i for the current
 // 16-channel chunk (one 32-byte vector straight from global memory, lazy InstanceNorm+LeakyReLU applied in registers), so a
 // chunk costs 8 MFMAs per tap with no LDS traffic at all; every tap of a transposed conv accumulates into its own
@@ -29,8 +60,9 @@ struct PwKParams {
 #ifndef PW_ABL
 #define PW_ABL 0      // timing ablations of pw_fast_kernel: 1 no stores, 2 no weight-fragment loads, 4 no MFMAs
 #endif
-template <int NT, int VEC>
+template <int NT, int VEC, int XS = MT_F32, int OS = MT_F32>
 __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
+  constexpr int XE = mt_ebytes<XS>(), OE = mt_ebytes<OS>();     // bytes per stored element
   const mt_pointwise_t& c = P.c;
   __shared__ float red[4 * 32 * 2];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -65,9 +97,9 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   int wb, hb, db;
   row_dhw(li, db, hb, wb);
   const size_t in_sample = (size_t)c.Di * c.Hi * c.Wi * S.cs;
-  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0,
-                                                                (int)(in_sample * 4), 0x00020000);
-  const int aoff = vok ? ((((db * c.siD) * c.Hi + hb * c.siH) * c.Wi + wb * c.siW) * S.cs + 8 * lhalf) * 4 : (int)0x80000000;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (size_t)nb * in_sample * XE), 0,
+                                                                (int)(in_sample * XE), 0x00020000);
+  const int aoff = vok ? ((((db * c.siD) * c.Hi + hb * c.siH) * c.Wi + wb * c.siW) * S.cs + 8 * lhalf) * XE : (int)0x80000000;
   const bool aff = S.scale != nullptr;
   const float slope = S.slope;
   const bool lrelu_ok = (slope >= 0.f) && (slope <= 1.f);
@@ -83,8 +115,10 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   }
 
   auto load_a = [&](int ch, float (&x)[8]) {
-    const int o = aoff + ch * (PW_CK * 4);
-    if constexpr (VEC == 4) {
+    const int o = aoff + ch * (PW_CK * XE);
+    if constexpr (XS != MT_F32) {
+      pw_load8<XS>(ra, o, x);
+    } else if constexpr (VEC == 4) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, o + g * 16, 0, 0));
@@ -164,8 +198,8 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   const float bias = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
   const int Ho = c.Hb * c.soH, Wo = c.Wb * c.soW, Do = c.Db * c.soD;
   const size_t out_sample = (size_t)Do * Ho * Wo * c.ocs;
-  __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out + (size_t)nb * out_sample), 0,
-                                                                (int)(out_sample * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out + (size_t)nb * out_sample * OE), 0,
+                                                                (int)(out_sample * OE), 0x00020000);
   if constexpr (NT >= 4 && VEC == 4) {
     // Wide epilogue of the transposed convolutions (soW == 2, the wave's 32 base voxels in one row, <= 32 even output channels):
     // the two kw taps of a (kd, kh) pair are 64 CONSECUTIVE output voxels.  The dword stores of the plain epilogue (one per
@@ -193,25 +227,35 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
         __builtin_amdgcn_wave_barrier();
         if (wok && P.wide == 2) {
           // dense output (channel stride == Cout): the pair's 64 voxels are ONE run of 64 * Cout floats
-          const int rowbase = ((((db0 * c.soD + tdd) * Ho + hb0 * c.soH + th) * Wo + wb0 * 2) * c.Cout) * 4;
-          const int n2 = 32 * c.Cout;                        // 8-byte units
+          const int rowbase = ((((db0 * c.soD + tdd) * Ho + hb0 * c.soH + th) * Wo + wb0 * 2) * c.Cout) * OE;
+          const int n2 = 32 * c.Cout;                        // channel pairs: 8-byte units (fp32) / dwords (16-bit)
           for (int u = lane; u < n2; u += 64) {
             const int e = 2 * u, ov = e / c.Cout, cc = e - ov * c.Cout;      // (Cout even: a unit never straddles two voxels)
             const float2 h = *(const float2*)(sg + ov * 32 + cc);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, h), ro, rowbase + u * 8, 0, 0);
+            if constexpr (OS == MT_F32) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, h), ro, rowbase + u * 8, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(mt_pk16<OS>(h.x, h.y), ro, rowbase + u * 4, 0, 0);
           }
         } else if (wok) {
-          const int rowbase = ((((db0 * c.soD + tdd) * Ho + hb0 * c.soH + th) * Wo + wb0 * 2) * c.ocs) * 4;      // bytes
+          const int rowbase = ((((db0 * c.soD + tdd) * Ho + hb0 * c.soH + th) * Wo + wb0 * 2) * c.ocs) * OE;      // bytes
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const int ov = pv + 8 * k;
             const f32x4 v = *(const f32x4*)(sg + ov * 32 + pc);
-            const int o = rowbase + (ov * c.ocs + pc) * 4;
-            if (pc + 4 <= c.Cout)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ro, o, 0, 0);
-            else if (pc + 2 <= c.Cout) {
-              float2 h; h.x = v[0]; h.y = v[1];
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, h), ro, o, 0, 0);
+            const int o = rowbase + (ov * c.ocs + pc) * OE;
+            if constexpr (OS == MT_F32) {
+              if (pc + 4 <= c.Cout)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), ro, o, 0, 0);
+              else if (pc + 2 <= c.Cout) {
+                float2 h; h.x = v[0]; h.y = v[1];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, h), ro, o, 0, 0);
+              }
+            } else {
+              if (pc + 4 <= c.Cout) {
+                uint2 h; h.x = mt_pk16<OS>(v[0], v[1]); h.y = mt_pk16<OS>(v[2], v[3]);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, h), ro, o, 0, 0);
+              } else if (pc + 2 <= c.Cout) {
+                __builtin_amdgcn_raw_buffer_store_b32(mt_pk16<OS>(v[0], v[1]), ro, o, 0, 0);
+              }
             }
           }
         }
@@ -220,6 +264,45 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
       return;
     }
   }
+  float s1 = 0.f, s2 = 0.f;
+  if constexpr (OS != MT_F32) {
+    // 16-bit destination: channel-pair dwords (pw_pair_exchange) — even lanes store accumulator row j, odd lanes row j + 1
+    const bool odd = li & 1;
+    const int coe = co & ~1;
+    const bool pvalid = coe + 1 < c.Cout;                 // (Cout, ocs even: mt_pointwise_io_supported)
+    int pbase[8];
+#pragma unroll
+    for (int jp = 0; jp < 8; ++jp) {
+      const int j = 2 * jp;
+      const int iv = (j & 3) + 8 * (j >> 2) + 4 * lhalf + (odd ? 1 : 0);
+      const long v = m0 + iv;
+      int w2, h2, d2;
+      row_dhw(iv, d2, h2, w2);
+      const bool ok = pvalid && v < P.Vb;
+      pbase[jp] = ok ? ((((d2 * c.soD) * Ho + h2 * c.soH) * Wo + w2 * c.soW) * c.ocs + coe) * 2 : (int)0x80000000;
+    }
+    float q1[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int tg = tap0 + t;
+      const int tw = tg % c.soW, th = (tg / c.soW) % c.soH, tdd = tg / (c.soW * c.soH);
+      const int toff = ((tdd * Ho + th) * Wo + tw) * c.ocs * 2;
+#pragma unroll
+      for (int jp = 0; jp < 8; ++jp) {
+        float a, b;
+        pw_pair_exchange(acc[t][2 * jp] + bias, acc[t][2 * jp + 1] + bias, odd, a, b);
+        if (c.accumulate) { const unsigned pv = __builtin_amdgcn_raw_buffer_load_b32(ro, pbase[jp], toff, 0); a += mt_lo16<OS>(pv); b += mt_hi16<OS>(pv); }
+        const unsigned pk = mt_pk16<OS>(a, b);
+        __builtin_amdgcn_raw_buffer_store_b32(pk, ro, pbase[jp], toff, 0);
+        if (c.stats_part != nullptr && pbase[jp] >= 0) {
+          const float ar = mt_lo16<OS>(pk), br = mt_hi16<OS>(pk);
+          q1[0] += ar; q2[0] = fmaf(ar, ar, q2[0]); q1[1] += br; q2[1] = fmaf(br, br, q2[1]);
+        }
+      }
+    }
+    s1 = pw_pair_combine(q1[0], q1[1], odd);
+    s2 = pw_pair_combine(q2[0], q2[1], odd);
+  } else {
   int obase[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -230,7 +313,6 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
     const bool ok = covalid && v < P.Vb;
     obase[j] = ok ? ((((d2 * c.soD) * Ho + h2 * c.soH) * Wo + w2 * c.soW) * c.ocs + co) * 4 : (int)0x80000000;
   }
-  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int tg = tap0 + t;
@@ -243,6 +325,7 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, obase[j], toff, 0);
       if (c.stats_part != nullptr && obase[j] >= 0) { s1 += val; s2 = fmaf(val, val, s2); }
     }
+  }
   }
   if (c.stats_part != nullptr) {
     s1 += __shfl_xor(s1, 32, 64);
@@ -413,6 +496,7 @@ __global__ __launch_bounds__(256) void head_flip_accumulate_kernel(const HeadAcc
 extern "C" int mt_head_flip_accumulate(const mt_pointwise_t* p, int sample, int flipD, int flipH, int flipW, int nonlin, float weight,
                                        float* acc, int first, mt_stream_t stream) {
   MT_REQUIRE(p != nullptr && acc != nullptr, "head_flip_accumulate: null pointers");
+  MT_REQUIRE(p->src.dtype == MT_F32, "head_flip_accumulate: fp32 source only (convert with mt_cast)");
   MT_REQUIRE(p->siD == 1 && p->siH == 1 && p->siW == 1 && p->soD == 1 && p->soH == 1 && p->soW == 1 && p->Db == p->Di && p->Hb == p->Hi &&
              p->Wb == p->Wi, "head_flip_accumulate: 1x1x1 stride-1 head only");
   MT_REQUIRE(p->Cout >= 1 && p->Cout <= 64 && p->src.C == p->Cin && sample >= 0 && sample < p->N, "head_flip_accumulate: needs 1..64 output channels");
@@ -583,6 +667,7 @@ __global__ __launch_bounds__(256) void head_mirror_accumulate_kernel(const HeadM
 extern "C" int mt_head_mirror_accumulate(const mt_pointwise_t* p, int sample0, int nsamples, const int32_t* flips, int nonlin, float weight,
                                          const float* gauss, float* agg, float* nb, long aX, long aY, long aZ, int x0, int y0, int z0,
                                          mt_stream_t stream) {
+  MT_REQUIRE(p == nullptr || p->src.dtype == MT_F32, "head_mirror_accumulate: fp32 source only (convert with mt_cast)");
   MT_REQUIRE(p != nullptr && agg != nullptr && flips != nullptr, "head_mirror_accumulate: null pointers");
   MT_REQUIRE(p->siD == 1 && p->siH == 1 && p->siW == 1 && p->soD == 1 && p->soH == 1 && p->soW == 1 && p->Db == p->Di && p->Hb == p->Hi &&
              p->Wb == p->Wi, "head_mirror_accumulate: 1x1x1 stride-1 head only");
@@ -615,7 +700,9 @@ extern "C" int mt_pointwise_stats_blocks(const mt_pointwise_t* p) {
 // computes both channel tiles from one read of the input, transposes its 128 x Cout block through LDS and writes it as ONE linear run
 // of 16-byte stores (128 * 47 * 4 = 24 064 contiguous bytes).  Requires V % 32 == 0, unit strides, no accumulation / statistics.
 #define PWH_MAXCO 64
+template <int XS = MT_F32>
 __global__ __launch_bounds__(256) void pw_head_kernel(const PwKParams P) {
+  constexpr int XE = mt_ebytes<XS>();
   const mt_pointwise_t& c = P.c;
   __shared__ __attribute__((aligned(16))) float ssc[PW_MAXC], ssh[PW_MAXC];
   __shared__ __attribute__((aligned(16))) float stage[4][32 * PWH_MAXCO];
@@ -628,8 +715,8 @@ __global__ __launch_bounds__(256) void pw_head_kernel(const PwKParams P) {
   const mt_src_t& S = c.src;
   const bool wok = m0 < P.Vb;                              // (whole waves: V % 32 == 0)
   const size_t in_sample = (size_t)P.Vb * S.cs;
-  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0, (int)(in_sample * 4), 0x00020000);
-  const int aoff = wok ? (int)(((m0 + li) * S.cs + 8 * lhalf) * 4) : (int)0x80000000;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (size_t)nb * in_sample * XE), 0, (int)(in_sample * XE), 0x00020000);
+  const int aoff = wok ? (int)(((m0 + li) * S.cs + 8 * lhalf) * XE) : (int)0x80000000;
   const bool aff = S.scale != nullptr;
   const float slope = S.slope;
   if (aff) {
@@ -644,19 +731,15 @@ __global__ __launch_bounds__(256) void pw_head_kernel(const PwKParams P) {
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
-  f32x4 xa[2], xn[2];
-  auto load_a = [&](int ch, f32x4 (&x)[2]) {
-    const int o = aoff + ch * (PW_CK * 4);
-    x[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, o, 0, 0));
-    x[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, o + 16, 0, 0));
-  };
+  float xa[8], xn[8];
+  auto load_a = [&](int ch, float (&x)[8]) { pw_load8<XS>(ra, aoff + ch * (PW_CK * XE), x); };
   load_a(0, xa);
   for (int ch = 0; ch < P.nchunks; ++ch) {
     if (ch + 1 < P.nchunks) load_a(ch + 1, xn);
     const int cb = ch * PW_CK + 8 * lhalf;
     float x[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = xa[e >> 2][e & 3];
+    for (int e = 0; e < 8; ++e) x[e] = xa[e];
     if (aff) {
       const f32x4 sc0 = *(const f32x4*)(ssc + cb), sc1 = *(const f32x4*)(ssc + cb + 4);
       const f32x4 sh0 = *(const f32x4*)(ssh + cb), sh1 = *(const f32x4*)(ssh + cb + 4);
@@ -680,7 +763,8 @@ __global__ __launch_bounds__(256) void pw_head_kernel(const PwKParams P) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[4 + e], b1[e], acc[t], 0, 0, 0);
     }
-    xa[0] = xn[0]; xa[1] = xn[1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xa[e] = xn[e];
   }
   // ---- epilogue: [32 voxels][Cout] of this wave through LDS, then a linear run of 16-byte stores
   float* sg = stage[wave];
@@ -715,8 +799,62 @@ __global__ __launch_bounds__(256) void pw_head_kernel(const PwKParams P) {
 // 32-byte pieces of 120-byte rows (2.7 TB/s); here a thread owns a voxel: its row is one contiguous run (consecutive lanes = consecutive
 // rows: the wave reads 7.5 KiB linearly), the lazy InstanceNorm+LeakyReLU and CIN x Cout multiply-adds run on the vector ALU
 // (60 FMAs per 120 bytes: far below the bandwidth bound), W / scale / shift come from LDS as broadcast reads.
-template <int CIN>
+// a dense CIN-channel row (byte offset o) as 16-byte loads + tail; CIN % 2 == 0
+template <int CIN, int XS>
+__device__ __forceinline__ void pw_load_row(__amdgpu_buffer_rsrc_t r, int o, float (&x)[CIN + 2]) {
+  if constexpr (XS == MT_F32) {
+#pragma unroll
+    for (int q = 0; q < CIN / 4; ++q) {
+      const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, o + q * 16, 0, 0));
+      x[4 * q] = t[0]; x[4 * q + 1] = t[1]; x[4 * q + 2] = t[2]; x[4 * q + 3] = t[3];
+    }
+    if constexpr ((CIN % 4) != 0) {
+      const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, o + (CIN / 4) * 16, 0, 0));
+      x[CIN - 2] = t.x; x[CIN - 1] = t.y;
+    }
+  } else {
+    constexpr int ND = CIN / 2;            // dwords of the row
+    unsigned d[ND + 3];
+#pragma unroll
+    for (int q = 0; q < ND / 4; ++q) {
+      const uint4 t = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, o + q * 16, 0, 0));
+      d[4 * q] = t.x; d[4 * q + 1] = t.y; d[4 * q + 2] = t.z; d[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int q = (ND / 4) * 4; q < ND; ++q) d[q] = __builtin_amdgcn_raw_buffer_load_b32(r, o + q * 4, 0, 0);
+#pragma unroll
+    for (int q = 0; q < ND; ++q) { x[2 * q] = mt_lo16<XS>(d[q]); x[2 * q + 1] = mt_hi16<XS>(d[q]); }
+  }
+}
+template <int CIN, int OS>
+__device__ __forceinline__ void pw_store_row(__amdgpu_buffer_rsrc_t r, int o, const float (&x)[CIN + 2]) {
+  if constexpr (OS == MT_F32) {
+#pragma unroll
+    for (int q = 0; q < CIN / 4; ++q) {
+      f32x4 t; t[0] = x[4 * q]; t[1] = x[4 * q + 1]; t[2] = x[4 * q + 2]; t[3] = x[4 * q + 3];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, t), r, o + q * 16, 0, 0);
+    }
+    if constexpr ((CIN % 4) != 0) {
+      float2 t; t.x = x[CIN - 2]; t.y = x[CIN - 1];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, t), r, o + (CIN / 4) * 16, 0, 0);
+    }
+  } else {
+    constexpr int ND = CIN / 2;
+    unsigned d[ND + 3];
+#pragma unroll
+    for (int q = 0; q < ND; ++q) d[q] = mt_pk16<OS>(x[2 * q], x[2 * q + 1]);
+#pragma unroll
+    for (int q = 0; q < ND / 4; ++q) {
+      uint4 t; t.x = d[4 * q]; t.y = d[4 * q + 1]; t.z = d[4 * q + 2]; t.w = d[4 * q + 3];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, t), r, o + q * 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = (ND / 4) * 4; q < ND; ++q) __builtin_amdgcn_raw_buffer_store_b32(d[q], r, o + q * 4, 0, 0);
+  }
+}
+template <int CIN, int XS = MT_F32>
 __global__ __launch_bounds__(256) void pw_narrow_kernel(const PwKParams P) {
+  constexpr int XE = mt_ebytes<XS>();
   const mt_pointwise_t& c = P.c;
   __shared__ __attribute__((aligned(16))) float sw[4][CIN + 2], ssc[CIN + 2], ssh[CIN + 2];
   const int tid = threadIdx.x;
@@ -739,20 +877,11 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(const PwKParams P) {
 #pragma unroll
   for (int co = 0; co < 4; ++co) bias[co] = (c.bias != nullptr && co < c.Cout) ? c.bias[co] : 0.f;
   const size_t in_sample = (size_t)P.Vb * CIN;
-  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0, (int)(in_sample * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (size_t)nb * in_sample * XE), 0, (int)(in_sample * XE), 0x00020000);
   float* outp = c.out + (size_t)nb * P.Vb * c.Cout;
   for (long v = (long)blockIdx.x * 256 + tid; v < P.Vb; v += (long)gridDim.x * 256) {
     float x[CIN + 2];
-    const int o = (int)(v * (CIN * 4));
-#pragma unroll
-    for (int q = 0; q < CIN / 4; ++q) {
-      const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, o + q * 16, 0, 0));
-      x[4 * q] = t[0]; x[4 * q + 1] = t[1]; x[4 * q + 2] = t[2]; x[4 * q + 3] = t[3];
-    }
-    if constexpr ((CIN % 4) != 0) {
-      const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra, o + (CIN / 4) * 16, 0, 0));
-      x[CIN - 2] = t.x; x[CIN - 1] = t.y;
-    }
+    pw_load_row<CIN, XS>(ra, (int)(v * (CIN * XE)), x);
     float y[4] = {bias[0], bias[1], bias[2], bias[3]};
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci) {
@@ -768,18 +897,36 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(const PwKParams P) {
   }
 }
 static bool pw_narrow_ok(const mt_pointwise_t* p, const PwKParams& P) {
-  return P.ntaps == 1 && p->siD == 1 && p->siH == 1 && p->siW == 1 && p->Cout <= 4 && (p->Cin == 30 || p->Cin == 32) && p->src.cs == p->Cin &&
+  return P.ntaps == 1 && p->soD * p->soH * p->soW == 1 && p->siD == 1 && p->siH == 1 && p->siW == 1 && p->Cout <= 4 && (p->Cin == 30 || p->Cin == 32) && p->src.cs == p->Cin &&
          p->ocs == p->Cout && !p->accumulate && p->stats_part == nullptr && p->Di == p->Db && p->Hi == p->Hb && p->Wi == p->Wb &&
          (p->src.slope >= 0.f && p->src.slope <= 1.f) && ((((uintptr_t)p->out) & 15) == 0);
 }
 // the dense-output head form (pw_head_kernel): 1x1x1, unit strides, 33..64 output channels written densely, whole waves of voxels
 static bool pw_head_ok(const mt_pointwise_t* p, const PwKParams& P) {
-  return P.ntaps == 1 && p->siD == 1 && p->siH == 1 && p->siW == 1 && p->Cout > 32 && p->Cout <= PWH_MAXCO && p->ocs == p->Cout &&
+  return P.ntaps == 1 && p->soD * p->soH * p->soW == 1 && p->siD == 1 && p->siH == 1 && p->siW == 1 && p->Cout > 32 && p->Cout <= PWH_MAXCO && p->ocs == p->Cout &&
          !p->accumulate && p->stats_part == nullptr && (P.Vb % 32) == 0 && p->Di == p->Db && p->Hi == p->Hb && p->Wi == p->Wb &&
          ((((uintptr_t)p->out) & 15) == 0) && ((P.Vb * p->Cout) % 4 == 0);
 }
+// Storage types mt_pointwise_fwd takes natively (mt_pointwise_t.src.dtype -> odtype): fp32 -> fp32 always; a 16-bit source needs an even
+// channel stride and a dword-aligned base (its 8-channel groups are 16-byte loads on dword boundaries), a 16-bit destination even Cout /
+// channel stride and a dword-aligned base (channel-pair dwords).  Combinations: fp16 -> fp16 | fp32 (forward over activations),
+// bf16 -> bf16 | fp32 and fp32 -> bf16 (backward-data over gradients).
+extern "C" int mt_pointwise_io_supported(const mt_pointwise_t* p) {
+  if (p == nullptr) return 0;
+  const int xs = p->src.dtype, os = p->odtype;
+  if (!mt_dtype_ok(xs) || !mt_dtype_ok(os)) return 0;
+  if (xs == MT_F32 && os == MT_F32) return 1;
+  if (mt_is16(xs) && ((p->src.cs & 1) || (((uintptr_t)p->src.ptr) & 3))) return 0;
+  if (mt_is16(os) && ((p->Cout & 1) || (p->ocs & 1) || (((uintptr_t)p->out) & 3))) return 0;
+  if (xs == MT_F16) return os == MT_F16 || os == MT_F32;
+  if (xs == MT_BF16) return os == MT_BF16 || os == MT_F32;
+  return os == MT_BF16;                       // fp32 source (the loss gradient) into a bf16 gradient
+}
 extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   MT_REQUIRE(p != nullptr, "pointwise: null params");
+  MT_REQUIRE(mt_pointwise_io_supported(p), "pointwise: storage types (src %d, out %d) not taken (ask mt_pointwise_io_supported, convert with mt_cast)", p->src.dtype, p->odtype);
+  const int xs = p->src.dtype, os = p->odtype;
+  const bool any16 = xs != MT_F32 || os != MT_F32;
   MT_REQUIRE(p->N > 0 && p->Db > 0 && p->Hb > 0 && p->Wb > 0 && p->Cin > 0 && p->Cout > 0, "pointwise: empty problem");
   MT_REQUIRE(p->siD >= 1 && p->siD <= 2 && p->siH >= 1 && p->siH <= 2 && p->siW >= 1 && p->siW <= 2, "pointwise: input stride must be 1 or 2");
   MT_REQUIRE(p->soD >= 1 && p->soD <= 2 && p->soH >= 1 && p->soH <= 2 && p->soW >= 1 && p->soW <= 2, "pointwise: output stride must be 1 or 2");
@@ -788,12 +935,12 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   MT_REQUIRE(p->src.ptr && p->wpack && p->out, "pointwise: null pointers");
   PwKParams P;
   P.c = *p;
-  P.ntaps = p->soD * p->soH * p->soW;
+  P.ntaps = p->scatter ? 1 : p->soD * p->soH * p->soW;       // scatter: only tap (0,0,0) exists (one packed tap)
   P.nchunks = mt_cdiv(p->Cin, PW_CK);
   P.Vb = (long)p->Db * p->Hb * p->Wb;
   P.nsb = mt_cdiv(P.Vb, 128);
   MT_REQUIRE((double)p->Di * p->Hi * p->Wi * p->src.cs * 4.0 < 2147483648.0 &&
-             (double)P.Vb * P.ntaps * p->ocs * 4.0 < 2147483648.0, "pointwise: sample larger than 2 GiB");
+             (double)P.Vb * (p->soD * p->soH * p->soW) * p->ocs * 4.0 < 2147483648.0, "pointwise: sample larger than 2 GiB");
   MT_REQUIRE(P.ntaps == 1 || P.ntaps == 2 || P.ntaps == 4 || P.ntaps == 8, "pointwise: unsupported tap count %d", P.ntaps);
   MT_REQUIRE(P.nchunks * PW_CK <= PW_MAXC, "pointwise: Cin = %d exceeds %d", p->Cin, PW_MAXC);
   {
@@ -802,8 +949,8 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
     const bool shape_ok = use_wide && P.ntaps >= 4 && p->soW == 2 && p->soH == 2 && (p->Wb % 32) == 0 && p->Cout <= 32 && (p->Cout % 2) == 0 &&
                           !p->accumulate && p->stats_part == nullptr && p->siD == 1 && p->siH == 1 && p->siW == 1;
     P.wide = 0;
-    if (shape_ok && p->ocs == p->Cout && ((((uintptr_t)p->out) & 7) == 0)) P.wide = 2;                       // dense output: linear 8-byte stores
-    else if (shape_ok && (p->ocs % 4) == 0 && ((((uintptr_t)p->out) & 15) == 0)) P.wide = 1;                 // concat slot: 16-byte pieces per voxel
+    if (shape_ok && p->ocs == p->Cout && ((((uintptr_t)p->out) & 7) == 0)) P.wide = 2;                       // dense output: linear 8-byte (fp32) / 4-byte (16-bit) stores
+    else if (shape_ok && (p->ocs % 4) == 0 && ((((uintptr_t)p->out) & 15) == 0)) P.wide = 1;                 // concat slot: 16 / 8-byte pieces per voxel
   }
   const mt_src_t& S = p->src;
   // 16-byte loads whatever the alignment: a raw buffer_load_dwordx4 only needs dword alignment and range-checks per dword
@@ -811,29 +958,42 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   static int force_vec = -1;
   if (force_vec < 0) { const char* e = getenv("MT_PW_VEC"); force_vec = e ? atoi(e) : 0; }
   int vec = 4;
-  if (force_vec == 1 || force_vec == 2 || force_vec == 4) vec = force_vec;
+  if (!any16 && (force_vec == 1 || force_vec == 2 || force_vec == 4)) vec = force_vec;
   if (vec == 2 && !((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0)) vec = 1;
   hipStream_t st = (hipStream_t)stream;
   {
     static int use_head = -1;
     if (use_head < 0) { const char* e = getenv("MT_PW_HEAD"); use_head = e ? atoi(e) : 1; }
-    if (use_head && pw_narrow_ok(p, P)) {
+    if (use_head && os == MT_F32 && pw_narrow_ok(p, P)) {
       long blocks = (P.Vb + 255) / 256; if (blocks > 4096) blocks = 4096;
-      if (p->Cin == 30) hipLaunchKernelGGL(pw_narrow_kernel<30>, dim3((unsigned)blocks, (unsigned)p->N), dim3(256), 0, st, P);
-      else hipLaunchKernelGGL(pw_narrow_kernel<32>, dim3((unsigned)blocks, (unsigned)p->N), dim3(256), 0, st, P);
+      const dim3 g2((unsigned)blocks, (unsigned)p->N);
+#define PW_NARROW(CIN_) do { if (xs == MT_F16) hipLaunchKernelGGL((pw_narrow_kernel<CIN_, MT_F16>), g2, dim3(256), 0, st, P);           \
+                             else if (xs == MT_BF16) hipLaunchKernelGGL((pw_narrow_kernel<CIN_, MT_BF16>), g2, dim3(256), 0, st, P);    \
+                             else hipLaunchKernelGGL((pw_narrow_kernel<CIN_, MT_F32>), g2, dim3(256), 0, st, P); } while (0)
+      if (p->Cin == 30) PW_NARROW(30); else PW_NARROW(32);
+#undef PW_NARROW
       MT_CHECK_LAUNCH("pointwise_narrow");
       return MT_OK;
     }
-    if (use_head && pw_head_ok(p, P)) {
-      hipLaunchKernelGGL(pw_head_kernel, dim3((unsigned)(P.nsb * p->N)), dim3(256), 0, st, P);
+    if (use_head && os == MT_F32 && pw_head_ok(p, P)) {
+      const dim3 g1((unsigned)(P.nsb * p->N));
+      if (xs == MT_F16) hipLaunchKernelGGL((pw_head_kernel<MT_F16>), g1, dim3(256), 0, st, P);
+      else if (xs == MT_BF16) hipLaunchKernelGGL((pw_head_kernel<MT_BF16>), g1, dim3(256), 0, st, P);
+      else hipLaunchKernelGGL((pw_head_kernel<MT_F32>), g1, dim3(256), 0, st, P);
       MT_CHECK_LAUNCH("pointwise_head");
       return MT_OK;
     }
   }
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
+#define PW_LAUNCH_T(NT, XS_, OS_) hipLaunchKernelGGL((pw_fast_kernel<NT, 4, XS_, OS_>), grid, dim3(256), 0, st, P)
 #define PW_LAUNCH(NT)                                                                              \
   do {                                                                                             \
-    if (vec == 4) hipLaunchKernelGGL((pw_fast_kernel<NT, 4>), grid, dim3(256), 0, st, P);           \
+    if (xs == MT_F16 && os == MT_F16) PW_LAUNCH_T(NT, MT_F16, MT_F16);                             \
+    else if (xs == MT_F16) PW_LAUNCH_T(NT, MT_F16, MT_F32);                                        \
+    else if (xs == MT_BF16 && os == MT_BF16) PW_LAUNCH_T(NT, MT_BF16, MT_BF16);                    \
+    else if (xs == MT_BF16) PW_LAUNCH_T(NT, MT_BF16, MT_F32);                                      \
+    else if (os == MT_BF16) PW_LAUNCH_T(NT, MT_F32, MT_BF16);                                      \
+    else if (vec == 4) hipLaunchKernelGGL((pw_fast_kernel<NT, 4>), grid, dim3(256), 0, st, P);      \
     else if (vec == 2) hipLaunchKernelGGL((pw_fast_kernel<NT, 2>), grid, dim3(256), 0, st, P);      \
     else hipLaunchKernelGGL((pw_fast_kernel<NT, 1>), grid, dim3(256), 0, st, P);                    \
   } while (0)
@@ -850,6 +1010,7 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
     }
   }
 #undef PW_LAUNCH
+#undef PW_LAUNCH_T
   MT_CHECK_LAUNCH("pointwise");
   return MT_OK;
 }
@@ -873,8 +1034,10 @@ struct HeadBwdParams {
   const float* wpack; float* dx; int dxcs; int accumulate_dx;
   float* part; int nwaves; long ntiles;
 };
-template <int NCI>
+// XS: storage type of the head's input x (fp32 | fp16 | bf16); OS: of dX (fp32 | bf16).  dY (the loss gradient) is fp32.
+template <int NCI, int XS = MT_F32, int OS = MT_F32>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
+  constexpr int XE = mt_ebytes<XS>(), OE = mt_ebytes<OS>();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lhalf = lane >> 5;
@@ -922,8 +1085,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
     }
     const size_t ysample = (size_t)P.V * P.dycs, xsample = (size_t)P.V * S.cs, dsample = (size_t)P.V * P.dxcs;
     __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dy + (size_t)nb * ysample), 0, (int)(ysample * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * xsample), 0, (int)(xsample * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dx + (size_t)nb * dsample), 0, (int)(dsample * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (size_t)nb * xsample * XE), 0, (int)(xsample * XE), 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)P.dx + (size_t)nb * dsample * OE), 0, (int)(dsample * OE), 0x00020000);
     // ---- dX = dY W^T: A operand = this lane's voxel row of dY, channels 16 ch + 8 lhalf .. +7
     const long bv = m0 + li;
     const bool vok = bv < P.V;
@@ -966,8 +1129,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
 #pragma unroll
       for (int t = 0; t < NCI; ++t) {
         const int ci = t * 32 + li;
-        const int o = (in && ci < P.Cin) ? (int)((v * S.cs + ci) * 4) : (int)0x80000000;
-        const float raw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        const int o = (in && ci < P.Cin) ? (int)((v * S.cs + ci) * XE) : (int)0x80000000;
+        float raw;
+        if constexpr (XS == MT_F32) raw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        else raw = mt_from16<XS>(__builtin_amdgcn_raw_buffer_load_b16(rx, o, 0, 0));
         const float tt = fmaf(raw, xsc[t], xsh[t]);
         av[t] = in ? fmaxf(tt, tt * slope) : 0.f;
         if (ones_free && t == NCI - 1 && li == 31) av[t] = in ? 1.f : 0.f;
@@ -988,6 +1153,19 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
 #pragma unroll
     for (int t = 0; t < NCI; ++t) {
       const int ci = t * 32 + li;
+      if constexpr (OS != MT_F32) {          // channel-pair dwords (pw_pair_exchange): even lanes row j, odd lanes row j + 1; Cin, dxcs even
+        const bool odd = li & 1;
+        const int cie = ci & ~1;
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+          const long v = m0 + (j & 3) + 8 * (j >> 2) + 4 * lhalf + (odd ? 1 : 0);
+          const int o = (cie + 1 < P.Cin && v < P.V) ? (int)((v * P.dxcs + cie) * 2) : (int)0x80000000;
+          float a, b;
+          pw_pair_exchange(ax[t][j], ax[t][j + 1], odd, a, b);
+          if (P.accumulate_dx) { const unsigned pv = __builtin_amdgcn_raw_buffer_load_b32(rd, o, 0, 0); a += mt_lo16<OS>(pv); b += mt_hi16<OS>(pv); }
+          __builtin_amdgcn_raw_buffer_store_b32(mt_pk16<OS>(a, b), rd, o, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const long v = m0 + (j & 3) + 8 * (j >> 2) + 4 * lhalf;
@@ -995,6 +1173,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
         float val = ax[t][j];
         if (P.accumulate_dx) val += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, o, 0, 0));
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rd, o, 0, 0);
+      }
       }
     }
   }
@@ -1051,8 +1230,9 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_b_kernel(const HeadBwdRed
 // dY[v][co] and dbias[co] = sum_v dY[v][co] in registers over the thread's voxels, reduced over the wave by DPP shuffles and over
 // the workgroup through LDS in a fixed order; one partial row per workgroup, summed in fp64 by head_narrow_reduce_kernel.
 #define HN_BLOCKS 1024
-template <int CIN, int NCO>
+template <int CIN, int NCO, int XS = MT_F32, int OS = MT_F32>
 __global__ __launch_bounds__(256) void head_bwd_narrow_kernel(const HeadBwdParams P) {
+  constexpr int XE = mt_ebytes<XS>(), OE = mt_ebytes<OS>();
   constexpr int NP = NCO * CIN + NCO;                       // partial sums per thread: dW rows, then dbias
   __shared__ __attribute__((aligned(16))) float sw[NCO][CIN + 2], ssc[CIN + 2], ssh[CIN + 2];
   __shared__ float red[4][NP];
@@ -1077,32 +1257,14 @@ __global__ __launch_bounds__(256) void head_bwd_narrow_kernel(const HeadBwdParam
     }
     __syncthreads();
     const size_t xs = (size_t)P.V * CIN;
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * xs), 0, (int)(xs * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(P.dx + (size_t)nb * xs), 0, (int)(xs * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (size_t)nb * xs * XE), 0, (int)(xs * XE), 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)P.dx + (size_t)nb * xs * OE), 0, (int)(xs * OE), 0x00020000);
     const float* dyp = P.dy + (size_t)nb * P.V * P.dycs;
     for (long v = b * 256 + tid; v < P.V; v += per_sample_blocks * 256) {
       float x[CIN + 2], old[CIN + 2], dy[NCO];
-      const int o = (int)(v * (CIN * 4));
-#pragma unroll
-      for (int q = 0; q < CIN / 4; ++q) {
-        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, o + q * 16, 0, 0));
-        x[4 * q] = t[0]; x[4 * q + 1] = t[1]; x[4 * q + 2] = t[2]; x[4 * q + 3] = t[3];
-      }
-      if constexpr ((CIN % 4) != 0) {
-        const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra, o + (CIN / 4) * 16, 0, 0));
-        x[CIN - 2] = t.x; x[CIN - 1] = t.y;
-      }
-      if (P.accumulate_dx) {
-#pragma unroll
-        for (int q = 0; q < CIN / 4; ++q) {
-          const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o + q * 16, 0, 0));
-          old[4 * q] = t[0]; old[4 * q + 1] = t[1]; old[4 * q + 2] = t[2]; old[4 * q + 3] = t[3];
-        }
-        if constexpr ((CIN % 4) != 0) {
-          const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rx, o + (CIN / 4) * 16, 0, 0));
-          old[CIN - 2] = t.x; old[CIN - 1] = t.y;
-        }
-      }
+      pw_load_row<CIN, XS>(ra, (int)(v * (CIN * XE)), x);
+      const int o = (int)(v * (CIN * OE));
+      if (P.accumulate_dx) pw_load_row<CIN, OS>(rx, o, old);
 #pragma unroll
       for (int co = 0; co < NCO; ++co) dy[co] = co < P.Cout ? dyp[v * P.dycs + co] : 0.f;
       float dx[CIN + 2];
@@ -1120,15 +1282,7 @@ __global__ __launch_bounds__(256) void head_bwd_narrow_kernel(const HeadBwdParam
       }
 #pragma unroll
       for (int co = 0; co < NCO; ++co) part[NCO * CIN + co] += dy[co];
-#pragma unroll
-      for (int q = 0; q < CIN / 4; ++q) {
-        f32x4 t; t[0] = dx[4 * q]; t[1] = dx[4 * q + 1]; t[2] = dx[4 * q + 2]; t[3] = dx[4 * q + 3];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, t), rx, o + q * 16, 0, 0);
-      }
-      if constexpr ((CIN % 4) != 0) {
-        float2 t; t.x = dx[CIN - 2]; t.y = dx[CIN - 1];
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, t), rx, o + (CIN / 4) * 16, 0, 0);
-      }
+      pw_store_row<CIN, OS>(rx, o, dx);
     }
   }
   // wave reduction (fixed butterfly), then the four waves through LDS in wave order
@@ -1183,10 +1337,20 @@ extern "C" size_t mt_head_bwd_workspace(int N, long V, int Cin, int Cout) {
   const size_t narrow = (Cout <= 4) ? (size_t)HN_BLOCKS * (4 * 32 + 4) * sizeof(float) : 0;      // head_bwd_narrow_kernel: one partial row per workgroup
   return wide > narrow ? wide : narrow;
 }
+// storage types mt_head_bwd takes natively: x fp32 with dX fp32; x fp16 or bf16 with dX bf16 (even Cin and channel strides, dword-aligned
+// bases); dY is the fp32 loss gradient
+extern "C" int mt_head_bwd_io_supported(int xdtype, int xcs, int dxdtype, int dxcs, int Cin, int Cout) {
+  if (xdtype == MT_F32 && dxdtype == MT_F32) return 1;
+  if (!(mt_is16(xdtype) && dxdtype == MT_BF16)) return 0;
+  return ((Cin & 1) || (xcs & 1) || (dxcs & 1)) ? 0 : 1;
+}
 extern "C" int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, long V, int Cin, int Cout, const float* wpack_bwd,
-                           float* dx, int dxcs, int accumulate_dx, float* dw, long s_ci, long s_co, float* dbias, int accumulate_dw,
+                           float* dx, int dxcs, int dxdtype, int accumulate_dx, float* dw, long s_ci, long s_co, float* dbias, int accumulate_dw,
                            int* dbias_done, void* ws, size_t ws_bytes, mt_stream_t stream) {
   MT_REQUIRE(x && x->ptr && dy && wpack_bwd && dx && dw && N > 0 && V > 0, "head_bwd: null / empty argument");
+  MT_REQUIRE(mt_head_bwd_io_supported(x->dtype, x->cs, dxdtype, dxcs, Cin, Cout) && !(((uintptr_t)x->ptr) & 3) && !(((uintptr_t)dx) & 3),
+             "head_bwd: storage types (x %d, dX %d) not taken (ask mt_head_bwd_io_supported, convert with mt_cast)", x->dtype, dxdtype);
+  const int xs = x->dtype;
   MT_REQUIRE(Cin >= 1 && Cin <= 64 && Cout >= 1 && Cout <= 64, "head_bwd: Cin (%d) and Cout (%d) must be <= 64", Cin, Cout);
   MT_REQUIRE(x->C == Cin, "head_bwd: x->C != Cin");
   MT_REQUIRE((double)V * x->cs * 4.0 < 2147483648.0 && (double)V * dycs * 4.0 < 2147483648.0 && (double)V * dxcs * 4.0 < 2147483648.0, "head_bwd: sample larger than 2 GiB");
@@ -1199,10 +1363,14 @@ extern "C" int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, 
     const int per_sample = HN_BLOCKS / N > 0 ? HN_BLOCKS / N : 1, nblocks = per_sample * N;
     MT_REQUIRE((size_t)nblocks * np * sizeof(float) <= ws_bytes, "head_bwd: workspace too small for the narrow form");
     hipStream_t st = (hipStream_t)stream;
-    if (Cin == 30 && nco == 2) hipLaunchKernelGGL((head_bwd_narrow_kernel<30, 2>), dim3(nblocks), dim3(256), 0, st, P);
-    else if (Cin == 30) hipLaunchKernelGGL((head_bwd_narrow_kernel<30, 4>), dim3(nblocks), dim3(256), 0, st, P);
-    else if (nco == 2) hipLaunchKernelGGL((head_bwd_narrow_kernel<32, 2>), dim3(nblocks), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((head_bwd_narrow_kernel<32, 4>), dim3(nblocks), dim3(256), 0, st, P);
+#define HBN(CIN_, NCO_) do { if (xs == MT_F16) hipLaunchKernelGGL((head_bwd_narrow_kernel<CIN_, NCO_, MT_F16, MT_BF16>), dim3(nblocks), dim3(256), 0, st, P);          \
+                             else if (xs == MT_BF16) hipLaunchKernelGGL((head_bwd_narrow_kernel<CIN_, NCO_, MT_BF16, MT_BF16>), dim3(nblocks), dim3(256), 0, st, P);   \
+                             else hipLaunchKernelGGL((head_bwd_narrow_kernel<CIN_, NCO_>), dim3(nblocks), dim3(256), 0, st, P); } while (0)
+    if (Cin == 30 && nco == 2) HBN(30, 2);
+    else if (Cin == 30) HBN(30, 4);
+    else if (nco == 2) HBN(32, 2);
+    else HBN(32, 4);
+#undef HBN
     hipLaunchKernelGGL(head_narrow_reduce_kernel, dim3(np), dim3(64), 0, st, (const float*)ws, nblocks, np, Cin, Cout, nco, dw, s_ci, s_co, dbias, accumulate_dw);
     MT_CHECK_LAUNCH("head_bwd_narrow");
     if (dbias_done != nullptr) *dbias_done = 1;
@@ -1211,8 +1379,11 @@ extern "C" int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, 
   P.nwaves = head_bwd_waves(N, V); P.ntiles = (long)N * ((V + 31) / 32);
   const int nci = (Cin + 31) / 32;
   hipStream_t st = (hipStream_t)stream;
-  if (nci == 1) hipLaunchKernelGGL(head_bwd_kernel<1>, dim3(P.nwaves / 4), dim3(256), 0, st, P);
-  else          hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(P.nwaves / 4), dim3(256), 0, st, P);
+#define HB(NCI_) do { if (xs == MT_F16) hipLaunchKernelGGL((head_bwd_kernel<NCI_, MT_F16, MT_BF16>), dim3(P.nwaves / 4), dim3(256), 0, st, P);          \
+                      else if (xs == MT_BF16) hipLaunchKernelGGL((head_bwd_kernel<NCI_, MT_BF16, MT_BF16>), dim3(P.nwaves / 4), dim3(256), 0, st, P);   \
+                      else hipLaunchKernelGGL((head_bwd_kernel<NCI_>), dim3(P.nwaves / 4), dim3(256), 0, st, P); } while (0)
+  if (nci == 1) HB(1); else HB(2);
+#undef HB
   MT_CHECK_LAUNCH("head_bwd");
   HeadBwdReduce R;
   R.part = (const float*)ws; R.nwaves = P.nwaves; R.nci = nci; R.Cin = Cin; R.Cout = Cout; R.dw = dw; R.s_ci = s_ci; R.s_co = s_co;

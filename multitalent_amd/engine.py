@@ -62,7 +62,13 @@ class ConvNormOp(_Op):
         self.stride = tuple(conv.stride)
         self.pad = tuple(conv.padding)
         self.slope = LRELU_DEFAULT
-        self.pointwise = pointwise   # 1x1x1 (possibly strided) conv on the pointwise kernel
+        self.pointwise = pointwise   # 1x1x1 conv on the pointwise kernel (heads)
+        # strided 1x1x1 skip projection of a residual block (conv_blocks.py:159-165): forward = the pointwise kernel gathering every
+        # stride-th voxel, backward-data = the pointwise kernel scattering to those voxels (mt_pointwise_t.scatter), backward-weight =
+        # the tiled kernel.  (Until round 3 all three ran on the runtime-geometry convolution kernels.)
+        self._pw_strided_geom = (not pointwise and self.kernel == (1, 1, 1) and self.stride != (1, 1, 1) and self.pad == (0, 0, 0)
+                                 and len(srcs) == 1 and os.environ.get('MT_PW_STRIDED', '1') != '0')
+        self.pw_strided = False      # decided in plan(): the input size must be a multiple of the stride (the scatter's output grid)
         self.bwd_part = None         # (partials, first column): first pass of this layer's norm backward, fused into the last writer of out.grad
 
     def inputs(self):
@@ -82,6 +88,7 @@ class ConvNormOp(_Op):
         self.geom = ConvGeom(sp, self.kernel, self.stride, self.pad)
         self.out.spatial = self.geom.out
         Cout = self.conv.out_channels
+        self.pw_strided = self._pw_strided_geom and tuple(o * st for o, st in zip(self.geom.out, self.stride)) == tuple(self.geom.inp)
         self.mma = eng.op_mma(self.geom.out)          # bf16 matrix inputs for this layer (forward, backward-data and backward-weight)
         buf = eng.buffer(self.name + '.y', (N,) + self.geom.out + (Cout,), self._out_dtype(eng))
         if self.norm is not None:
@@ -99,7 +106,7 @@ class ConvNormOp(_Op):
         """storage types of the forward launch: the operands as they are where the kernel takes them, fp32 copies elsewhere (Engine.io)"""
         Cout = self.conv.out_channels
         acts = [s.act for s in self.srcs]
-        if self.pointwise:
+        if self.pointwise or self.pw_strided:
             def build(ins, outs):
                 a = ins[0]
                 return ops.fill_pointwise(a, self.geom.out, a.spatial, self.stride, (1, 1, 1), Cout, eng.dummy, self.conv.bias, outs[0])
@@ -112,7 +119,7 @@ class ConvNormOp(_Op):
         io = io if io is not None else self._fwd_io(eng)
         p = io.build()
         if self.norm is not None and self.part is None:
-            nsb = ops.pointwise_stats_blocks(p) if self.pointwise else ops.conv_stats_blocks(p)
+            nsb = ops.pointwise_stats_blocks(p) if (self.pointwise or self.pw_strided) else ops.conv_stats_blocks(p)
             self.part = eng.buffer(self.name + '.part', (io.ins[0].N, nsb, Cout, 2))
         if self.part is not None:
             p.stats_part = self.part.data_ptr()
@@ -126,6 +133,11 @@ class ConvNormOp(_Op):
         if self.pointwise:
             self.wf = ops.pack_conv_weights(w, C0, 0, Cout, (1, 1, 1), _strides(w), False, ops.POINTWISE_CK, out=self.wf)
             if need_bwd and self.srcs[0].grad is not None and self.stride == (1, 1, 1):
+                self.wb = ops.pack_conv_weights(w, Cout, 0, C0, (1, 1, 1), _strides(w, as_bwd_data=True), False, ops.POINTWISE_CK, out=self.wb)
+            return
+        if self.pw_strided:
+            self.wf = ops.pack_conv_weights(w, C0, 0, Cout, (1, 1, 1), _strides(w), False, ops.POINTWISE_CK, out=self.wf)
+            if need_bwd and self.srcs[0].grad is not None:
                 self.wb = ops.pack_conv_weights(w, Cout, 0, C0, (1, 1, 1), _strides(w, as_bwd_data=True), False, ops.POINTWISE_CK, out=self.wb)
             return
         p = self._fwd_params(eng)
@@ -189,7 +201,7 @@ class ConvNormOp(_Op):
         p = self._fwd_params(eng, io)
         p.wpack = self.wf.data_ptr()
         io.pre()
-        if self.pointwise:
+        if self.pointwise or self.pw_strided:
             ops.pointwise_fwd(p)
         else:
             ops.conv3d_fwd(p)
@@ -255,6 +267,25 @@ class ConvNormOp(_Op):
                         ops.pointwise_io_supported, grad_ins=True)
             p = io.build()
             p.accumulate = io.accumulate(acc)
+            io.pre()
+            ops.pointwise_fwd(p)
+            io.post(acc)
+        elif self.pw_strided:
+            # dX[stride * m] (+)= W^T dY[m]; the other voxels of X receive nothing from this convolution
+            s0 = self.srcs[0]
+            if not acc:
+                s0.grad.zero_()
+                acc = True
+
+            def build(ins, outs):
+                p = ops.fill_pointwise(ins[0], self.geom.out, self.geom.out, (1, 1, 1), self.stride, s0.C, self.wb, None, outs[0])
+                p.scatter = 1
+                return p
+            io = eng.io(self.name + '.bwdd', [gact], [Act(s0.grad)], build, ops.pointwise_io_supported, grad_ins=True)
+            p = io.build()
+            p.accumulate = io.accumulate(acc)
+            for t, _ in io._cout:
+                t.buf.zero_()                    # (an fp32 copy of the destination: the scatter only writes every stride-th voxel)
             io.pre()
             ops.pointwise_fwd(p)
             io.post(acc)

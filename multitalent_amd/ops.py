@@ -303,8 +303,7 @@ def conv_bwd_weight_io_supported(p, y):
 
 
 def pointwise_io_supported(p):
-    """mt_pointwise_fwd reads and writes fp32 only (for now): bf16 operands go through cast()."""
-    return p.src.dtype == _lib.MT_F32 and p.odtype == _lib.MT_F32
+    return bool(_lib.load().mt_pointwise_io_supported(C.byref(p)))
 
 
 def cast(src, dst, accumulate=False):
@@ -368,18 +367,17 @@ def head_bwd(x, dy, wpack_bwd, dx, accumulate_dx, dw, s_ci, s_co, dbias, accumul
     """Fused backward of a 1x1x1 head: x = Act (head input, lazy), dy = Act over the dense gradient of the logits, dx = Act over the
     gradient buffer of the head's input.  Returns True when dbias was produced (see mt_head_bwd)."""
     lib = _lib.load()
-    assert x.dt == dy.dt == dx.dt == _lib.MT_F32, "mt_head_bwd reads and writes fp32 (convert with cast())"
+    assert dy.dt == _lib.MT_F32, "mt_head_bwd reads the fp32 loss gradient"
     xs = x.src()
     done = C.c_int(0)
     _lib.check(lib.mt_head_bwd(C.byref(xs), C.c_void_p(dy.data_ptr()), dy.cs, x.N, x.V, x.C, dy.C, _ptr(wpack_bwd),
-                               C.c_void_p(dx.data_ptr()), dx.cs, int(accumulate_dx), _ptr(dw), int(s_ci), int(s_co), _ptr(dbias),
+                               C.c_void_p(dx.data_ptr()), dx.cs, dx.dt, int(accumulate_dx), _ptr(dw), int(s_ci), int(s_co), _ptr(dbias),
                                int(accumulate_dw), C.byref(done), _ptr(ws), ws.numel() * ws.element_size(), _stream()), 'head_bwd')
     return bool(done.value)
 
 
 def head_bwd_io_supported(x, dx, Cout):
-    """mt_head_bwd reads and writes fp32 only (for now)"""
-    return x.dt == _lib.MT_F32 and dx.dt == _lib.MT_F32
+    return bool(_lib.load().mt_head_bwd_io_supported(x.dt, x.cs, dx.dt, dx.cs, x.C, int(Cout)))
 
 
 def head_bwd_workspace(N, V, Cin, Cout):

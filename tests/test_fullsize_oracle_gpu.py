@@ -263,13 +263,15 @@ def _resenc_fp32_and_bf16(dev):
         assert mx < (0.12 if lowest else 0.06) and l2 < (0.10 if lowest else 0.05), "bf16 logits level %d: %.3f of max, rel. L2 %.4f" % (i, mx, l2)
     for a, b in zip(lossb, rl):
         assert abs(a - float(b)) < 1e-2 * max(1.0, abs(float(b))), (lossb, [float(r) for r in rl])
-    # r3: with ALL five outputs weighted (MultiTalent_meets_resenc.py:157-170; until r2 this test masked the 3x6x6 level) the bf16
-    # gradient of this B = 1 problem sits at cos 0.90 of the exact one (0.984 without that level: 108 voxels per channel average
-    # very little rounding noise, and the whole deep half of the network hangs off that output) — recorded, bounded, and listed in
-    # DESIGN.md as the open weakness of the mixed-precision mode; fp32 stays the parity path
-    assert cos > 0.87, cos
+    # r3: with ALL five outputs weighted (MultiTalent_meets_resenc.py:157-170) the r3 mode — bf16 operands everywhere — sat at cos 0.90
+    # of the exact gradient and the bound had been lowered to 0.87.  r4: the direction of the gradient hangs on the LeakyReLU decisions
+    # of the FORWARD pass (a voxel whose pre-activation crosses zero passes or blocks its gradient hundredfold), i.e. on the forward
+    # rounding noise; with fp16 activations and fp16 forward products (the reference's autocast type, 11 significand bits) and bf16
+    # only in the backward products the same measurement gives 0.979 (tools/bf16_accuracy.py; bf16 activations: 0.856) — the
+    # round-2 bound is back
+    assert cos > 0.975, cos
     # per-tensor direction for the big convolution weights (every one of them went through a bf16 kernel somewhere)
     worst = min(((float((gb[n].double().reshape(-1) * sd[n].grad.reshape(-1)).sum() / (gb[n].double().norm() * sd[n].grad.norm() + 1e-30)), n)
                  for n in gb if n.endswith('.weight') and gb[n].dim() == 5 and gb[n].numel() > 50000), key=lambda t: t[0])
     print("   worst per-tensor gradient cosine of the large conv weights: %.4f (%s)" % worst)
-    assert worst[0] > 0.75, worst
+    assert worst[0] > 0.93, worst          # (r3: 0.825; measured 0.964)

@@ -429,3 +429,233 @@ def test_unsupported_storage_types_are_refused(dev):
     ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
     with pytest.raises(RuntimeError, match="storage types"):
         ops.conv3d_bwd_weight(p, y, dw, ops.conv_weight_strides(dw), False, ws)
+
+
+# ---- pointwise kernels (transposed convolutions, heads, their backward-data), gather, tiled backward-weight, stem: fp32 arithmetic with
+# ---- 16-bit storage -> bit-exact against the fp32-storage launch of the same kernel family, rounded
+def _pointwise(dev, x, lazy, w_pack_args, base, in_spatial, si, so, Cout, bias, xdt, odt, ocs=None, prev=None, scatter=False, stats=False):
+    ops = _ops()
+    xb = x.to(dev).to(xdt)
+    a = ops.Act(xb) if lazy is None else ops.Act(xb, scale=lazy[0].to(dev), shift=lazy[1].to(dev), slope=lazy[2])
+    N = x.shape[0]
+    osp = tuple(b * s for b, s in zip(base, so))
+    ocs = Cout if ocs is None else ocs
+    out = (prev.to(dev) if prev is not None else torch.full((N,) + osp + (ocs,), float('nan'))).to(dev).to(odt)
+    w, Cin, taps, strides = w_pack_args
+    wd = w.to(dev).contiguous()
+    wp = ops.pack_conv_weights(wd, Cin, 0, Cout, taps, strides(wd), False, ops.POINTWISE_CK)
+    bd = bias.to(dev) if bias is not None else None
+    p = ops.fill_pointwise(a, base, in_spatial, si, so, Cout, wp, bd, ops.Act(out, 0, Cout), accumulate=prev is not None)
+    p.scatter = 1 if scatter else 0
+    part = None
+    if stats:
+        part = torch.zeros((N, ops.pointwise_stats_blocks(p), Cout, 2), device=dev)
+        p.stats_part = part.data_ptr()
+    assert ops.pointwise_io_supported(p), (xdt, odt)
+    ops.pointwise_fwd(p)
+    torch.cuda.synchronize()
+    return out, part
+
+
+@pytest.mark.parametrize("Cin,Cout,base,k,ocs_mult", [
+    (60, 30, (4, 8, 32), (2, 2, 2), 1),       # dense output, whole rows: wide epilogue, linear stores
+    (60, 30, (4, 8, 32), (2, 2, 2), 2),       # into a concat slot (channel stride 2 * Cout); 30 % 4 != 0 -> plain epilogue
+    (64, 32, (4, 8, 32), (2, 2, 2), 2),       # concat slot, wide epilogue with 8-byte pieces
+    (120, 60, (3, 5, 9), (2, 2, 2), 1),       # ragged: plain epilogue, two output-channel tiles
+    (60, 30, (5, 6, 16), (1, 2, 2), 1),
+])
+def test_transposed_conv_fp16_storage_bitexact(dev, Cin, Cout, base, k, ocs_mult):
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    N = 2
+    x = rbf(torch.randn((N,) + base + (Cin,), generator=g), torch.float16)
+    lazy = (torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)
+    w = torch.randn((Cin, Cout) + k, generator=g) / np.sqrt(Cin)
+    wargs = (w, Cin, k, lambda wd: ops.conv_weight_strides(wd, transposed_layout=True))
+    o32, _ = _pointwise(dev, x, lazy, wargs, base, base, (1, 1, 1), k, Cout, None, torch.float32, torch.float32, ocs=Cout * ocs_mult)
+    o16, _ = _pointwise(dev, x, lazy, wargs, base, base, (1, 1, 1), k, Cout, None, torch.float16, torch.float16, ocs=Cout * ocs_mult)
+    assert torch.equal(o16[..., :Cout], o32[..., :Cout].to(torch.float16))
+
+
+@pytest.mark.parametrize("Cin,Cout", [(30, 47), (30, 2), (32, 3), (60, 47), (120, 20)])
+def test_heads_read_fp16_activations(dev, Cin, Cout):
+    """pw_head_kernel (33..64 logits), pw_narrow_kernel (<= 4), pw_fast_kernel: fp16 input, fp32 logits — the same fp32 arithmetic"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(32)
+    N, base = 2, (4, 8, 16)
+    x = rbf(torch.randn((N,) + base + (Cin,), generator=g), torch.float16)
+    lazy = (torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)
+    w = torch.randn((Cout, Cin, 1, 1, 1), generator=g) / np.sqrt(Cin)
+    b = torch.randn(Cout, generator=g)
+    wargs = (w, Cin, (1, 1, 1), lambda wd: ops.conv_weight_strides(wd))
+    o32, _ = _pointwise(dev, x, lazy, wargs, base, base, (1, 1, 1), (1, 1, 1), Cout, b, torch.float32, torch.float32)
+    o16, _ = _pointwise(dev, x, lazy, wargs, base, base, (1, 1, 1), (1, 1, 1), Cout, b, torch.float16, torch.float32)
+    assert torch.equal(o16, o32)
+
+
+@pytest.mark.parametrize("stride", [(2, 2, 2), (1, 2, 2)])
+def test_strided_projection_pointwise_forward_and_scatter_backward(dev, stride):
+    """the strided 1x1x1 skip projection of a residual block (conv_blocks.py:159-165) on the pointwise kernel: forward gathers every
+    stride-th voxel (fp16 -> fp16 with statistics), backward-data scatters to them (mt_pointwise_t.scatter, bf16 -> bf16 accumulating)"""
+    import torch.nn.functional as F
+    ops = _ops()
+    g = torch.Generator().manual_seed(33)
+    N, Cin, Cout, shape = 2, 30, 60, (6, 12, 16)
+    osp = tuple(-(-s // st) for s, st in zip(shape, stride))
+    x = rbf(torch.randn((N,) + shape + (Cin,), generator=g), torch.float16)
+    w = torch.randn((Cout, Cin, 1, 1, 1), generator=g) / np.sqrt(Cin)
+    wargs = (w, Cin, (1, 1, 1), lambda wd: ops.conv_weight_strides(wd))
+    o16, part = _pointwise(dev, x, None, wargs, osp, shape, stride, (1, 1, 1), Cout, None, torch.float16, torch.float16, stats=True)
+    ref = F.conv3d(x.permute(0, 4, 1, 2, 3), w, None, stride=stride).permute(0, 2, 3, 4, 1)
+    assert float((o16.float().cpu() - ref).abs().max()) < 2.0 ** -10 * float(ref.abs().max()) + 1e-6
+    o = o16.float().double()
+    sm = part.double().sum(1)
+    assert torch.allclose(sm[..., 0], o.sum((1, 2, 3)), rtol=1e-4, atol=1e-3 * o[0, ..., 0].numel() ** 0.5)
+    assert torch.allclose(sm[..., 1], (o * o).sum((1, 2, 3)), rtol=1e-4)
+    # backward-data: dX[stride * m] += W^T dY[m]
+    dy = rbf(torch.randn((N,) + osp + (Cout,), generator=g))
+    prev = rbf(torch.randn((N,) + shape + (Cin,), generator=g))
+    wb = (w, Cout, (1, 1, 1), lambda wd: ops.conv_weight_strides(wd, as_bwd_data=True))
+    d16, _ = _pointwise(dev, dy, None, wb, osp, osp, (1, 1, 1), stride, Cin, None, torch.bfloat16, torch.bfloat16, prev=prev, scatter=True)
+    xr = torch.zeros((N, Cin) + shape, requires_grad=True)
+    F.conv3d(xr, w, None, stride=stride).backward(dy.permute(0, 4, 1, 2, 3).contiguous())
+    want = prev + xr.grad.permute(0, 2, 3, 4, 1)
+    got = d16.float().cpu()
+    assert float((got - want).abs().max()) < 2.0 ** -7 * float(want.abs().max())
+    untouched = (xr.grad.permute(0, 2, 3, 4, 1) == 0).all(-1)              # voxels the convolution never read keep their old gradient
+    assert torch.equal(got[untouched], prev[untouched])
+
+
+@pytest.mark.parametrize("Cin,Cout", [(30, 47), (30, 2), (32, 4)])
+@pytest.mark.parametrize("acc", [False, True])
+def test_head_backward_fp16_x_bf16_dx_bitexact(dev, Cin, Cout, acc):
+    ops = _ops()
+    g = torch.Generator().manual_seed(34)
+    N, base = 2, (4, 8, 16)
+    V = int(np.prod(base))
+    x = rbf(torch.randn((N,) + base + (Cin,), generator=g), torch.float16)
+    sc, sh = torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g)
+    dy = torch.randn((N,) + base + (Cout,), generator=g)
+    prev = rbf(torch.randn((N,) + base + (Cin,), generator=g))
+    w = torch.randn((Cout, Cin, 1, 1, 1), generator=g) / np.sqrt(Cin)
+    wd = w.to(dev).contiguous()
+    wb = ops.pack_conv_weights(wd, Cout, 0, Cin, (1, 1, 1), ops.conv_weight_strides(wd, as_bwd_data=True), False, ops.POINTWISE_CK)
+    st = ops.conv_weight_strides(wd)
+    res = []
+    for xdt, ddt in ((torch.float32, torch.float32), (torch.float16, torch.bfloat16)):
+        a = ops.Act(x.to(dev).to(xdt), scale=sc.to(dev), shift=sh.to(dev), slope=0.01)
+        dx = (prev if acc else torch.full(prev.shape, float('nan'))).to(dev).to(ddt)
+        dyd = dy.to(dev)
+        assert ops.head_bwd_io_supported(a, ops.Act(dx), Cout)
+        dw = torch.zeros_like(wd)
+        db = torch.zeros(Cout, device=dev)
+        ws = torch.empty(ops.head_bwd_workspace(N, V, Cin, Cout) // 4 + 16, device=dev)
+        done = ops.head_bwd(a, ops.Act(dyd), wb, ops.Act(dx), acc, dw, st[0], st[1], db, False, ws)
+        torch.cuda.synchronize()
+        res.append((dx, dw, db if done else None))
+    assert torch.equal(res[1][0], res[0][0].to(torch.bfloat16))
+    assert torch.equal(res[1][1], res[0][1])
+    if res[0][2] is not None:
+        assert torch.equal(res[1][2], res[0][2])
+
+
+@pytest.mark.parametrize("k", [(2, 2, 2), (1, 2, 2)])
+@pytest.mark.parametrize("acc", [False, True])
+def test_gather_backward_of_transposed_conv_bf16_bitexact(dev, k, acc):
+    ops = _ops()
+    g = torch.Generator().manual_seed(35)
+    N, Ct_in, Ct_out, low = 2, 60, 30, (4, 6, 16)
+    hi = tuple(a * b for a, b in zip(low, k))
+    dy = rbf(torch.randn((N,) + hi + (Ct_out,), generator=g))
+    prev = rbf(torch.randn((N,) + low + (Ct_in,), generator=g))
+    w = torch.randn((Ct_in, Ct_out) + k, generator=g) / np.sqrt(Ct_out * np.prod(k))
+    wd = w.to(dev).contiguous()
+    geom = ops.ConvGeom(hi, k, k, (0, 0, 0))
+    res = []
+    for dt in (torch.float32, torch.bfloat16):
+        dyd = dy.to(dev).to(dt)
+        dx = (prev if acc else torch.full(prev.shape, float('nan'))).to(dev).to(dt)
+        p = ops.fill_conv([ops.Act(dyd)], geom, Ct_in, out0=ops.Act(dx), accumulate=acc)
+        p.csplit = Ct_in
+        assert ops.conv_kernel_name(p).startswith('conv_gather_kernel') and ops.conv_io_supported(p)
+        wp = ops.pack_conv_weights(wd, Ct_out, 0, Ct_in, k, ops.conv_weight_strides(wd, transposed_layout=True, as_bwd_data=True), False, ops.conv_ck(p))
+        p.wpack = wp.data_ptr()
+        ops.conv3d_fwd(p)
+        torch.cuda.synchronize()
+        res.append(dx)
+    assert torch.equal(res[1], res[0].to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("kind", ["strided222", "strided122", "tconv222", "head", "proj222", "k133"])
+def test_tiled_backward_weight_16bit_storage_bitexact(dev, kind):
+    """conv_bwdw_fast_kernel: X / dY widened on load, fp32 products — identical to the fp32-storage launch"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(36)
+    N = 2
+    cfg = {'strided222': ((3, 3, 3), (2, 2, 2), (1, 1, 1), 30, 60, (8, 12, 34), torch.float16, torch.bfloat16, True),
+           'strided122': ((3, 3, 3), (1, 2, 2), (1, 1, 1), 32, 64, (5, 12, 34), torch.float16, torch.bfloat16, True),
+           'tconv222': ((2, 2, 2), (2, 2, 2), (0, 0, 0), 30, 60, (8, 12, 36), torch.bfloat16, torch.float16, False),   # X = dOut, Y = tconv input (lazy)
+           'head': ((1, 1, 1), (1, 1, 1), (0, 0, 0), 60, 47, (4, 8, 34), torch.float16, torch.float32, True),
+           'proj222': ((1, 1, 1), (2, 2, 2), (0, 0, 0), 30, 60, (8, 12, 34), torch.float16, torch.bfloat16, True),
+           'k133': ((1, 3, 3), (1, 1, 1), (0, 1, 1), 30, 30, (4, 8, 12), torch.float16, torch.bfloat16, True)}[kind]
+    k, stride, pad, Cin, Cout, shape, xdt, ydt, xlazy = cfg
+    geom = ops.ConvGeom(shape, k, stride, pad)
+    x = rbf(torch.randn((N,) + shape + (Cin,), generator=g), xdt)
+    y = rbf(torch.randn((N,) + tuple(geom.out) + (Cout,), generator=g), ydt if ydt != torch.float32 else torch.bfloat16)
+    lz = (torch.rand((N, Cin if xlazy else Cout), generator=g) + 0.5, torch.randn((N, Cin if xlazy else Cout), generator=g))
+    res = []
+    for xd, yd in ((torch.float32, torch.float32), (xdt, ydt)):
+        xb, yb = x.to(dev).to(xd), y.to(dev).to(yd)
+        a = ops.Act(xb, scale=lz[0].to(dev), shift=lz[1].to(dev), slope=0.01) if xlazy else ops.Act(xb)
+        ya = ops.Act(yb) if xlazy else ops.Act(yb, scale=lz[0].to(dev), shift=lz[1].to(dev), slope=0.01)
+        p = ops.fill_conv([a], geom, Cout, mma=0)
+        name = ops.conv_bwd_weight_kernel_name(p, ya)
+        assert name.startswith('conv_bwdw_fast_kernel'), name
+        assert ops.conv_bwd_weight_io_supported(p, ya), (name, xd, yd)
+        dw = torch.full((Cout, Cin) + k, float('nan'), device=dev)
+        ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
+        ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
+        torch.cuda.synchronize()
+        res.append(dw)
+    assert torch.isfinite(res[1]).all() and torch.equal(res[0], res[1]), float((res[0] - res[1]).abs().max())
+
+
+def test_stem_kernels_16bit_storage_bitexact(dev):
+    """first convolution (one input channel, fp32 network input): fp16 output with statistics; its backward-weight reads a bf16 dY"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(37)
+    N, Cout, shape = 2, 30, (6, 10, 40)
+    geom = ops.ConvGeom(shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    x = torch.randn((N,) + shape + (1,), generator=g).to(dev)
+    w = torch.randn((Cout, 1, 3, 3, 3), generator=g) / 5
+    b = torch.randn(Cout, generator=g).to(dev)
+    wd = w.to(dev).contiguous()
+    outs = []
+    for odt in (torch.float32, torch.float16):
+        out = torch.full((N,) + shape + (Cout,), float('nan'), device=dev).to(odt)
+        p = ops.fill_conv([ops.Act(x)], geom, Cout, out0=ops.Act(out), bias=b)
+        assert ops.conv_kernel_name(p) == 'conv_stem_kernel' and ops.conv_io_supported(p)
+        wp = ops.pack_conv_weights(wd, 1, 0, Cout, (3, 3, 3), ops.conv_weight_strides(wd), False, ops.conv_ck(p), layout=ops.conv_pack_layout(p))
+        p.wpack = wp.data_ptr()
+        part = torch.zeros((N, ops.conv_stats_blocks(p), Cout, 2), device=dev)
+        p.stats_part = part.data_ptr()
+        ops.conv3d_fwd(p)
+        torch.cuda.synchronize()
+        outs.append((out, part))
+    assert torch.equal(outs[1][0], outs[0][0].to(torch.float16))
+    o = outs[1][0].float().double()
+    sm = outs[1][1].double().sum(1)
+    assert torch.allclose(sm[..., 0], o.sum((1, 2, 3)), rtol=1e-4, atol=1e-3 * o[0, ..., 0].numel() ** 0.5)
+    assert torch.allclose(sm[..., 1], (o * o).sum((1, 2, 3)), rtol=1e-4)
+    dy = rbf(torch.randn((N,) + shape + (Cout,), generator=g))
+    res = []
+    for ydt in (torch.float32, torch.bfloat16):
+        ya = ops.Act(dy.to(dev).to(ydt))
+        p = ops.fill_conv([ops.Act(x)], geom, Cout)
+        assert ops.conv_bwd_weight_kernel_name(p, ya) == 'conv_bwdw_stem_kernel' and ops.conv_bwd_weight_io_supported(p, ya)
+        dw = torch.full((Cout, 1, 3, 3, 3), float('nan'), device=dev)
+        ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
+        ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
+        torch.cuda.synchronize()
+        res.append(dw)
+    assert torch.equal(res[0], res[1])
