@@ -391,24 +391,57 @@ def bench_infer(args, dev, rank, world, ddp, emit=True):
     net.inference_apply_nonlin = nn.Sigmoid()
     vol = np.random.RandomState(7).randn(1, *args.volume).astype(np.float32)
     shard = (rank, world) if world > 1 else None
-    run = lambda: predict_3D(net, vol, bool(args.mirror), (0, 1, 2), True, 0.5, patch, None, True, 'constant', None, True,
-                             False, True, tile_shard=shard, return_device_tensors=True)
-    for _ in range(max(1, min(args.warmup, 1))):
-        run()
-    torch.cuda.synchronize()
-    if ddp:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    if ddp:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if ddp:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    mixed = args.precision == 'bf16'          # predict_3D(mixed_precision=...): the reference's autocast switch
+    mk = lambda mode: (lambda v=vol: predict_3D(net, v, bool(args.mirror), (0, 1, 2), True, 0.5, patch, None, True, 'constant', None, True,
+                                                False, mixed, tile_shard=shard, return_device_tensors=mode))
+
+    def timed(fn):
+        for _ in range(max(1, min(args.warmup, 1))):
+            fn()
+        torch.cuda.synchronize()
+        if ddp:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        if ddp:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if ddp:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            all_reduce_dev(tmax, dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+    run = mk(True)
+    dt_sharded = timed(run)             # result left sharded on the devices (slab per rank)
+    variants, check = None, None
+    if world > 1:
+        # the reference returns a WHOLE (seg, probabilities) per case (predict_MultiTalent.py:222-266): the gathered variant ends with the
+        # whole mask on every rank (one uint8 all_gather: 134 MB at 512^3; the 25 GB of probabilities stay sharded) — that is `value`
+        dt = timed(mk('mask'))
+        variants = {"sharded_volumes_per_min": round(60.0 * args.steps / dt_sharded, 3), "mask_gathered_volumes_per_min": round(60.0 * args.steps / dt, 3),
+                    "value_is": "mask_gathered"}
+        # correctness inside the run: tile-sharded == unsharded on a smaller volume (own slab of the probabilities, whole gathered mask)
+        small = np.random.RandomState(11).randn(1, 160, 256, 256).astype(np.float32)
+        net._sliding_window_cache = None
+        seg1, p1 = predict_3D(net, small, False, (0, 1, 2), True, 0.5, patch, None, True, 'constant', None, True, False, mixed, return_device_tensors=True)
+        seg1, p1 = seg1.clone(), p1.clone()
+        net._sliding_window_cache = None
+        segf, pslab, (x0, x1) = predict_3D(net, small, False, (0, 1, 2), True, 0.5, patch, None, True, 'constant', None, True, False, mixed,
+                                           tile_shard=shard, return_device_tensors='mask')
+        dp = (pslab - p1[:, x0:x1]).abs().max() if x1 > x0 else torch.zeros((), device=dev)
+        stable = (p1 - 0.5).abs().amin(0) > 1e-4                      # voxels away from a decision boundary
+        nm = ((segf != seg1) & stable).sum().double()
+        t = torch.stack([dp.double(), nm])
+        all_reduce_dev(t, dist.ReduceOp.MAX)
+        check = {"volume": [160, 256, 256], "max_abs_probability_difference_sharded_vs_unsharded": float(t[0]),
+                 "mask_mismatches_away_from_ties": int(t[1]), "ok": bool(float(t[0]) < 1e-5 and int(t[1]) == 0)}
+        net._sliding_window_cache = None
+        del seg1, p1, segf, pslab
+        torch.cuda.empty_cache()
+    else:
+        dt = dt_sharded
     groups = None
     if not args.no_roofline:          # every rank repeats one volume with per-launch events (the sharded run exchanges slabs)
         with ConvTimer() as t:
@@ -434,6 +467,9 @@ def bench_infer(args, dev, rank, world, ddp, emit=True):
         stats = getattr(net, '_slab_exchange_stats', None)
         if stats is not None:
             line["comm"] = stats
+        if variants is not None:
+            line["variants"] = variants
+            line["sharded_equals_unsharded"] = check
     else:
         line = None
     del net
@@ -461,7 +497,7 @@ def child_argv(args):
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run and hand over."""
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < n:
+    if have < n and os.environ.get('MT_BENCH_ONE_GPU', '0') != '1':
         raise SystemExit("bench.py --gpus %d: this node exposes %d GPU(s); a data-parallel run needs one rank per GPU" % (n, have))
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
@@ -475,6 +511,17 @@ DEFAULT_BATCH = {'task009': 2, 'task100': 4, 'resenc': 2}
 WORKLOAD_NAMES = {"task009": "Task009_Spleen Generic_UNet nc=2 softmax Dice+CE",
                   "task100": "Task100_MultiTalent Generic_UNet nc=47 MultiTalent BCE+Dice loss",
                   "resenc": "Task100_MultiTalent FabiansUNet (residual encoder) nc=47 MultiTalent BCE+Dice loss"}
+
+
+def all_reduce_dev(t, op):
+    """dist.all_reduce of a small device tensor; through the host when the backend is gloo (MT_BENCH_ONE_GPU test mode)"""
+    if dist.get_backend() == 'gloo' and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
 
 
 def time_training(workload, precision, patch, B, steps, warmup, dev, rank, world, ddp):
@@ -504,11 +551,25 @@ def time_training(workload, precision, patch, B, steps, warmup, dev, rank, world
     dt = time.perf_counter() - t0
     if ddp:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce_dev(tmax, dist.ReduceOp.MAX)
         dt = float(tmax.item())
     loss = res[0] if isinstance(res, tuple) else res
+    comm = step.reducer.stats() if step.reducer is not None else None
+    if ddp:
+        # the ranks must hold bit-identical parameters after the timed steps (same initial weights, all-reduced gradients, the same
+        # optimizer arithmetic): a checksum of the flat parameter buffer, max - min over the ranks, must be exactly 0
+        flat = step.eng.flat
+        cs = torch.stack([flat.double().sum(), flat.double().abs().sum(), (flat.double() * torch.arange(1, flat.numel() + 1, device=flat.device, dtype=torch.float64)).sum()])
+        hi, lo = cs.clone(), cs.clone()
+        all_reduce_dev(hi, dist.ReduceOp.MAX)
+        all_reduce_dev(lo, dist.ReduceOp.MIN)
+        spread = float((hi - lo).abs().max())
+        comm = dict(comm or {})
+        comm['param_checksum_spread_over_ranks'] = spread
+        comm['params_identical_on_all_ranks'] = spread == 0.0
+        comm['loss_finite'] = bool(np.isfinite(float(loss)))
     return {'dt': dt, 'ms': dt / steps * 1e3, 'value': world * B * steps / dt, 'loss': float(loss), 'step': step, 'x': x, 'largs': largs,
-            'net': net, 'comm': step.reducer.stats() if step.reducer is not None else None}
+            'net': net, 'comm': comm}
 
 
 def training_line(r, workload, precision, patch, B, steps, warmup, world):
@@ -557,8 +618,19 @@ def measure_also(args, dev, rank, world, ddp):
     ia.workload, ia.mirror, ia.steps, ia.warmup, ia.no_cpu_baseline, ia.no_traffic, ia.precision = 'infer', 0, 2, 1, True, True, 'fp32'
     e = bench_infer(ia, dev, rank, world, ddp, emit=False)
     if rank == 0:
-        also['infer_512_nomirror'] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "scaling", "comm") if k in e}
+        also['infer_512_nomirror'] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "scaling", "comm", "variants",
+                                                       "sharded_equals_unsharded") if k in e}
     net_cache_clear()
+    if world == 1:
+        # the reference's DEFAULT inference mode — 8-fold mirror TTA (neural_network.py:502-591) — on a smaller volume (45 tiles x 8
+        # mirrored passes; the 512^3 volume takes 17 s per pass in this mode), fp32
+        ia = argparse.Namespace(**vars(args))
+        ia.workload, ia.mirror, ia.steps, ia.warmup, ia.no_cpu_baseline, ia.no_traffic, ia.no_roofline, ia.precision = 'infer', 1, 1, 1, True, True, True, 'fp32'
+        ia.volume = [128, 384, 384]
+        e = bench_infer(ia, dev, rank, world, ddp, emit=False)
+        also['infer_128x384x384_mirror_tta'] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config") if k in e}
+        also['infer_128x384x384_mirror_tta']['network_passes_per_s'] = round(e['config']['tiles'] * 8 / (e['ms_per_step'] * 1e-3), 1)
+        net_cache_clear()
     return also
 
 
@@ -594,12 +666,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # MT_BENCH_ONE_GPU=1 (tests on a one-GPU box): every rank on cuda:0 with gloo as the transport (device tensors of the collectives
+    # travel through the host) — exercises the N > 1 code path, its checks and its JSON; the numbers mean nothing
+    one_gpu = os.environ.get('MT_BENCH_ONE_GPU', '0') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     ddp = world > 1 or ('RANK' in os.environ and int(os.environ.get('MT_FORCE_REDUCER', '0')))
     if ddp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', init_method='env://')
+        dist.init_process_group('gloo' if one_gpu else 'nccl', init_method='env://')
     workload = args.workload or 'task009'      # same per-GPU workload at every N (weak scaling on BASELINE configs[1])
     if workload == 'infer':
         return bench_infer(args, dev, rank, world, ddp)

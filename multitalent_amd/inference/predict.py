@@ -25,10 +25,8 @@ def predict_case_on_device(network, cropped_data, properties, target_spacing, in
     if tile_shard is not None and tile_shard[1] > 1:
         # tiles sharded over the ranks; the export below needs whole x-columns of the probabilities, so the slabs are gathered
         # (every rank then holds the full result)
-        from .sliding_window import gather_slabs
-        _, slab, x_range = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
-                                      'constant', None, True, verbose, True, tile_shard=tile_shard, return_device_tensors=True)
-        _, probs = gather_slabs(None, slab, x_range, int(x.shape[1]), tile_shard[1])
+        _, probs = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
+                              'constant', None, True, verbose, True, tile_shard=tile_shard, return_device_tensors='full')
     else:
         _, probs = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
                               'constant', None, True, verbose, True, return_device_tensors=True)

@@ -83,7 +83,8 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
     """Signature of SegmentationNetwork.predict_3D (neural_network.py:73-76) + `tile_shard=(rank, world)`.
     x: np.ndarray [C, X, Y, Z].  Returns (seg [X,Y,Z], probabilities [num_classes, X, Y, Z]) as numpy.
     With tile_shard and return_device_tensors=True: (seg slab, probabilities slab, (x0, x1)) — this rank's rows [x0, x1) of the
-    result, left on its device (the per-voxel export stage works on slabs)."""
+    result, left on its device (the per-voxel export stage works on slabs); 'mask': (whole seg gathered on every rank — one uint8
+    all_gather —, probabilities slab, (x0, x1)); 'full': whole (seg, probabilities) gathered on every rank's device."""
     assert step_size <= 1, 'step_size must be smaller than 1. Otherwise there will be a gap between consecutive predictions'
     pad_kwargs = {'constant_values': 0} if pad_kwargs is None else pad_kwargs
     if len(mirror_axes):
@@ -170,6 +171,10 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
     _, agg, nb, acc, batch_buf = cache
     agg.zero_(); nb.zero_()
     eng = net.engine()
+    # mixed_precision: the reference runs the forward passes under autocast (neural_network.py:136-137, its predict default) — here the
+    # engine's mixed mode (fp16 activations and forward products); False = fp32, the parity path.  The engine is left as it was found.
+    prev_mma = eng.mma
+    eng.set_precision('bf16' if (mixed_precision and os.environ.get('MT_INFER_MIXED', '1') != '0') else 'fp32')
     was_training = net.training
     with torch.no_grad():
         # all mirrored versions of a tile — and several consecutive tiles — go through the network as ONE batch (per-sample
@@ -202,6 +207,7 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
                     else:
                         ops.flip_accumulate(Act(logits[k:k + 1]), (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
                 ops.tile_accumulate(acc, mult, num_classes, patch_size, agg, nb, local_shape, origin)
+    eng.set_precision(prev_mma)
     if plan is not None:
         # slab ownership: every rank ends with the finished aggregate of ITS x-slab; only the zones where neighbouring ranks'
         # tiles overlap travel (partial sums, added in rank order = the reference's tile order at rank granularity)
@@ -230,9 +236,16 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
         net.train()
     if plan is not None:
         x_range = (c_lo - sx.start, c_hi - sx.start)         # rows of the UNPADDED volume this rank's slab holds
+        if return_device_tensors == 'mask':                  # the whole mask on every rank, probabilities left sharded (bench: gathered variant)
+            full_seg, _ = gather_slabs(seg, None, slab_ranges(plan, sx, world), world)
+            return full_seg, probs, x_range
+        if return_device_tensors == 'full':                  # whole (seg, probabilities) on every rank's device
+            return gather_slabs(seg, probs, slab_ranges(plan, sx, world), world)
         if return_device_tensors:
             return seg, probs, x_range
-        seg, probs = gather_slabs(seg, probs, x_range, sx.stop - sx.start, world)
+        seg, probs = gather_slabs(seg, probs, slab_ranges(plan, sx, world), world)
+    elif return_device_tensors == 'mask':
+        return seg, probs, (0, sx.stop - sx.start)
     elif return_device_tensors:
         return seg, probs
     seg_np = seg.cpu().numpy()
@@ -275,18 +288,27 @@ def exchange_slabs(agg, nb, plan, rank, world, cache=None, stats=None):
     Rank r sends to every q != r the part of its TOUCHED range that q owns (in practice: the half-patch zones shared with its two
     neighbours — 2 x 47 x 24 x 512 x 512 floats at 512^3 instead of the 25 GB aggregate) and folds what it receives into its own
     slab in ascending rank order, starting from zeros, so the result does not depend on arrival order.  `cache` (a dict kept on the
-    network) holds the receive buffers and the finished slab between volumes — no multi-GB device allocation per volume; `stats`
-    (a dict) receives the bytes this rank sent / received and the wall time of the exchange."""
+    network) holds ONE growable buffer per role (receive zones, finished slab) between volumes — no multi-GB device allocation per
+    volume and no growth with the number of distinct volume shapes; the returned (agg, nb) ALIAS those buffers until the next call
+    (clone them to keep a result).  `stats` (a dict) receives the bytes this rank sent / received and the wall time of the exchange."""
     import time
     import torch.distributed as dist
     cache = {} if cache is None else cache
 
     def buf(tag, shape, dev, zero=False):
-        k = (tag, tuple(shape), str(dev))
+        # ONE flat buffer per (tag, device), grown when a volume needs more and viewed at the requested shape: cases differ in shape,
+        # and a cache keyed by shape kept a multi-GB slab per shape ever seen (HBM grew without bound across cases)
+        k = (tag, str(dev))
+        n = 1
+        for d in shape:
+            n *= int(d)
         t = cache.get(k)
-        if t is None:
-            t = cache[k] = torch.empty(shape, dtype=torch.float32, device=dev)
-        return t.zero_() if zero else t
+        if t is None or t.numel() < n:
+            cache.pop(k, None)
+            t = None                     # (release the old allocation before asking for the larger one)
+            t = cache[k] = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        v = t[:n].view(shape)
+        return v.zero_() if zero else v
     if stats is not None and agg.is_cuda:
         torch.cuda.synchronize(agg.device)
     t_start = time.perf_counter()
@@ -339,29 +361,53 @@ def exchange_slabs(agg, nb, plan, rank, world, cache=None, stats=None):
     return fa, fn
 
 
-def gather_slabs(seg, probs, x_range, X, world):
-    """the per-rank slabs -> the whole (seg, probs) on every rank (API mode; the bench leaves the result sharded).  `seg` may be
-    None (callers that classify after their own resampling only need the probabilities): then only `probs` travels."""
+def slab_ranges(plan, slicer_x, world):
+    """rows of the UNPADDED volume each rank's finished slab holds — a pure function of the plan (identical on every rank)"""
+    out = []
+    for q in range(world):
+        o_lo, o_hi = plan['owned'][q]
+        c_lo = max(slicer_x.start, o_lo)
+        c_hi = max(min(slicer_x.stop, o_hi), c_lo)
+        out.append((c_lo - slicer_x.start, c_hi - slicer_x.start))
+    return out
+
+
+def _all_gather_padded(t, ranges, axis, world, via_host):
+    """every rank's slab `t` (rows ranges[rank] along `axis`) -> the whole tensor on every rank: ONE all_gather of equally padded slabs
+    (the reference returns the whole (seg, probabilities) of a case: predict_MultiTalent.py:222-266)"""
     import torch.distributed as dist
-    dev = probs.device
-    via_host = probs.is_cuda and dist.get_backend() == 'gloo'
-    ranges = [None] * world
-    dist.all_gather_object(ranges, tuple(int(i) for i in x_range))
-    full_seg = torch.empty((X,) + tuple(seg.shape[1:]), dtype=seg.dtype, device=dev) if seg is not None else None
-    full_probs = torch.empty((probs.shape[0], X) + tuple(probs.shape[2:]), dtype=probs.dtype, device=dev)
-    me = dist.get_rank()
+    rows = max(1, max(b - a for a, b in ranges))
+    shape = list(t.shape)
+    shape[axis] = rows
+    send = torch.zeros(shape, dtype=t.dtype, device=t.device)
+    send.narrow(axis, 0, t.shape[axis]).copy_(t)
+    if via_host:
+        send = send.cpu()
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send)
+    full_shape = list(t.shape)
+    full_shape[axis] = ranges[-1][1] if ranges else 0
+    full_shape[axis] = max(b for _, b in ranges)
+    full = torch.empty(full_shape, dtype=t.dtype, device=t.device)
     for q, (a, b) in enumerate(ranges):
-        if b <= a:
-            continue
-        p = probs.contiguous() if q == me else torch.empty((probs.shape[0], b - a) + tuple(probs.shape[2:]), dtype=probs.dtype, device=dev)
-        if via_host:
-            p = p.cpu()
-        dist.broadcast(p, q)
-        full_probs[:, a:b] = p.to(dev)
-        if seg is not None:
-            s = seg.contiguous() if q == me else torch.empty((b - a,) + tuple(seg.shape[1:]), dtype=seg.dtype, device=dev)
-            if via_host:
-                s = s.cpu()
-            dist.broadcast(s, q)
-            full_seg[a:b] = s.to(dev)
+        if b > a:
+            full.narrow(axis, a, b - a).copy_(parts[q].narrow(axis, 0, b - a).to(t.device))
+    return full
+
+
+def gather_slabs(seg, probs, ranges, world):
+    """the per-rank slabs -> the whole (seg, probs) on every rank (API mode).  Either may be None: callers that classify after their own
+    resampling only need the probabilities, the benchmark's gathered variant only the mask (uint8: 134 MB for 512^3 instead of 25 GB of
+    47-channel probabilities).  One all_gather per tensor on padded slabs; the row ranges come from the plan (slab_ranges), not from
+    another collective."""
+    import torch.distributed as dist
+    ref = probs if probs is not None else seg
+    via_host = ref.is_cuda and dist.get_backend() == 'gloo'
+    full_seg = full_probs = None
+    if seg is not None:
+        small = seg.dtype in (torch.int32, torch.int64) and (seg.numel() == 0 or int(seg.max()) < 256)      # labels fit a byte: 4x less traffic
+        s8 = seg.to(torch.uint8) if small else seg
+        full_seg = _all_gather_padded(s8.contiguous(), ranges, 0, world, via_host).to(seg.dtype)
+    if probs is not None:
+        full_probs = _all_gather_padded(probs.contiguous(), ranges, 1, world, via_host)
     return full_seg, full_probs

@@ -44,13 +44,16 @@ class GradAllReducer:
                "bucket_bytes": int(self.bucket * 4), "world": self.world}
         if self._ev_wait:
             torch.cuda.synchronize()
-            out["exposed_wait_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in self._ev_wait) / self._steps, 3)
-            out["side_stream_busy_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in self._ev_comm) / self._steps, 3)
+            timed = len(self._ev_wait)          # steps whose events were kept (the first 4096: see begin()); averages are over THOSE steps
+            out["exposed_wait_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in self._ev_wait) / timed, 3)
+            out["side_stream_busy_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in self._ev_comm) / timed, 3)
+            out["timed_steps"] = timed
         return out
 
     def begin(self):
         self.sent = 0
         self.handles = []
+        self._timing = len(self._ev_wait) < 4096     # keep the events of the first 4096 steps only (one decision per step)
         self.on_gpu = self.eng.flat_grad.is_cuda
         active = self.world > 1 or self.force
         # gloo has no device path here: two ranks sharing ONE GPU (the single-GPU test box) or CPU tensors.  Device slices then
@@ -89,7 +92,7 @@ class GradAllReducer:
                     self.handles.append(dist.all_reduce(sl, op=dist.ReduceOp.SUM, async_op=True))
                     self.handles[-1].wait()          # orders the side stream behind the collective (no host block for NCCL work)
                     c1.record(self.stream)
-                if len(self._ev_comm) < 4096:
+                if self._timing:
                     self._ev_comm.append((c0, c1))
             else:       # host tensors (gloo): used by the CPU tests of the bucketing logic
                 sl.div_(self.world)
@@ -117,7 +120,7 @@ class GradAllReducer:
                 h.wait()
             cur.wait_stream(self.stream)
             w1.record(cur)
-            if len(self._ev_wait) < 4096:
+            if self._timing:
                 self._ev_wait.append((w0, w1))
         else:
             for h in self.handles:

@@ -283,6 +283,28 @@ def test_grad_allreducer_side_stream_on_rccl_world1(dev):
     assert p.exitcode == 0 and ret[0] is True
 
 
+@pytest.mark.parametrize("extra", [['--batch', '1'], ['--workload', 'infer', '--mirror', '0', '--volume', '96', '256', '256']])
+def test_bench_two_ranks_self_validation_on_one_gpu(extra):
+    """The N > 1 code path of bench.py with both ranks on cuda:0 and gloo as the transport (MT_BENCH_ONE_GPU=1; a box with one GPU
+    cannot run RCCL with two ranks): the line must carry the correctness signals of a multi-GPU run — bit-identical parameters on all
+    ranks after the timed steps; the tile-sharded sliding window equal to the unsharded one, the mask-gathered variant as `value`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-also', '--no-roofline'] + extra,
+                         capture_output=True, text=True, timeout=1200, env=dict(os.environ, MT_BENCH_ONE_GPU='1'))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and 'comm' in line, line
+    if 'infer' in extra:
+        assert line['sharded_equals_unsharded']['ok'], line['sharded_equals_unsharded']
+        assert line['variants']['value_is'] == 'mask_gathered' and line['variants']['sharded_volumes_per_min'] >= line['value'] * 0.999
+    else:
+        assert line['comm']['params_identical_on_all_ranks'] and line['comm']['param_checksum_spread_over_ranks'] == 0.0, line['comm']
+        assert line['comm']['loss_finite']
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
 @pytest.mark.parametrize("extra", [[], ['--workload', 'task100'], ['--workload', 'infer', '--mirror', '0', '--volume', '160', '256', '256']])
 def test_bench_two_ranks_smoke(extra):
@@ -299,5 +321,7 @@ def test_bench_two_ranks_smoke(extra):
     assert line['n_gpus'] == 2 and line['value'] > 0 and 'comm' in line, line
     if 'infer' in extra:
         assert line['comm']['bytes_sent'] > 0 and line['scaling'] == 'strong'
+        assert line['sharded_equals_unsharded']['ok'] and line['variants']['value_is'] == 'mask_gathered'
     else:
         assert line['comm']['allreduce_bytes_per_step'] > 1e8 and line['comm']['world'] == 2 and line['scaling'] == 'weak'
+        assert line['comm']['params_identical_on_all_ranks']

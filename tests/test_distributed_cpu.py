@@ -174,3 +174,51 @@ def test_tile_shard_plan_partitions_the_volume():
                 else:
                     z = _intersect(plan['touched'][q], plan['owned'][r])
                     assert z is not None and z[0] <= min(rows) and max(rows) < z[1]
+
+
+def _gather(rank, world):
+    """gather_slabs / slab_ranges / the growable slab cache of exchange_slabs on CPU tensors over gloo: every rank ends with the whole
+    (seg, probabilities); ragged and EMPTY slabs; one cache entry per role however many volume shapes pass through."""
+    from multitalent_amd.inference.sliding_window import (compute_steps_for_sliding_window, exchange_slabs, gather_slabs, shard_plan,
+                                                          slab_ranges)
+    rng = np.random.RandomState(11)
+    cache = {}
+    for X, Y, Z, px, pad in ((37, 5, 6, 8, 0), (16, 4, 4, 8, 3), (64, 3, 5, 16, 0)):
+        steps = compute_steps_for_sliding_window((px, Y, Z), (X, Y, Z), 0.5)
+        tiles = [(a, b, c) for a in steps[0] for b in steps[1] for c in steps[2]]
+        plan = shard_plan(tiles, px, X, world)
+        sx = slice(pad, X - pad)                       # the crop of pad_nd_image
+        ranges = slab_ranges(plan, sx, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == X - 2 * pad and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        full_p = torch.from_numpy(rng.rand(3, X - 2 * pad, Y, Z).astype(np.float32))
+        full_s = torch.from_numpy(rng.randint(0, 5, (X - 2 * pad, Y, Z)).astype(np.int32))
+        a, b = ranges[rank]
+        seg, probs = gather_slabs(full_s[a:b].clone(), full_p[:, a:b].clone(), ranges, world)
+        assert torch.equal(seg, full_s) and seg.dtype == torch.int32 and torch.equal(probs, full_p)
+        seg2, none = gather_slabs(full_s[a:b].clone(), None, ranges, world)
+        assert none is None and torch.equal(seg2, full_s)
+        # exchange_slabs: partial aggregates of this rank's tiles -> the owned slab == the slab of the full sum
+        C = 2
+        tot_a, tot_n = torch.zeros((C, X, Y, Z)), torch.zeros((X, Y, Z))
+        mine_a, mine_n = None, None
+        for q in range(world):
+            qa, qn = torch.zeros((C, X, Y, Z)), torch.zeros((X, Y, Z))
+            for t in plan['tiles'][q]:
+                w = torch.from_numpy(np.random.RandomState(hash(t) % 1000).rand(C, px, Y, Z).astype(np.float32))
+                qa[:, t[0]:t[0] + px] += w
+                qn[t[0]:t[0] + px] += 1
+            tot_a += qa; tot_n += qn
+            if q == rank:
+                lo, hi = plan['local'][q]
+                mine_a, mine_n = qa[:, lo:hi].contiguous(), qn[lo:hi].contiguous()
+        fa, fn = exchange_slabs(mine_a, mine_n, plan, rank, world, cache=cache)
+        o = plan['owned'][rank]
+        assert torch.allclose(fa, tot_a[:, o[0]:o[1]], atol=1e-5) and torch.equal(fn, tot_n[o[0]:o[1]])
+    # ONE flat buffer per role and device, however many shapes went through (the round-3 cache grew by an entry per shape)
+    assert len(cache) <= 2 * world + 2 and all(v.dim() == 1 for v in cache.values()), sorted(cache)
+    return len(cache)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_slabs_and_slab_cache(world):
+    run_world(_gather, world)

@@ -1,0 +1,76 @@
+"""The sliding window AT THE BENCHMARK'S OWN TILE (parity soft spot 3): one 48x192x192 tile of the 47-region network through
+the fused inference head — mirror TTA (8 flips) + Gaussian + overlap-add in one launch (mt_head_mirror_accumulate), and the un-mirrored
+form (mt_head_flip_accumulate + mt_tile_accumulate) — into a volume aggregate of MORE THAN 2^32 elements, placed at a high offset, so
+that every index of the kernels passes 32 bits.  Oracle: the reference's per-tile arithmetic (neural_network.py:502-591, 384-394) on the
+host: pred = sigmoid(net(flip(x))), un-flip, mean over the combinations, times the Gaussian."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tile_48x192x192_nc47_into_an_aggregate_beyond_2_to_32_elements(dev):
+    import bench
+    from multitalent_amd import ops
+    from multitalent_amd.inference.sliding_window import get_gaussian
+    from oracle import reference_ops as R
+    patch = (48, 192, 192)
+    torch.manual_seed(99)
+    net = bench.build_network('task100').to(dev)
+    net.eval()
+    eng = net.engine()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    tile = torch.randn((1,) + patch, generator=g)
+    combos = [(), (2,), (1,), (2, 1), (0,), (2, 0), (1, 0), (2, 1, 0)]                  # neural_network.py:531-586 order
+    flips = [(0 in c, 1 in c, 2 in c) for c in combos]
+    # ---- oracle (host)
+    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 0 else 32))
+    gauss = torch.from_numpy(get_gaussian(patch, 1. / 8))
+    ref = torch.zeros((47,) + patch)
+    with torch.no_grad():
+        for c in combos:
+            x = torch.flip(tile[None], [a + 2 for a in c]) if c else tile[None]
+            p = torch.sigmoid(R.generic_unet_forward(sd, x, bench.POOLS, bench.KERNELS, deep_supervision=False))[0]
+            ref += (torch.flip(p, [a + 1 for a in c]) if c else p) / 8.0
+    ref_nomirror = None
+    with torch.no_grad():
+        ref_nomirror = torch.sigmoid(R.generic_unet_forward(sd, tile[None], bench.POOLS, bench.KERNELS, deep_supervision=False))[0]
+    # ---- device: the aggregate of a 360 x 512 x 512 volume, tile in its far corner
+    shape = (360, 512, 512)
+    assert 47 * shape[0] * shape[1] * shape[2] > 2 ** 32
+    origin = tuple(s - p for s, p in zip(shape, patch))
+    agg = torch.zeros((47,) + shape, dtype=torch.float32, device=dev)
+    nb = torch.zeros(shape, dtype=torch.float32, device=dev)
+    vol = tile.to(dev).contiguous()
+    gd = gauss.to(dev)
+    with torch.no_grad():
+        batch = ops.extract_tiles(vol, patch, [((0, 0, 0), f) for f in flips], torch.empty((8, 1) + patch, device=dev))
+        hp = eng.forward_to_final_head(batch)
+        ops.head_mirror_accumulate(hp, 0, flips, 1, 1.0 / 8, gd, agg, nb, shape, origin)
+    torch.cuda.synchronize()
+    sl = tuple(slice(o, o + p) for o, p in zip(origin, patch))
+    got = agg[(slice(None),) + sl].cpu()
+    want = ref * gauss
+    err = float((got - want).abs().max())
+    print("mirror-TTA tile vs oracle: max |d| %.3e (probabilities x Gaussian in [0, 1])" % err)
+    assert err < 1e-4, err
+    assert torch.allclose(nb[sl].cpu(), gauss, atol=1e-7)
+    # nothing outside the tile was touched (sums over the whole 4.4 G-element aggregate)
+    assert abs(float(agg.double().sum()) - float(got.double().sum())) < 1e-3 * max(1.0, float(got.double().sum()))
+    assert float(nb.double().sum()) == pytest.approx(float(gauss.double().sum()), rel=1e-6)
+    # ---- the un-mirrored form on the same aggregate (second tile contribution: overlap-ADD)
+    with torch.no_grad():
+        batch1 = ops.extract_tiles(vol, patch, [((0, 0, 0), (False, False, False))], torch.empty((1, 1) + patch, device=dev))
+        hp1 = eng.forward_to_final_head(batch1)
+        acc = torch.empty((47,) + patch, dtype=torch.float32, device=dev)
+        ops.head_flip_accumulate(hp1, 0, (False, False, False), 1, 1.0, acc, True)
+        ops.tile_accumulate(acc, gd, 47, patch, agg, nb, shape, origin)
+    torch.cuda.synchronize()
+    got2 = agg[(slice(None),) + sl].cpu()
+    err2 = float((got2 - (want + ref_nomirror * gauss)).abs().max())
+    print("un-mirrored tile added on top: max |d| %.3e" % err2)
+    assert err2 < 2e-4, err2
+    assert torch.allclose(nb[sl].cpu(), 2 * gauss, atol=1e-6)

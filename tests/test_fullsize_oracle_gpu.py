@@ -160,6 +160,16 @@ def test_task009_fullsize_forward_loss_backward_vs_oracle(dev):
 
 
 def test_task100_fullsize_multitalent_loss_vs_oracle(dev):
+    _task100(dev, PATCH, 2, 'task100')
+
+
+def test_task100_native_patch_96x192x192_vs_oracle(dev):
+    """the patch a real Task100 run uses (MultiTalent_plans/MultiTalent_bs4_plans_3D.pkl stage 1, tests/golden/plans_stage1.json): 96x192x192,
+    one sample (the same number of voxels as the B = 2 benchmark batch) — logits, loss and gradients against the fp32 / fp64 oracle"""
+    _task100(dev, (96, 192, 192), 1, 'task100 96x192x192')
+
+
+def _task100(dev, PATCH, B, tag):
     import bench
     from oracle import reference_ops as R
     from multitalent_amd.dataset_conversion.Task100_MultiTalent import (MultiTalent_region_output_idx_mapping, MultiTalent_regions,
@@ -170,8 +180,7 @@ def test_task100_fullsize_multitalent_loss_vs_oracle(dev):
     net = bench.build_network('task100')
     sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
     net.train()
-    B = 2
-    valid = [MultiTalent_valid_regions['Task046_AbdOrgSegm2'], MultiTalent_valid_regions['Task003_Liver']]
+    valid = [MultiTalent_valid_regions['Task046_AbdOrgSegm2'], MultiTalent_valid_regions['Task003_Liver']][:B]
     label_sets = [sorted({l for r in v for l in MultiTalent_regions[r]}) for v in valid]
     x = synthetic_ct(B, PATCH, 78, dev)
     tg = synthetic_targets(B, PATCH, ds_scales(bench.POOLS), label_sets, 78, dev)
@@ -185,7 +194,7 @@ def test_task100_fullsize_multitalent_loss_vs_oracle(dev):
         rl = R.multitalent_loss(list(out), [t.cpu() for t in tg], valid, MultiTalent_regions, MultiTalent_region_output_idx_mapping, w)
         rl[0].backward()
         return sd, [o.detach().float() for o in out], [r.detach() for r in rl]
-    compare('task100', logits, loss, grads, *oracle_two_precisions(run))
+    compare(tag, logits, loss, grads, *oracle_two_precisions(run))
     assert any(n.startswith('conv_wino') for n in names['fwd']) and any(n.startswith('conv_bwdw_wino_kernel') for n in names['bwdw'])
 
 
