@@ -431,7 +431,9 @@ def bench_infer(args, dev, rank, world, ddp, emit=True):
         segf, pslab, (x0, x1) = predict_3D(net, small, False, (0, 1, 2), True, 0.5, patch, None, True, 'constant', None, True, False, mixed,
                                            tile_shard=shard, return_device_tensors='mask')
         dp = (pslab - p1[:, x0:x1]).abs().max() if x1 > x0 else torch.zeros((), device=dev)
-        stable = (p1 - 0.5).abs().amin(0) > 1e-4                      # voxels away from a decision boundary
+        top2 = p1.topk(2, dim=0).values
+        stable = (top2[0] - top2[1]) > 1e-4                           # voxels away from a tie of the argmax (regions_class_order=None)
+        del top2
         nm = ((segf != seg1) & stable).sum().double()
         t = torch.stack([dp.double(), nm])
         all_reduce_dev(t, dist.ReduceOp.MAX)

@@ -2521,7 +2521,10 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   const int i = pl.cfg;
   if (i < 0) return MT_EINVAL;
   if (pl.kind == CONV_BF16) {
-    snprintf(buf, n, "conv_bf16_kernel<%d, %d, %d, %d, 1, 4, %d>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, conv_bf16_vec(p), p->KD);
+    // the instance launch_bf16 picks, as the profiler prints it: <MW, RH, TD, VEC, NT, NW, KD, XS, OS, MTY>
+    const int sd = conv_src_dtype(p);
+    snprintf(buf, n, "conv_bf16_kernel<%d, %d, %d, %d, 1, 4, %d, %d, %d, %d>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, sd > 0 ? 4 : conv_bf16_vec(p), p->KD,
+             sd > 0 ? sd : 0, sd > 0 ? sd : 0, sd == MT_F16 ? MT_F16 : MT_BF16);
     return MT_OK;
   }
   const ConvCfg& g = kCfgs[i];
@@ -2529,16 +2532,26 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   if (pl.kind == CONV_FAST)
     snprintf(buf, n, "conv_fast_kernel<%d, %d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p), p->KD);
   else if (pl.kind == CONV_TAPSPLIT)
-    snprintf(buf, n, strided_use_bf16(p) ? "conv_tapsplit_kernel<%d, true>" : "conv_tapsplit_kernel<%d, false>", (strided_use_bf16(p) && conv_src_dtype(p) != MT_F32) ? 4 : conv_fast_vec(p));
+  {
+    const int sd = conv_src_dtype(p);
+    if (strided_use_bf16(p) && sd > 0) snprintf(buf, n, "conv_tapsplit_kernel<4, true, %d, %d, %d>", sd, p->odtype == sd ? sd : 0, sd == MT_F16 ? MT_F16 : MT_BF16);
+    else snprintf(buf, n, strided_use_bf16(p) ? "conv_tapsplit_kernel<%d, true, 0, 0, 1>" : "conv_tapsplit_kernel<%d, false, 0, 0, 1>", conv_fast_vec(p));
+  }
   else if (pl.kind == CONV_STEM)
-    snprintf(buf, n, "conv_stem_kernel");
+    snprintf(buf, n, "conv_stem_kernel<%d>", p->odtype);
   else if (pl.kind == CONV_WINO)
     snprintf(buf, n, g_wino_waves == 8 ? ((g_wino_persist && wino_persist_geometry_ok(p)) ? (g_wino_dma > 0 ? "conv_wino8d_kernel" : (p->bstats.y != nullptr ? "conv_wino8pb_kernel" : "conv_wino8p_kernel")) : "conv_wino8_kernel") : "conv_wino_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
-    snprintf(buf, n, strided_use_bf16(p) ? "conv_fast_strided_kernel<%d, %d, %d, %d, true>" : "conv_fast_strided_kernel<%d, %d, %d, %d, false>",
-             p->SD, p->SH, p->SW, conv_fast_vec(p));
+  {
+    const int sd = conv_src_dtype(p);
+    if (strided_use_bf16(p) && sd > 0)
+      snprintf(buf, n, "conv_fast_strided_kernel<%d, %d, %d, 4, true, %d, %d, %d>", p->SD, p->SH, p->SW, sd, p->odtype == sd ? sd : 0, sd == MT_F16 ? MT_F16 : MT_BF16);
+    else
+      snprintf(buf, n, strided_use_bf16(p) ? "conv_fast_strided_kernel<%d, %d, %d, %d, true, 0, 0, 1>" : "conv_fast_strided_kernel<%d, %d, %d, %d, false, 0, 0, 1>",
+               p->SD, p->SH, p->SW, conv_fast_vec(p));
+  }
   else if (pl.kind == CONV_RT && conv_gather_ok(p))
-    snprintf(buf, n, "conv_gather_kernel");
+    snprintf(buf, n, "conv_gather_kernel<4, %d, %d>", p->src[0].dtype, p->odtype);
   else if (pl.kind == CONV_RT)
     snprintf(buf, n, "conv_rt_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
   else
@@ -2703,8 +2716,10 @@ extern "C" int mt_conv3d_bwd_data_strided_kernel_name(const mt_conv3d_t* p, char
   if (p == nullptr || buf == nullptr || n == 0 || !mt_conv3d_bwd_data_strided_supported(p)) return MT_EINVAL;
   const mt_src_t& s0 = p->src[0];
   const bool v2 = !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7));
-  if (bwdd_strided_use_bf16(p)) snprintf(buf, n, "conv_bwdd_strided_kernel<%d, 2, 2, 2, true>", p->SD);
-  else snprintf(buf, n, "conv_bwdd_strided_kernel<%d, 2, 2, %d>", p->SD, v2 ? 2 : 1);
+  if (bwdd_strided_use_bf16(p)) {
+    if (s0.dtype == MT_BF16 && p->odtype == MT_BF16) snprintf(buf, n, "conv_bwdd_strided_kernel<%d, 2, 2, 4, true, 1, 1>", p->SD);
+    else snprintf(buf, n, "conv_bwdd_strided_kernel<%d, 2, 2, 2, true, 0, %d>", p->SD, p->odtype == MT_BF16 ? 1 : 0);
+  } else snprintf(buf, n, "conv_bwdd_strided_kernel<%d, 2, 2, %d, false, 0, 0>", p->SD, v2 ? 2 : 1);
   return MT_OK;
 }
 extern "C" int mt_conv3d_bwd_data_strided(const mt_conv3d_t* p, mt_stream_t stream) {
@@ -3632,6 +3647,8 @@ __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P)
 
 #include "bwdw_wino.inc"
 #include "bwdw_bf16.inc"
+static int conv_src_dtype(const mt_conv3d_t* p);
+#include "bwdw_gemm.inc"
 
 // compile-time geometries of the fast backward-weight kernel: (K, S) with pad (K-1)/2 for K=3/1 and 0 for K=2
 struct BwGeo { int KD, KH, KW, SD, SH, SW; };
@@ -3683,6 +3700,11 @@ static bool bwdw_use_wino(const mt_conv3d_t* p) {
   for (int i = 0; i < p->nsrc; ++i)
     if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
   return g_bwdw_wino && bwdw_use_march(p) && p->Wo > 16 && p->Ho >= 2 && conv_fast_vec(p) == 2;
+}
+static bool bwdw_staged() {        // MT_BWDW_STAGED=0: the register-fed bf16 Winograd backward-weight kernel also for 16-bit operands
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_BWDW_STAGED"); use = e ? atoi(e) : 1; }
+  return use != 0;
 }
 static bool bwdw_use_bf16(const mt_conv3d_t* p) {
   if (g_bwdw_bf16 < 0) { const char* e = getenv("MT_BWDW_BF16"); g_bwdw_bf16 = e ? atoi(e) : 1; }
@@ -3848,6 +3870,10 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
     const size_t stem = (size_t)mt_cdiv(p->Cout, 32) * BW_STEM_WGS * 27 * 512 * sizeof(float);
     if (stem > generic) generic = stem;
   }
+  {
+    mt_src_t ys; std::memset(&ys, 0, sizeof(ys));
+    if (bwdw_use_gemm(p, &ys)) { const size_t g = bwdw_gemm_workspace(p); if (g > generic) generic = g; }
+  }
   return generic;
 }
 
@@ -3855,17 +3881,21 @@ extern "C" int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_s
   if (p == nullptr || ysrc == nullptr || buf == nullptr || n == 0) return MT_EINVAL;
   const char* e = getenv("MT_BWDW_FAST");
   const int use_fast = e ? atoi(e) : 1;
-  if (use_fast && bwdw_is_stem(p, ysrc)) { snprintf(buf, n, "conv_bwdw_stem_kernel"); return MT_OK; }
+  if (use_fast && bwdw_is_stem(p, ysrc)) { snprintf(buf, n, "conv_bwdw_stem_kernel<%d>", ysrc->dtype); return MT_OK; }
   const int geo = use_fast ? bwdw_fast_geo(p, ysrc) : -1;
   if (geo < 0) { snprintf(buf, n, "conv_bwdw_kernel"); return MT_OK; }
+  if (use_fast && bwdw_use_gemm(p, ysrc)) { snprintf(buf, n, "bwdw_gemm_kernel"); return MT_OK; }
   if (geo == 0) {
-    if (bwdw_use_bf16(p)) snprintf(buf, n, "conv_bwdw_wino_bf16_kernel<3>");
+    if (bwdw_use_bf16(p)) snprintf(buf, n, (conv_src_dtype(p) > 0 && ysrc->dtype == MT_BF16 && bwdw_staged()) ? "conv_bwdw_wino_bf16s_kernel<3, %d, %d>" : "conv_bwdw_wino_bf16_kernel<3, %d, %d>", conv_src_dtype(p), ysrc->dtype);
     else if (bwdw_use_wino(p)) snprintf(buf, n, "conv_bwdw_wino_kernel<2>");
     else if (bwdw_use_march(p)) snprintf(buf, n, "conv_bwdw_march_kernel<3, 3, 1, 1>");
     else snprintf(buf, n, "conv_bwdw_fast_kernel<3, 3, 3, 1, 1, 1>");
     return MT_OK;
   }
-  if (geo == 6 && bwdw_use_bf16_133(p)) { snprintf(buf, n, "conv_bwdw_wino_bf16_kernel<1>"); return MT_OK; }
+  if (geo == 6 && bwdw_use_bf16_133(p)) {
+    snprintf(buf, n, (conv_src_dtype(p) > 0 && ysrc->dtype == MT_BF16 && bwdw_staged()) ? "conv_bwdw_wino_bf16s_kernel<1, %d, %d>" : "conv_bwdw_wino_bf16_kernel<1, %d, %d>", conv_src_dtype(p), ysrc->dtype);
+    return MT_OK;
+  }
   static const char* kGeo[9] = {"", "3, 3, 3, 2, 2, 2", "3, 3, 3, 1, 2, 2", "2, 2, 2, 2, 2, 2", "1, 2, 2, 1, 2, 2", "1, 1, 1, 1, 1, 1",
                                 "1, 3, 3, 1, 1, 1", "1, 1, 1, 2, 2, 2", "1, 1, 1, 1, 2, 2"};
   if (geo > 8) return MT_EINVAL;
@@ -3887,6 +3917,7 @@ extern "C" int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_
   if (bwdw_is_stem(p, ysrc)) return (xdt == MT_F32 && ydt != MT_F16) ? 1 : 0;       // fp32 network input, fp32 | bf16 gradient
   const int geo = bwdw_fast_geo(p, ysrc);
   if (geo < 0) return 0;
+  if (bwdw_use_gemm(p, ysrc)) return 1;                        // im2col + GEMM: every storage type on either side
   if ((geo == 0 && bwdw_use_bf16(p)) || (geo == 6 && bwdw_use_bf16_133(p))) return ydt != MT_F16 ? 1 : 0;   // bf16 Winograd marching kernels
   if (geo == 0) return 0;                                     // fp32 Winograd / marching kernels: fp32 storage only
   // conv_bwdw_fast_kernel (strided 3x3x3, transposed-conv weights, 1x1x1, 1x3x3): 16-bit X as channel pairs
@@ -3936,6 +3967,8 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     return MT_OK;
   }
   const int geo = use_fast ? bwdw_fast_geo(p, ysrc) : -1;
+  if (geo >= 0 && bwdw_use_gemm(p, ysrc))
+    return launch_bwdw_gemm(p, ysrc, dw, s_ci, s_co, s_kd, s_kh, s_kw, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
   if (geo >= 0) {
     bwdw_fast_plan(p, &P);
     MT_REQUIRE(P.nchunks > 0, "bwd_weight: too many channel chunks");
@@ -3950,6 +3983,21 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
         if (bwdw_use_bf16(p)) {
           const dim3 g3(P.nsg, P.ncot, P.nchunks);
           const bool yb = ysrc->dtype == MT_BF16;
+          if (yb && xdt != MT_F32 && bwdw_staged()) {       // 16-bit X and dY: raw planes staged through LDS with 16-byte loads
+            auto kfn = xdt == MT_F16 ? conv_bwdw_wino_bf16s_kernel<3, MT_F16, MT_BF16> : conv_bwdw_wino_bf16s_kernel<3, MT_BF16, MT_BF16>;
+            static std::atomic<uint64_t> attr_s[2];
+            const int devid = mt_current_device();
+            std::atomic<uint64_t>& at = attr_s[xdt == MT_F16 ? 0 : 1];
+            if (mt_device_pending(at, devid)) {
+              hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWS_LDS_BYTES);
+              if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
+              mt_mark_device_done(at, devid);
+            }
+            hipLaunchKernelGGL(kfn, g3, dim3(256), BWS_LDS_BYTES, st, P);
+            MT_CHECK_LAUNCH("conv_bwdw_wino_bf16s");
+            rc = MT_OK;
+            break;
+          }
 #define MT_BWB(XS_) do { if (yb) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, XS_, MT_BF16>), g3, dim3(256), BWB_LDS_BYTES, st, P); \
                          else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, XS_, MT_F32>), g3, dim3(256), BWB_LDS_BYTES, st, P); } while (0)
           if (xdt == MT_F16) MT_BWB(MT_F16);
@@ -3990,6 +4038,21 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
         if (bwdw_use_bf16_133(p)) {
           const dim3 g3(P.nsg, P.ncot, P.nchunks);
           const bool yb = ysrc->dtype == MT_BF16;
+          if (yb && xdt != MT_F32 && bwdw_staged()) {       // 16-bit X and dY: raw planes staged through LDS with 16-byte loads
+            auto kfn = xdt == MT_F16 ? conv_bwdw_wino_bf16s_kernel<1, MT_F16, MT_BF16> : conv_bwdw_wino_bf16s_kernel<1, MT_BF16, MT_BF16>;
+            static std::atomic<uint64_t> attr_s[2];
+            const int devid = mt_current_device();
+            std::atomic<uint64_t>& at = attr_s[xdt == MT_F16 ? 0 : 1];
+            if (mt_device_pending(at, devid)) {
+              hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWS_LDS_BYTES);
+              if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
+              mt_mark_device_done(at, devid);
+            }
+            hipLaunchKernelGGL(kfn, g3, dim3(256), BWS_LDS_BYTES, st, P);
+            MT_CHECK_LAUNCH("conv_bwdw_wino_bf16s");
+            rc = MT_OK;
+            break;
+          }
 #define MT_BWB(XS_) do { if (yb) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, XS_, MT_BF16>), g3, dim3(256), BWB_LDS_BYTES, st, P); \
                          else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, XS_, MT_F32>), g3, dim3(256), BWB_LDS_BYTES, st, P); } while (0)
           if (xdt == MT_F16) MT_BWB(MT_F16);

@@ -60,6 +60,7 @@ class nnUNetTrainer(object):
         self.initial_lr = 1e-2                    # nnUNetTrainerV2.py:49-50
         self.weight_decay = 3e-5
         self.all_tr_losses, self.all_val_losses, self.all_val_losses_tr_mode, self.all_val_eval_metrics = [], [], [], []
+        self.online_eval_foreground_dc, self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], [], []      # nnUNetTrainer.py:108-111
         self.best_epoch_based_on_MA_tr_loss = self.best_MA_tr_loss_for_patience = self.best_val_eval_criterion_MA = None
         self.save_every = 50
         # network_trainer.py:73-135 / nnUNetTrainer.py:113-117: moving averages, patience, what gets saved
@@ -274,9 +275,44 @@ class nnUNetTrainer(object):
         net.do_ds = v
 
     # ---- epoch-end bookkeeping (network_trainer.py:509-640) -------------------------------------------------------
+    def run_online_evaluation(self, output, target, data=None):
+        """nnUNetTrainer.py:683-705 (nnUNetTrainerV2.py:219-223 hands it the full-resolution output and target): hard tp / fp / fn per
+        foreground class of argmax(softmax(output)) against the label map, summed over the batch, appended to online_eval_tp / fp / fn
+        (+ the per-batch foreground Dice).  Counting is exact integer arithmetic on the device (torch glue: validation only)."""
+        with torch.no_grad():
+            if output is None:
+                x = self.network.engine().forward(data, need_grad=False, all_heads=True)[0]               # NDHWC logits
+                seg = x.argmax(-1)                                                                        # softmax is monotone
+                nc = x.shape[-1]
+            else:
+                o = output[0] if isinstance(output, (list, tuple)) else output
+                seg = o.argmax(1)
+                nc = o.shape[1]
+            t = target[0] if isinstance(target, (list, tuple)) else target
+            t = t[:, 0].to(seg.device).long()
+            tp = np.zeros(nc - 1); fp = np.zeros(nc - 1); fn = np.zeros(nc - 1)
+            for c in range(1, nc):
+                ps, ts = seg == c, t == c
+                tp[c - 1] = float((ps & ts).sum()); fp[c - 1] = float((ps & ~ts).sum()); fn[c - 1] = float((~ps & ts).sum())
+            self.online_eval_foreground_dc.append(list((2 * tp) / (2 * tp + fp + fn + 1e-8)))
+            self.online_eval_tp.append(list(tp))
+            self.online_eval_fp.append(list(fp))
+            self.online_eval_fn.append(list(fn))
+
     def finish_online_evaluation(self):
-        """may fill all_val_eval_metrics (network_trainer.py:676-681); the softmax trainers here do not evaluate online,
-        so the moving average below falls back to -validation loss exactly like the reference does for an empty list."""
+        """nnUNetTrainer.py:707-728: global foreground Dice per class from the epoch's summed tp / fp / fn (classes never seen dropped),
+        its mean appended to all_val_eval_metrics — what update_eval_criterion_MA / model_best selection and the epoch-100 "Dice == 0"
+        re-initialisation read.  Without online evaluation this epoch (no validation iterations) the list is left alone and the
+        moving average falls back to -validation loss like the reference does for an empty list."""
+        if not getattr(self, 'online_eval_tp', None):
+            return
+        tp, fp, fn = np.sum(self.online_eval_tp, 0), np.sum(self.online_eval_fp, 0), np.sum(self.online_eval_fn, 0)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            dc = [i for i in [2 * a / (2 * a + b + c) for a, b, c in zip(tp, fp, fn)] if not np.isnan(i)]
+        self.all_val_eval_metrics.append(np.mean(dc))
+        self.print_to_log_file("Average global foreground Dice:", [np.round(i, 4) for i in dc])
+        self.print_to_log_file("(interpret this as an estimate for the Dice of the different classes. This is not exact.)")
+        self.online_eval_foreground_dc, self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], [], []
 
     def update_train_loss_MA(self):
         last = self.all_tr_losses[-1]
@@ -530,8 +566,11 @@ class nnUNetTrainerV2(nnUNetTrainer):
         """nnUNetTrainerV2.py:225-274: fwd, loss, bwd, clip 12, step — one call into the fused hot loop."""
         data_dict = next(data_generator)
         data = self._to_device(data_dict['data'])
-        res = self.train_step(data, *self.loss_args(data_dict), do_backprop=do_backprop)
+        largs = self.loss_args(data_dict)
+        res = self.train_step(data, *largs, do_backprop=do_backprop)
         l = res[0] if isinstance(res, tuple) else res
+        if run_online_evaluation:
+            self.run_online_evaluation(None, largs[0], data=data)
         return l.detach().cpu().numpy()
 
     def on_epoch_end(self):

@@ -118,15 +118,18 @@ def _read_nifti(fname):
     arr = arr.astype(dt.newbyteorder('='))
     if slope != 0 and not (slope == 1 and inter == 0) and np.isfinite(slope):
         arr = arr.astype(np.float64) * slope + inter
-    if sform_code > 0:
+    # geometry precedence as ITK's NiftiImageIO (the reference reads through SimpleITK): the qform (rotation from the quaternion, spacing
+    # from pixdim) when qform_code > 0, else the sform (spacing = column norms); a file whose two transforms disagree then gives the
+    # same spacing / direction whether or not SimpleITK is installed
+    if qform_code > 0:
+        b, c, d, qx, qy, qz = struct.unpack(end + '6f', raw[256:280])
+        Rras = _quaternion_to_matrix(b, c, d, -1.0 if pixdim[0] < 0 else 1.0)
+        spacing, t = np.abs(np.array(pixdim[1:4], dtype=np.float64)), np.array([qx, qy, qz], dtype=np.float64)
+    elif sform_code > 0:
         A = np.array([struct.unpack(end + '4f', raw[280 + 16 * r:296 + 16 * r]) for r in range(3)], dtype=np.float64)
         M, t = A[:, :3], A[:, 3]
         spacing = np.sqrt((M * M).sum(0))
         Rras = M / spacing
-    elif qform_code > 0:
-        b, c, d, qx, qy, qz = struct.unpack(end + '6f', raw[256:280])
-        Rras = _quaternion_to_matrix(b, c, d, -1.0 if pixdim[0] < 0 else 1.0)
-        spacing, t = np.abs(np.array(pixdim[1:4], dtype=np.float64)), np.array([qx, qy, qz], dtype=np.float64)
     else:
         Rras, spacing, t = np.diag([-1.0, -1.0, 1.0]), np.abs(np.array(pixdim[1:4], dtype=np.float64)), np.zeros(3)
     return Image(arr, spacing, _LPS @ t, (_LPS @ Rras).ravel())

@@ -39,6 +39,20 @@ def test_nifti_roundtrip_and_header(tmp_path):
         open(g, 'wb').write(bytes(b))
         iq = N._read_nifti(g)
         assert np.allclose(np.array(iq.direction).reshape(3, 3), direction, atol=1e-5) and np.allclose(iq.origin, im.origin, rtol=1e-6)
+        # a file whose sform DIFFERS from its qform (resliced / sheared sform): the qform + pixdim win while qform_code > 0 (ITK's
+        # precedence — the reference reads through SimpleITK), the sform only when qform_code == 0
+        b = bytearray(raw)
+        for r in range(3):
+            row = list(struct.unpack('<4f', raw[280 + 16 * r:296 + 16 * r]))
+            struct.pack_into('<4f', b, 280 + 16 * r, row[0] * 2.0, row[1] * 2.0, row[2] * 2.0, row[3] + 5.0)
+        g2 = str(tmp_path / 'qs.nii')
+        open(g2, 'wb').write(bytes(b))
+        i2 = N._read_nifti(g2)
+        assert np.allclose(i2.spacing, (0.8, 0.9, 2.5), rtol=1e-6) and np.allclose(i2.origin, im.origin, rtol=1e-6)
+        struct.pack_into('<h', b, 252, 0)                 # qform_code = 0: now the (doubled) sform is the geometry
+        open(g2, 'wb').write(bytes(b))
+        i3 = N._read_nifti(g2)
+        assert np.allclose(i3.spacing, (1.6, 1.8, 5.0), rtol=1e-6)
     with pytest.raises(IOError):
         open(str(tmp_path / 'bad.nii'), 'wb').write(b'\0' * 400)
         N._read_nifti(str(tmp_path / 'bad.nii'))
@@ -132,3 +146,33 @@ def test_epoch_end_bookkeeping_writes_model_best(tmp_path):
     assert tr.output_folder == os.path.join(str(tmp_path), 'fold_3')
     tr.update_fold('all')
     assert tr.output_folder == os.path.join(str(tmp_path), 'all')
+
+
+def test_softmax_trainers_online_evaluation_matches_the_reference_formulas():
+    """nnUNetTrainer.run_online_evaluation / finish_online_evaluation (nnUNetTrainer.py:683-728): hard tp / fp / fn per foreground class of
+    the argmax, the epoch's global Dice mean appended to all_val_eval_metrics — restated here exactly as the reference writes it."""
+    import types
+    import torch
+    from multitalent_amd.training.network_training.nnUNetTrainer import nnUNetTrainer
+    g = torch.Generator().manual_seed(0)
+    logs = []
+    t = types.SimpleNamespace(online_eval_foreground_dc=[], online_eval_tp=[], online_eval_fp=[], online_eval_fn=[], all_val_eval_metrics=[],
+                              print_to_log_file=lambda *a, **k: logs.append(a))
+    tps, fps, fns = [], [], []
+    for _ in range(3):
+        out = torch.randn((2, 4, 5, 6, 7), generator=g)
+        tgt = torch.randint(0, 4, (2, 1, 5, 6, 7), generator=g).float()
+        nnUNetTrainer.run_online_evaluation(t, [out], [tgt])
+        seg = torch.softmax(out, 1).argmax(1)
+        tp = [float(((seg == c).float() * (tgt[:, 0] == c).float()).sum()) for c in range(1, 4)]
+        fp = [float(((seg == c).float() * (tgt[:, 0] != c).float()).sum()) for c in range(1, 4)]
+        fn = [float(((seg != c).float() * (tgt[:, 0] == c).float()).sum()) for c in range(1, 4)]
+        tps.append(tp); fps.append(fp); fns.append(fn)
+        assert t.online_eval_tp[-1] == tp and t.online_eval_fp[-1] == fp and t.online_eval_fn[-1] == fn
+    nnUNetTrainer.finish_online_evaluation(t)
+    a, b, c = np.sum(tps, 0), np.sum(fps, 0), np.sum(fns, 0)
+    want = np.mean([i for i in [2 * i / (2 * i + j + k) for i, j, k in zip(a, b, c)] if not np.isnan(i)])
+    assert len(t.all_val_eval_metrics) == 1 and abs(t.all_val_eval_metrics[0] - want) < 1e-12
+    assert t.online_eval_tp == [] and t.online_eval_foreground_dc == []
+    nnUNetTrainer.finish_online_evaluation(t)             # an epoch without validation iterations leaves the list alone
+    assert len(t.all_val_eval_metrics) == 1

@@ -313,7 +313,7 @@ def test_conv_tapsplit_bf16(dev, N, Cin, Cout, shape, two):
         b = torch.randn(Cout, generator=g)
         acts = [ops.Act(to_ndhwc(s).to(dev)) for s in srcs]
         pq = ops.fill_conv(acts, ops.ConvGeom(shape, (3, 3, 3), (1, 1, 1), (1, 1, 1)), Cout)
-        assert ops.conv_kernel_name(pq) == 'conv_tapsplit_kernel<2, true>'
+        assert ops.conv_kernel_name(pq).startswith('conv_tapsplit_kernel<2, true')
         out, part = run_conv(dev, srcs, w, b, (1, 1, 1), (1, 1, 1), lazy=lazy, stats=True)
         ref = F.conv3d(_bf16_round(ref_inputs(srcs, lazy)).double(), _bf16_round(w).double(), b.double(), padding=1)
         assert relerr(to_ncdhw(out.cpu()), ref) < 1e-4
@@ -692,7 +692,7 @@ def test_conv_kernel_equals_stride_gather(dev, N, Cin, Cout, shape, k):
     base = torch.randn((N,) + geom.out + (Cout,), generator=g)
     out = base.to(dev)
     p = ops.fill_conv([act], geom, Cout, out0=ops.Act(out), accumulate=True)
-    assert ops.conv_kernel_name(p) == 'conv_gather_kernel'
+    assert ops.conv_kernel_name(p).startswith('conv_gather_kernel')
     wd = w.to(dev).contiguous()
     wp = ops.pack_conv_weights(wd, Cin, 0, Cout, k, ops.conv_weight_strides(wd), False, ops.conv_ck(p), layout=ops.conv_pack_layout(p))
     p.wpack = wp.data_ptr()
