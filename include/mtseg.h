@@ -177,6 +177,13 @@ int mt_set_option(const char* name, int value);
  *   instead of pw_head_kernel; also the narrow-head kernels), MT_PW_WIDE (0: dword stores in the transposed-conv epilogue), MT_PW_SPLIT8 (0: all
  *   eight taps of a 2x2x2 transposed conv in one workgroup), MT_WINO_DMA (1: conv_wino8d_kernel), MT_PACK_BLOCKS (workgroups per descriptor of mt_pack_batched,
  *   default 1024), MT_HEAD_BWD_WIDE, MT_CONV_CFG / MT_BF16_CFG (force a tile configuration), MT_CONV_STAGGER, MT_CONV_DBG (debugging).
+ *   Round 4 (mixed precision): MT_BWDW_STAGED (0: conv_bwdw_wino_bf16_kernel with per-thread gathers instead of the LDS-staged
+ *   conv_bwdw_wino_bf16s_kernel), MT_BWDW_GEMM (0: the low-resolution backward-weight on the fp32 marching kernel instead of
+ *   im2col + bf16 GEMM).
+ * The HOST side above this ABI (multitalent_amd/engine.py, inference/, bench.py) reads: MT_BF16_STORAGE (0: fp32 storage in mixed
+ * precision), MT_ACT_STORAGE (fp16 | bf16), MT_BF16_MIN_VOXELS, MT_PW_STRIDED (0: strided 1x1x1 projections on conv_rt_kernel),
+ * MT_BWDW_STREAMS, MT_FUSE_NORM_BWD, MT_HEAD_BWD_FUSED, MT_INFER_FUSED_HEAD, MT_INFER_MIXED, MT_PACK_SPLIT, MT_IO_DEBUG (1: print
+ * every launch that needed an mt_cast), MT_FORCE_REDUCER, MT_BENCH_ONE_GPU (bench.py: all ranks on cuda:0 over gloo), MT_LIB_VARIANT.
  * Which workgroup computes which tile (block id -> XCD -> tile order) is a compile-time choice (-DMT_TILE_ORDER=0 builds
  * the round-2 order for A/B measurements); results do not depend on it. */
 
