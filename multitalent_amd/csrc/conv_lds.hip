@@ -966,7 +966,8 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
       const unsigned* wlane = (const unsigned*)c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 256) + lane * 4;
       mt_stage_bf16<LD, LH, LW, VEC, 4, XS, MTY>((unsigned*)lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
       __syncthreads();
-      bf16_chunk<1, 1, LH, LWP, 3, MTY>((const unsigned*)lds, abase, wlane, 0, accb);
+      const int abase3[1][3] = {{abase[0], abase[0], abase[0]}};
+      bf16_chunk<1, 1, LH, LWP, 3, MTY>((const unsigned*)lds, abase3, wlane, 0, accb);
     } else {
       const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
       mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
@@ -2236,7 +2237,7 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   P.ntaps = KD * 9; P.dbg = 0; P.stagger = 0;
   P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
-  const size_t ldsb = bstage_lds_bytes<TD + KD - 1, TH + 2, TW + 2, VEC, NW>();
+  const size_t ldsb = bstage_lds_bytes<TD + KD - 1, TH + 2, TW + 2, VEC, NW, (BF_SWZ ? BFP_SWZ : BFP)>();
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(mt_cdiv(p->Cout, 32), NT), 1);
   auto kfn = conv_bf16_kernel<MW, RH, TD, VEC, NT, NW, KD, XS, OS, MTY>;
   if (ldsb > 64 * 1024) {
@@ -2829,6 +2830,32 @@ __device__ __forceinline__ void pack_weights_body(const PackParams& P, long firs
       const bool v0 = c0 < cc.ck && co < P.Cout, v1 = P.layout >= 3 && (c0 + 1) < cc.ck && co < P.Cout;
       const float* w0 = P.w + (long)(cc.cglob + c0) * P.s_ci + (long)co * P.s_co;
       float* dp = P.dst + ((size_t)(nt * P.nchunks + ch) * K3) * per_tap + (q * 64 + l) * 4 + e;
+      // all taps of the item's (cin, cout) pair(s) are requested BEFORE the first store (the compiler may not move a load over a
+      // store to dst): the 108-byte run of a pair is one or two cache lines, and 27 dependent round trips through a thrashing L2
+      // fetched 2.4 GB for 124 MB of weights (profiles/r04_pmc_per_kernel.json)
+      if (K3 <= 27) {
+        float a0[27], a1[27];
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+          a0[tap] = 0.f; a1[tap] = 0.f;
+          if (tap < K3) {
+            const int kw = tap % P.KW, kh = (tap / P.KW) % P.KH, kd = tap / (P.KW * P.KH);
+            int zd = P.flip ? P.KD - 1 - kd : kd, zh = P.flip ? P.KH - 1 - kh : kh, zw = P.flip ? P.KW - 1 - kw : kw;
+            if (P.has_tm) { zd = P.tb[0] + P.ts[0] * kd; zh = P.tb[1] + P.ts[1] * kh; zw = P.tb[2] + P.ts[2] * kw; }
+            const long o = zd * P.s_kd + zh * P.s_kh + zw * P.s_kw;
+            if (v0) a0[tap] = w0[o];
+            if (v1) a1[tap] = w0[o + P.s_ci];
+          }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap)
+          if (tap < K3) {
+            if (P.layout == 1) dp[(size_t)tap * per_tap] = a0[tap];
+            else if (P.layout == 3) ((unsigned*)dp)[(size_t)tap * per_tap] = mt_pk16<MT_BF16>(a0[tap], a1[tap]);
+            else ((unsigned*)dp)[(size_t)tap * per_tap] = mt_pk16<MT_F16>(a0[tap], a1[tap]);
+          }
+        continue;
+      }
       int tap = 0;
       for (int kd = 0; kd < P.KD; ++kd)
         for (int kh = 0; kh < P.KH; ++kh)

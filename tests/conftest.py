@@ -18,3 +18,13 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device('cuda:0')
+
+
+@pytest.fixture(autouse=True)
+def _fresh_matrix_mode():
+    """ops._MMA is process-wide state an engine sets on entry (the mode of the LAST engine that ran); kernel-level tests that build
+    mt_conv3d_t structs directly must not inherit it from whichever test ran before them."""
+    mod = sys.modules.get('multitalent_amd.ops')
+    if mod is not None:
+        mod.set_mma(0)
+    yield
