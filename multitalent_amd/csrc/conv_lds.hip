@@ -3676,6 +3676,7 @@ __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P)
 #include "bwdw_bf16.inc"
 static int conv_src_dtype(const mt_conv3d_t* p);
 #include "bwdw_gemm.inc"
+#include "bwdw_fast16.inc"
 
 // compile-time geometries of the fast backward-weight kernel: (K, S) with pad (K-1)/2 for K=3/1 and 0 for K=2
 struct BwGeo { int KD, KH, KW, SD, SH, SW; };
@@ -3754,6 +3755,8 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   int pairs = P->nchunks * P->ncot; if (pairs < 1) pairs = 1;
   int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
   if ((bwdw_use_march(p) && bwdw_use_bf16(p)) || bwdw_use_bf16_133(p)) nsg = (512 + pairs - 1) / pairs;      // 64 KiB ring: two workgroups per CU
+  // conv_bwdw_fast16_kernel with few taps (transposed-conv weights, 1x1x1): <= 180 registers and <= 49 KiB of LDS — two workgroups per CU
+  if (p->mma == 1 && p->src[0].dtype != MT_F32 && P->ntaps <= 8 && !bwdw_use_march(p)) nsg = (512 + pairs - 1) / pairs;
   P->nsg_cap = nsg;
   if (nsg > P->ntiles_total) nsg = P->ntiles_total;
   if (nsg < 1) nsg = 1;
@@ -3822,6 +3825,7 @@ static int launch_bwdw_march(const BwdWParams& P, int vec, int yv, hipStream_t s
 
 template <int KD, int KH, int KW, int SD, int SH, int SW>
 static int launch_bwdw_fast(const BwdWParams& P, int vec, hipStream_t st) {
+  if (bwdw_fast16_ok(&P.c, &P.y)) return launch_bwdw_fast16<KD, KH, KW, SD, SH, SW>(P, st);      // mixed precision: bf16 products
   constexpr int LHa = 3 * SH + KH, LWa = 31 * SW + KW, LHb = 7 * SH + KH, LWb = 15 * SW + KW;
   size_t ldsb = (size_t)KD * (P.TW == 32 ? LHa * LWa : LHb * LWb) * FCKP * sizeof(float);
   if (ldsb < BW_RED_LDS(KD * KH * KW)) ldsb = BW_RED_LDS(KD * KH * KW);
@@ -3916,7 +3920,7 @@ extern "C" int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_s
     if (bwdw_use_bf16(p)) snprintf(buf, n, (conv_src_dtype(p) > 0 && ysrc->dtype == MT_BF16 && bwdw_staged()) ? "conv_bwdw_wino_bf16s_kernel<3, %d, %d>" : "conv_bwdw_wino_bf16_kernel<3, %d, %d>", conv_src_dtype(p), ysrc->dtype);
     else if (bwdw_use_wino(p)) snprintf(buf, n, "conv_bwdw_wino_kernel<2>");
     else if (bwdw_use_march(p)) snprintf(buf, n, "conv_bwdw_march_kernel<3, 3, 1, 1>");
-    else snprintf(buf, n, "conv_bwdw_fast_kernel<3, 3, 3, 1, 1, 1>");
+    else snprintf(buf, n, bwdw_fast16_ok(p, ysrc) ? "conv_bwdw_fast16_kernel<3, 3, 3, 1, 1, 1>" : "conv_bwdw_fast_kernel<3, 3, 3, 1, 1, 1>");
     return MT_OK;
   }
   if (geo == 6 && bwdw_use_bf16_133(p)) {
@@ -3926,7 +3930,7 @@ extern "C" int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_s
   static const char* kGeo[9] = {"", "3, 3, 3, 2, 2, 2", "3, 3, 3, 1, 2, 2", "2, 2, 2, 2, 2, 2", "1, 2, 2, 1, 2, 2", "1, 1, 1, 1, 1, 1",
                                 "1, 3, 3, 1, 1, 1", "1, 1, 1, 2, 2, 2", "1, 1, 1, 1, 2, 2"};
   if (geo > 8) return MT_EINVAL;
-  snprintf(buf, n, "conv_bwdw_fast_kernel<%s>", kGeo[geo]);
+  snprintf(buf, n, bwdw_fast16_ok(p, ysrc) ? "conv_bwdw_fast16_kernel<%s>" : "conv_bwdw_fast_kernel<%s>", kGeo[geo]);
   return MT_OK;
 }
 
@@ -3946,6 +3950,7 @@ extern "C" int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_
   if (geo < 0) return 0;
   if (bwdw_use_gemm(p, ysrc)) return 1;                        // im2col + GEMM: every storage type on either side
   if ((geo == 0 && bwdw_use_bf16(p)) || (geo == 6 && bwdw_use_bf16_133(p))) return ydt != MT_F16 ? 1 : 0;   // bf16 Winograd marching kernels
+  if (bwdw_fast16_ok(p, ysrc) && !(geo == 0 && bwdw_use_march(p))) return 1;   // conv_bwdw_fast16_kernel (mixed precision, bf16 products)
   if (geo == 0) return 0;                                     // fp32 Winograd / marching kernels: fp32 storage only
   // conv_bwdw_fast_kernel (strided 3x3x3, transposed-conv weights, 1x1x1, 1x3x3): 16-bit X as channel pairs
   if (conv_fast_vec(p) != 2) return 0;

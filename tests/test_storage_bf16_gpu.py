@@ -620,6 +620,67 @@ def test_tiled_backward_weight_16bit_storage_bitexact(dev, kind):
     assert torch.isfinite(res[1]).all() and torch.equal(res[0], res[1]), float((res[0] - res[1]).abs().max())
 
 
+@pytest.mark.parametrize("kind", ["strided222", "strided222_narrow", "strided122", "tconv222", "tconv122", "head", "proj222", "proj122", "k333_shallow", "two_sources"])
+def test_tiled_backward_weight_bf16_products(dev, kind):
+    """conv_bwdw_fast16_kernel (mixed precision: 16-bit X and dY, bf16 products, fp32 accumulation) against autograd on the host with the
+    same operand rounding (activated operands rounded to bf16, exact products); ragged tiles, both tile shapes, accumulate"""
+    import torch.nn.functional as F
+    ops = _ops()
+    g = torch.Generator().manual_seed(46)
+    N = 2
+    f16, b16, f32 = torch.float16, torch.bfloat16, torch.float32
+    cfg = {'strided222': ((3, 3, 3), (2, 2, 2), (1, 1, 1), (30,), 60, (8, 12, 70), f16, b16, True),
+           'strided222_narrow': ((3, 3, 3), (2, 2, 2), (1, 1, 1), (64,), 40, (6, 18, 26), f16, b16, True),      # Wo <= 16: the 8 x 16 tile
+           'strided122': ((3, 3, 3), (1, 2, 2), (1, 1, 1), (32,), 64, (5, 12, 34), f16, b16, True),
+           'tconv222': ((2, 2, 2), (2, 2, 2), (0, 0, 0), (30,), 60, (8, 12, 36), b16, f16, False),   # X = dOut, Y = tconv input (lazy)
+           'tconv122': ((1, 2, 2), (1, 2, 2), (0, 0, 0), (32,), 64, (3, 8, 72), b16, f16, False),
+           'head': ((1, 1, 1), (1, 1, 1), (0, 0, 0), (60,), 47, (4, 8, 34), f16, f32, True),
+           'proj222': ((1, 1, 1), (2, 2, 2), (0, 0, 0), (30,), 60, (8, 12, 34), f16, b16, True),
+           'proj122': ((1, 1, 1), (1, 2, 2), (0, 0, 0), (32,), 64, (3, 12, 34), f16, b16, True),
+           'k333_shallow': ((3, 3, 3), (1, 1, 1), (1, 1, 1), (30,), 30, (2, 9, 40), f16, b16, True),          # Do < 3: not a marching problem
+           'two_sources': ((3, 3, 3), (2, 2, 2), (1, 1, 1), (30, 18), 60, (6, 10, 36), f16, b16, True)}[kind]
+    k, stride, pad, Cins, Cout, shape, xdt, ydt, xlazy = cfg
+    geom = ops.ConvGeom(shape, k, stride, pad)
+    xs = [rbf(torch.randn((N,) + shape + (C,), generator=g), xdt) for C in Cins]
+    y = rbf(torch.randn((N,) + tuple(geom.out) + (Cout,), generator=g), ydt if ydt != f32 else b16)
+    xl = [(torch.rand((N, C), generator=g) + 0.5, torch.randn((N, C), generator=g)) for C in Cins]
+    yl = (torch.rand((N, Cout), generator=g) + 0.5, torch.randn((N, Cout), generator=g))
+    keep = [x.to(dev).to(xdt) for x in xs]
+    acts = [ops.Act(b, scale=l[0].to(dev), shift=l[1].to(dev), slope=0.01) if xlazy else ops.Act(b) for b, l in zip(keep, xl)]
+    yb = y.to(dev).to(ydt)
+    ya = ops.Act(yb) if xlazy else ops.Act(yb, scale=yl[0].to(dev), shift=yl[1].to(dev), slope=0.01)
+    p = ops.fill_conv(acts, geom, Cout, mma=1)
+    name = ops.conv_bwd_weight_kernel_name(p, ya)
+    assert name.startswith('conv_bwdw_fast16_kernel'), name
+    assert ops.conv_bwd_weight_io_supported(p, ya), name
+    Cin = sum(Cins)
+    dw = torch.full((Cout, Cin) + k, float('nan'), device=dev)
+    ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
+    ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
+    torch.cuda.synchronize()
+
+    def act(t, l):
+        u = torch.addcmul(l[1][:, None, None, None, :], t, l[0][:, None, None, None, :])
+        return torch.maximum(u, u * 0.01)
+    xa = [rbf(act(x, l)) if xlazy else x for x, l in zip(xs, xl)]              # (a bf16 X without activation is copied exactly)
+    yy = y if xlazy else rbf(act(y, yl))
+    xin = torch.cat(xa, -1).permute(0, 4, 1, 2, 3).double()
+    w0 = torch.zeros((Cout, Cin) + k, dtype=torch.float64, requires_grad=True)
+    F.conv3d(xin, w0, None, stride=stride, padding=pad).backward(yy.permute(0, 4, 1, 2, 3).double().contiguous())
+    ref = w0.grad.float()
+    got = dw.cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-3, err                       # (fma vs mul + add before the bf16 rounding of the activated operand: isolated operand ulps)
+    dw2 = dw.clone()
+    ops.conv3d_bwd_weight(p, ya, dw2, ops.conv_weight_strides(dw2), True, ws)
+    torch.cuda.synchronize()
+    assert torch.allclose(dw2, 2 * dw, rtol=1e-6, atol=1e-6)
+    # MT_BWDW_FAST16 decides between kernels of the same result up to the product type: the fp32-product kernel is within bf16 operand rounding
+    p0 = ops.fill_conv(acts, geom, Cout, mma=0)
+    assert ops.conv_bwd_weight_kernel_name(p0, ya).startswith('conv_bwdw_fast_kernel')
+
+
 def test_stem_kernels_16bit_storage_bitexact(dev):
     """first convolution (one input channel, fp32 network input): fp16 output with statistics; its backward-weight reads a bf16 dY"""
     ops = _ops()
