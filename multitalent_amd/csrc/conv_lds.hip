@@ -3788,6 +3788,8 @@ static bool bwdw_use_bf16(const mt_conv3d_t* p) {
 }
 static bool bwdw_use_bf16_133(const mt_conv3d_t* p) {       // 1x3x3 stride-1 backward-weight on the bf16 Winograd marching kernel
   if (g_bwdw_bf16 < 0) { const char* e = getenv("MT_BWDW_BF16"); g_bwdw_bf16 = e ? atoi(e) : 1; }
+  for (int i = 0; i < p->nsrc; ++i)          // (the staged kernel applies LeakyReLU as max(t, slope * t))
+    if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
   return g_bwdw_bf16 && p->mma == 1 && p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 &&
          p->PD == 0 && p->PH == 1 && p->PW == 1 && p->Wo > 16 && p->Ho >= 2 && p->Do >= 1 && conv_fast_vec(p) == 2;
 }
