@@ -357,8 +357,10 @@ struct HeadAccParams {
   float weight;
   float* acc;
 };
-template <int VEC>
+// XS: storage type of the source (fp32, or 16-bit activations of the mixed mode: a lane's 8 channels are ONE 16-byte load)
+template <int VEC, int XS = MT_F32>
 __global__ __launch_bounds__(256) void head_flip_accumulate_kernel(const HeadAccParams P) {
+  constexpr int XE = mt_ebytes<XS>();
   const mt_pointwise_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -370,8 +372,8 @@ __global__ __launch_bounds__(256) void head_flip_accumulate_kernel(const HeadAcc
   const long bv = m0 + li;
   const bool vok = bv < P.V;
   const size_t in_sample = (size_t)P.V * S.cs;
-  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb * in_sample), 0, (int)(in_sample * 4), 0x00020000);
-  const int aoff = vok ? (int)((bv * S.cs + 8 * lhalf) * 4) : (int)0x80000000;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (size_t)nb * in_sample * XE), 0, (int)(in_sample * XE), 0x00020000);
+  const int aoff = vok ? (int)((bv * S.cs + 8 * lhalf) * XE) : (int)0x80000000;
   const bool aff = S.scale != nullptr;
   const float slope = S.slope;
   const bool lrelu_ok = (slope >= 0.f) && (slope <= 1.f);
@@ -383,9 +385,12 @@ __global__ __launch_bounds__(256) void head_flip_accumulate_kernel(const HeadAcc
     }
     __syncthreads();
   }
-  auto load_a = [&](int ch, float (&x)[8]) {
-    const int o = aoff + ch * (PW_CK * 4);
-    if constexpr (VEC == 2) {
+  auto load_a = [&](int ch, float (&x)[8]) {        // (16-bit: raw dwords in x[0..3], widened in finish_a — a conversion here would wait for the prefetch)
+    const int o = aoff + ch * (PW_CK * XE);
+    if constexpr (XS != MT_F32) {
+      const uint4 t = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ra, o, 0, 0));
+      x[0] = __builtin_bit_cast(float, t.x); x[1] = __builtin_bit_cast(float, t.y); x[2] = __builtin_bit_cast(float, t.z); x[3] = __builtin_bit_cast(float, t.w);
+    } else if constexpr (VEC == 2) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra, o + g * 8, 0, 0));
@@ -398,6 +403,11 @@ __global__ __launch_bounds__(256) void head_flip_accumulate_kernel(const HeadAcc
   };
   auto finish_a = [&](int ch, float (&x)[8]) {
     const int cb = ch * PW_CK + 8 * lhalf;
+    if constexpr (XS != MT_F32) {
+      const unsigned r0 = __builtin_bit_cast(unsigned, x[0]), r1 = __builtin_bit_cast(unsigned, x[1]), r2 = __builtin_bit_cast(unsigned, x[2]), r3 = __builtin_bit_cast(unsigned, x[3]);
+      x[0] = mt_lo16<XS>(r0); x[1] = mt_hi16<XS>(r0); x[2] = mt_lo16<XS>(r1); x[3] = mt_hi16<XS>(r1);
+      x[4] = mt_lo16<XS>(r2); x[5] = mt_hi16<XS>(r2); x[6] = mt_lo16<XS>(r3); x[7] = mt_hi16<XS>(r3);
+    }
     if (aff) {
       const f32x4 sc0 = *(const f32x4*)(ssc + cb), sc1 = *(const f32x4*)(ssc + cb + 4);
       const f32x4 sh0 = *(const f32x4*)(ssh + cb), sh1 = *(const f32x4*)(ssh + cb + 4);
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(256) void head_flip_accumulate_kernel(const HeadAcc
       for (int e = 0; e < 4; ++e) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[e], xa[4 + e], acc[n], 0, 0, 0);
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) xa[e] = xn[e];
+    for (int e = 0; e < (XS != MT_F32 ? 4 : 8); ++e) xa[e] = xn[e];
   }
   // ---- epilogue: this lane's voxel, channels n*32 + (j&3) + 8*(j>>2) + 4*lhalf
   if (c.bias != nullptr) {
@@ -496,7 +506,8 @@ __global__ __launch_bounds__(256) void head_flip_accumulate_kernel(const HeadAcc
 extern "C" int mt_head_flip_accumulate(const mt_pointwise_t* p, int sample, int flipD, int flipH, int flipW, int nonlin, float weight,
                                        float* acc, int first, mt_stream_t stream) {
   MT_REQUIRE(p != nullptr && acc != nullptr, "head_flip_accumulate: null pointers");
-  MT_REQUIRE(p->src.dtype == MT_F32, "head_flip_accumulate: fp32 source only (convert with mt_cast)");
+  MT_REQUIRE(mt_dtype_ok(p->src.dtype), "head_flip_accumulate: bad source storage type %d", p->src.dtype);
+  MT_REQUIRE(p->src.dtype == MT_F32 || (!(p->src.cs & 1) && !(((uintptr_t)p->src.ptr) & 3)), "head_flip_accumulate: a 16-bit source needs an even channel stride");
   MT_REQUIRE(p->siD == 1 && p->siH == 1 && p->siW == 1 && p->soD == 1 && p->soH == 1 && p->soW == 1 && p->Db == p->Di && p->Hb == p->Hi &&
              p->Wb == p->Wi, "head_flip_accumulate: 1x1x1 stride-1 head only");
   MT_REQUIRE(p->Cout >= 1 && p->Cout <= 64 && p->src.C == p->Cin && sample >= 0 && sample < p->N, "head_flip_accumulate: needs 1..64 output channels");
@@ -507,7 +518,9 @@ extern "C" int mt_head_flip_accumulate(const mt_pointwise_t* p, int sample, int 
   P.sample = sample; P.fD = flipD; P.fH = flipH; P.fW = flipW; P.nonlin = nonlin; P.first = first; P.weight = weight; P.acc = acc;
   const mt_src_t& S = p->src;
   const bool v2 = (S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0;
-  if (v2) hipLaunchKernelGGL(head_flip_accumulate_kernel<2>, dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
+  if (S.dtype == MT_F16) hipLaunchKernelGGL((head_flip_accumulate_kernel<2, MT_F16>), dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
+  else if (S.dtype == MT_BF16) hipLaunchKernelGGL((head_flip_accumulate_kernel<2, MT_BF16>), dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
+  else if (v2) hipLaunchKernelGGL(head_flip_accumulate_kernel<2>, dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
   else    hipLaunchKernelGGL(head_flip_accumulate_kernel<1>, dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
   MT_CHECK_LAUNCH("head_flip_accumulate");
   return MT_OK;
@@ -530,8 +543,9 @@ struct HeadMirParams {
   float* agg; float* nb;        // agg[C][aX][aY][aZ], nb[aX][aY][aZ] (nb may be NULL)
   long aX, aY, aZ; int x0, y0, z0;
 };
-template <int VEC>
+template <int VEC, int XS = MT_F32>
 __global__ __launch_bounds__(256) void head_mirror_accumulate_kernel(const HeadMirParams P) {
+  constexpr int XE = mt_ebytes<XS>();
   const mt_pointwise_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -563,9 +577,9 @@ __global__ __launch_bounds__(256) void head_mirror_accumulate_kernel(const HeadM
 
   for (int k = 0; k < P.nsamples; ++k) {
     const int nb_ = P.sample0 + k, f = P.flips[k];
-    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(S.ptr + (size_t)nb_ * in_sample), 0, (int)(in_sample * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (size_t)nb_ * in_sample * XE), 0, (int)(in_sample * XE), 0x00020000);
     const long sv = ((long)((f & 1) ? c.Db - 1 - d : d) * c.Hb + ((f & 2) ? c.Hb - 1 - h : h)) * c.Wb + ((f & 4) ? c.Wb - 1 - w : w);
-    const int aoff = vok ? (int)((sv * S.cs + 8 * lhalf) * 4) : (int)0x80000000;
+    const int aoff = vok ? (int)((sv * S.cs + 8 * lhalf) * XE) : (int)0x80000000;
     if (aff) {
       __syncthreads();
       for (int i = tid; i < P.nchunks * PW_CK; i += 256) {
@@ -581,8 +595,12 @@ __global__ __launch_bounds__(256) void head_mirror_accumulate_kernel(const HeadM
       for (int j = 0; j < 16; ++j) acc[n][j] = bias[n][j];
     for (int ch = 0; ch < P.nchunks; ++ch) {
       float x[8];
-      const int o = aoff + ch * (PW_CK * 4);
-      if constexpr (VEC == 2) {
+      const int o = aoff + ch * (PW_CK * XE);
+      if constexpr (XS != MT_F32) {
+        const uint4 t = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ra, o, 0, 0));
+        x[0] = mt_lo16<XS>(t.x); x[1] = mt_hi16<XS>(t.x); x[2] = mt_lo16<XS>(t.y); x[3] = mt_hi16<XS>(t.y);
+        x[4] = mt_lo16<XS>(t.z); x[5] = mt_hi16<XS>(t.z); x[6] = mt_lo16<XS>(t.w); x[7] = mt_hi16<XS>(t.w);
+      } else if constexpr (VEC == 2) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ra, o + g * 8, 0, 0));
@@ -667,7 +685,8 @@ __global__ __launch_bounds__(256) void head_mirror_accumulate_kernel(const HeadM
 extern "C" int mt_head_mirror_accumulate(const mt_pointwise_t* p, int sample0, int nsamples, const int32_t* flips, int nonlin, float weight,
                                          const float* gauss, float* agg, float* nb, long aX, long aY, long aZ, int x0, int y0, int z0,
                                          mt_stream_t stream) {
-  MT_REQUIRE(p == nullptr || p->src.dtype == MT_F32, "head_mirror_accumulate: fp32 source only (convert with mt_cast)");
+  MT_REQUIRE(p == nullptr || mt_dtype_ok(p->src.dtype), "head_mirror_accumulate: bad source storage type");
+  MT_REQUIRE(p == nullptr || p->src.dtype == MT_F32 || (!(p->src.cs & 1) && !(((uintptr_t)p->src.ptr) & 3)), "head_mirror_accumulate: a 16-bit source needs an even channel stride");
   MT_REQUIRE(p != nullptr && agg != nullptr && flips != nullptr, "head_mirror_accumulate: null pointers");
   MT_REQUIRE(p->siD == 1 && p->siH == 1 && p->siW == 1 && p->soD == 1 && p->soH == 1 && p->soW == 1 && p->Db == p->Di && p->Hb == p->Hi &&
              p->Wb == p->Wi, "head_mirror_accumulate: 1x1x1 stride-1 head only");
@@ -683,7 +702,9 @@ extern "C" int mt_head_mirror_accumulate(const mt_pointwise_t* p, int sample0, i
   P.aX = aX; P.aY = aY; P.aZ = aZ; P.x0 = x0; P.y0 = y0; P.z0 = z0;
   const mt_src_t& S = p->src;
   const bool v2 = (S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0;
-  if (v2) hipLaunchKernelGGL(head_mirror_accumulate_kernel<2>, dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
+  if (S.dtype == MT_F16) hipLaunchKernelGGL((head_mirror_accumulate_kernel<2, MT_F16>), dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
+  else if (S.dtype == MT_BF16) hipLaunchKernelGGL((head_mirror_accumulate_kernel<2, MT_BF16>), dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
+  else if (v2) hipLaunchKernelGGL(head_mirror_accumulate_kernel<2>, dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
   else    hipLaunchKernelGGL(head_mirror_accumulate_kernel<1>, dim3((unsigned)P.nsb), dim3(256), 0, (hipStream_t)stream, P);
   MT_CHECK_LAUNCH("head_mirror_accumulate");
   return MT_OK;

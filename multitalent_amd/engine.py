@@ -893,7 +893,9 @@ class Engine:
         nonlinearity, the un-flip and the accumulation of the sliding window (the logits are never stored)."""
         self.forward(x, need_grad=False, all_heads=False, _skip_final=True)
         op = next(o for o in self.ops if isinstance(o, HeadOp) and o.out is self.heads[self.final_head])
-        a = self.as_fp32(op.srcs[0].act)        # (the fused inference head reads fp32)
+        a = op.srcs[0].act                      # the fused inference heads take fp32 and 16-bit sources (even channel stride)
+        if a.dtype != torch.float32 and (a.cs & 1):
+            a = self.as_fp32(a)
         p = ops.fill_pointwise(a, op.geom.out, a.spatial, (1, 1, 1), (1, 1, 1), op.conv.out_channels, op.wf, op.conv.bias, op.out.act)
         p._keep = (op.wf, op.conv.bias, a.buf)  # the struct only holds raw pointers
         return p

@@ -767,3 +767,45 @@ def test_lowres_backward_weight_im2col_gemm(dev, Cins, Cout, shape, k, xdt, ydt)
     ops.conv3d_bwd_weight(p, ya, dw2, ops.conv_weight_strides(dw2), True, ws)
     torch.cuda.synchronize()
     assert torch.allclose(dw2, 2 * dw, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("nonlin", [1, 2])
+def test_fused_inference_heads_take_the_16bit_source(dev, nonlin):
+    """mt_head_flip_accumulate / mt_head_mirror_accumulate over the fp16 decoder output of the mixed mode: identical to the same launch
+    over an fp32 copy of the stored values (the kernels widen exactly and compute in fp32)"""
+    import test_mixed_precision_gpu as M
+    from multitalent_amd.engine import HeadOp
+    ops = _ops()
+    net = M._net(dev)
+    net.eval()
+    eng = net.engine()
+    eng.set_precision('bf16')
+    try:
+        g = torch.Generator().manual_seed(12)
+        patch = (16, 32, 48)
+        x = torch.randn((2, 1) + patch, generator=g).to(dev)
+        with torch.no_grad():
+            hp = eng.forward_to_final_head(x)
+        op = next(o for o in eng.ops if isinstance(o, HeadOp) and o.out is eng.heads[eng.final_head])
+        a16 = op.srcs[0].act
+        assert a16.dtype == torch.float16 and hp.src.dtype == 2, (a16.dtype, hp.src.dtype)      # no cast in front of the fused head
+        a32 = a16.with_buf(a16.buf.float())
+        hp32 = ops.fill_pointwise(a32, op.geom.out, a32.spatial, (1, 1, 1), (1, 1, 1), op.conv.out_channels, op.wf, op.conv.bias, op.out.act)
+        C = op.conv.out_channels
+        res = []
+        for p in (hp, hp32):
+            acc = torch.full((C,) + patch, float('nan'), device=dev)
+            ops.head_flip_accumulate(p, 1, (True, False, True), nonlin, 0.5, acc, True)
+            ops.head_flip_accumulate(p, 0, (False, True, False), nonlin, 0.5, acc, False)
+            shape = (20, 40, 56)
+            agg = torch.zeros((C,) + shape, device=dev)
+            nb = torch.zeros(shape, device=dev)
+            gs = torch.rand(patch, generator=g).to(dev) if not res else res[0][3]
+            ops.head_mirror_accumulate(p, 0, [(False, False, False), (True, True, False)], nonlin, 0.5, gs, agg, nb, shape, (2, 4, 8))
+            torch.cuda.synchronize()
+            res.append((acc, agg, nb, gs))
+        assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0])
+        assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+        assert float(res[0][1].abs().max()) > 0
+    finally:
+        eng.set_precision('fp32')
