@@ -2248,6 +2248,35 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   MT_CHECK_LAUNCH("conv3d_bf16");
   return MT_OK;
 }
+static bool bf16_persist() {           // MT_BF16_PERSIST=1: conv_bf16p_kernel (persistent, wave-specialised; measured SLOWER: DESIGN.md 3.3) for 16-bit storage
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_BF16_PERSIST"); use = e ? atoi(e) : 0; }
+  return use != 0;
+}
+template <int MW, int RH, int TD, int KD, int XS, int OS, int MTY>
+static int launch_bf16p_t(const mt_conv3d_t* p, hipStream_t st) {
+  ConvKParams P;
+  P.c = *p;
+  if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
+  constexpr int TH = (32 / MW) * RH, TW = MW;
+  P.tilesD = mt_cdiv(p->Do, TD); P.tilesH = mt_cdiv(p->Ho, TH); P.tilesW = mt_cdiv(p->Wo, TW);
+  P.nsb = P.tilesD * P.tilesH * P.tilesW;
+  P.ntaps = KD * 9; P.dbg = 0; P.stagger = 0;
+  P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
+  MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
+  const size_t ldsb = bf16p_lds_bytes<MW, RH, TD, KD>();
+  const long items = (long)P.nsb * p->N * mt_cdiv(p->Cout, 32);
+  int G = mt_device_cus(mt_current_device());           // one workgroup (12 waves) per CU
+  if (G > items) G = (int)items;
+  auto kfn = conv_bf16p_kernel<MW, RH, TD, KD, XS, OS, MTY>;
+  if (ldsb > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
+  }
+  hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(64 * (BF16P_NC + 4)), ldsb, st, P);
+  MT_CHECK_LAUNCH("conv3d_bf16p");
+  return MT_OK;
+}
 static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
   // NT = 2 (64 output channels per workgroup) measured slower: 0.197 vs 0.179 ms on 64->64 @ 24x96x96; 8 waves: no gain
   // storage: all fp32 (bf16 matrix type), all bf16 (backward-data over gradients) or all fp16 (forward over activations: fp16 matrix
@@ -2255,6 +2284,8 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
   const int sd = conv_src_dtype(p);
   MT_REQUIRE(sd >= 0 && sd == p->odtype, "conv3d: conv_bf16_kernel takes ONE storage type on all operands (ask mt_conv3d_io_supported)");
 #define MT_BF_CASE(I_, MW_, RH_, TD_, NW_)                                                   \
+  if (cfg == I_ && bf16_persist() && sd == MT_F16) return p->KD == 1 ? launch_bf16p_t<MW_, RH_, TD_, 1, MT_F16, MT_F16, MT_F16>(p, st) : launch_bf16p_t<MW_, RH_, TD_, 3, MT_F16, MT_F16, MT_F16>(p, st); \
+  if (cfg == I_ && bf16_persist() && sd == MT_BF16) return p->KD == 1 ? launch_bf16p_t<MW_, RH_, TD_, 1, MT_BF16, MT_BF16, MT_BF16>(p, st) : launch_bf16p_t<MW_, RH_, TD_, 3, MT_BF16, MT_BF16, MT_BF16>(p, st); \
   if (cfg == I_) {                                                                           \
     if (sd == MT_F16) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 1, MT_F16, MT_F16, MT_F16>(p, st) : launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 3, MT_F16, MT_F16, MT_F16>(p, st); \
     if (sd == MT_BF16) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 1, MT_BF16, MT_BF16, MT_BF16>(p, st) : launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 3, MT_BF16, MT_BF16, MT_BF16>(p, st); \
@@ -2524,6 +2555,10 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   if (pl.kind == CONV_BF16) {
     // the instance launch_bf16 picks, as the profiler prints it: <MW, RH, TD, VEC, NT, NW, KD, XS, OS, MTY>
     const int sd = conv_src_dtype(p);
+    if (sd > 0 && bf16_persist()) {     // <MW, RH, TD, KD, XS, OS, MTY>
+      snprintf(buf, n, "conv_bf16p_kernel<%d, %d, %d, %d, %d, %d, %d>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, p->KD, sd, sd, sd == MT_F16 ? MT_F16 : MT_BF16);
+      return MT_OK;
+    }
     snprintf(buf, n, "conv_bf16_kernel<%d, %d, %d, %d, 1, 4, %d, %d, %d, %d>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, sd > 0 ? 4 : conv_bf16_vec(p), p->KD,
              sd > 0 ? sd : 0, sd > 0 ? sd : 0, sd == MT_F16 ? MT_F16 : MT_BF16);
     return MT_OK;

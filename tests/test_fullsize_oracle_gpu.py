@@ -256,7 +256,7 @@ def _resenc_fp32_and_bf16(dev):
     del grads, logits
     torch.cuda.empty_cache()
     _, _, _, _, _, lb, lossb, gb, nb = _resenc(dev, 'bf16')
-    assert sum(n.startswith('conv_bf16_kernel') for n in nb['fwd']) >= 20, nb['fwd']
+    assert sum(n.startswith('conv_bf16') for n in nb['fwd']) >= 20, nb['fwd']
     assert any(n.startswith(('conv_bwdw_wino_bf16_kernel<3', 'conv_bwdw_wino_bf16s_kernel<3')) for n in nb['bwdw'])
     assert any(n.startswith(('conv_bwdw_wino_bf16_kernel<1', 'conv_bwdw_wino_bf16s_kernel<1')) for n in nb['bwdw'])
     assert any(n.startswith('bwdw_gemm_kernel') for n in nb['bwdw'])                      # the low-resolution stages

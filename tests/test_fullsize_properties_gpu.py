@@ -159,7 +159,7 @@ def test_adjoint_identity_at_full_size_mixed_precision(dev, Cin, Cout):
         x = torch.randn((N,) + shape + (Cin,), generator=gen).to(dev)
         w = (torch.randn((Cout, Cin) + k, generator=gen) / np.sqrt(Cin * 27)).to(dev)
         y, geom, name, part = conv_fwd(ops, x, w, stride, pad, stats=True)
-        assert name.startswith('conv_bf16_kernel'), name
+        assert name.startswith('conv_bf16'), name
         g = torch.randn(y.shape, generator=gen).to(dev)
         dx = conv_bwd_data(ops, g, w, geom, shape)
         dw = conv_bwd_weight(ops, x, g, tuple(w.shape), geom)
