@@ -162,7 +162,7 @@ int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_src_t* ysrc
  * (default, also MT_CONV_WINO), 2 Winograd wherever the geometry is eligible; "wino_waves" 8 | 4; "wino_persist" 1 | 0 | n (8-wave
  * kernel: persistent over spatial tiles (default; n > 1: at most n workers per output-channel tile) or one tile per workgroup); "bwdw_wino" 0 | 1;
  * "conv_bf16" (problems with mma == 1) = 0 never, 1 where the grid fills the chip (default), 2 wherever eligible;
- * "bwdw_bf16" 0 | 1. */
+ * "bwdw_bf16" 0 | 1; "bf16_persist" 0 (default) | 1: conv_bf16p_kernel (persistent, wave-specialised) for 16-bit storage (also MT_BF16_PERSIST). */
 int mt_set_option(const char* name, int value);
 /* Process-wide tuning knobs.  mt_set_option and the environment variables below choose BETWEEN KERNELS THAT COMPUTE THE SAME
  * RESULT (to fp32 rounding); they are the only mutable state of the library (atomics: setting one while other threads launch is
@@ -179,7 +179,7 @@ int mt_set_option(const char* name, int value);
  *   default 1024), MT_HEAD_BWD_WIDE, MT_CONV_CFG / MT_BF16_CFG (force a tile configuration), MT_CONV_STAGGER, MT_CONV_DBG (debugging).
  *   Round 4 (mixed precision): MT_BWDW_STAGED (0: conv_bwdw_wino_bf16_kernel with per-thread gathers instead of the LDS-staged
  *   conv_bwdw_wino_bf16s_kernel), MT_BWDW_GEMM (0: the low-resolution backward-weight on the fp32 marching kernel instead of
- *   im2col + bf16 GEMM).
+ *   im2col + bf16 GEMM), MT_BWDW_FAST16 (0: the tiled backward-weight geometries keep fp32 products in mixed precision), MT_BF16_PERSIST (1: conv_bf16p_kernel).
  * The HOST side above this ABI (multitalent_amd/engine.py, inference/, bench.py) reads: MT_BF16_STORAGE (0: fp32 storage in mixed
  * precision), MT_ACT_STORAGE (fp16 | bf16), MT_BF16_MIN_VOXELS, MT_PW_STRIDED (0: strided 1x1x1 projections on conv_rt_kernel),
  * MT_BWDW_STREAMS, MT_FUSE_NORM_BWD, MT_HEAD_BWD_FUSED, MT_INFER_FUSED_HEAD, MT_INFER_MIXED, MT_PACK_SPLIT, MT_IO_DEBUG (1: print

@@ -2248,9 +2248,10 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   MT_CHECK_LAUNCH("conv3d_bf16");
   return MT_OK;
 }
-static bool bf16_persist() {           // MT_BF16_PERSIST=1: conv_bf16p_kernel (persistent, wave-specialised; measured SLOWER: DESIGN.md 3.3) for 16-bit storage
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_BF16_PERSIST"); use = e ? atoi(e) : 0; }
+static std::atomic<int> g_bf16_persist{-1};     // -1: read MT_BF16_PERSIST (default 0); option "bf16_persist"
+static bool bf16_persist() {           // 1: conv_bf16p_kernel (persistent, wave-specialised; measured SLOWER: DESIGN.md 3.3) for 16-bit storage
+  int use = g_bf16_persist.load();
+  if (use < 0) { const char* e = getenv("MT_BF16_PERSIST"); use = e ? atoi(e) : 0; g_bf16_persist = use; }
   return use != 0;
 }
 template <int MW, int RH, int TD, int KD, int XS, int OS, int MTY>
@@ -2316,6 +2317,7 @@ extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "wino_dma") == 0) { g_wino_dma = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "conv_bf16") == 0) { g_bf16_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_bf16") == 0) { g_bwdw_bf16 = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "bf16_persist") == 0) { g_bf16_persist = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
 }

@@ -193,9 +193,12 @@ def _conv_pair(dev, srcs, lazy, w, bias, geom, split=None, accumulate=False, sta
     (32, 60, (8, 16, 64), (3, 3, 3), False, 30, True),             # backward-data shape: two destinations, accumulate
     (64, 64, (8, 16, 32), (3, 3, 3), False, None, True),
 ])
-def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, split, acc):
+@pytest.mark.parametrize("persist", [0, 1])
+def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, split, acc, persist):
+    """persist = 1: conv_bf16p_kernel (the opt-in persistent wave-specialised form) serves the 16-bit launch"""
     ops = _ops()
     ops.set_option('conv_bf16', 2)
+    ops.set_option('bf16_persist', persist)
     try:
         g = torch.Generator().manual_seed(5)
         N = 2
@@ -210,7 +213,7 @@ def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, s
         w = torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))
         b = torch.randn(Cout, generator=g)
         f32, b16, names = _conv_pair(dev, srcs, lazy, w, b, geom, split=split, accumulate=acc, stats=not acc)
-        assert names[0].startswith('conv_bf16_kernel') and names[1].startswith('conv_bf16'), names
+        assert names[0].startswith('conv_bf16_kernel') and names[1].startswith('conv_bf16p_kernel' if persist else 'conv_bf16_kernel'), names
         assert b16[0].dtype == torch.bfloat16
         assert torch.equal(b16[0], f32[0].to(torch.bfloat16)), float((b16[0].float() - f32[0]).abs().max())
         if split is not None:
@@ -223,6 +226,7 @@ def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, s
             assert torch.allclose(s[..., 1], (o * o).sum((1, 2, 3)), rtol=1e-4)
     finally:
         ops.set_option('conv_bf16', 1)
+        ops.set_option('bf16_persist', 0)
 
 
 def _host_conv_16(srcs, lazy, w, b, stride, pad, dt):
