@@ -2776,9 +2776,50 @@ struct PackParams {
   const float* w; float* dst;
   int Cout, KD, KH, KW, nkp, nchunks, ntiles, flip, layout;
   int has_tm, tb[3], ts[3];
+  int contig;          // the K3 taps of a (cin, cout) pair and the cin of a cout are contiguous (torch Conv3d weight): LDS-transposed path
   long s_ci, s_co, s_kd, s_kh, s_kw;
   ConvChunk chunk[MT_MAX_CHUNKS];
 };
+#define PACK_TP (16 * 27 + 1)       // floats per cout row of the LDS tile
+#define PACK_LDS_BYTES (32 * PACK_TP * 4)
+// Layouts 1 / 3 / 4 over a contiguous torch weight: a workgroup takes one (cout tile, chunk) block — 32 rows of ck * K3 CONTIGUOUS floats,
+// read as linear runs into an LDS tile — and writes the block's K3 x per_tap packed dwords as linear runs.  (The per-item form below
+// reads 108-byte runs at 64 different addresses per instruction: texture-path bound, 255 us for 124 MB of weights.)
+__device__ __forceinline__ void pack_weights_tiled(const PackParams& P, float* __restrict__ tile, int blk, int nblk) {
+  const int K3 = P.KD * P.KH * P.KW;
+  const int nq = P.layout == 1 ? P.nkp / 4 : 1;
+  const int per_tap = nq * 256;
+  const int tid = threadIdx.x;
+  for (int g = blk; g < P.ntiles * P.nchunks; g += nblk) {
+    const int nt = g / P.nchunks, ch = g - nt * P.nchunks;
+    const ConvChunk cc = P.chunk[ch];
+    const int rowlen = cc.ck * K3;
+    __syncthreads();                         // the previous block's reads of the tile are done
+    for (int co = 0; co < 32; ++co) {
+      const int cog = nt * 32 + co;
+      const float* src = P.w + (long)cog * P.s_co + (long)cc.cglob * K3;
+      for (int r = tid; r < rowlen; r += 256) tile[co * PACK_TP + r] = cog < P.Cout ? src[r] : 0.f;
+    }
+    __syncthreads();
+    float* dst = P.dst + (size_t)g * K3 * per_tap;
+    for (int i = tid; i < per_tap; i += 256) {
+      const int e = i & 3, l = (i >> 2) & 63, qq = i >> 8;
+      const int co = l & 31;
+      const int c0 = P.layout == 1 ? (l >> 5) * P.nkp + qq * 4 + e : (l >> 5) * 8 + 2 * e;
+      const bool v0 = c0 < cc.ck, v1 = P.layout >= 3 && (c0 + 1) < cc.ck;
+      const float* tp = tile + co * PACK_TP + c0 * K3;
+      for (int tap = 0; tap < K3; ++tap) {
+        const int zt = P.flip ? K3 - 1 - tap : tap;
+        const float a0 = v0 ? tp[zt] : 0.f;
+        if (P.layout == 1) dst[(size_t)tap * per_tap + i] = a0;
+        else {
+          const float a1 = v1 ? tp[K3 + zt] : 0.f;
+          ((unsigned*)dst)[(size_t)tap * per_tap + i] = P.layout == 3 ? mt_pk16<MT_BF16>(a0, a1) : mt_pk16<MT_F16>(a0, a1);
+        }
+      }
+    }
+  }
+}
 __device__ __forceinline__ void pack_weights_body(const PackParams& P, long first, long stride) {
   if (P.layout == 2) {     // Winograd F(2x2x2, 3x3x3): U = G g G^T (3D) in B-fragment order [ntile][chunk of 8][xi 64][lane][4]
     // one work item per (cin, cout) pair: the 27 weights are read once and transformed separably into the 64 xi values
@@ -2945,8 +2986,11 @@ __global__ void pack_weights_kernel(const PackParams P) {
   pack_weights_body(P, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 // every layer's packing of one optimizer step in ONE launch: blockIdx.y selects the descriptor (table in device memory)
-__global__ void pack_weights_batched_kernel(const PackParams* __restrict__ tab) {
-  pack_weights_body(tab[blockIdx.y], (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackParams* __restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) float pack_tile[];
+  const PackParams& P = tab[blockIdx.y];
+  if (P.contig && (P.layout == 1 || P.layout >= 3)) { pack_weights_tiled(P, pack_tile, (int)blockIdx.x, (int)gridDim.x); return; }   // block-uniform
+  pack_weights_body(P, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 static int pack_fill(PackParams& P, size_t* packed_floats, const float* w, float* dst, int C0, int C1, int Cout, int KD, int KH,
@@ -2968,6 +3012,9 @@ static int pack_fill(PackParams& P, size_t* packed_floats, const float* w, float
   P.has_tm = tapmap != nullptr;
   for (int d = 0; d < 3; ++d) { P.tb[d] = tapmap ? tapmap[2 * d] : 0; P.ts[d] = tapmap ? tapmap[2 * d + 1] : 1; }
   P.s_ci = s_ci; P.s_co = s_co; P.s_kd = s_kd; P.s_kh = s_kh; P.s_kw = s_kw;
+  static int tiled = -1;
+  if (tiled < 0) { const char* e = getenv("MT_PACK_TILED"); tiled = e ? atoi(e) : 1; }
+  P.contig = (tiled && tapmap == nullptr && ck <= 16 && KD * KH * KW <= 27 && s_kw == 1 && s_kh == KW && s_kd == (long)KH * KW && s_ci == (long)KD * KH * KW) ? 1 : 0;
   return MT_OK;
 }
 extern "C" size_t mt_pack_desc_size(void) { return sizeof(PackParams); }
@@ -2986,7 +3033,7 @@ static unsigned g_pack_blocks() {
 }
 extern "C" int mt_pack_batched(const void* descs_device, int n, mt_stream_t stream) {
   MT_REQUIRE(descs_device != nullptr && n > 0, "pack_batched: empty table");
-  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(g_pack_blocks(), (unsigned)n, 1), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(g_pack_blocks(), (unsigned)n, 1), dim3(256), PACK_LDS_BYTES, (hipStream_t)stream,
                      (const PackParams*)descs_device);
   MT_CHECK_LAUNCH("pack_weights_batched");
   return MT_OK;
