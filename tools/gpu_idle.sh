@@ -10,10 +10,14 @@ O = sys.argv[1]
 f = [os.path.join(dp, x) for dp, _, fs in os.walk(O + '/t') for x in fs if x.endswith('kernel_trace.csv')][0]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f))]
 rows.sort()
-# steady state: the last 60 % of the trace
-t0 = rows[0][0]; t1 = max(r[1] for r in rows)
-lo = t0 + int(0.5 * (t1 - t0))
-sel = [r for r in rows if r[0] >= lo]
+# steady state: the longest run of kernels without a gap above 2 ms (warm-up, allocation and teardown phases are separated by such gaps)
+segs = []; cur = [rows[0]]; ce = rows[0][1]
+for r in rows[1:]:
+    if r[0] - ce > 2000000:
+        segs.append(cur); cur = []
+    cur.append(r); ce = max(ce, r[1])
+segs.append(cur)
+sel = max(segs, key=len)
 busy = 0; cur_s, cur_e = sel[0][0], sel[0][1]
 gaps = []
 for s, e, _ in sel[1:]:
