@@ -3901,6 +3901,7 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
     P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N;
     bwdw_march_plan(p, P);
   }
+  if (bwdw_march16_geo(p)) bwdw_march_plan(p, P);      // conv_bwdw_march16_kernel: columns x D segments (tile 4 x 32: Wo > 16)
   if (bwdw_use_march(p)) {
     static int tall = -1;
     if (tall < 0) { const char* e = getenv("MT_BWDW_TALL"); tall = e ? atoi(e) : 1; }
@@ -3959,6 +3960,9 @@ static int launch_bwdw_march(const BwdWParams& P, int vec, int yv, hipStream_t s
 
 template <int KD, int KH, int KW, int SD, int SH, int SW>
 static int launch_bwdw_fast(const BwdWParams& P, int vec, hipStream_t st) {
+  if constexpr (KD == 3 && KH == 3 && KW == 3 && SH == 2 && SW == 2) {
+    if (bwdw_march16_ok(&P.c, &P.y) && P.nunits > 0 && P.TW == 32) return launch_bwdw_march16<SD>(P, st);      // marching form of the strided stage convs
+  }
   if (bwdw_fast16_ok(&P.c, &P.y)) return launch_bwdw_fast16<KD, KH, KW, SD, SH, SW>(P, st);      // mixed precision: bf16 products
   constexpr int LHa = 3 * SH + KH, LWa = 31 * SW + KW, LHb = 7 * SH + KH, LWb = 15 * SW + KW;
   size_t ldsb = (size_t)KD * (P.TW == 32 ? LHa * LWa : LHb * LWb) * FCKP * sizeof(float);
@@ -4064,6 +4068,7 @@ extern "C" int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_s
   static const char* kGeo[9] = {"", "3, 3, 3, 2, 2, 2", "3, 3, 3, 1, 2, 2", "2, 2, 2, 2, 2, 2", "1, 2, 2, 1, 2, 2", "1, 1, 1, 1, 1, 1",
                                 "1, 3, 3, 1, 1, 1", "1, 1, 1, 2, 2, 2", "1, 1, 1, 1, 2, 2"};
   if (geo > 8) return MT_EINVAL;
+  if ((geo == 1 || geo == 2) && bwdw_march16_ok(p, ysrc)) { snprintf(buf, n, "conv_bwdw_march16_kernel<%d, %d, %d>", p->SD, p->src[0].dtype, ysrc->dtype); return MT_OK; }
   snprintf(buf, n, bwdw_fast16_ok(p, ysrc) ? "conv_bwdw_fast16_kernel<%s>" : "conv_bwdw_fast_kernel<%s>", kGeo[geo]);
   return MT_OK;
 }

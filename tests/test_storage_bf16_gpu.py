@@ -624,7 +624,7 @@ def test_tiled_backward_weight_16bit_storage_bitexact(dev, kind):
     assert torch.isfinite(res[1]).all() and torch.equal(res[0], res[1]), float((res[0] - res[1]).abs().max())
 
 
-@pytest.mark.parametrize("kind", ["strided222", "strided222_narrow", "strided122", "tconv222", "tconv122", "head", "proj222", "proj122", "k333_shallow", "two_sources"])
+@pytest.mark.parametrize("kind", ["strided222", "strided222_narrow", "strided222_deep", "strided122", "tconv222", "tconv122", "head", "proj222", "proj122", "k333_shallow", "two_sources"])
 def test_tiled_backward_weight_bf16_products(dev, kind):
     """conv_bwdw_fast16_kernel (mixed precision: 16-bit X and dY, bf16 products, fp32 accumulation) against autograd on the host with the
     same operand rounding (activated operands rounded to bf16, exact products); ragged tiles, both tile shapes, accumulate"""
@@ -635,6 +635,7 @@ def test_tiled_backward_weight_bf16_products(dev, kind):
     f16, b16, f32 = torch.float16, torch.bfloat16, torch.float32
     cfg = {'strided222': ((3, 3, 3), (2, 2, 2), (1, 1, 1), (30,), 60, (8, 12, 70), f16, b16, True),
            'strided222_narrow': ((3, 3, 3), (2, 2, 2), (1, 1, 1), (64,), 40, (6, 18, 26), f16, b16, True),      # Wo <= 16: the 8 x 16 tile
+           'strided222_deep': ((3, 3, 3), (2, 2, 2), (1, 1, 1), (32,), 64, (23, 10, 66), f16, b16, True),        # odd depth: 12 output planes, ragged h tiles, D segments
            'strided122': ((3, 3, 3), (1, 2, 2), (1, 1, 1), (32,), 64, (5, 12, 34), f16, b16, True),
            'tconv222': ((2, 2, 2), (2, 2, 2), (0, 0, 0), (30,), 60, (8, 12, 36), b16, f16, False),   # X = dOut, Y = tconv input (lazy)
            'tconv122': ((1, 2, 2), (1, 2, 2), (0, 0, 0), (32,), 64, (3, 8, 72), b16, f16, False),
@@ -655,7 +656,9 @@ def test_tiled_backward_weight_bf16_products(dev, kind):
     ya = ops.Act(yb) if xlazy else ops.Act(yb, scale=yl[0].to(dev), shift=yl[1].to(dev), slope=0.01)
     p = ops.fill_conv(acts, geom, Cout, mma=1)
     name = ops.conv_bwd_weight_kernel_name(p, ya)
-    assert name.startswith('conv_bwdw_fast16_kernel'), name
+    # the strided 3x3x3 stage convs with Wo > 16 and Do >= 3 take the marching form (a ring of input planes), everything else the tiled one
+    marching = kind in ('strided222', 'strided122', 'two_sources', 'strided222_deep')
+    assert name.startswith('conv_bwdw_march16_kernel' if marching else 'conv_bwdw_fast16_kernel'), name
     assert ops.conv_bwd_weight_io_supported(p, ya), name
     Cin = sum(Cins)
     dw = torch.full((Cout, Cin) + k, float('nan'), device=dev)
