@@ -2284,9 +2284,9 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
   // type); 16-bit sources are read as 8-byte groups of four channels, 16-bit destinations written as channel-pair dwords
   const int sd = conv_src_dtype(p);
   MT_REQUIRE(sd >= 0 && sd == p->odtype, "conv3d: conv_bf16_kernel takes ONE storage type on all operands (ask mt_conv3d_io_supported)");
+  if (cfg == 0 && bf16_persist() && sd == MT_F16) return p->KD == 1 ? launch_bf16p_t<32, 4, 4, 1, MT_F16, MT_F16, MT_F16>(p, st) : launch_bf16p_t<32, 4, 4, 3, MT_F16, MT_F16, MT_F16>(p, st);
+  if (cfg == 0 && bf16_persist() && sd == MT_BF16) return p->KD == 1 ? launch_bf16p_t<32, 4, 4, 1, MT_BF16, MT_BF16, MT_BF16>(p, st) : launch_bf16p_t<32, 4, 4, 3, MT_BF16, MT_BF16, MT_BF16>(p, st);
 #define MT_BF_CASE(I_, MW_, RH_, TD_, NW_)                                                   \
-  if (cfg == I_ && bf16_persist() && sd == MT_F16) return p->KD == 1 ? launch_bf16p_t<MW_, RH_, TD_, 1, MT_F16, MT_F16, MT_F16>(p, st) : launch_bf16p_t<MW_, RH_, TD_, 3, MT_F16, MT_F16, MT_F16>(p, st); \
-  if (cfg == I_ && bf16_persist() && sd == MT_BF16) return p->KD == 1 ? launch_bf16p_t<MW_, RH_, TD_, 1, MT_BF16, MT_BF16, MT_BF16>(p, st) : launch_bf16p_t<MW_, RH_, TD_, 3, MT_BF16, MT_BF16, MT_BF16>(p, st); \
   if (cfg == I_) {                                                                           \
     if (sd == MT_F16) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 1, MT_F16, MT_F16, MT_F16>(p, st) : launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 3, MT_F16, MT_F16, MT_F16>(p, st); \
     if (sd == MT_BF16) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 1, MT_BF16, MT_BF16, MT_BF16>(p, st) : launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 3, MT_BF16, MT_BF16, MT_BF16>(p, st); \
@@ -2557,7 +2557,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   if (pl.kind == CONV_BF16) {
     // the instance launch_bf16 picks, as the profiler prints it: <MW, RH, TD, VEC, NT, NW, KD, XS, OS, MTY>
     const int sd = conv_src_dtype(p);
-    if (sd > 0 && bf16_persist()) {     // <MW, RH, TD, KD, XS, OS, MTY>
+    if (sd > 0 && i == 0 && bf16_persist()) {     // (the 4x4x32 tile only) <MW, RH, TD, KD, XS, OS, MTY>
       snprintf(buf, n, "conv_bf16p_kernel<%d, %d, %d, %d, %d, %d, %d>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, p->KD, sd, sd, sd == MT_F16 ? MT_F16 : MT_BF16);
       return MT_OK;
     }

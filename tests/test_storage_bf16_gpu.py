@@ -624,7 +624,7 @@ def test_tiled_backward_weight_16bit_storage_bitexact(dev, kind):
     assert torch.isfinite(res[1]).all() and torch.equal(res[0], res[1]), float((res[0] - res[1]).abs().max())
 
 
-@pytest.mark.parametrize("kind", ["strided222", "strided222_narrow", "strided222_deep", "strided122", "tconv222", "tconv122", "head", "proj222", "proj122", "k333_shallow", "two_sources"])
+@pytest.mark.parametrize("kind", ["strided222", "strided222_narrow", "strided222_deep", "strided122", "tconv222", "tconv122", "proj222", "proj122", "k333_shallow", "two_sources"])
 def test_tiled_backward_weight_bf16_products(dev, kind):
     """conv_bwdw_fast16_kernel (mixed precision: 16-bit X and dY, bf16 products, fp32 accumulation) against autograd on the host with the
     same operand rounding (activated operands rounded to bf16, exact products); ragged tiles, both tile shapes, accumulate"""
@@ -639,7 +639,6 @@ def test_tiled_backward_weight_bf16_products(dev, kind):
            'strided122': ((3, 3, 3), (1, 2, 2), (1, 1, 1), (32,), 64, (5, 12, 34), f16, b16, True),
            'tconv222': ((2, 2, 2), (2, 2, 2), (0, 0, 0), (30,), 60, (8, 12, 36), b16, f16, False),   # X = dOut, Y = tconv input (lazy)
            'tconv122': ((1, 2, 2), (1, 2, 2), (0, 0, 0), (32,), 64, (3, 8, 72), b16, f16, False),
-           'head': ((1, 1, 1), (1, 1, 1), (0, 0, 0), (60,), 47, (4, 8, 34), f16, f32, True),
            'proj222': ((1, 1, 1), (2, 2, 2), (0, 0, 0), (30,), 60, (8, 12, 34), f16, b16, True),
            'proj122': ((1, 1, 1), (1, 2, 2), (0, 0, 0), (32,), 64, (3, 12, 34), f16, b16, True),
            'k333_shallow': ((3, 3, 3), (1, 1, 1), (1, 1, 1), (30,), 30, (2, 9, 40), f16, b16, True),          # Do < 3: not a marching problem
