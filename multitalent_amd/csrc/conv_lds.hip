@@ -2795,10 +2795,21 @@ __device__ __forceinline__ void pack_weights_tiled(const PackParams& P, float* _
     const ConvChunk cc = P.chunk[ch];
     const int rowlen = cc.ck * K3;
     __syncthreads();                         // the previous block's reads of the tile are done
-    for (int co = 0; co < 32; ++co) {
-      const int cog = nt * 32 + co;
-      const float* src = P.w + (long)cog * P.s_co + (long)cc.cglob * K3;
-      for (int r = tid; r < rowlen; r += 256) tile[co * PACK_TP + r] = cog < P.Cout ? src[r] : 0.f;
+    {   // all 64 loads of a thread (32 rows x 2 pieces of <= 432 floats) are requested before the first LDS store: one round trip per block
+      float v0[32], v1[32];
+      const float* src0 = P.w + (long)(nt * 32) * P.s_co + (long)cc.cglob * K3;
+      const int nrow = P.Cout - nt * 32;              // valid rows of this cout tile
+#pragma unroll
+      for (int co = 0; co < 32; ++co) {
+        const float* src = src0 + (long)co * P.s_co;
+        v0[co] = (co < nrow && tid < rowlen) ? src[tid] : 0.f;
+        v1[co] = (co < nrow && tid + 256 < rowlen) ? src[tid + 256] : 0.f;
+      }
+#pragma unroll
+      for (int co = 0; co < 32; ++co) {
+        if (tid < rowlen) tile[co * PACK_TP + tid] = v0[co];
+        if (tid + 256 < rowlen) tile[co * PACK_TP + tid + 256] = v1[co];
+      }
     }
     __syncthreads();
     float* dst = P.dst + (size_t)g * K3 * per_tap;
