@@ -73,11 +73,10 @@ __global__ __launch_bounds__(64) void loss_stats_finalize_kernel(const float* pa
 #define LF_KMAX 240          // elements per thread per block (block covers LF_KMAX * (A / C) voxels, at most LF_VMAX)
 #define LF_VMAX 4096
 __host__ __device__ static inline long lf_vpb(int nsub) { const long v = (long)LF_KMAX * nsub; return v < LF_VMAX ? v : LF_VMAX; }
-__global__ __launch_bounds__(256) void mt_loss_fwd_flat_kernel(const float* __restrict__ logits, const float* __restrict__ target, long V, int C,
-                                                               const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
-                                                               int nblk, int A, float* __restrict__ part) {
-  __shared__ float red[256][4];
-  __shared__ signed char slab[LF_VMAX];                            // the block's labels (-1 = none of the 64 label values)
+__device__ __forceinline__ void lf_fwd_flat_body(const float* __restrict__ logits, const float* __restrict__ target, long V, int C,
+                                                 const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
+                                                 int nblk, int A, float* __restrict__ part, float (*red)[4], signed char* slab) {
+  // red[256][4]; slab[LF_VMAX]: the block's labels (-1 = none of the 64 label values)
   const int b = blockIdx.y, t = threadIdx.x;
   const int c = t % C, sub = t / C, nsub = A / C;                  // `sub`-th voxel of every group of nsub voxels
   const bool act = (t < A) && ((valid[b] >> c) & 1ull);
@@ -128,6 +127,13 @@ __global__ __launch_bounds__(256) void mt_loss_fwd_flat_kernel(const float* __re
     for (int q = 0; q < nsub; ++q) sum += red[q * C + cc][k];
     part[(((size_t)b * nblk + blockIdx.x) * C + cc) * 4 + k] = sum;
   }
+}
+__global__ __launch_bounds__(256) void mt_loss_fwd_flat_kernel(const float* __restrict__ logits, const float* __restrict__ target, long V, int C,
+                                                               const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
+                                                               int nblk, int A, float* __restrict__ part) {
+  __shared__ float red[256][4];
+  __shared__ signed char slab[LF_VMAX];
+  lf_fwd_flat_body(logits, target, V, C, valid, lut, nblk, A, part, red, slab);
 }
 
 __global__ __launch_bounds__(256) void mt_loss_bwd_flat_kernel(const float* __restrict__ logits, const float* __restrict__ target, long V, int C,
@@ -180,6 +186,137 @@ __global__ __launch_bounds__(256) void mt_loss_bwd_flat_kernel(const float* __re
     }
   }
 }
+// ---- few valid regions (round 4).  A MultiTalent sample carries the regions of ITS dataset only (2-3 of 47 for most of the thirteen):
+// in the flat kernels above 15 of 256 threads then do all the work (forward) resp. every thread walks its channel's elements to store
+// zeros one dword at a time (backward): 1.2 / 2.5 TB/s by the counters (profiles/r04_pmc_per_kernel.json), 9 % of a Task100 mixed step.
+// Forward: the block's threads are spread over (voxel, ACTIVE channel) pairs — thread t owns active channel alist[t % nact] of every
+// (256 / nact)-th voxel, per-channel constants in registers as before, partials in the same [block][C][4] layout (zeros for the other
+// channels), fixed-order sums.
+#define LF_SPARSE_MAX 23      // at most this many valid regions: every thread of the block can be given work
+__global__ __launch_bounds__(256) void mt_loss_fwd_sparse_kernel(const float* __restrict__ logits, const float* __restrict__ target, long V, int C,
+                                                                 const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
+                                                                 int nblk, long vpb, float* __restrict__ part) {
+  __shared__ float red[256][4];
+  __shared__ signed char slab[LF_VMAX];
+  __shared__ int alist[64];
+  const int b = blockIdx.y, t = threadIdx.x;
+  const uint64_t vm = valid[b] & (C < 64 ? ((1ull << C) - 1ull) : ~0ull);
+  const int nact = __popcll(vm);                                   // block-uniform
+  if (nact < 1 || nact > LF_SPARSE_MAX) {                          // a sample with many valid regions: the flat form keeps every thread busy
+    lf_fwd_flat_body(logits, target, V, C, valid, lut, nblk, (256 / C) * C, part, red, slab);
+    return;
+  }
+  if (t < C && ((vm >> t) & 1ull)) alist[__popcll(vm & ((1ull << t) - 1ull))] = t;
+  const long v0 = (long)blockIdx.x * vpb;
+  const long v1 = (v0 + vpb < V) ? v0 + vpb : V;
+  const float* tg = target + (size_t)b * V;
+  for (int i = t; i < (int)(v1 - v0); i += 256) {
+    const int lab = (int)tg[v0 + i];
+    slab[i] = (signed char)((lab >= 0 && lab < 64) ? lab : -1);
+  }
+  __syncthreads();
+  const int nsub = 256 / nact, A = nsub * nact;
+  const int k = t % nact, sub = t / nact;
+  const bool act = t < A;
+  const int c = alist[act ? k : 0];
+  const uint64_t l = lut[c];
+  const float* x = logits + ((size_t)b * V) * C + c;
+  float bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
+  if (act) {
+    for (long vb = v0 + sub; vb < v1; vb += 4 * nsub) {
+      float xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long v = vb + (long)u * nsub;
+        xv[u] = (v < v1) ? x[(size_t)v * C] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long v = vb + (long)u * nsub;
+        if (v < v1) {
+          const float xx = xv[u];
+          const int lab = slab[v - v0];
+          const float y = (lab >= 0 && ((l >> lab) & 1ull)) ? 1.f : 0.f;
+          const float ex = __expf(-fabsf(xx));
+          const float r = __builtin_amdgcn_rcpf(1.f + ex);
+          bce += fmaxf(xx, 0.f) - xx * y + __logf(1.f + ex);
+          const float sg = (xx >= 0.f) ? r : ex * r;
+          tp += sg * y;
+          fp += sg * (1.f - y);
+          fn += (1.f - sg) * y;
+        }
+      }
+    }
+  }
+  red[t][0] = bce; red[t][1] = tp; red[t][2] = fp; red[t][3] = fn;
+  __syncthreads();
+  float* pb = part + ((size_t)b * nblk + blockIdx.x) * C * 4;
+  if (t < C * 4 && !((vm >> (t >> 2)) & 1ull)) pb[t] = 0.f;         // regions this sample does not carry
+  if (t < nact * 4) {                                               // fixed-order sum over the nsub threads of an active channel
+    const int kk = t >> 2, st = t & 3;
+    float sum = 0.f;
+    for (int q = 0; q < nsub; ++q) sum += red[q * nact + kk][st];
+    pb[alist[kk] * 4 + st] = sum;
+  }
+}
+// Backward: the gradient is dense (zeros for the regions a sample does not carry), so every thread owns FOUR CONSECUTIVE floats of the
+// flat [V][C] slab and stores them as one 16-byte vector; the logit is read (a scalar load) only for the few elements whose channel is
+// valid.  (V * C and the block's first element are multiples of four.)
+__global__ __launch_bounds__(256) void mt_loss_bwd_wide_kernel(const float* __restrict__ logits, const float* __restrict__ target, long V, int C,
+                                                               const uint64_t* __restrict__ valid, const uint64_t* __restrict__ lut,
+                                                               const float* __restrict__ gstats, long vpb, float* __restrict__ dlogits) {
+  __shared__ signed char slab[LF_VMAX];
+  __shared__ float gsl[64][4];
+  __shared__ uint64_t lutl[64];
+  const int b = blockIdx.y, t = threadIdx.x;
+  const uint64_t vm = valid[b] & (C < 64 ? ((1ull << C) - 1ull) : ~0ull);
+  const long v0 = (long)blockIdx.x * vpb;
+  const long v1 = (v0 + vpb < V) ? v0 + vpb : V;
+  for (int i = t; i < (int)(v1 - v0); i += 256) {
+    const int lab = (int)target[(size_t)b * V + v0 + i];
+    slab[i] = (signed char)((lab >= 0 && lab < 64) ? lab : -1);
+  }
+  if (t < C) {
+    lutl[t] = lut[t];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gsl[t][k] = gstats[((size_t)b * C + t) * 4 + k];
+  }
+  __syncthreads();
+  const size_t base = ((size_t)b * V + v0) * C;                    // first element of the block
+  const int nel = (int)((v1 - v0) * C);                            // multiple of 4
+  int fr = 4 * t;                                                  // element offset inside the block
+  int vr = fr / C, c = fr - vr * C;                                // its voxel (relative) and channel
+  const int dv = 1024 / C, dc = 1024 - dv * C;                     // advance of 256 threads x 4 elements
+  const float* xb = logits + base;
+  float* db = dlogits + base;
+  for (; fr < nel; fr += 1024) {
+    float d[4];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int ce = (c + e >= C) ? c + e - C : c + e; any = any || ((vm >> ce) & 1ull); }
+    float4 xq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (any) xq = *(const float4*)(xb + fr);
+    const float xa[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int ce = c + e, ve = vr;
+      if (ce >= C) { ce -= C; ve += 1; }
+      d[e] = 0.f;
+      if ((vm >> ce) & 1ull) {
+        const float xx = xa[e];
+        const int lab = slab[ve];
+        const float y = (lab >= 0 && ((lutl[ce] >> lab) & 1ull)) ? 1.f : 0.f;
+        const float ex = __expf(-fabsf(xx));
+        const float r = __builtin_amdgcn_rcpf(1.f + ex);
+        const float sg = (xx >= 0.f) ? r : ex * r;
+        d[e] = gsl[ce][0] * (sg - y) + sg * (1.f - sg) * (y * (gsl[ce][1] - gsl[ce][3]) + (1.f - y) * gsl[ce][2]);
+      }
+    }
+    *(float4*)(db + fr) = make_float4(d[0], d[1], d[2], d[3]);
+    vr += dv; c += dc;
+    if (c >= C) { c -= C; vr += 1; }
+  }
+}
 static inline int lf_A(int C) { return (256 / C) * C; }
 static inline int lf_blocks(long V, int C) { return mt_cdiv(V, lf_vpb(lf_A(C) / C)); }
 
@@ -198,7 +335,10 @@ extern "C" int mt_multitalent_loss_fwd(const float* logits, int cs, const float*
   int nblk;
   if (cs == C) {            // contiguous logits (what the engine produces): flat coalesced kernel
     nblk = lf_blocks(V, C);
-    hipLaunchKernelGGL(mt_loss_fwd_flat_kernel, dim3(nblk, B), dim3(256), 0, st, logits, target, V, C, valid, lut, nblk, lf_A(C), (float*)ws);
+    static int sparse = -1;
+    if (sparse < 0) { const char* e = getenv("MT_LOSS_SPARSE"); sparse = e ? atoi(e) : 1; }
+    if (sparse) hipLaunchKernelGGL(mt_loss_fwd_sparse_kernel, dim3(nblk, B), dim3(256), 0, st, logits, target, V, C, valid, lut, nblk, lf_vpb(lf_A(C) / C), (float*)ws);
+    else hipLaunchKernelGGL(mt_loss_fwd_flat_kernel, dim3(nblk, B), dim3(256), 0, st, logits, target, V, C, valid, lut, nblk, lf_A(C), (float*)ws);
   } else {
     nblk = mt_cdiv(V, LS_VB);
     hipLaunchKernelGGL(mt_loss_fwd_kernel, dim3(nblk, B), dim3(256), 0, st, logits, cs, target, V, C, valid, lut, nblk, (float*)ws);
@@ -247,7 +387,13 @@ extern "C" int mt_multitalent_loss_bwd(const float* logits, int cs, const float*
                                        const uint64_t* valid, const uint64_t* lut, const float* gstats,
                                        float* dlogits, int dcs, mt_stream_t stream) {
   MT_REQUIRE(logits && target && valid && lut && gstats && dlogits && B > 0 && V > 0 && C > 0 && C <= 64, "multitalent_loss_bwd: bad args");
-  if (cs == C && dcs == C)
+  static int wide = -1;
+  if (wide < 0) { const char* e = getenv("MT_LOSS_SPARSE"); wide = e ? atoi(e) : 1; }
+  const long vpb = lf_vpb(lf_A(C) / C);
+  if (cs == C && dcs == C && wide && ((V * C) & 3) == 0 && ((vpb * C) & 3) == 0 && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0)
+    hipLaunchKernelGGL(mt_loss_bwd_wide_kernel, dim3(lf_blocks(V, C), B), dim3(256), 0, (hipStream_t)stream, logits, target, V, C, valid, lut,
+                       gstats, vpb, dlogits);
+  else if (cs == C && dcs == C)
     hipLaunchKernelGGL(mt_loss_bwd_flat_kernel, dim3(lf_blocks(V, C), B), dim3(256), 0, (hipStream_t)stream, logits, target, V, C, valid, lut,
                        gstats, lf_A(C), dlogits);
   else
