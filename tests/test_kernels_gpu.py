@@ -763,6 +763,53 @@ def test_multitalent_loss_kernels_flat_and_strided(dev, B, C, V, wide):
         assert torch.isnan(dbuf[..., C:]).all()            # the neighbouring channels of the wider buffer are untouched
 
 
+@pytest.mark.parametrize("C,V,masks", [
+    (47, 48 * 20 * 21, [0b111 << 5, (1 << 20) | (1 << 46)]),                 # 3 and 2 valid regions: sparse forward, wide backward
+    (47, 4 * 1201, [1 << 0, 0]),                                             # one region; a sample with NO valid region
+    (47, 6000, [(1 << 23) - 1, (1 << 24) - 1, (1 << 47) - 1]),               # 23 (sparse), 24 and 47 (flat form inside the same launch)
+    (47, 3001, [0b1011 << 10, 0b1 << 40]),                                   # V * C not a multiple of 4: the dword backward
+    (5, 1236, [0b10001, 0b00100]),
+])
+def test_multitalent_loss_few_valid_regions(dev, C, V, masks):
+    """round 4: mt_loss_fwd_sparse_kernel / mt_loss_bwd_wide_kernel (a sample carries the regions of its dataset only) against the formula of
+    MultiTalent_Trainer_DDP.py:574-594 in torch fp64, and bit-identical results on a second run"""
+    ops = _ops()
+    B = len(masks)
+    g = torch.Generator().manual_seed(C * 7 + V)
+    buf = (2.5 * torch.randn((B, V, 1, 1, C), generator=g)).to(dev)
+    a = ops.Act(buf, 0, C)
+    target = torch.randint(-1, 50, (B, V), generator=g).float().to(dev)
+    lut_h = torch.randint(0, 2 ** 62, (C,), generator=g, dtype=torch.int64)
+    valid_h = torch.tensor(masks, dtype=torch.int64)
+    lut, valid = lut_h.to(dev), valid_h.to(dev)
+    ws = torch.empty(ops.loss_workspace(B, V, C) // 4 + 16, device=dev)
+    runs = []
+    for _ in range(2):
+        stats = torch.full((B, C, 4), float('nan'), device=dev)
+        ops.multitalent_loss_fwd(a, target, valid, lut, stats, ws)
+        runs.append(stats.clone())
+    assert torch.equal(runs[0], runs[1])
+    x = buf.reshape(B, V, C).double().cpu()
+    t = target.cpu().long()
+    y = torch.zeros((B, V, C), dtype=torch.float64)
+    for c in range(C):
+        m = int(lut_h[c])
+        y[:, :, c] = ((t >= 0) & (t < 64) & (((torch.tensor(m, dtype=torch.int64) >> t.clamp(0, 63)) & 1) == 1)).double()
+    act = torch.tensor([[(int(valid_h[b]) >> c) & 1 for c in range(C)] for b in range(B)], dtype=torch.float64)[:, None, :]
+    sg = torch.sigmoid(x)
+    bce = torch.clamp(x, min=0) - x * y + torch.log1p(torch.exp(-x.abs()))
+    ref = torch.stack(((bce * act).sum(1), (sg * y * act).sum(1), (sg * (1 - y) * act).sum(1), ((1 - sg) * y * act).sum(1)), -1)
+    assert torch.allclose(runs[0].cpu().double(), ref, rtol=2e-5, atol=1e-3)
+    gst = torch.randn((B, C, 4), generator=g)
+    dbuf = torch.full((B, V, 1, 1, C), float('nan'), device=dev)
+    ops.multitalent_loss_bwd(a, target, valid, lut, gst.to(dev), ops.Act(dbuf, 0, C))
+    gd = gst.double()[:, None]
+    dref = act * (gd[..., 0] * (sg - y) + sg * (1 - sg) * (y * (gd[..., 1] - gd[..., 3]) + (1 - y) * gd[..., 2]))
+    got = dbuf.reshape(B, V, C).cpu().double()
+    assert torch.allclose(got, dref, rtol=1e-4, atol=1e-5)
+    assert (got[act.expand(B, V, C) == 0] == 0).all()          # exact zeros where the sample carries no region
+
+
 @pytest.mark.parametrize("N,Cin,Cout,V,lazy,acc,bias", [(2, 30, 47, 48 * 20 * 21 + 5, True, False, True), (1, 30, 2, 1000, True, True, False),
                                                         (2, 60, 47, 777, False, True, True), (1, 64, 5, 4096, True, False, True), (3, 8, 64, 33, True, False, True),
                                                         (2, 30, 2, 48 * 20 * 21 + 5, True, False, True), (1, 32, 3, 1000, False, True, True),
