@@ -3720,14 +3720,15 @@ __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P)
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  // 16-bit dY (even channel stride): the tile's 256 voxels x 32 channels arrive as 1024 cooperative 16-byte pieces (4 per thread,
-  // requested one tile ahead) in an LDS image [voxel][17 dwords]; the B operands are 2-byte LDS reads.  The per-lane form below
-  // issues 32 two-byte gathers per wave and tile: 442 us for the 30-channel full-resolution gradient against 197 us in fp32.
-  constexpr bool Y16 = YS != MT_F32;
-  constexpr int YSP = 17;
-  __shared__ unsigned ysl[Y16 ? TD * TH * TW * YSP : 1];
-  const bool staged = Y16 && !(Y.cs & 1) && !((uintptr_t)Y.ptr & 3);       // block-uniform
-  uint4 yq[4];
+  // Staged dY (voxel stride a multiple of 4 bytes): the tile's 256 voxels x 32 channels arrive as
+  // cooperative 16-byte pieces (4 per thread for 16-bit dY, 8 for fp32, requested one tile ahead) in an LDS image [voxel][YSP dwords];
+  // the B operands are LDS reads.  The per-lane form below issues 32 gathers per wave and tile: 442 us (bf16) / 197 us (fp32) for the
+  // 30-channel full-resolution gradient.
+  constexpr int EPP = 16 / YE, PPV = 32 / EPP;                     // elements per piece, pieces per voxel (= pieces per thread)
+  constexpr int YSP = 32 * YE / 4 + 1;                             // dwords per voxel of the image (odd: the two voxel parities on disjoint banks)
+  __shared__ unsigned ysl[TD * TH * TW * YSP];
+  const bool staged = ((Y.cs * YE) & 3) == 0 && !((uintptr_t)Y.ptr & 3);       // block-uniform: dword-aligned 16-byte loads
+  uint4 yq[PPV];
   auto tile_of = [&](int tile, int& nb, int& od0, int& oh0, int& ow0) {
     int r = tile;
     const int tw = r % P.tilesW; r /= P.tilesW;
@@ -3740,12 +3741,12 @@ __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P)
     int nb, od0, oh0, ow0; tile_of(tile, nb, od0, oh0, ow0);
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Y.ptr + (size_t)nb * ysample * YE), 0, (int)(ysample * YE), 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < PPV; ++j) {
       const int pc = tid + 256 * j;
-      const int vox = pc >> 2, q = pc & 3;
+      const int vox = pc / PPV, q = pc % PPV;
       const int od = od0 + (vox >> 7), oh = oh0 + ((vox >> 5) & 3), ow = ow0 + (vox & 31);
-      const bool ok = (tile < P.ntiles_total) && od < c.Do && oh < c.Ho && ow < c.Wo && (cot * 32 + 8 * q < c.Cout);
-      const int off = ok ? (((od * c.Ho + oh) * c.Wo + ow) * Y.cs + cot * 32 + 8 * q) * 2 : (int)0x80000000;
+      const bool ok = (tile < P.ntiles_total) && od < c.Do && oh < c.Ho && ow < c.Wo && (cot * 32 + EPP * q < c.Cout);
+      const int off = ok ? (((od * c.Ho + oh) * c.Wo + ow) * Y.cs + cot * 32 + EPP * q) * YE : (int)0x80000000;
       yq[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(yr, off, 0, 0));
     }
   };
@@ -3754,28 +3755,29 @@ __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P)
     int nb, od0, oh0, ow0; tile_of(tile, nb, od0, oh0, ow0);
     __syncthreads();
     stem_stage<TD, TH, TW>(xs, c, nb, od0, oh0, ow0, tid);
-    if constexpr (Y16) {
-      if (staged) {
+    if (staged) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int pc = tid + 256 * j;
-          unsigned* d = ysl + (pc >> 2) * YSP + 4 * (pc & 3);
-          d[0] = yq[j].x; d[1] = yq[j].y; d[2] = yq[j].z; d[3] = yq[j].w;
-        }
-        __syncthreads();
-        fetch_tile(tile + P.nsg);
-        const unsigned short* yh = (const unsigned short*)ysl + li;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          float b[16];
-#pragma unroll
-          for (int v = 0; v < 16; ++v) b[v] = mt_from16<YS>(yh[(((dm * TH + r0 + m) * TW) + 2 * v + lhalf) * (2 * YSP)]);
-#pragma unroll
-          for (int v = 0; v < 16; ++v)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[xlane + m * LW + 2 * v], b[v], acc, 0, 0, 0);
-        }
-        continue;
+      for (int j = 0; j < PPV; ++j) {
+        const int pc = tid + 256 * j;
+        unsigned* d = ysl + (pc / PPV) * YSP + 4 * (pc % PPV);
+        d[0] = yq[j].x; d[1] = yq[j].y; d[2] = yq[j].z; d[3] = yq[j].w;
       }
+      __syncthreads();
+      fetch_tile(tile + P.nsg);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float b[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int vox = ((dm * TH + r0 + m) * TW) + 2 * v + lhalf;
+          if constexpr (YS == MT_F32) b[v] = __builtin_bit_cast(float, ysl[vox * YSP + li]);
+          else b[v] = mt_from16<YS>(((const unsigned short*)ysl)[vox * (2 * YSP) + li]);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[xlane + m * LW + 2 * v], b[v], acc, 0, 0, 0);
+      }
+      continue;
     }
     __syncthreads();
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Y.ptr + (size_t)nb * ysample * YE), 0, (int)(ysample * YE), 0x00020000);
