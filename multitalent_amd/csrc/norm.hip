@@ -357,6 +357,107 @@ __global__ __launch_bounds__(256) void inorm_bwd_fast_kernel(const InBwdFast P) 
   }
 }
 
+// ---- small tensors (round 4): the low-resolution layers (<= 16 K voxels over the batch) are three latency-bound launches of ~15 us each
+// (reduce, finalize, apply) + the dbias column sum — 37 layers of the residual encoder, 1.2 ms of its 26-ms mixed step.  Here ONE
+// launch: a workgroup owns a group of VEC channels of ALL samples, so the per-(n, c) sums never leave it: pass 1 over its slab ->
+// block reduction (wave sums, then the waves in a fixed order, in double) -> m -> pass 2 re-reads the slab (L2) and applies; dgamma,
+// dbeta (+=) and dbias (=) from the same workgroup.  Same arithmetic per element as inorm_bwd_fast_kernel.
+struct InBwdSmall {
+  void* g; const void* y;
+  const float* mean; const float* rstd; const float* gamma; const float* beta; float slope;
+  long V; int C, N;
+  float* dgamma; float* dbeta; float* dbias;
+};
+template <int VEC, int AT, int GT>
+__global__ __launch_bounds__(256) void inorm_bwd_small_kernel(const InBwdSmall P) {
+  static_assert(mt_ebytes<AT>() == mt_ebytes<GT>(), "one vector index addresses both tensors");
+  __shared__ double redd[4][2 * VEC];
+  __shared__ float msh[2 * VEC];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int grp = blockIdx.x, G = P.C / VEC;
+  float ga[VEC], be[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { const int c = grp * VEC + e; ga[e] = P.gamma ? P.gamma[c] : 1.f; be[e] = P.beta ? P.beta[c] : 0.f; }
+  double tA = 0.0, tB = 0.0, tD = 0.0;         // thread e < VEC: sums over the samples of channel grp * VEC + e
+  for (int n = 0; n < P.N; ++n) {
+    float mu[VEC], rs[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { const int c = grp * VEC + e; mu[e] = P.mean[(size_t)n * P.C + c]; rs[e] = P.rstd[(size_t)n * P.C + c]; }
+    const size_t sbytes = (size_t)n * P.V * P.C * mt_ebytes<GT>();
+    char* gp = (char*)P.g + sbytes;
+    const char* yp = (const char*)P.y + sbytes;
+    // ---- pass 1
+    float a0[VEC], a1[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+    for (long v = t; v < P.V; v += 256) {
+      float gv[VEC], yv[VEC];
+      mt_ldv<VEC, GT>(gp, (size_t)(v * G + grp), gv);
+      mt_ldv<VEC, AT>(yp, (size_t)(v * G + grp), yv);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float zh = (yv[e] - mu[e]) * rs[e];
+        const float z = fmaf(zh, ga[e], be[e]);
+        float dz = gv[e];
+        dz = z > 0.f ? dz : dz * P.slope;
+        a0[e] += dz;
+        a1[e] = fmaf(dz, zh, a1[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float s0 = mt_wave_sum(a0[e]), s1 = mt_wave_sum(a1[e]);
+      if (lane == 0) { redd[wave][2 * e] = (double)s0; redd[wave][2 * e + 1] = (double)s1; }
+    }
+    __syncthreads();
+    if (t < 2 * VEC) {
+      const double s = (redd[0][t] + redd[1][t]) + (redd[2][t] + redd[3][t]);
+      msh[t] = (float)(s / (double)P.V);
+      if (t & 1) tB += s; else tA += s;         // thread 2e: A of channel e, thread 2e + 1: B
+    }
+    __syncthreads();
+    float m1[VEC], m2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { m1[e] = msh[2 * e]; m2[e] = msh[2 * e + 1]; }
+    // ---- pass 2
+    float d0[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) d0[e] = 0.f;
+    for (long v = t; v < P.V; v += 256) {
+      float gv[VEC], yv[VEC], out[VEC];
+      mt_ldv<VEC, GT>(gp, (size_t)(v * G + grp), gv);
+      mt_ldv<VEC, AT>(yp, (size_t)(v * G + grp), yv);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float zh = (yv[e] - mu[e]) * rs[e];
+        const float z = fmaf(zh, ga[e], be[e]);
+        float dz = gv[e];
+        dz = z > 0.f ? dz : dz * P.slope;
+        const float dy = mt_round_st<GT>(ga[e] * rs[e] * (dz - m1[e] - zh * m2[e]));
+        out[e] = dy;
+        d0[e] += dy;
+      }
+      mt_stv<VEC, GT>(gp, (size_t)(v * G + grp), out);
+    }
+    if (P.dbias != nullptr) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float s0 = mt_wave_sum(d0[e]);
+        if (lane == 0) redd[wave][e] = (double)s0;
+      }
+      __syncthreads();
+      if (t < VEC) tD += (redd[0][t] + redd[1][t]) + (redd[2][t] + redd[3][t]);
+    }
+    __syncthreads();                             // redd / msh are rewritten for the next sample
+  }
+  if (t < 2 * VEC) {
+    const int c = grp * VEC + (t >> 1);
+    if (t & 1) { if (P.dgamma) P.dgamma[c] += (float)tB; }
+    else if (P.dbeta) P.dbeta[c] += (float)tA;
+  }
+  if (t < VEC && P.dbias != nullptr) P.dbias[grp * VEC + t] = (float)tD;
+}
+#define INORM_SMALL_MAX 16384        // voxels over the batch
 extern "C" size_t mt_inorm_bwd_workspace(int N, long V, int C) {
   const size_t nvb = (size_t)nb_blocks(V);
   return ((size_t)N * nvb * C * 3 + (size_t)N * C * 2) * sizeof(float);
@@ -402,6 +503,20 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
   // contiguous tensors take the vectorised lane-constant-channel path
   const int vec = (gcs == C && ycs == C && ag_fast(ydtype, gdtype)) ? dense_vec(C, V * C, gdtype, {g, y}) : 0;
   const bool contig = vec > 0 && (C / vec <= 256);
+  static int small_on = -1;
+  if (small_on < 0) { const char* e = getenv("MT_INORM_SMALL"); small_on = e ? atoi(e) : 1; }
+  const int svec = gdtype == MT_F32 ? 4 : 8;
+  if (small_on && contig && part == nullptr && vec == svec && (long)N * V <= INORM_SMALL_MAX) {
+    InBwdSmall S;
+    S.g = g; S.y = y; S.mean = mean; S.rstd = rstd; S.gamma = gamma; S.beta = beta; S.slope = slope; S.V = V; S.C = C; S.N = N;
+    S.dgamma = dgamma; S.dbeta = dbeta; S.dbias = dbias;
+    const dim3 grid(C / svec);
+    if (gdtype == MT_F32) hipLaunchKernelGGL((inorm_bwd_small_kernel<4, MT_F32, MT_F32>), grid, dim3(256), 0, st, S);
+    else if (ydtype == MT_F16) hipLaunchKernelGGL((inorm_bwd_small_kernel<8, MT_F16, MT_BF16>), grid, dim3(256), 0, st, S);
+    else hipLaunchKernelGGL((inorm_bwd_small_kernel<8, MT_BF16, MT_BF16>), grid, dim3(256), 0, st, S);
+    MT_CHECK_LAUNCH("inorm_lrelu_bwd(small)");
+    return MT_OK;
+  }
   if (contig) {
     InBwdFast F;
     F.g = g; F.y = y; F.mean = mean; F.rstd = rstd; F.gamma = gamma; F.beta = beta; F.slope = slope;
