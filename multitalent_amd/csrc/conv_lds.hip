@@ -1324,7 +1324,10 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvKParams P) {
 // (generic_UNet.py:335-336) — every output voxel reads its own kD*kH*kW block, nothing is shared between outputs, so there is
 // no halo to stage: A fragments come straight from global memory (32-byte per-lane vectors, lazy activation in registers) as in
 // the pointwise kernel, one accumulator tile per wave of 32 output voxels x 32 channels.
-template <int VEC, int XS = MT_F32, int OS = MT_F32>
+// BF (mixed precision, bf16 source without a lazy activation = a gradient): the lane's 16-byte load IS the A fragment of
+// v_mfma_f32_32x32x16_bf16 (8 channels of its voxel), the weights are pack layout 3 — one MFMA per (chunk, tap) instead of eight fp32
+// ones.  (In fp32 this kernel is AT the fp32 matrix rate: 29 padded GFLOP in 185 us for the 60 -> 30 transposed conv of Task009.)
+template <int VEC, int XS = MT_F32, int OS = MT_F32, bool BF = false>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
   constexpr int XE = mt_ebytes<XS>(), OE = mt_ebytes<OS>();
   const mt_conv3d_t& c = P.c;
@@ -1381,6 +1384,40 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
   f32x16 acc;
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  if constexpr (BF) {
+    static_assert(XS == MT_BF16, "the bf16 matrix path reads a bf16 source");
+    const unsigned* wq = (const unsigned*)c.wpack + (size_t)ntile * P.nchunks * ntaps * 256 + lane * 4;
+    // channel tail of the last chunk as AND masks on the fragment's dwords (the bytes belong to the next voxel)
+    int g_kd = 0, g_kh = 0, g_kw = 0, g_ch = 0;
+    auto load_raw = [&]() -> uint4 {
+      const int so = __builtin_amdgcn_readfirstlane((((g_kd * c.Hi + g_kh) * c.Wi + g_kw) * S.cs + g_ch * FCK) * XE);
+      if (++g_kw == c.KW) { g_kw = 0; if (++g_kh == c.KH) { g_kh = 0; if (++g_kd == c.KD) { g_kd = 0; ++g_ch; } } }
+      return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ra, abase, so, 0));
+    };
+    constexpr int PF = 4;                      // fragments in flight
+    uint4 ar[PF], br[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) if (u < total) { ar[u] = load_raw(); br[u] = *(const uint4*)(wq + (size_t)u * 256); }
+    int ch = 0, tap = 0;
+    for (int it0 = 0; it0 < total; it0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int it = it0 + u;
+        if (it < total) {
+          uint4 a = ar[u]; const uint4 b = br[u];
+          const int cb = ch * FCK + 8 * lhalf;           // first channel of this lane's fragment
+          if (cb + 8 > c.Cin) {
+            const unsigned m0 = (cb + 0 < c.Cin ? 0xffffu : 0u) | (cb + 1 < c.Cin ? 0xffff0000u : 0u), m1 = (cb + 2 < c.Cin ? 0xffffu : 0u) | (cb + 3 < c.Cin ? 0xffff0000u : 0u);
+            const unsigned m2 = (cb + 4 < c.Cin ? 0xffffu : 0u) | (cb + 5 < c.Cin ? 0xffff0000u : 0u), m3 = (cb + 6 < c.Cin ? 0xffffu : 0u) | (cb + 7 < c.Cin ? 0xffff0000u : 0u);
+            a.x &= m0; a.y &= m1; a.z &= m2; a.w &= m3;
+          }
+          if (it + PF < total) { ar[u] = load_raw(); br[u] = *(const uint4*)(wq + (size_t)(it + PF) * 256); }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+          if (++tap == ntaps) { tap = 0; ++ch; }
+        }
+      }
+    }
+  } else {
   float xa[8], xn[8], sc[8], sh[8];
   load_a(xa);
   for (int it = 0, ch = 0, tap = 0; it < total; ++it) {
@@ -1409,6 +1446,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) xa[e] = xn[e];
     if (++tap == ntaps) { tap = 0; ++ch; }
+  }
   }
 
   const int co = ntile * 32 + li;
@@ -1936,6 +1974,7 @@ static int pick_rt_cfg(const mt_conv3d_t* p);
 static bool conv_fast_strided_ok(const mt_conv3d_t* p);
 static bool conv_wino_ok(const mt_conv3d_t* p);
 static bool conv_gather_ok(const mt_conv3d_t* p);
+static bool gather_use_bf16(const mt_conv3d_t* p);
 static int launch_gather(const mt_conv3d_t* p, hipStream_t st);
 static bool conv_is_133(const mt_conv3d_t* p);
 static int conv_bf16_cfg(const mt_conv3d_t* p);
@@ -1983,10 +2022,12 @@ extern "C" int mt_conv3d_ck(const mt_conv3d_t* p) {
   const ConvPlan pl = conv_plan(p);
   if (pl.kind == CONV_WINO) return WCK;
   if (pl.kind == CONV_BF16) return FCK;
+  if (pl.kind == CONV_RT && conv_gather_ok(p)) return FCK;          // (conv_gather_kernel chunks the channels by FCK)
   return pl.cfg < 0 ? -1 : kCfgs[pl.cfg].CK;
 }
 extern "C" int mt_conv3d_pack_layout(const mt_conv3d_t* p) {      // layout argument of mt_pack_conv_weights for this problem
   const int k = conv_plan(p).kind;
+  if (k == CONV_RT && conv_gather_ok(p) && gather_use_bf16(p)) return 3;
   const int l16 = conv_matrix_type(p) == MT_F16 ? 4 : 3;
   if ((k == CONV_FAST_STRIDED || k == CONV_TAPSPLIT) && strided_use_bf16(p)) return l16;
   return k == CONV_WINO ? 2 : k == CONV_BF16 ? l16 : 1;
@@ -2435,6 +2476,11 @@ static bool conv_gather_ok(const mt_conv3d_t* p) {
   if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return false;
   return true;
 }
+static bool gather_use_bf16(const mt_conv3d_t* p) {          // mixed precision: a bf16 gradient without a lazy activation
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_GATHER_BF16"); use = e ? atoi(e) : 1; }
+  return use && p->mma == 1 && p->src[0].dtype == MT_BF16 && p->src[0].scale == nullptr && !(p->src[0].cs & 1) && !(((uintptr_t)p->src[0].ptr) & 3);
+}
 static int launch_gather(const mt_conv3d_t* p, hipStream_t st) {
   ConvKParams P;
   P.c = *p;
@@ -2454,7 +2500,9 @@ static int launch_gather(const mt_conv3d_t* p, hipStream_t st) {
   if (vec == 2 && !((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0)) vec = 1;
   (void)S;
   // gradients: bf16 -> bf16 (backward-data of a transposed convolution between two 16-bit levels), bf16 -> fp32, fp32 -> bf16
-  if (S.dtype == MT_BF16 && p->odtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_BF16, MT_BF16>), grid, dim3(256), 0, st, P);
+  if (gather_use_bf16(p) && p->odtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_BF16, MT_BF16, true>), grid, dim3(256), 0, st, P);
+  else if (gather_use_bf16(p)) hipLaunchKernelGGL((conv_gather_kernel<4, MT_BF16, MT_F32, true>), grid, dim3(256), 0, st, P);
+  else if (S.dtype == MT_BF16 && p->odtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_BF16, MT_BF16>), grid, dim3(256), 0, st, P);
   else if (S.dtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_BF16, MT_F32>), grid, dim3(256), 0, st, P);
   else if (p->odtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_F32, MT_BF16>), grid, dim3(256), 0, st, P);
   else if (vec == 4) hipLaunchKernelGGL(conv_gather_kernel<4>, grid, dim3(256), 0, st, P);
@@ -2589,7 +2637,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
                p->SD, p->SH, p->SW, conv_fast_vec(p));
   }
   else if (pl.kind == CONV_RT && conv_gather_ok(p))
-    snprintf(buf, n, "conv_gather_kernel<4, %d, %d>", p->src[0].dtype, p->odtype);
+    snprintf(buf, n, gather_use_bf16(p) ? "conv_gather_kernel<4, %d, %d, true>" : "conv_gather_kernel<4, %d, %d>", p->src[0].dtype, p->odtype);
   else if (pl.kind == CONV_RT)
     snprintf(buf, n, "conv_rt_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
   else

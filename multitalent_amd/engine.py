@@ -378,7 +378,7 @@ class TConvOp(_Op):
             p = self._bwd_io(eng).build()
             self.ck_b = ops.conv_ck(p)
             self.wb = ops.pack_conv_weights(w, Cout, 0, Cin, self.k, _strides(w, transposed_layout=True, as_bwd_data=True),
-                                            False, self.ck_b, out=self.wb)
+                                            False, self.ck_b, out=self.wb, layout=ops.conv_pack_layout(p))
 
     def forward(self, eng):
         io = eng.io(self.name + '.fwd', [self.src.act], [self.out.act],

@@ -590,6 +590,44 @@ def test_gather_backward_of_transposed_conv_bf16_bitexact(dev, k, acc):
     assert torch.equal(res[1], res[0].to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("k", [(2, 2, 2), (1, 2, 2)])
+@pytest.mark.parametrize("acc,odt", [(False, torch.bfloat16), (True, torch.bfloat16), (False, torch.float32)])
+def test_gather_backward_of_transposed_conv_bf16_products(dev, k, acc, odt):
+    """mixed precision (mma = 1): a bf16 gradient is the A fragment of v_mfma_f32_32x32x16_bf16 as loaded, the weights are pack layout 3 —
+    against the host sum with the weights rounded to bf16 (exact products), channel tail 30 of 32"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(38)
+    N, Ct_in, Ct_out, low = 2, 60, 30, (4, 6, 21)
+    hi = tuple(a * b for a, b in zip(low, k))
+    dy = rbf(torch.randn((N,) + hi + (Ct_out,), generator=g))
+    prev = rbf(torch.randn((N,) + low + (Ct_in,), generator=g), odt) if odt != torch.float32 else torch.randn((N,) + low + (Ct_in,), generator=g)
+    w = torch.randn((Ct_in, Ct_out) + k, generator=g) / np.sqrt(Ct_out * np.prod(k))
+    wd = w.to(dev).contiguous()
+    geom = ops.ConvGeom(hi, k, k, (0, 0, 0))
+    dyd = dy.to(dev).to(torch.bfloat16)
+    dx = (prev if acc else torch.full(prev.shape, float('nan'))).to(dev).to(odt)
+    p = ops.fill_conv([ops.Act(dyd)], geom, Ct_in, out0=ops.Act(dx), accumulate=acc, mma=1)
+    p.csplit = Ct_in
+    name = ops.conv_kernel_name(p)
+    assert name.startswith('conv_gather_kernel') and name.endswith('true>') and ops.conv_io_supported(p), name
+    assert ops.conv_pack_layout(p) == 3
+    wp = ops.pack_conv_weights(wd, Ct_out, 0, Ct_in, k, ops.conv_weight_strides(wd, transposed_layout=True, as_bwd_data=True), False, ops.conv_ck(p),
+                               layout=ops.conv_pack_layout(p))
+    p.wpack = wp.data_ptr()
+    ops.conv3d_fwd(p)
+    torch.cuda.synchronize()
+    # host: dX[n, v, ci] = sum over taps, co of dY[n, s v + tap, co] * bf16(W[ci, co, tap])
+    wb = rbf(w).double()
+    d = dy.double().reshape((N, low[0], k[0], low[1], k[1], low[2], k[2], Ct_out))
+    ref = torch.einsum('ndahbwcq,iqabc->ndhwi', d, wb)
+    if acc:
+        ref = ref + prev.double()
+    got = dx.float().cpu().double()
+    assert torch.isfinite(got).all()
+    tol = 2.0 ** -8 if odt != torch.float32 else 1e-5
+    assert float((got - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-6, float((got - ref).abs().max())
+
+
 @pytest.mark.parametrize("kind", ["strided222", "strided122", "tconv222", "head", "proj222", "k133"])
 def test_tiled_backward_weight_16bit_storage_bitexact(dev, kind):
     """conv_bwdw_fast_kernel: X / dY widened on load, fp32 products — identical to the fp32-storage launch"""
