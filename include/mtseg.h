@@ -35,7 +35,7 @@ extern "C" {
 #define MT_EHIP (-3)    /* HIP runtime error on launch */
 #define MT_EUNSUPPORTED (-4) /* the device is not the one this library is built for (gfx950) */
 
-#define MT_ABI_VERSION 2   /* 2: storage dtypes (mt_src_t.dtype, odtype fields, dtype arguments of the streaming kernels, mt_cast) */
+#define MT_ABI_VERSION 3   /* 2: storage dtypes (mt_src_t.dtype, odtype fields, dtype arguments of the streaming kernels, mt_cast); 3: mt_pointwise_t.mma + mt_pointwise_pack_layout */
 #define MT_MAX_CHUNKS 64
 
 /* Storage type of an activation / gradient tensor in HBM.  fp32 is the parity path.  The mixed-precision mode (the reference's
@@ -235,10 +235,16 @@ typedef struct {
   int32_t scatter;     /* 0: all prod(so) taps (transposed convolution).  1: ONLY tap (0,0,0) — out[base*so] (+)= W x in[base], one packed
                           tap: the backward-data of a strided 1x1x1 convolution (conv_blocks.py:159-165); the other output positions are
                           not touched (the caller zero-fills or accumulates) */
+  int32_t mma;         /* ABI v3.  0: fp32 products.  1 (mixed precision): fp16 products where the source is stored in fp16 and the kernel
+                          that serves the problem has the 16-bit matrix form — the packed weights must then be in the layout
+                          mt_pointwise_pack_layout(p) returns (4 instead of 1) */
 } mt_pointwise_t;
 int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream);
 int mt_pointwise_stats_blocks(const mt_pointwise_t* p);
-int mt_pointwise_io_supported(const mt_pointwise_t* p);   /* 1 when p->src.dtype / p->odtype are read / written natively (see MT_F16) */
+int mt_pointwise_io_supported(const mt_pointwise_t* p);
+/* pack layout (mt_pack_conv_weights, ck = 16) of the weights this problem's launch reads: 1, or 4 (fp16 B fragments) when p->mma == 1
+ * and the launch multiplies in fp16 (transposed convolutions and 33..64-channel heads over fp16 activations). */
+int mt_pointwise_pack_layout(const mt_pointwise_t* p);   /* 1 when p->src.dtype / p->odtype are read / written natively (see MT_F16) */
 /* Backward of a 1x1x1 segmentation head (generic_UNet.py:349-351, generic_modular_UNet.py:244,251: seg_outputs / deep_supervision_outputs)
  * in ONE pass over (x, dY):  dX[n,v,ci] (+)= sum_co dY[n,v,co] W[co,ci] (gradient w.r.t. the lazily ACTIVATED head input),
  * dW[co*s_co + ci*s_ci] (+)= sum_{n,v} act(x)[n,v,ci] dY[n,v,co], dbias[co] (+)= sum dY.  Cin, Cout <= 64; mt_head_bwd_supported says

@@ -53,11 +53,11 @@ class mt_pointwise_t(C.Structure):
                 ('Cin', C.c_int32), ('Cout', C.c_int32),
                 ('wpack', C.c_void_p), ('bias', C.c_void_p),
                 ('out', C.c_void_p), ('ocs', C.c_int32), ('accumulate', C.c_int32),
-                ('stats_part', C.c_void_p), ('odtype', C.c_int32), ('scatter', C.c_int32)]
+                ('stats_part', C.c_void_p), ('odtype', C.c_int32), ('scatter', C.c_int32), ('mma', C.c_int32)]
 
 
 MT_F32, MT_BF16, MT_F16 = 0, 1, 2
-MT_ABI_VERSION = 2
+MT_ABI_VERSION = 3
 
 _vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
 _P = C.POINTER
@@ -94,6 +94,7 @@ SIGNATURES = {
     'mt_head_bwd': (_i, [_P(mt_src_t), _vp, _i, _i, _l, _i, _i, _vp, _vp, _i, _i, _i, _vp, _l, _l, _vp, _i, _P(C.c_int), _vp, _sz, _vp]),
     'mt_head_bwd_io_supported': (_i, [_i, _i, _i, _i, _i, _i]),
     'mt_pointwise_io_supported': (_i, [_P(mt_pointwise_t)]),
+    'mt_pointwise_pack_layout': (_i, [_P(mt_pointwise_t)]),
     'mt_inorm_finalize': (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     'mt_inorm_lrelu_apply': (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _f, _vp, _i, _i, _l, _i, _i, _vp]),
     'mt_inorm_bwd_workspace': (_sz, [_i, _l, _i]),

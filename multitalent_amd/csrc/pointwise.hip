@@ -60,7 +60,9 @@ __device__ __forceinline__ void pw_load8(__amdgpu_buffer_rsrc_t r, int o, float 
 #ifndef PW_ABL
 #define PW_ABL 0      // timing ablations of pw_fast_kernel: 1 no stores, 2 no weight-fragment loads, 4 no MFMAs
 #endif
-template <int NT, int VEC, int XS = MT_F32, int OS = MT_F32>
+// M16 (mixed precision, fp16 source, mt_pointwise_t.mma == 1): the activated fragment is rounded to fp16 and multiplied by pack-layout-4
+// weights — one v_mfma_f32_32x32x16_f16 per (chunk, tap) instead of eight fp32 MFMAs (the forward transposed convs ran AT the fp32 matrix rate)
+template <int NT, int VEC, int XS = MT_F32, int OS = MT_F32, bool M16 = false>
 __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   constexpr int XE = mt_ebytes<XS>(), OE = mt_ebytes<OS>();     // bytes per stored element
   const mt_pointwise_t& c = P.c;
@@ -167,6 +169,20 @@ __global__ __launch_bounds__(256) void pw_fast_kernel(const PwKParams P) {
   for (int ch = 0; ch < P.nchunks; ++ch) {
     if (ch + 1 < P.nchunks) load_a(ch + 1, xn);
     finish_a(ch, xa);
+    if constexpr (M16) {
+      typedef _Float16 pw_f16x8 __attribute__((ext_vector_type(8)));
+      uint4 af;
+      af.x = mt_pk16<MT_F16>(xa[0], xa[1]); af.y = mt_pk16<MT_F16>(xa[2], xa[3]); af.z = mt_pk16<MT_F16>(xa[4], xa[5]); af.w = mt_pk16<MT_F16>(xa[6], xa[7]);
+      const unsigned* wq16 = (const unsigned*)c.wpack + ((size_t)(ntile * P.nchunks + ch) * P.ntaps + tap0) * 256 + lane * 4;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const uint4 b = *(const uint4*)(wq16 + t * 256);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pw_f16x8, af), __builtin_bit_cast(pw_f16x8, b), acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xa[e] = xn[e];
+      continue;
+    }
     const float* wq = c.wpack + ((size_t)(ntile * P.nchunks + ch) * P.ntaps + tap0) * 512 + lane * 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -721,7 +737,7 @@ extern "C" int mt_pointwise_stats_blocks(const mt_pointwise_t* p) {
 // computes both channel tiles from one read of the input, transposes its 128 x Cout block through LDS and writes it as ONE linear run
 // of 16-byte stores (128 * 47 * 4 = 24 064 contiguous bytes).  Requires V % 32 == 0, unit strides, no accumulation / statistics.
 #define PWH_MAXCO 64
-template <int XS = MT_F32>
+template <int XS = MT_F32, bool M16 = false>
 __global__ __launch_bounds__(256) void pw_head_kernel(const PwKParams P) {
   constexpr int XE = mt_ebytes<XS>();
   const mt_pointwise_t& c = P.c;
@@ -773,6 +789,19 @@ __global__ __launch_bounds__(256) void pw_head_kernel(const PwKParams P) {
     if (cb + 8 > c.Cin) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = (cb + e < c.Cin) ? x[e] : 0.f;
+    }
+    if constexpr (M16) {
+      typedef _Float16 pw_f16x8 __attribute__((ext_vector_type(8)));
+      uint4 af;
+      af.x = mt_pk16<MT_F16>(x[0], x[1]); af.y = mt_pk16<MT_F16>(x[2], x[3]); af.z = mt_pk16<MT_F16>(x[4], x[5]); af.w = mt_pk16<MT_F16>(x[6], x[7]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint4 b = *(const uint4*)((const unsigned*)c.wpack + (size_t)(t * P.nchunks + ch) * 256 + lane * 4);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pw_f16x8, af), __builtin_bit_cast(pw_f16x8, b), acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xa[e] = xn[e];
+      continue;
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -928,6 +957,18 @@ static bool pw_head_ok(const mt_pointwise_t* p, const PwKParams& P) {
          !p->accumulate && p->stats_part == nullptr && (P.Vb % 32) == 0 && p->Di == p->Db && p->Hi == p->Hb && p->Wi == p->Wb &&
          ((((uintptr_t)p->out) & 15) == 0) && ((P.Vb * p->Cout) % 4 == 0);
 }
+static int pw_use_head_env() { static int v = -1; if (v < 0) { const char* e = getenv("MT_PW_HEAD"); v = e ? atoi(e) : 1; } return v; }
+// the part of the launch plan the kernel choice depends on (shared by mt_pointwise_fwd and mt_pointwise_pack_layout)
+static void pw_plan(const mt_pointwise_t* p, PwKParams& P, bool& narrow, bool& head) {
+  P.c = *p;
+  P.ntaps = p->scatter ? 1 : p->soD * p->soH * p->soW;
+  P.nchunks = mt_cdiv(p->Cin, PW_CK);
+  P.Vb = (long)p->Db * p->Hb * p->Wb;
+  P.nsb = mt_cdiv(P.Vb, 128);
+  P.wide = 0;
+  narrow = pw_use_head_env() && p->odtype == MT_F32 && pw_narrow_ok(p, P);
+  head = !narrow && pw_use_head_env() && p->odtype == MT_F32 && pw_head_ok(p, P);
+}
 // Storage types mt_pointwise_fwd takes natively (mt_pointwise_t.src.dtype -> odtype): fp32 -> fp32 always; a 16-bit source needs an even
 // channel stride and a dword-aligned base (its 8-channel groups are 16-byte loads on dword boundaries), a 16-bit destination even Cout /
 // channel stride and a dword-aligned base (channel-pair dwords).  Combinations: fp16 -> fp16 | fp32 (forward over activations),
@@ -942,6 +983,21 @@ extern "C" int mt_pointwise_io_supported(const mt_pointwise_t* p) {
   if (xs == MT_F16) return os == MT_F16 || os == MT_F32;
   if (xs == MT_BF16) return os == MT_BF16 || os == MT_F32;
   return os == MT_BF16;                       // fp32 source (the loss gradient) into a bf16 gradient
+}
+// 16-bit products (mt_pointwise_t.mma == 1): fp16 source; pw_head_kernel (fp32 logits) or pw_fast_kernel writing fp16 (transposed convs)
+static bool pw_m16(const mt_pointwise_t* p, const PwKParams& P, bool narrow, bool head) {
+  static int use = -1;
+  if (use < 0) { const char* e = getenv("MT_PW_M16"); use = e ? atoi(e) : 1; }
+  if (!use || p->mma != 1 || p->src.dtype != MT_F16 || narrow || p->scatter) return false;
+  if ((p->src.cs & 1) || (((uintptr_t)p->src.ptr) & 3)) return false;
+  return head ? true : (p->odtype == MT_F16 && P.ntaps >= 2);
+}
+static void pw_plan(const mt_pointwise_t* p, PwKParams& P, bool& narrow, bool& head);
+extern "C" int mt_pointwise_pack_layout(const mt_pointwise_t* p) {
+  if (p == nullptr || !mt_pointwise_io_supported(p)) return 1;
+  PwKParams P; bool narrow, head;
+  pw_plan(p, P, narrow, head);
+  return pw_m16(p, P, narrow, head) ? 4 : 1;
 }
 extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   MT_REQUIRE(p != nullptr, "pointwise: null params");
@@ -998,7 +1054,8 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
     }
     if (use_head && os == MT_F32 && pw_head_ok(p, P)) {
       const dim3 g1((unsigned)(P.nsb * p->N));
-      if (xs == MT_F16) hipLaunchKernelGGL((pw_head_kernel<MT_F16>), g1, dim3(256), 0, st, P);
+      if (pw_m16(p, P, false, true)) hipLaunchKernelGGL((pw_head_kernel<MT_F16, true>), g1, dim3(256), 0, st, P);
+      else if (xs == MT_F16) hipLaunchKernelGGL((pw_head_kernel<MT_F16>), g1, dim3(256), 0, st, P);
       else if (xs == MT_BF16) hipLaunchKernelGGL((pw_head_kernel<MT_BF16>), g1, dim3(256), 0, st, P);
       else hipLaunchKernelGGL((pw_head_kernel<MT_F32>), g1, dim3(256), 0, st, P);
       MT_CHECK_LAUNCH("pointwise_head");
@@ -1009,7 +1066,8 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
 #define PW_LAUNCH_T(NT, XS_, OS_) hipLaunchKernelGGL((pw_fast_kernel<NT, 4, XS_, OS_>), grid, dim3(256), 0, st, P)
 #define PW_LAUNCH(NT)                                                                              \
   do {                                                                                             \
-    if (xs == MT_F16 && os == MT_F16) PW_LAUNCH_T(NT, MT_F16, MT_F16);                             \
+    if (NT >= 2 && pw_m16(p, P, false, false)) hipLaunchKernelGGL((pw_fast_kernel<(NT >= 2 ? NT : 2), 4, MT_F16, MT_F16, true>), grid, dim3(256), 0, st, P); \
+    else if (xs == MT_F16 && os == MT_F16) PW_LAUNCH_T(NT, MT_F16, MT_F16);                        \
     else if (xs == MT_F16) PW_LAUNCH_T(NT, MT_F16, MT_F32);                                        \
     else if (xs == MT_BF16 && os == MT_BF16) PW_LAUNCH_T(NT, MT_BF16, MT_BF16);                    \
     else if (xs == MT_BF16) PW_LAUNCH_T(NT, MT_BF16, MT_F32);                                      \

@@ -109,7 +109,8 @@ class ConvNormOp(_Op):
         if self.pointwise or self.pw_strided:
             def build(ins, outs):
                 a = ins[0]
-                return ops.fill_pointwise(a, self.geom.out, a.spatial, self.stride, (1, 1, 1), Cout, eng.dummy, self.conv.bias, outs[0])
+                return ops.fill_pointwise(a, self.geom.out, a.spatial, self.stride, (1, 1, 1), Cout, eng.dummy, self.conv.bias, outs[0],
+                                          mma=eng.mma if self.pointwise else 0)
             return eng.io(self.name + '.fwd', acts, [self.out.act], build, ops.pointwise_io_supported)
         build = lambda ins, outs: ops.fill_conv(ins, self.geom, Cout, bias=self.conv.bias, out0=outs[0], mma=self.mma)
         return eng.io(self.name + '.fwd', acts, [self.out.act], build, ops.conv_io_supported)
@@ -132,6 +133,10 @@ class ConvNormOp(_Op):
         C1 = self.srcs[1].C if len(self.srcs) > 1 else 0
         if self.pointwise:
             self.wf = ops.pack_conv_weights(w, C0, 0, Cout, (1, 1, 1), _strides(w), False, ops.POINTWISE_CK, out=self.wf)
+            # training forward in mixed precision: fp16 products where the head kernel has them (the fused inference heads keep `wf`)
+            lay = ops.pointwise_pack_layout(self._fwd_io(eng).build())
+            self.wf16 = ops.pack_conv_weights(w, C0, 0, Cout, (1, 1, 1), _strides(w), False, ops.POINTWISE_CK, out=getattr(self, 'wf16', None),
+                                              layout=lay) if lay != 1 else None
             if need_bwd and self.srcs[0].grad is not None and self.stride == (1, 1, 1):
                 self.wb = ops.pack_conv_weights(w, Cout, 0, C0, (1, 1, 1), _strides(w, as_bwd_data=True), False, ops.POINTWISE_CK, out=self.wb)
             return
@@ -199,7 +204,11 @@ class ConvNormOp(_Op):
     def forward(self, eng):
         io = self._fwd_io(eng)
         p = self._fwd_params(eng, io)
-        p.wpack = self.wf.data_ptr()
+        wf = self.wf
+        if self.pointwise and ops.pointwise_pack_layout(p) != 1:
+            wf = getattr(self, 'wf16', None)
+            assert wf is not None, "head: fp16-product launch without fp16 weights (repack after a precision change)"
+        p.wpack = wf.data_ptr()
         io.pre()
         if self.pointwise or self.pw_strided:
             ops.pointwise_fwd(p)
@@ -373,18 +382,25 @@ class TConvOp(_Op):
     def pack(self, eng, need_bwd):
         w = self.tu.weight
         Cin, Cout = self.tu.in_channels, self.tu.out_channels
-        self.wf = ops.pack_conv_weights(w, Cin, 0, Cout, self.k, _strides(w, transposed_layout=True), False, ops.POINTWISE_CK, out=self.wf)
+        self.wf_layout = ops.pointwise_pack_layout(self._fwd_io(eng, eng.dummy).build())     # 4: fp16 products (mixed precision), else 1
+        self.wf = ops.pack_conv_weights(w, Cin, 0, Cout, self.k, _strides(w, transposed_layout=True), False, ops.POINTWISE_CK, out=self.wf,
+                                        layout=self.wf_layout)
         if need_bwd and self.src.grad is not None:
             p = self._bwd_io(eng).build()
             self.ck_b = ops.conv_ck(p)
             self.wb = ops.pack_conv_weights(w, Cout, 0, Cin, self.k, _strides(w, transposed_layout=True, as_bwd_data=True),
                                             False, self.ck_b, out=self.wb, layout=ops.conv_pack_layout(p))
 
+    def _fwd_io(self, eng, wf):
+        return eng.io(self.name + '.fwd', [self.src.act], [self.out.act],
+                      lambda ins, outs: ops.fill_pointwise(ins[0], ins[0].spatial, ins[0].spatial, (1, 1, 1), self.k, self.tu.out_channels, wf, None, outs[0],
+                                                           mma=eng.mma),
+                      ops.pointwise_io_supported)
+
     def forward(self, eng):
-        io = eng.io(self.name + '.fwd', [self.src.act], [self.out.act],
-                    lambda ins, outs: ops.fill_pointwise(ins[0], ins[0].spatial, ins[0].spatial, (1, 1, 1), self.k, self.tu.out_channels, self.wf, None, outs[0]),
-                    ops.pointwise_io_supported)
+        io = self._fwd_io(eng, self.wf)
         p = io.build()
+        assert ops.pointwise_pack_layout(p) == self.wf_layout, "transposed conv: the packed weights do not match the launch (repack after a precision change)"
         io.pre()
         ops.pointwise_fwd(p)
         io.post()

@@ -335,7 +335,7 @@ def conv3d_bwd_weight(p, y, dw, strides, accumulate, ws):
 POINTWISE_CK = 16   # mt_pointwise_fwd takes weights packed with layout 1, ck 16
 
 
-def fill_pointwise(src, base, in_spatial, si, so, Cout, wpack, bias, out, accumulate=False, stats_part=None):
+def fill_pointwise(src, base, in_spatial, si, so, Cout, wpack, bias, out, accumulate=False, stats_part=None, mma=0):
     p = mt_pointwise_t()
     p.src = src.src()
     p.N = src.N
@@ -352,7 +352,12 @@ def fill_pointwise(src, base, in_spatial, si, so, Cout, wpack, bias, out, accumu
     p.odtype = out.dt
     p.accumulate = 1 if accumulate else 0
     p.stats_part = stats_part.data_ptr() if stats_part is not None else None
+    p.mma = int(mma)
     return p
+
+
+def pointwise_pack_layout(p):
+    return _lib.load().mt_pointwise_pack_layout(C.byref(p))
 
 
 def pointwise_fwd(p):

@@ -437,7 +437,7 @@ def test_unsupported_storage_types_are_refused(dev):
 
 # ---- pointwise kernels (transposed convolutions, heads, their backward-data), gather, tiled backward-weight, stem: fp32 arithmetic with
 # ---- 16-bit storage -> bit-exact against the fp32-storage launch of the same kernel family, rounded
-def _pointwise(dev, x, lazy, w_pack_args, base, in_spatial, si, so, Cout, bias, xdt, odt, ocs=None, prev=None, scatter=False, stats=False):
+def _pointwise(dev, x, lazy, w_pack_args, base, in_spatial, si, so, Cout, bias, xdt, odt, ocs=None, prev=None, scatter=False, stats=False, mma=0, want_layout=None):
     ops = _ops()
     xb = x.to(dev).to(xdt)
     a = ops.Act(xb) if lazy is None else ops.Act(xb, scale=lazy[0].to(dev), shift=lazy[1].to(dev), slope=lazy[2])
@@ -447,10 +447,14 @@ def _pointwise(dev, x, lazy, w_pack_args, base, in_spatial, si, so, Cout, bias, 
     out = (prev.to(dev) if prev is not None else torch.full((N,) + osp + (ocs,), float('nan'))).to(dev).to(odt)
     w, Cin, taps, strides = w_pack_args
     wd = w.to(dev).contiguous()
-    wp = ops.pack_conv_weights(wd, Cin, 0, Cout, taps, strides(wd), False, ops.POINTWISE_CK)
     bd = bias.to(dev) if bias is not None else None
-    p = ops.fill_pointwise(a, base, in_spatial, si, so, Cout, wp, bd, ops.Act(out, 0, Cout), accumulate=prev is not None)
+    p = ops.fill_pointwise(a, base, in_spatial, si, so, Cout, wd, bd, ops.Act(out, 0, Cout), accumulate=prev is not None, mma=mma)
     p.scatter = 1 if scatter else 0
+    lay = ops.pointwise_pack_layout(p)
+    if want_layout is not None:
+        assert lay == want_layout, (lay, want_layout)
+    wp = ops.pack_conv_weights(wd, Cin, 0, Cout, taps, strides(wd), False, ops.POINTWISE_CK, layout=lay)
+    p.wpack = wp.data_ptr()
     part = None
     if stats:
         part = torch.zeros((N, ops.pointwise_stats_blocks(p), Cout, 2), device=dev)
@@ -495,6 +499,56 @@ def test_heads_read_fp16_activations(dev, Cin, Cout):
     o32, _ = _pointwise(dev, x, lazy, wargs, base, base, (1, 1, 1), (1, 1, 1), Cout, b, torch.float32, torch.float32)
     o16, _ = _pointwise(dev, x, lazy, wargs, base, base, (1, 1, 1), (1, 1, 1), Cout, b, torch.float16, torch.float32)
     assert torch.equal(o16, o32)
+
+
+@pytest.mark.parametrize("Cin,Cout,base,k,ocs_mult", [
+    (60, 30, (4, 8, 32), (2, 2, 2), 1), (60, 30, (4, 8, 32), (2, 2, 2), 2), (64, 32, (4, 8, 32), (2, 2, 2), 2), (120, 60, (3, 5, 9), (2, 2, 2), 1),
+    (60, 30, (5, 6, 16), (1, 2, 2), 1),
+])
+def test_transposed_conv_fp16_products(dev, Cin, Cout, base, k, ocs_mult):
+    """mt_pointwise_t.mma = 1 (ABI v3): the forward transposed conv over fp16 activations multiplies in fp16 (pack layout 4) — against the host
+    sum with the activated input and the weights rounded to fp16 (exact products), output within one fp16 rounding"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(61)
+    N = 2
+    x = rbf(torch.randn((N,) + base + (Cin,), generator=g), torch.float16)
+    lazy = (torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)
+    w = torch.randn((Cin, Cout) + k, generator=g) / np.sqrt(Cin)
+    wargs = (w, Cin, k, lambda wd: ops.conv_weight_strides(wd, transposed_layout=True))
+    o16, _ = _pointwise(dev, x, lazy, wargs, base, base, (1, 1, 1), k, Cout, None, torch.float16, torch.float16, ocs=Cout * ocs_mult, mma=1, want_layout=4)
+    t = torch.addcmul(lazy[1][:, None, None, None, :], x, lazy[0][:, None, None, None, :])
+    a = rbf(torch.maximum(t, t * 0.01), torch.float16).double()
+    wh = rbf(w, torch.float16).double()
+    ref = torch.einsum('ndhwi,ioabc->ndahbwco', a, wh).reshape((N, base[0] * k[0], base[1] * k[1], base[2] * k[2], Cout))
+    got = o16[..., :Cout].float().cpu().double()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 2.0 ** -10 * float(ref.abs().max()) + 1e-6, float((got - ref).abs().max())
+    # mma = 0 keeps the fp32-product kernel and layout 1
+    _pointwise(dev, x, lazy, wargs, base, base, (1, 1, 1), k, Cout, None, torch.float16, torch.float16, ocs=Cout * ocs_mult, mma=0, want_layout=1)
+
+
+@pytest.mark.parametrize("Cin,Cout,lay", [(30, 47, 4), (60, 47, 4), (30, 2, 1), (120, 20, 1)])
+def test_heads_fp16_products(dev, Cin, Cout, lay):
+    """pw_head_kernel with fp16 products (33..64 logits); the narrow and generic head kernels keep fp32 products (layout 1)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(62)
+    N, base = 2, (4, 8, 16)
+    x = rbf(torch.randn((N,) + base + (Cin,), generator=g), torch.float16)
+    lazy = (torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)
+    w = torch.randn((Cout, Cin, 1, 1, 1), generator=g) / np.sqrt(Cin)
+    b = torch.randn(Cout, generator=g)
+    wargs = (w, Cin, (1, 1, 1), lambda wd: ops.conv_weight_strides(wd))
+    o, _ = _pointwise(dev, x, lazy, wargs, base, base, (1, 1, 1), (1, 1, 1), Cout, b, torch.float16, torch.float32, mma=1, want_layout=lay)
+    t = torch.addcmul(lazy[1][:, None, None, None, :], x, lazy[0][:, None, None, None, :])
+    a = torch.maximum(t, t * 0.01)
+    if lay == 4:
+        ref = torch.einsum('ndhwi,oi->ndhwo', rbf(a, torch.float16).double(), rbf(w[:, :, 0, 0, 0], torch.float16).double()) + b.double()
+        tol = 1e-5
+    else:
+        ref = torch.einsum('ndhwi,oi->ndhwo', a.double(), w[:, :, 0, 0, 0].double()) + b.double()
+        tol = 1e-5
+    got = o.cpu().double()
+    assert float((got - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-6, float((got - ref).abs().max())
 
 
 @pytest.mark.parametrize("stride", [(2, 2, 2), (1, 2, 2)])
