@@ -181,7 +181,8 @@ int mt_set_option(const char* name, int value);
  *   conv_bwdw_wino_bf16s_kernel), MT_BWDW_GEMM (0: the low-resolution backward-weight on the fp32 marching kernel instead of
  *   im2col + bf16 GEMM), MT_BWDW_FAST16 (0: the tiled backward-weight geometries keep fp32 products in mixed precision), MT_BF16_PERSIST (1: conv_bf16p_kernel), MT_BWDW_MARCH16 (0: the strided stage convs' backward-weight on the tiled
  *   kernel), MT_PACK_TILED (0: per-item weight packing), MT_LOSS_SPARSE (0: the flat MultiTalent loss kernels for every sample),
- *   MT_GATHER_BF16 (0: fp32 products in the backward-data of the transposed convs), MT_INORM_SMALL (0: three launches for the InstanceNorm backward of small tensors instead of one).
+ *   MT_GATHER_BF16 (0: fp32 products in the backward-data of the transposed convs), MT_PW_M16 (0: fp32 products in the pointwise kernels
+ *   whatever mt_pointwise_t.mma says — the weights must then be packed with layout 1), MT_INORM_SMALL (0: three launches for the InstanceNorm backward of small tensors instead of one).
  * The HOST side above this ABI (multitalent_amd/engine.py, inference/, bench.py) reads: MT_BF16_STORAGE (0: fp32 storage in mixed
  * precision), MT_ACT_STORAGE (fp16 | bf16), MT_BF16_MIN_VOXELS, MT_PW_STRIDED (0: strided 1x1x1 projections on conv_rt_kernel),
  * MT_BWDW_STREAMS, MT_FUSE_NORM_BWD, MT_HEAD_BWD_FUSED, MT_INFER_FUSED_HEAD, MT_INFER_MIXED, MT_PACK_SPLIT, MT_IO_DEBUG (1: print
