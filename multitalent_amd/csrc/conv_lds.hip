@@ -2343,6 +2343,7 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
 
 static int g_bwdw_bf16 = -1;       // -1: read MT_BWDW_BF16 (default 1): bf16 Winograd backward-weight kernel when mt_conv3d_t.mma == 1
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
+static int g_bwdw_cw = -1;         // -1: read MT_BWDW_CW (default 4): most cout tiles per workgroup of conv_bwdw_fast_kernel (1 | 2 | 4)
 static std::atomic<int> g_wino_waves{8};       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
 static std::atomic<int> g_wino_persist{1};     // 8-wave kernel: 1 persistent over spatial tiles (conv_wino8p_kernel), 0 one tile per workgroup, n > 1: at most n workers
 #ifndef WINO_DMA_DEFAULT
@@ -2359,6 +2360,7 @@ extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "conv_bf16") == 0) { g_bf16_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_bf16") == 0) { g_bwdw_bf16 = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bf16_persist") == 0) { g_bf16_persist = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "bwdw_cw") == 0) { g_bwdw_cw = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
 }
@@ -3127,6 +3129,7 @@ struct BwdWParams {
   int tilesD, tilesH, tilesW, ntiles_total;
   int nchunks, ntaps, ncot, nsg;
   int nsg_cap, nunits, nseg, dseg;   // marching kernel: units = (sample, h-tile, w-tile, D segment of dseg planes)
+  int cw;             // conv_bwdw_fast_kernel: cout tiles per workgroup (1 | 2 | 4; grid.y = ceil(ncot / cw))
   float* part;        // [chunk][cot][sg][tap][16][32]
   ConvChunk chunk[MT_MAX_CHUNKS];
 };
@@ -3329,10 +3332,25 @@ __global__ void bwdw_reduce_kernel(const BwdWReduceParams P) {
 // Deterministic in-workgroup reduction of the four waves' accumulator tiles through LDS (waves 2,3 -> 0,1, then 1 -> 0) and
 // ONE partial per workgroup in global memory: [chunk][cot][sg][tap][16 ci][32 co].  Needs 2 * NT * 512 floats of LDS.
 #define BW_RED_LDS(NT_) ((size_t)2 * (NT_) * 512 * sizeof(float))
-template <int NT, bool NPERM = false>
+template <int NT, bool NPERM = false, int CW = 1>
 __device__ __forceinline__ void bwdw_wg_reduce_store(f32x4 (&acc)[NT][2], float* __restrict__ lds, float* __restrict__ pp,
-                                                     int wave, int lane) {
+                                                     int wave, int lane, bool valid = true) {
   const int li = lane & 15, lk = lane >> 4;
+  // CW cout tiles per workgroup (wave = kq * CW + cw): only the 4 / CW waves of one cout tile are summed — CW = 4: every wave
+  // stores its own tile, CW = 2: waves 2, 3 -> 0, 1 and both store.  pp / valid belong to THIS wave's cout tile.
+  auto store = [&](const float* b) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          pp[(size_t)t * 512 + (lk * 4 + j) * 32 + (NPERM ? 2 * li + h : h * 16 + li)] = acc[t][h][j] + (b ? b[((t * 2 + h) * 4 + j) * 64] : 0.f);
+  };
+  if constexpr (CW == 4) {
+    if (valid) store(nullptr);
+    return;
+  }
   __syncthreads();                     // every wave is done with the X tiles
   if (wave >= 2) {
     float* b = lds + (wave - 2) * (NT * 512) + lane;
@@ -3344,6 +3362,10 @@ __device__ __forceinline__ void bwdw_wg_reduce_store(f32x4 (&acc)[NT][2], float*
         for (int j = 0; j < 4; ++j) b[((t * 2 + h) * 4 + j) * 64] = acc[t][h][j];
   }
   __syncthreads();
+  if constexpr (CW == 2) {
+    if (wave < 2 && valid) store(lds + wave * (NT * 512) + lane);
+    return;
+  }
   if (wave < 2) {
     const float* b = lds + wave * (NT * 512) + lane;
 #pragma unroll
@@ -3364,16 +3386,7 @@ __device__ __forceinline__ void bwdw_wg_reduce_store(f32x4 (&acc)[NT][2], float*
         for (int j = 0; j < 4; ++j) b[((t * 2 + h) * 4 + j) * 64] = acc[t][h][j];
   }
   __syncthreads();
-  if (wave == 0) {
-    const float* b = lds + lane;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          pp[(size_t)t * 512 + (lk * 4 + j) * 32 + (NPERM ? 2 * li + h : h * 16 + li)] = acc[t][h][j] + b[((t * 2 + h) * 4 + j) * 64];
-  }
+  if (wave == 0) store(lds + lane);
 }
 
 // ================================================================================================
@@ -3385,7 +3398,7 @@ __device__ __forceinline__ void bwdw_wg_reduce_store(f32x4 (&acc)[NT][2], float*
 // buffer loads straight into registers in B-fragment order.  A workgroup walks a strided list of tiles and writes
 // one partial per WAVE; bwdw_reduce_kernel sums them deterministically.
 // XS / YS: storage types of X (p->src) and dY (ysrc)
-template <int KD, int KH, int KW, int SD, int SH, int SW, int TH, int TW, int VEC, int XS = MT_F32, int YS = MT_F32>
+template <int KD, int KH, int KW, int SD, int SH, int SW, int TH, int TW, int VEC, int XS = MT_F32, int YS = MT_F32, int CW = 1>
 __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P) {
   constexpr int YE = mt_ebytes<YS>();
   // compile-time geometry: kernel K, stride S, pad (K-1)/2 for odd K and 0 for K = 2 (transposed-conv weights); tile 1 x TH x TW
@@ -3395,12 +3408,18 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
   constexpr int KS = TV / 16;            // k-steps (4 voxels each) per wave
   constexpr int SPR = TW / 4;            // k-steps per tile row
   static_assert(TV == 128, "tile must hold 128 voxels");
+  // CW cout tiles per workgroup: wave = kq * CW + cw takes cout tile cw and the blocks kq * CW ... kq * CW + CW - 1 of the tile's four
+  // blocks of KS k-steps (CW = 1: one block per wave and a four-wave reduction at the end, the original form).  The staged X tile
+  // then feeds CW times the MFMAs: staging (texture path + vector ALU, as long as the matrix phase at CW = 1) is amortised CW-fold.
+  static_assert((CW == 1 || CW == 2 || CW == 4) && KS % SPR == 0, "cout tiles per workgroup");
+  constexpr int GOFF = (KS / SPR) * SH * LW * FCKP;      // LDS distance between consecutive blocks
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const mt_conv3d_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const int sg = blockIdx.x, cot = blockIdx.y, chi = blockIdx.z;
+  const int cw = wave & (CW - 1), kq = wave / CW;
+  const int sg = blockIdx.x, cot = blockIdx.y * CW + cw, chi = blockIdx.z;
   const ConvChunk cc = P.chunk[chi];
   const mt_src_t& Y = P.y;
 
@@ -3413,8 +3432,8 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
       for (int j = 0; j < 4; ++j) acc[t][h][j] = 0.f;
 
   // this wave's first voxel inside the tile: k-step ks = wave*KS + s -> (row, w0) = (ks / SPR, 4*(ks % SPR))
-  const int row0 = (wave * KS) / SPR;
-  const int xbase = ((row0 * SH * LW) + lk * SW) * FCKP + li;      // + compile-time (step voxel + tap voxel) * FCKP
+  const int row0 = (kq * CW * KS) / SPR;
+  const int xbase0 = ((row0 * SH * LW) + lk * SW) * FCKP + li;     // + block * GOFF + compile-time (step voxel + tap voxel) * FCKP
   const int co = cot * 32 + li;
   const bool yaff = Y.scale != nullptr;
   const size_t ysample = (size_t)c.Do * c.Ho * c.Wo * Y.cs;
@@ -3430,12 +3449,12 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
   // Y fragments of this wave's KS k-steps (2 cout halves each), straight from global in B-fragment order.
   // ISSUE ONLY: the optional lazy-activation transform is applied when the fragments are rotated in (finish_y), never
   // right behind the loads — otherwise hipcc parks an s_waitcnt vmcnt(0) after every load pair and drains the prefetch.
-  auto issue_y = [&](float (&yb)[KS][2], unsigned& okmask, int nb, int od0, int oh0, int ow0) {
+  auto issue_y = [&](float (&yb)[KS][2], unsigned& okmask, int nb, int od0, int oh0, int ow0, int kb) {
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)Y.ptr + (size_t)nb * ysample * YE), 0, (int)(ysample * YE), 0x00020000);
     okmask = 0;
 #pragma unroll
     for (int s2 = 0; s2 < KS; ++s2) {
-      const int ks = wave * KS + s2;                    // wave-uniform
+      const int ks = kb * KS + s2;                      // wave-uniform
       const int oh = oh0 + ks / SPR, ow = ow0 + 4 * (ks % SPR) + lk;
       const bool vok = (oh < c.Ho) && (ow < c.Wo);
       const int base = ((od0 * c.Ho + oh) * c.Wo + ow) * Y.cs + co;
@@ -3478,11 +3497,12 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
   unsigned yok = 0;
   int ynb = 0;
   int tile = sg;
+  int cnb = 0, cod0 = 0, coh0 = 0, cow0 = 0;       // coordinates of the tile in LDS
   if (tile < P.ntiles_total) {
-    int nb, od0, oh0, ow0; tile_coords(tile, nb, od0, oh0, ow0);
-    stage2_load<LD, LH, LW, VEC, XS>(xr, c, cc, nb, od0 * SD - PD, oh0 * SH - PH, ow0 * SW - PW, lane, wave);
-    issue_y(ynxt, yok, nb, od0, oh0, ow0);
-    ynb = nb;
+    tile_coords(tile, cnb, cod0, coh0, cow0);
+    stage2_load<LD, LH, LW, VEC, XS>(xr, c, cc, cnb, cod0 * SD - PD, coh0 * SH - PH, cow0 * SW - PW, lane, wave);
+    issue_y(ynxt, yok, cnb, cod0, coh0, cow0, kq * CW);
+    ynb = cnb;
   }
   for (; tile < P.ntiles_total; tile += P.nsg) {
     __syncthreads();     // previous tile's X reads are done
@@ -3490,36 +3510,47 @@ __global__ __launch_bounds__(256) void conv_bwdw_fast_kernel(const BwdWParams P)
     if (!(BW_ABL & 2)) finish_y(ycur, ynxt, yok, ynb);
     __syncthreads();
     const int tnext = tile + P.nsg;
-    if (tnext < P.ntiles_total) {
-      int nb, od0, oh0, ow0; tile_coords(tnext, nb, od0, oh0, ow0);
-      if (!(BW_ABL & 1)) stage2_load<LD, LH, LW, VEC, XS>(xr, c, cc, nb, od0 * SD - PD, oh0 * SH - PH, ow0 * SW - PW, lane, wave);
-      if (!(BW_ABL & 2)) issue_y(ynxt, yok, nb, od0, oh0, ow0);
-      ynb = nb;
+    const bool more = tnext < P.ntiles_total;
+    int nnb = 0, nod0 = 0, noh0 = 0, now0 = 0;
+    if (more) {
+      tile_coords(tnext, nnb, nod0, noh0, now0);
+      if (!(BW_ABL & 1)) stage2_load<LD, LH, LW, VEC, XS>(xr, c, cc, nnb, nod0 * SD - PD, noh0 * SH - PH, now0 * SW - PW, lane, wave);
     }
-    if (BW_ABL & 8) continue;
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- MFMA phase: KS k-steps x 27 taps x 2 cout halves; all LDS offsets are immediates and the A fragments of
-    // k-step s+1 are fetched (ping-pong register sets) while the 54 MFMAs of k-step s issue
-    float a0[NT], a1[NT];
+#pragma unroll 1
+    for (int g = 0; g < CW; ++g) {
+      if (CW > 1 && g > 0 && !(BW_ABL & 2)) finish_y(ycur, ynxt, yok, ynb);
+      // dY fragments of the next block: the same tile's block g + 1, or block 0 of the next tile
+      if (!(BW_ABL & 2)) {
+        if (CW > 1 && g + 1 < CW) issue_y(ynxt, yok, cnb, cod0, coh0, cow0, kq * CW + g + 1);
+        else if (more) { issue_y(ynxt, yok, nnb, nod0, noh0, now0, kq * CW); ynb = nnb; }
+      }
+      if (BW_ABL & 8) continue;
+      const int xbase = xbase0 + g * GOFF;
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- MFMA phase: KS k-steps x 27 taps x 2 cout halves; all LDS offsets are immediates and the A fragments of
+      // k-step s+1 are fetched (ping-pong register sets) while the 54 MFMAs of k-step s issue
+      float a0[NT], a1[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) a0[t] = lds[xbase + (((t / (KH * KW)) * LH + (t / KW) % KH) * LW + (t % KW)) * FCKP];
+      for (int t = 0; t < NT; ++t) a0[t] = lds[xbase + (((t / (KH * KW)) * LH + (t / KW) % KH) * LW + (t % KW)) * FCKP];
 #pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) {
-      float (&ac)[NT] = (s2 & 1) ? a1 : a0;
-      float (&an)[NT] = (s2 & 1) ? a0 : a1;
-      // one A read of the next k-step rides behind every MFMA pair: the LDS queue never fills, so MFMA issue never waits
-      // on a burst of reads
-      const int svox = ((s2 + 1) / SPR) * SH * LW + 4 * ((s2 + 1) % SPR) * SW;
+      for (int s2 = 0; s2 < KS; ++s2) {
+        float (&ac)[NT] = (s2 & 1) ? a1 : a0;
+        float (&an)[NT] = (s2 & 1) ? a0 : a1;
+        // one A read of the next k-step rides behind every MFMA pair: the LDS queue never fills, so MFMA issue never waits
+        // on a burst of reads
+        const int svox = ((s2 + 1) / SPR) * SH * LW + 4 * ((s2 + 1) % SPR) * SW;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        if (s2 + 1 < KS) an[t] = lds[xbase + (svox + ((t / (KH * KW)) * LH + (t / KW) % KH) * LW + (t % KW)) * FCKP];
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][0], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][1], acc[t][1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < NT; ++t) {
+          if (s2 + 1 < KS) an[t] = lds[xbase + (svox + ((t / (KH * KW)) * LH + (t / KW) % KH) * LW + (t % KW)) * FCKP];
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][0], acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t], ycur[s2][1], acc[t][1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
+    cnb = nnb; cod0 = nod0; coh0 = noh0; cow0 = now0;
   }
-  bwdw_wg_reduce_store<NT>(acc, lds, P.part + ((size_t)((size_t)(chi * P.ncot + cot) * P.nsg + sg) * NT) * 512, wave, lane);
+  bwdw_wg_reduce_store<NT, false, CW>(acc, lds, P.part + ((size_t)((size_t)(chi * P.ncot + cot) * P.nsg + sg) * NT) * 512, wave, lane, cot < P.ncot);
 }
 
 
@@ -3938,8 +3969,22 @@ static bool bwdw_use_bf16_133(const mt_conv3d_t* p) {       // 1x3x3 stride-1 ba
   return g_bwdw_bf16 && p->mma == 1 && p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 &&
          p->PD == 0 && p->PH == 1 && p->PW == 1 && p->Wo > 16 && p->Ho >= 2 && p->Do >= 1 && conv_fast_vec(p) == 2;
 }
+// conv_bwdw_fast_kernel with several cout tiles per workgroup (fp32 storage on both sides, channel-pair staging; the geometries
+// launch_bwdw_fast instantiates it for): 4 when the cout tiles divide by 4, else 2, else 1.  MT_BWDW_CW=1 switches it off.
+static int bwdw_fast_cw(const mt_conv3d_t* p) {
+  if (g_bwdw_cw < 0) { const char* e = getenv("MT_BWDW_CW"); g_bwdw_cw = e ? atoi(e) : 4; }
+  const int cap = g_bwdw_cw;
+  if (cap < 2 || conv_src_dtype(p) != MT_F32 || conv_fast_vec(p) != 2) return 1;
+  const bool g333 = p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SH == 2 && p->SW == 2 && (p->SD == 1 || p->SD == 2);      // strided stage convs
+  const bool g222 = p->KH == 2 && p->KW == 2 && p->SH == 2 && p->SW == 2 && ((p->KD == 2 && p->SD == 2) || (p->KD == 1 && p->SD == 1));   // transposed-conv weights
+  const bool g133 = p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1;                      // residual-encoder stage 0
+  if (!(g333 || g222 || g133)) return 1;
+  const int ncot = mt_cdiv(p->Cout, 32);
+  const int cw = (ncot % 4 == 0) ? 4 : ((ncot % 2 == 0) ? 2 : 1);
+  return cw > cap ? cap : cw;
+}
 // plan for the fast kernel: tile 1 x TH x TW with (TH,TW) = (4,32) or (8,16)
-static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
+static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = false) {
   const bool wide = p->Wo > 16;
   P->TD = 1; P->TH = wide ? 4 : 8; P->TW = wide ? 32 : 16;
   P->tilesD = p->Do; P->tilesH = mt_cdiv(p->Ho, P->TH); P->tilesW = mt_cdiv(p->Wo, P->TW);
@@ -3947,7 +3992,8 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P) {
   P->ntaps = p->KD * p->KH * p->KW;
   P->nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, BW_CK, P->chunk);
   P->ncot = mt_cdiv(p->Cout, 32);
-  int pairs = P->nchunks * P->ncot; if (pairs < 1) pairs = 1;
+  P->cw = allow_cw ? bwdw_fast_cw(p) : 1;
+  int pairs = P->nchunks * mt_cdiv(P->ncot, P->cw); if (pairs < 1) pairs = 1;
   int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
   if ((bwdw_use_march(p) && bwdw_use_bf16(p)) || bwdw_use_bf16_133(p)) nsg = (512 + pairs - 1) / pairs;      // 64 KiB ring: two workgroups per CU
   // conv_bwdw_fast16_kernel with few taps (transposed-conv weights, 1x1x1): <= 180 registers and <= 49 KiB of LDS — two workgroups per CU
@@ -4029,7 +4075,7 @@ static int launch_bwdw_fast(const BwdWParams& P, int vec, hipStream_t st) {
   size_t ldsb = (size_t)KD * (P.TW == 32 ? LHa * LWa : LHb * LWb) * FCKP * sizeof(float);
   if (ldsb < BW_RED_LDS(KD * KH * KW)) ldsb = BW_RED_LDS(KD * KH * KW);
   MT_REQUIRE(ldsb <= 160 * 1024, "bwd_weight: LDS tile too large (%zu)", ldsb);
-  dim3 grid(P.nsg, P.ncot, P.nchunks);
+  dim3 grid(P.nsg, mt_cdiv(P.ncot, P.cw), P.nchunks);
 #define MT_BW_LAUNCH_K(KFN_)                                                                                  \
   do {                                                                                                        \
     auto kfn = KFN_;                                                                                          \
@@ -4050,6 +4096,22 @@ static int launch_bwdw_fast(const BwdWParams& P, int vec, hipStream_t st) {
     else if (VEC_ == 2 && xs == MT_BF16 && ys == MT_BF16) MT_BW_LAUNCH_K((conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, TH_, TW_, 2, MT_BF16, MT_BF16>)); \
     else { mt_set_error("bwd_weight: storage types (X %d, dY %d) not compiled into conv_bwdw_fast_kernel", xs, ys); return MT_EINVAL; } \
   } while (0)
+  // several cout tiles per workgroup (bwdw_fast_cw: fp32 storage, channel pairs, these geometries)
+  constexpr bool CWG = (KD == 3 && KH == 3 && KW == 3 && SH == 2 && SW == 2) || (KH == 2 && KW == 2 && SH == 2 && SW == 2) ||
+                       (KD == 1 && KH == 3 && KW == 3 && SD == 1 && SH == 1 && SW == 1);
+  if (P.cw > 1) {
+    if constexpr (CWG) {
+      MT_REQUIRE(vec == 2 && xs == MT_F32 && ys == MT_F32 && (P.cw == 2 || P.cw == 4), "bwd_weight: cout tiles per workgroup (%d) on a problem the kernel is not compiled for", P.cw);
+      if (P.TW == 32) { if (P.cw == 4) MT_BW_LAUNCH_K((conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, 4, 32, 2, MT_F32, MT_F32, 4>));
+                        else           MT_BW_LAUNCH_K((conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, 4, 32, 2, MT_F32, MT_F32, 2>)); }
+      else            { if (P.cw == 4) MT_BW_LAUNCH_K((conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, 8, 16, 2, MT_F32, MT_F32, 4>));
+                        else           MT_BW_LAUNCH_K((conv_bwdw_fast_kernel<KD, KH, KW, SD, SH, SW, 8, 16, 2, MT_F32, MT_F32, 2>)); }
+      MT_CHECK_LAUNCH("conv_bwdw_fast (cout tiles per workgroup)");
+      return MT_OK;
+    } else {
+      mt_set_error("bwd_weight: cout tiles per workgroup (%d) on a geometry the kernel is not compiled for", P.cw); return MT_EINVAL;
+    }
+  }
   if (P.TW == 32) { if (vec == 2) MT_BW_LAUNCH(4, 32, 2); else MT_BW_LAUNCH(4, 32, 1); }
   else            { if (vec == 2) MT_BW_LAUNCH(8, 16, 2); else MT_BW_LAUNCH(8, 16, 1); }
 #undef MT_BW_LAUNCH
@@ -4090,10 +4152,12 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
   if (P.nchunks <= 0) return 0;
   size_t generic = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
   {
-    BwdWParams F; bwdw_fast_plan(p, &F);
-    if (F.nchunks > 0) {
-      const size_t fast = (size_t)F.nchunks * F.ncot * F.nsg * F.ntaps * 512 * sizeof(float);
-      if (fast > generic) generic = fast;
+    for (int cwp = 0; cwp < 2; ++cwp) {          // with and without several cout tiles per workgroup (decided with dY's type at launch)
+      BwdWParams F; bwdw_fast_plan(p, &F, cwp == 1);
+      if (F.nchunks > 0) {
+        const size_t fast = (size_t)F.nchunks * F.ncot * F.nsg * F.ntaps * 512 * sizeof(float);
+        if (fast > generic) generic = fast;
+      }
     }
   }
   if (bwdw_is_stem(p, nullptr)) {
@@ -4202,7 +4266,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
   if (geo >= 0 && bwdw_use_gemm(p, ysrc))
     return launch_bwdw_gemm(p, ysrc, dw, s_ci, s_co, s_kd, s_kh, s_kw, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
   if (geo >= 0) {
-    bwdw_fast_plan(p, &P);
+    bwdw_fast_plan(p, &P, xdt == MT_F32 && ysrc->dtype == MT_F32 && !bwdw_fast16_ok(p, ysrc) && !(geo == 0 && bwdw_use_march(p)));
     MT_REQUIRE(P.nchunks > 0, "bwd_weight: too many channel chunks");
     const size_t need = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need) { mt_set_error("bwd_weight: workspace %zu < %zu", workspace_bytes, need); return MT_EWORKSPACE; }

@@ -625,8 +625,22 @@ class Engine:
         # 0 off, 1 on, 2 convolutions only, 3 residual adds only.  Default: on only when everything runs on ONE stream — beside the
         # weight-gradient stream the separate (bandwidth-bound) reduction overlaps the (matrix-bound) backward-weight launches and
         # fusing it into the matrix-bound kernel on the chain measured 0 ... +0.3 ms per step
-        self.fuse_norm_bwd = int(os.environ.get('MT_FUSE_NORM_BWD', '1' if self.bwdw_streams == 0 else '0'))
+        # Mixed precision beside that stream: the residual-add form only (3) — the add's backward is bandwidth-bound itself, so the
+        # extra sums cost nothing there (residual encoder mixed 25.48 -> 25.27 ms, fp32 unchanged: tools/r4_run47.sh)
+        self._fuse_norm_bwd = os.environ.get('MT_FUSE_NORM_BWD')
         self.producer, self.pending = {}, {}
+
+    @property
+    def fuse_norm_bwd(self):
+        if self._fuse_norm_bwd is not None:
+            return int(self._fuse_norm_bwd)
+        if self.bwdw_streams == 0:
+            return 1
+        return 3 if self.mma else 0
+
+    @fuse_norm_bwd.setter
+    def fuse_norm_bwd(self, v):
+        self._fuse_norm_bwd = v
 
     def set_precision(self, precision):
         """'fp32' (exact, default) or 'bf16': mixed precision — the reference's autocast mode (nnUNetTrainerV2.py:236-249) on

@@ -296,6 +296,53 @@ def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
         assert relerr(dw2.cpu(), w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("Cin,Cout,shape,k,stride,lazy", [
+    (30, 60, (6, 12, 68), (3, 3, 3), (2, 2, 2), False),      # two cout tiles -> 2 per workgroup, tile 4 x 32, ragged in W
+    (30, 120, (6, 12, 34), (3, 3, 3), (2, 2, 2), True),      # four -> 4 per workgroup, lazily activated X
+    (20, 240, (4, 10, 20), (3, 3, 3), (2, 2, 2), False),     # eight -> 4 per workgroup, two block rows; tile 8 x 16
+    (40, 320, (3, 8, 16), (3, 3, 3), (1, 2, 2), False),      # ten -> 2 per workgroup, anisotropic stride, three cin chunks
+    (30, 70, (5, 9, 37), (3, 3, 3), (2, 2, 2), False),       # three cout tiles: stays at one per workgroup
+    (16, 64, (3, 9, 40), (1, 3, 3), (1, 1, 1), True),        # 1x3x3 (residual encoder, stage 0)
+    (30, 128, (2, 6, 70), (1, 3, 3), (1, 1, 1), False),
+    (30, 60, (4, 8, 36), (2, 2, 2), (2, 2, 2), False),       # ConvTranspose3d(k = s) weight geometry
+    (24, 120, (3, 8, 20), (1, 2, 2), (1, 2, 2), False),
+])
+def test_conv_bwd_weight_cout_tiles_per_workgroup(dev, Cin, Cout, shape, k, stride, lazy):
+    """conv_bwdw_fast_kernel with 2 / 4 cout tiles per workgroup (option bwdw_cw, default 4: a wave takes one cout tile and 2 / 4 of the
+    tile's four k-step blocks; the staged X tile feeds 2 / 4 times the MFMAs): against host autograd (F.conv3d, fp32) and against the
+    one-tile-per-workgroup form of the same kernel, accumulate mode included."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    N = 2
+    x = torch.randn((N, Cin) + shape, generator=g)
+    sc = (torch.rand((N, Cin), generator=g) + 0.5) if lazy else None
+    sh = torch.randn((N, Cin), generator=g) * 0.3 if lazy else None
+    xa_host = F.leaky_relu(x * sc[:, :, None, None, None] + sh[:, :, None, None, None], 0.01) if lazy else x
+    w = (torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))).requires_grad_(True)
+    pad = tuple((kk - 1) // 2 if kk == 3 else 0 for kk in k)
+    y = F.conv3d(xa_host, w, None, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xa = ops.Act(to_ndhwc(x).to(dev), scale=sc.to(dev), shift=sh.to(dev), slope=0.01) if lazy else ops.Act(to_ndhwc(x).to(dev))
+    ya = ops.Act(to_ndhwc(dy).to(dev))
+    geom = ops.ConvGeom(shape, k, stride, pad)
+    p = ops.fill_conv([xa], geom, Cout)
+    res = {}
+    try:
+        for cw in (4, 1):
+            ops.set_option('bwdw_cw', cw)
+            ws = torch.full((max(ops.conv3d_bwd_weight_workspace(p) // 4, 1),), float('nan'), device=dev)
+            dw = torch.full(w.shape, float('nan'), device=dev)
+            ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
+            ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), True, ws)       # accumulate: twice the gradient
+            torch.cuda.synchronize()
+            res[cw] = dw.cpu()
+            assert relerr(res[cw], 2 * w.grad) < 2e-5, cw
+    finally:
+        ops.set_option('bwdw_cw', 4)
+    assert relerr(res[4], res[1]) < 1e-5
+
+
 @pytest.mark.parametrize("N,Cin,Cout,shape,two", [(2, 64, 64, (3, 12, 12), False), (2, 48, 40, (3, 6, 6), False), (1, 32, 64, (3, 10, 7), True)])
 def test_conv_tapsplit_bf16(dev, N, Cin, Cout, shape, two):
     """low-resolution layers in mixed precision: conv_tapsplit_kernel<2, true> (taps split over the waves, one bf16 MFMA per tap),
