@@ -3969,12 +3969,12 @@ static bool bwdw_use_bf16_133(const mt_conv3d_t* p) {       // 1x3x3 stride-1 ba
   return g_bwdw_bf16 && p->mma == 1 && p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 &&
          p->PD == 0 && p->PH == 1 && p->PW == 1 && p->Wo > 16 && p->Ho >= 2 && p->Do >= 1 && conv_fast_vec(p) == 2;
 }
-// conv_bwdw_fast_kernel with several cout tiles per workgroup (fp32 storage on both sides, channel-pair staging; the geometries
-// launch_bwdw_fast instantiates it for): 4 when the cout tiles divide by 4, else 2, else 1.  MT_BWDW_CW=1 switches it off.
+// conv_bwdw_fast_kernel (fp32 storage on both sides) / conv_bwdw_fast16_kernel with several cout tiles per workgroup (channel-pair
+// staging; the geometries launch_bwdw_fast / launch_bwdw_fast16 instantiate them for): 4 when the cout tiles divide by 4, else 2, else 1.  MT_BWDW_CW=1 switches it off.
 static int bwdw_fast_cw(const mt_conv3d_t* p) {
   if (g_bwdw_cw < 0) { const char* e = getenv("MT_BWDW_CW"); g_bwdw_cw = e ? atoi(e) : 4; }
   const int cap = g_bwdw_cw;
-  if (cap < 2 || conv_src_dtype(p) != MT_F32 || conv_fast_vec(p) != 2) return 1;
+  if (cap < 2 || conv_src_dtype(p) < 0 || conv_fast_vec(p) != 2) return 1;
   const bool g333 = p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SH == 2 && p->SW == 2 && (p->SD == 1 || p->SD == 2);      // strided stage convs
   const bool g222 = p->KH == 2 && p->KW == 2 && p->SH == 2 && p->SW == 2 && ((p->KD == 2 && p->SD == 2) || (p->KD == 1 && p->SD == 1));   // transposed-conv weights
   const bool g133 = p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1;                      // residual-encoder stage 0
@@ -4266,7 +4266,10 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
   if (geo >= 0 && bwdw_use_gemm(p, ysrc))
     return launch_bwdw_gemm(p, ysrc, dw, s_ci, s_co, s_kd, s_kh, s_kw, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
   if (geo >= 0) {
-    bwdw_fast_plan(p, &P, xdt == MT_F32 && ysrc->dtype == MT_F32 && !bwdw_fast16_ok(p, ysrc) && !(geo == 0 && bwdw_use_march(p)));
+    // several cout tiles per workgroup: conv_bwdw_fast_kernel with fp32 storage on both sides, conv_bwdw_fast16_kernel and its marching form
+    const bool cw_ok = (bwdw_fast16_ok(p, ysrc) || (xdt == MT_F32 && ysrc->dtype == MT_F32)) &&
+                       !(geo == 0 && bwdw_use_march(p)) && !(geo == 6 && bwdw_use_bf16_133(p));
+    bwdw_fast_plan(p, &P, cw_ok);
     MT_REQUIRE(P.nchunks > 0, "bwd_weight: too many channel chunks");
     const size_t need = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need) { mt_set_error("bwd_weight: workspace %zu < %zu", workspace_bytes, need); return MT_EWORKSPACE; }

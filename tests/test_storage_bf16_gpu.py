@@ -700,23 +700,28 @@ def test_tiled_backward_weight_16bit_storage_bitexact(dev, kind):
     y = rbf(torch.randn((N,) + tuple(geom.out) + (Cout,), generator=g), ydt if ydt != torch.float32 else torch.bfloat16)
     lz = (torch.rand((N, Cin if xlazy else Cout), generator=g) + 0.5, torch.randn((N, Cin if xlazy else Cout), generator=g))
     res = []
-    for xd, yd in ((torch.float32, torch.float32), (xdt, ydt)):
-        xb, yb = x.to(dev).to(xd), y.to(dev).to(yd)
-        a = ops.Act(xb, scale=lz[0].to(dev), shift=lz[1].to(dev), slope=0.01) if xlazy else ops.Act(xb)
-        ya = ops.Act(yb) if xlazy else ops.Act(yb, scale=lz[0].to(dev), shift=lz[1].to(dev), slope=0.01)
-        p = ops.fill_conv([a], geom, Cout, mma=0)
-        name = ops.conv_bwd_weight_kernel_name(p, ya)
-        assert name.startswith('conv_bwdw_fast_kernel'), name
-        assert ops.conv_bwd_weight_io_supported(p, ya), (name, xd, yd)
-        dw = torch.full((Cout, Cin) + k, float('nan'), device=dev)
-        ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
-        ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
-        torch.cuda.synchronize()
-        res.append(dw)
+    ops.set_option('bwdw_cw', 1)       # (several cout tiles per workgroup exist for fp32 storage only: same products, another order of the sums)
+    try:
+        for xd, yd in ((torch.float32, torch.float32), (xdt, ydt)):
+            xb, yb = x.to(dev).to(xd), y.to(dev).to(yd)
+            a = ops.Act(xb, scale=lz[0].to(dev), shift=lz[1].to(dev), slope=0.01) if xlazy else ops.Act(xb)
+            ya = ops.Act(yb) if xlazy else ops.Act(yb, scale=lz[0].to(dev), shift=lz[1].to(dev), slope=0.01)
+            p = ops.fill_conv([a], geom, Cout, mma=0)
+            name = ops.conv_bwd_weight_kernel_name(p, ya)
+            assert name.startswith('conv_bwdw_fast_kernel'), name
+            assert ops.conv_bwd_weight_io_supported(p, ya), (name, xd, yd)
+            dw = torch.full((Cout, Cin) + k, float('nan'), device=dev)
+            ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
+            ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
+            torch.cuda.synchronize()
+            res.append(dw)
+    finally:
+        ops.set_option('bwdw_cw', 4)
     assert torch.isfinite(res[1]).all() and torch.equal(res[0], res[1]), float((res[0] - res[1]).abs().max())
 
 
-@pytest.mark.parametrize("kind", ["strided222", "strided222_narrow", "strided222_deep", "strided122", "tconv222", "tconv122", "proj222", "proj122", "k333_shallow", "two_sources"])
+@pytest.mark.parametrize("kind", ["strided222", "strided222_narrow", "strided222_deep", "strided122", "tconv222", "tconv122", "proj222", "proj122", "k333_shallow", "two_sources",
+                                  "strided222_narrow_cw4", "strided122_narrow_cw2", "tconv222_cw4", "strided222_cw4", "strided122_deep_cw2"])
 def test_tiled_backward_weight_bf16_products(dev, kind):
     """conv_bwdw_fast16_kernel (mixed precision: 16-bit X and dY, bf16 products, fp32 accumulation) against autograd on the host with the
     same operand rounding (activated operands rounded to bf16, exact products); ragged tiles, both tile shapes, accumulate"""
@@ -734,7 +739,13 @@ def test_tiled_backward_weight_bf16_products(dev, kind):
            'proj222': ((1, 1, 1), (2, 2, 2), (0, 0, 0), (30,), 60, (8, 12, 34), f16, b16, True),
            'proj122': ((1, 1, 1), (1, 2, 2), (0, 0, 0), (32,), 64, (3, 12, 34), f16, b16, True),
            'k333_shallow': ((3, 3, 3), (1, 1, 1), (1, 1, 1), (30,), 30, (2, 9, 40), f16, b16, True),          # Do < 3: not a marching problem
-           'two_sources': ((3, 3, 3), (2, 2, 2), (1, 1, 1), (30, 18), 60, (6, 10, 36), f16, b16, True)}[kind]
+           'two_sources': ((3, 3, 3), (2, 2, 2), (1, 1, 1), (30, 18), 60, (6, 10, 36), f16, b16, True),
+           # several cout tiles per workgroup (option bwdw_cw): four / two (ten cout tiles) / four; marching form: four / two
+           'strided222_narrow_cw4': ((3, 3, 3), (2, 2, 2), (1, 1, 1), (48,), 128, (6, 18, 26), f16, b16, True),
+           'strided122_narrow_cw2': ((3, 3, 3), (1, 2, 2), (1, 1, 1), (40,), 320, (3, 8, 16), f16, b16, True),
+           'tconv222_cw4': ((2, 2, 2), (2, 2, 2), (0, 0, 0), (30,), 120, (8, 12, 36), b16, f16, False),
+           'strided222_cw4': ((3, 3, 3), (2, 2, 2), (1, 1, 1), (30,), 120, (8, 12, 70), f16, b16, True),
+           'strided122_deep_cw2': ((3, 3, 3), (1, 2, 2), (1, 1, 1), (32,), 64, (7, 18, 40), f16, b16, True)}[kind]
     k, stride, pad, Cins, Cout, shape, xdt, ydt, xlazy = cfg
     geom = ops.ConvGeom(shape, k, stride, pad)
     xs = [rbf(torch.randn((N,) + shape + (C,), generator=g), xdt) for C in Cins]
@@ -748,7 +759,7 @@ def test_tiled_backward_weight_bf16_products(dev, kind):
     p = ops.fill_conv(acts, geom, Cout, mma=1)
     name = ops.conv_bwd_weight_kernel_name(p, ya)
     # the strided 3x3x3 stage convs with Wo > 16 and Do >= 3 take the marching form (a ring of input planes), everything else the tiled one
-    marching = kind in ('strided222', 'strided122', 'two_sources', 'strided222_deep')
+    marching = kind in ('strided222', 'strided122', 'two_sources', 'strided222_deep', 'strided222_cw4', 'strided122_deep_cw2')
     assert name.startswith('conv_bwdw_march16_kernel' if marching else 'conv_bwdw_fast16_kernel'), name
     assert ops.conv_bwd_weight_io_supported(p, ya), name
     Cin = sum(Cins)
@@ -774,6 +785,15 @@ def test_tiled_backward_weight_bf16_products(dev, kind):
     ops.conv3d_bwd_weight(p, ya, dw2, ops.conv_weight_strides(dw2), True, ws)
     torch.cuda.synchronize()
     assert torch.allclose(dw2, 2 * dw, rtol=1e-6, atol=1e-6)
+    if True:                  # one cout tile per workgroup: the same products, fp32 sums in another order
+        ops.set_option('bwdw_cw', 1)
+        try:
+            dw1 = torch.full((Cout, Cin) + k, float('nan'), device=dev)
+            ops.conv3d_bwd_weight(p, ya, dw1, ops.conv_weight_strides(dw1), False, ws)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_option('bwdw_cw', 4)
+        assert float((dw1 - dw).abs().max()) <= 1e-5 * float(dw.abs().max())
     # MT_BWDW_FAST16 decides between kernels of the same result up to the product type: the fp32-product kernel is within bf16 operand rounding
     p0 = ops.fill_conv(acts, geom, Cout, mma=0)
     assert ops.conv_bwd_weight_kernel_name(p0, ya).startswith('conv_bwdw_fast_kernel')

@@ -1,0 +1,8 @@
+# conv_bwdw_fast16_kernel with several cout tiles per workgroup: parity, then A/B over the mixed workloads
+timeout 900 python -m pytest tests/test_storage_bf16_gpu.py tests/test_kernels_gpu.py -x -q -k "backward_weight or bwd_weight" 2>&1 | tail -5
+run() { python bench.py "$@" --steps 10 --warmup 3 --no-also --no-cpu-baseline --no-traffic --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"; }
+for i in 1 2; do for f in 1 4; do
+echo -n "task009 mixed MT_BWDW_CW=$f: "; MT_BWDW_CW=$f run --precision bf16
+echo -n "task100 mixed MT_BWDW_CW=$f: "; MT_BWDW_CW=$f run --workload task100 --precision bf16
+echo -n "resenc mixed MT_BWDW_CW=$f: "; MT_BWDW_CW=$f run --workload resenc --precision bf16
+done; done
