@@ -2343,7 +2343,7 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
 
 static int g_bwdw_bf16 = -1;       // -1: read MT_BWDW_BF16 (default 1): bf16 Winograd backward-weight kernel when mt_conv3d_t.mma == 1
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
-static int g_bwdw_cw = -1;         // -1: read MT_BWDW_CW (default 4): most cout tiles per workgroup of conv_bwdw_fast_kernel (1 | 2 | 4)
+static int g_bwdw_cw = -1;         // -1: read MT_BWDW_CW (default 4): most cout tiles per workgroup of the tiled backward-weight kernels (1 | 2 | 4; + 100: also on small problems)
 static std::atomic<int> g_wino_waves{8};       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
 static std::atomic<int> g_wino_persist{1};     // 8-wave kernel: 1 persistent over spatial tiles (conv_wino8p_kernel), 0 one tile per workgroup, n > 1: at most n workers
 #ifndef WINO_DMA_DEFAULT
@@ -3971,17 +3971,22 @@ static bool bwdw_use_bf16_133(const mt_conv3d_t* p) {       // 1x3x3 stride-1 ba
 }
 // conv_bwdw_fast_kernel (fp32 storage on both sides) / conv_bwdw_fast16_kernel with several cout tiles per workgroup (channel-pair
 // staging; the geometries launch_bwdw_fast / launch_bwdw_fast16 instantiate them for): 4 when the cout tiles divide by 4, else 2, else 1.  MT_BWDW_CW=1 switches it off.
-static int bwdw_fast_cw(const mt_conv3d_t* p) {
+static int bwdw_fast_cw(const mt_conv3d_t* p, int ntiles_total, int nchunks) {
   if (g_bwdw_cw < 0) { const char* e = getenv("MT_BWDW_CW"); g_bwdw_cw = e ? atoi(e) : 4; }
-  const int cap = g_bwdw_cw;
+  const int cap = g_bwdw_cw % 100;
+  const bool force = g_bwdw_cw >= 100;          // 104 / 102: without the tiles-per-workgroup condition below (tests on small volumes)
   if (cap < 2 || conv_src_dtype(p) < 0 || conv_fast_vec(p) != 2) return 1;
   const bool g333 = p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SH == 2 && p->SW == 2 && (p->SD == 1 || p->SD == 2);      // strided stage convs
   const bool g222 = p->KH == 2 && p->KW == 2 && p->SH == 2 && p->SW == 2 && ((p->KD == 2 && p->SD == 2) || (p->KD == 1 && p->SD == 1));   // transposed-conv weights
   const bool g133 = p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1;                      // residual-encoder stage 0
   if (!(g333 || g222 || g133)) return 1;
   const int ncot = mt_cdiv(p->Cout, 32);
-  const int cw = (ncot % 4 == 0) ? 4 : ((ncot % 2 == 0) ? 2 : 1);
-  return cw > cap ? cap : cw;
+  int cw = (ncot % 4 == 0) ? 4 : ((ncot % 2 == 0) ? 2 : 1);
+  if (cw > cap) cw = cap;
+  // every workgroup should still walk >= 6 tiles: below that its fixed costs (prologue, CW partials of ntaps x 512 floats) outweigh the
+  // saved staging (the 3 x 6 x 6 layers measured 102 -> 111 us with two tiles per workgroup)
+  while (!force && cw > 1 && (long)ntiles_total * nchunks * (ncot / cw) < 1536) cw >>= 1;
+  return cw;
 }
 // plan for the fast kernel: tile 1 x TH x TW with (TH,TW) = (4,32) or (8,16)
 static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = false) {
@@ -3992,7 +3997,7 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = 
   P->ntaps = p->KD * p->KH * p->KW;
   P->nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, BW_CK, P->chunk);
   P->ncot = mt_cdiv(p->Cout, 32);
-  P->cw = allow_cw ? bwdw_fast_cw(p) : 1;
+  P->cw = allow_cw ? bwdw_fast_cw(p, P->ntiles_total, P->nchunks) : 1;
   int pairs = P->nchunks * mt_cdiv(P->ncot, P->cw); if (pairs < 1) pairs = 1;
   int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
   if ((bwdw_use_march(p) && bwdw_use_bf16(p)) || bwdw_use_bf16_133(p)) nsg = (512 + pairs - 1) / pairs;      // 64 KiB ring: two workgroups per CU

@@ -628,13 +628,14 @@ class Engine:
         # Mixed precision beside that stream: the residual-add form only (3) — the add's backward is bandwidth-bound itself, so the
         # extra sums cost nothing there (residual encoder mixed 25.48 -> 25.27 ms, fp32 unchanged: tools/r4_run47.sh)
         self._fuse_norm_bwd = os.environ.get('MT_FUSE_NORM_BWD')
+        self._one_stream_at_init = self.bwdw_streams == 0       # (the default follows the stream setting the engine was built with)
         self.producer, self.pending = {}, {}
 
     @property
     def fuse_norm_bwd(self):
         if self._fuse_norm_bwd is not None:
             return int(self._fuse_norm_bwd)
-        if self.bwdw_streams == 0:
+        if self._one_stream_at_init:
             return 1
         return 3 if self.mma else 0
 

@@ -28,3 +28,8 @@ def _fresh_matrix_mode():
     if mod is not None:
         mod.set_mma(0)
     yield
+    # library options a test may have turned (cout tiles per workgroup of the tiled backward-weight kernels: 104 = also on small volumes)
+    mod = sys.modules.get('multitalent_amd.ops')
+    lib = sys.modules.get('multitalent_amd._lib')
+    if mod is not None and lib is not None and getattr(lib, '_lib', None) is not None:
+        mod.set_option('bwdw_cw', 4)

@@ -727,6 +727,7 @@ def test_tiled_backward_weight_bf16_products(dev, kind):
     same operand rounding (activated operands rounded to bf16, exact products); ragged tiles, both tile shapes, accumulate"""
     import torch.nn.functional as F
     ops = _ops()
+    ops.set_option('bwdw_cw', 104)          # several cout tiles per workgroup also on volumes this small (conftest resets the option)
     g = torch.Generator().manual_seed(46)
     N = 2
     f16, b16, f32 = torch.float16, torch.bfloat16, torch.float32
@@ -792,7 +793,7 @@ def test_tiled_backward_weight_bf16_products(dev, kind):
             ops.conv3d_bwd_weight(p, ya, dw1, ops.conv_weight_strides(dw1), False, ws)
             torch.cuda.synchronize()
         finally:
-            ops.set_option('bwdw_cw', 4)
+            ops.set_option('bwdw_cw', 104)
         assert float((dw1 - dw).abs().max()) <= 1e-5 * float(dw.abs().max())
     # MT_BWDW_FAST16 decides between kernels of the same result up to the product type: the fp32-product kernel is within bf16 operand rounding
     p0 = ops.fill_conv(acts, geom, Cout, mma=0)
