@@ -3998,6 +3998,12 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = 
   P->nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, BW_CK, P->chunk);
   P->ncot = mt_cdiv(p->Cout, 32);
   P->cw = allow_cw ? bwdw_fast_cw(p, P->ntiles_total, P->nchunks) : 1;
+  // fp32 Winograd marching kernel: two cout tiles per workgroup where the cout tiles pair up and a workgroup still gets >= 12 planes
+  if (allow_cw && bwdw_use_wino(p) && !bwdw_use_bf16(p) && conv_src_dtype(p) == MT_F32) {
+    if (g_bwdw_cw < 0) { const char* e = getenv("MT_BWDW_CW"); g_bwdw_cw = e ? atoi(e) : 4; }
+    const long planes = (long)p->N * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 32) * p->Do;
+    if ((g_bwdw_cw % 100) >= 2 && P->ncot % 2 == 0 && (g_bwdw_cw >= 100 || planes * P->nchunks * (P->ncot / 2) >= 3072)) P->cw = 2;
+  }
   int pairs = P->nchunks * mt_cdiv(P->ncot, P->cw); if (pairs < 1) pairs = 1;
   int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
   if ((bwdw_use_march(p) && bwdw_use_bf16(p)) || bwdw_use_bf16_133(p)) nsg = (512 + pairs - 1) / pairs;      // 64 KiB ring: two workgroups per CU
@@ -4273,7 +4279,8 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
   if (geo >= 0) {
     // several cout tiles per workgroup: conv_bwdw_fast_kernel with fp32 storage on both sides, conv_bwdw_fast16_kernel and its marching form
     const bool cw_ok = (bwdw_fast16_ok(p, ysrc) || (xdt == MT_F32 && ysrc->dtype == MT_F32)) &&
-                       !(geo == 0 && bwdw_use_march(p)) && !(geo == 6 && bwdw_use_bf16_133(p));
+                       !(geo == 0 && bwdw_use_march(p) && !(bwdw_use_wino(p) && !bwdw_use_bf16(p) && xdt == MT_F32 && ysrc->dtype == MT_F32)) &&
+                       !(geo == 6 && bwdw_use_bf16_133(p));
     bwdw_fast_plan(p, &P, cw_ok);
     MT_REQUIRE(P.nchunks > 0, "bwd_weight: too many channel chunks");
     const size_t need = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
@@ -4318,11 +4325,22 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
           static std::atomic<uint64_t> attr{0};
           const int devid = mt_current_device();
           if (mt_device_pending(attr, devid)) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv_bwdw_wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            hipError_t e = hipFuncSetAttribute((const void*)conv_bwdw_wino_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
             if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
             mt_mark_device_done(attr, devid);
           }
-          hipLaunchKernelGGL(conv_bwdw_wino_kernel<2>, dim3(P.nsg, P.ncot, P.nchunks), dim3(256), ldsb, st, P);
+          if (P.cw == 2) {
+            static std::atomic<uint64_t> attr2{0};
+            if (mt_device_pending(attr2, devid)) {
+              hipError_t e = hipFuncSetAttribute((const void*)conv_bwdw_wino_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+              if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
+              mt_mark_device_done(attr2, devid);
+            }
+            hipLaunchKernelGGL((conv_bwdw_wino_kernel<2, 2>), dim3(P.nsg, P.ncot / 2, P.nchunks), dim3(256), ldsb, st, P);
+          } else {
+            MT_REQUIRE(P.cw == 1, "bwd_weight: %d cout tiles per workgroup in the Winograd kernel", P.cw);
+            hipLaunchKernelGGL((conv_bwdw_wino_kernel<2, 1>), dim3(P.nsg, P.ncot, P.nchunks), dim3(256), ldsb, st, P);
+          }
           MT_CHECK_LAUNCH("conv_bwdw_wino");
           rc = MT_OK;
           break;

@@ -306,11 +306,15 @@ def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
     (30, 128, (2, 6, 70), (1, 3, 3), (1, 1, 1), False),
     (30, 60, (4, 8, 36), (2, 2, 2), (2, 2, 2), False),       # ConvTranspose3d(k = s) weight geometry
     (24, 120, (3, 8, 20), (1, 2, 2), (1, 2, 2), False),
+    (24, 40, (5, 9, 37), (3, 3, 3), (1, 1, 1), False),       # Winograd backward-weight, two cout tiles per workgroup: ragged tiles, channel tails
+    (30, 128, (6, 10, 70), (3, 3, 3), (1, 1, 1), True),      # ... four cout tiles = two workgroup columns, lazily activated X, two cin chunks
+    (60, 64, (3, 5, 33), (3, 3, 3), (1, 1, 1), False),       # ... odd H (half tile), four cin chunks
 ])
 def test_conv_bwd_weight_cout_tiles_per_workgroup(dev, Cin, Cout, shape, k, stride, lazy):
     """conv_bwdw_fast_kernel with 2 / 4 cout tiles per workgroup (option bwdw_cw, default 4: a wave takes one cout tile and 2 / 4 of the
-    tile's four k-step blocks; the staged X tile feeds 2 / 4 times the MFMAs): against host autograd (F.conv3d, fp32) and against the
-    one-tile-per-workgroup form of the same kernel, accumulate mode included."""
+    tile's four k-step blocks; the staged X tile feeds 2 / 4 times the MFMAs) and conv_bwdw_wino_kernel with 2 (a wave takes 16 output
+    channels and both tile rows): against host autograd (F.conv3d, fp32) and against the one-tile-per-workgroup form of the same
+    kernel, accumulate mode included."""
     ops = _ops()
     g = torch.Generator().manual_seed(11)
     N = 2
