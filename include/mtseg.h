@@ -185,7 +185,8 @@ int mt_set_option(const char* name, int value);
  *   whatever mt_pointwise_t.mma says — the weights must then be packed with layout 1), MT_INORM_SMALL (0: three launches for the InstanceNorm backward of small tensors instead of one).
  *   MT_BWDW_CW / option "bwdw_cw" (4 | 2 | 1: most cout tiles per workgroup of the tiled backward-weight kernels conv_bwdw_fast_kernel (fp32 storage),
  *   conv_bwdw_fast16_kernel and conv_bwdw_march16_kernel — a wave then takes one cout tile and 4 / 2 of the tile's k-step blocks, so that the staged
- *   X tile feeds 4 / 2 times the MFMAs; + 100 (104 | 102): also where a workgroup would walk fewer than six tiles).
+ *   X tile feeds 4 / 2 times the MFMAs — and of conv_bwdw_wino_kernel (at most 2: a wave takes 16 output channels and both tile rows);
+ *   + 100 (104 | 102): also where a workgroup would walk fewer than six tiles / twelve planes).
  * The HOST side above this ABI (multitalent_amd/engine.py, inference/, bench.py) reads: MT_BF16_STORAGE (0: fp32 storage in mixed
  * precision), MT_ACT_STORAGE (fp16 | bf16), MT_BF16_MIN_VOXELS, MT_PW_STRIDED (0: strided 1x1x1 projections on conv_rt_kernel),
  * MT_BWDW_STREAMS, MT_FUSE_NORM_BWD, MT_HEAD_BWD_FUSED, MT_INFER_FUSED_HEAD, MT_INFER_MIXED, MT_PACK_SPLIT, MT_IO_DEBUG (1: print
