@@ -547,14 +547,17 @@ def time_training(workload, precision, patch, B, steps, warmup, dev, rank, world
     for _ in range(steps):
         res = step(x, *largs)
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0           # this rank's own K steps, before it waits for the others
     if ddp:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if ddp:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt, dt_own, -dt_own], dtype=torch.float64, device=dev)
         all_reduce_dev(tmax, dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = float(tmax[0].item())
+        rank_ms = {'max': round(float(tmax[1]) / steps * 1e3, 3), 'min': round(-float(tmax[2]) / steps * 1e3, 3)}
     loss = res[0] if isinstance(res, tuple) else res
     comm = step.reducer.stats() if step.reducer is not None else None
     if ddp:
@@ -570,6 +573,7 @@ def time_training(workload, precision, patch, B, steps, warmup, dev, rank, world
         comm['param_checksum_spread_over_ranks'] = spread
         comm['params_identical_on_all_ranks'] = spread == 0.0
         comm['loss_finite'] = bool(np.isfinite(float(loss)))
+        comm['ms_per_step_over_ranks_before_barrier'] = rank_ms
     return {'dt': dt, 'ms': dt / steps * 1e3, 'value': world * B * steps / dt, 'loss': float(loss), 'step': step, 'x': x, 'largs': largs,
             'net': net, 'comm': comm}
 
@@ -603,36 +607,56 @@ def measure_also(args, dev, rank, world, ddp):
     also = {}
     patch = tuple(args.patch)
     todo = [('task100', 'fp32'), ('resenc', 'fp32'), ('resenc', 'bf16')] if world == 1 else [('task100', 'fp32'), ('resenc', 'bf16')]
-    for workload, precision in todo:
+    fail = os.environ.get('MT_BENCH_INJECT_ALSO_FAILURE', '')      # tests: names of entries that raise, or 'all' (first-contact robustness)
+
+    def guarded(name, fn):
+        # an `also` entry must never take the headline line with it: whatever it raises becomes {"error": ...} under its name
+        try:
+            if fail == 'all' or name in fail.split(','):
+                raise RuntimeError("injected failure in the also leg %r" % name)
+            e = fn()
+            if rank == 0:
+                also[name] = e
+        except Exception as ex:        # noqa: BLE001 - reported, not swallowed
+            import traceback
+            sys.stderr.write("bench.py: also[%s] failed on rank %d:\n%s\n" % (name, rank, traceback.format_exc()))
+            also[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        net_cache_clear()
+
+    def train_entry(workload, precision):
         B = DEFAULT_BATCH[workload]
         r = time_training(workload, precision, patch, B, args.also_steps, 3, dev, rank, world, ddp)
         rf = None if args.no_roofline else measure_roofline(r['step'], r['x'], r['largs'], precision, nrep=2)     # all ranks (collectives inside)
-        if rank == 0:
-            e = training_line(r, workload, precision, patch, B, args.also_steps, 3, world)
-            e = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "algorithmic_tflop_per_step",
-                                   "step_frac_of_fp32_mfma_roofline", "comm") if k in e}
-            if rf is not None:
-                e["roofline"] = rf
-            also[workload + ('' if precision == 'fp32' else '_bf16')] = e
-        del r
-        torch.cuda.empty_cache()
-    ia = argparse.Namespace(**vars(args))
-    ia.workload, ia.mirror, ia.steps, ia.warmup, ia.no_cpu_baseline, ia.no_traffic, ia.precision = 'infer', 0, 2, 1, True, True, 'fp32'
-    e = bench_infer(ia, dev, rank, world, ddp, emit=False)
-    if rank == 0:
-        also['infer_512_nomirror'] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "scaling", "comm", "variants",
-                                                       "sharded_equals_unsharded") if k in e}
-    net_cache_clear()
+        e = training_line(r, workload, precision, patch, B, args.also_steps, 3, world)
+        e = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "algorithmic_tflop_per_step",
+                               "step_frac_of_fp32_mfma_roofline", "comm") if k in e}
+        if rf is not None:
+            e["roofline"] = rf
+        return e
+
+    for workload, precision in todo:
+        guarded(workload + ('' if precision == 'fp32' else '_bf16'), lambda: train_entry(workload, precision))
+
+    def infer_entry():
+        ia = argparse.Namespace(**vars(args))
+        ia.workload, ia.mirror, ia.steps, ia.warmup, ia.no_cpu_baseline, ia.no_traffic, ia.precision = 'infer', 0, 2, 1, True, True, 'fp32'
+        e = bench_infer(ia, dev, rank, world, ddp, emit=False)
+        return None if e is None else {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "scaling", "comm",
+                                                         "variants", "sharded_equals_unsharded") if k in e}
+    guarded('infer_512_nomirror', infer_entry)
     if world == 1:
         # the reference's DEFAULT inference mode — 8-fold mirror TTA (neural_network.py:502-591) — on a smaller volume (45 tiles x 8
         # mirrored passes; the 512^3 volume takes 17 s per pass in this mode), fp32
         ia = argparse.Namespace(**vars(args))
         ia.workload, ia.mirror, ia.steps, ia.warmup, ia.no_cpu_baseline, ia.no_traffic, ia.no_roofline, ia.precision = 'infer', 1, 1, 1, True, True, True, 'fp32'
         ia.volume = [128, 384, 384]
-        e = bench_infer(ia, dev, rank, world, ddp, emit=False)
-        also['infer_128x384x384_mirror_tta'] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config") if k in e}
-        also['infer_128x384x384_mirror_tta']['network_passes_per_s'] = round(e['config']['tiles'] * 8 / (e['ms_per_step'] * 1e-3), 1)
-        net_cache_clear()
+
+        def tta_entry():
+            e = bench_infer(ia, dev, rank, world, ddp, emit=False)
+            o = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config") if k in e}
+            o['network_passes_per_s'] = round(e['config']['tiles'] * 8 / (e['ms_per_step'] * 1e-3), 1)
+            return o
+        guarded('infer_128x384x384_mirror_tta', tta_entry)
     return also
 
 
@@ -700,6 +724,14 @@ def main():
     del r
     torch.cuda.empty_cache()
     if args.workload is None and not args.no_also:
+        if ddp:
+            # N > 1: the headline line leaves the process BEFORE the other configs run (they are the first RCCL contact of the sharded
+            # sliding window and of two more networks: a hang or a crash there must not cost the headline).  The complete line, with
+            # "also", follows as the LAST line of the job; both carry the same headline fields.
+            flush_c_stdio()
+            dist.barrier()
+            if rank == 0:
+                print(json.dumps(dict(line, also="pending: the complete line follows")), flush=True)
         also = measure_also(args, dev, rank, world, ddp)
         if rank == 0:
             line["also"] = also

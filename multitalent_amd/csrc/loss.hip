@@ -390,7 +390,8 @@ extern "C" int mt_multitalent_loss_bwd(const float* logits, int cs, const float*
   static int wide = -1;
   if (wide < 0) { const char* e = getenv("MT_LOSS_SPARSE"); wide = e ? atoi(e) : 1; }
   const long vpb = lf_vpb(lf_A(C) / C);
-  if (cs == C && dcs == C && wide && ((V * C) & 3) == 0 && ((vpb * C) & 3) == 0 && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0)
+  // C >= 2: the quad's channel index is unwrapped by ONE conditional subtraction (c + 3 < 2C), wrong for a single channel
+  if (cs == C && dcs == C && wide && C >= 2 && ((V * C) & 3) == 0 && ((vpb * C) & 3) == 0 && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0)
     hipLaunchKernelGGL(mt_loss_bwd_wide_kernel, dim3(lf_blocks(V, C), B), dim3(256), 0, (hipStream_t)stream, logits, target, V, C, valid, lut,
                        gstats, vpb, dlogits);
   else if (cs == C && dcs == C)

@@ -657,6 +657,7 @@ class Engine:
         self._packed_version = None
         self._pack_programs = {}
         self._io_cache = {}
+        self._fp32_copies.clear()           # keyed by data_ptr: a re-planned buffer set may recycle an address with another shape / meaning
 
     # ---- mixed precision: which level computes / stores what ------------------------------------------
     def op_mma(self, out_spatial):
@@ -848,6 +849,7 @@ class Engine:
         self._packed_version = None
         self._pack_programs = {}
         self._io_cache = {}
+        self._fp32_copies.clear()
 
     def _pack(self, need_grad):
         ver = (self.params_version, self.flat._version, need_grad)

@@ -13,10 +13,11 @@ from .sliding_window import predict_3D
 def predict_case_on_device(network, cropped_data, properties, target_spacing, intensityproperties, patch_size,
                            regions_class_order=None, do_mirroring=True, mirror_axes=(0, 1, 2), step_size=0.5,
                            transpose_forward=(0, 1, 2), force_separate_z=None, tile_shard=None, verbose=False,
-                           transpose_backward=None):
+                           transpose_backward=None, mixed_precision=True):
     """cropped_data: [C, X, Y, Z] (numpy or device tensor) already transposed by `transpose_forward`; properties: the case's
     dict (`original_spacing`, `size_after_cropping`, `original_size_of_raw_data`, `crop_bbox`).  Returns the uint8 label volume
-    (device tensor, shape `original_size_of_raw_data`) and the properties with the resampling entries filled in."""
+    (device tensor, shape `original_size_of_raw_data`) and the properties with the resampling entries filled in.
+    mixed_precision: the reference's predict default (predict_MultiTalent.py `--disable_mixed_precision` turns it off); False = the fp32 parity path."""
     spacing = np.array(properties['original_spacing'])[list(transpose_forward)]
     x = resample_and_normalize_ct(cropped_data, spacing, target_spacing, intensityproperties, force_separate_z)
     properties = dict(properties)
@@ -26,10 +27,10 @@ def predict_case_on_device(network, cropped_data, properties, target_spacing, in
         # tiles sharded over the ranks; the export below needs whole x-columns of the probabilities, so the slabs are gathered
         # (every rank then holds the full result)
         _, probs = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
-                              'constant', None, True, verbose, True, tile_shard=tile_shard, return_device_tensors='full')
+                              'constant', None, True, verbose, mixed_precision, tile_shard=tile_shard, return_device_tensors='full')
     else:
         _, probs = predict_3D(network, x, do_mirroring, mirror_axes, True, step_size, patch_size, regions_class_order, True,
-                              'constant', None, True, verbose, True, return_device_tensors=True)
+                              'constant', None, True, verbose, mixed_precision, return_device_tensors=True)
     # the reference transposes the probabilities back before the export matches them to size_after_cropping / crop_bbox
     # (predict_MultiTalent.py:238-240: softmax.transpose([0] + [i + 1 for i in transpose_backward]))
     if transpose_backward is None:

@@ -176,38 +176,40 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
     prev_mma = eng.mma
     eng.set_precision('bf16' if (mixed_precision and os.environ.get('MT_INFER_MIXED', '1') != '0') else 'fp32')
     was_training = net.training
-    with torch.no_grad():
-        # all mirrored versions of a tile — and several consecutive tiles — go through the network as ONE batch (per-sample
-        # results do not depend on the batch, and the aggregate is still updated tile by tile in the reference's x -> y -> z
-        # order with the reference's mirror order inside a tile): up to 8x larger grids on the low-resolution stages.  The
-        # batch is cut out of the volume by ONE kernel with the flips folded into its index arithmetic (mt_extract_tiles).
-        fuse_head = num_classes <= 64 and os.environ.get('MT_INFER_FUSED_HEAD', '1') != '0'
-        for g0 in range(0, len(tiles), group):
-            chunk = tiles[g0:g0 + group]
-            desc = [(t, (0 in c, 1 in c, 2 in c)) for t in chunk for c in combos]
-            batch = ops.extract_tiles(vol, patch_size, desc, batch_buf[:len(desc)])
-            if fuse_head:
-                # head + nonlinearity + un-flip + accumulation in one kernel per sample: the logits never reach HBM
-                hp = eng.forward_to_final_head(batch)
-            else:
-                logits = eng.forward(batch, need_grad=False, all_heads=False)[0]                      # [B, D, H, W, C]
-            for t, (xs, ys, zs) in enumerate(chunk):
-                origin = (xs - x_lo, ys, zs)
-                if fuse_head and len(combos) > 1:
-                    # every mirror combination of the tile, the Gaussian and the overlap-add in one launch (the sum over the
-                    # combinations stays in registers).  Without mirroring the two-kernel form below is faster (47.4 vs 43.0
-                    # volumes/min in bf16): its streaming overlap-add beats 128-byte read-modify-writes from the MFMA epilogue.
-                    ops.head_mirror_accumulate(hp, t * len(combos), [(0 in c, 1 in c, 2 in c) for c in combos], nonlin,
-                                               1.0 / num_results, mult, agg, nb, local_shape, origin)
-                    continue
-                for i, c in enumerate(combos):
-                    k = t * len(combos) + i
-                    if fuse_head:
-                        ops.head_flip_accumulate(hp, k, (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
-                    else:
-                        ops.flip_accumulate(Act(logits[k:k + 1]), (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
-                ops.tile_accumulate(acc, mult, num_classes, patch_size, agg, nb, local_shape, origin)
-    eng.set_precision(prev_mma)
+    try:
+        with torch.no_grad():
+            # all mirrored versions of a tile — and several consecutive tiles — go through the network as ONE batch (per-sample
+            # results do not depend on the batch, and the aggregate is still updated tile by tile in the reference's x -> y -> z
+            # order with the reference's mirror order inside a tile): up to 8x larger grids on the low-resolution stages.  The
+            # batch is cut out of the volume by ONE kernel with the flips folded into its index arithmetic (mt_extract_tiles).
+            fuse_head = num_classes <= 64 and os.environ.get('MT_INFER_FUSED_HEAD', '1') != '0'
+            for g0 in range(0, len(tiles), group):
+                chunk = tiles[g0:g0 + group]
+                desc = [(t, (0 in c, 1 in c, 2 in c)) for t in chunk for c in combos]
+                batch = ops.extract_tiles(vol, patch_size, desc, batch_buf[:len(desc)])
+                if fuse_head:
+                    # head + nonlinearity + un-flip + accumulation in one kernel per sample: the logits never reach HBM
+                    hp = eng.forward_to_final_head(batch)
+                else:
+                    logits = eng.forward(batch, need_grad=False, all_heads=False)[0]                      # [B, D, H, W, C]
+                for t, (xs, ys, zs) in enumerate(chunk):
+                    origin = (xs - x_lo, ys, zs)
+                    if fuse_head and len(combos) > 1:
+                        # every mirror combination of the tile, the Gaussian and the overlap-add in one launch (the sum over the
+                        # combinations stays in registers).  Without mirroring the two-kernel form below is faster (47.4 vs 43.0
+                        # volumes/min in bf16): its streaming overlap-add beats 128-byte read-modify-writes from the MFMA epilogue.
+                        ops.head_mirror_accumulate(hp, t * len(combos), [(0 in c, 1 in c, 2 in c) for c in combos], nonlin,
+                                                   1.0 / num_results, mult, agg, nb, local_shape, origin)
+                        continue
+                    for i, c in enumerate(combos):
+                        k = t * len(combos) + i
+                        if fuse_head:
+                            ops.head_flip_accumulate(hp, k, (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
+                        else:
+                            ops.flip_accumulate(Act(logits[k:k + 1]), (0 in c, 1 in c, 2 in c), nonlin, 1.0 / num_results, acc, i == 0)
+                    ops.tile_accumulate(acc, mult, num_classes, patch_size, agg, nb, local_shape, origin)
+    finally:
+        eng.set_precision(prev_mma)          # also when a tile raises (out of memory mid-volume): the shared engine is left as found
     if plan is not None:
         # slab ownership: every rank ends with the finished aggregate of ITS x-slab; only the zones where neighbouring ranks'
         # tiles overlap travel (partial sums, added in rank order = the reference's tile order at rank granularity)
@@ -234,16 +236,17 @@ def predict_3D(net, x, do_mirroring, mirror_axes=(0, 1, 2), use_sliding_window=F
     seg = seg[sl]
     if was_training:
         net.train()
+    max_label = max(int(c) for c in regions_class_order) if regions_class_order is not None else num_classes - 1
     if plan is not None:
         x_range = (c_lo - sx.start, c_hi - sx.start)         # rows of the UNPADDED volume this rank's slab holds
         if return_device_tensors == 'mask':                  # the whole mask on every rank, probabilities left sharded (bench: gathered variant)
-            full_seg, _ = gather_slabs(seg, None, slab_ranges(plan, sx, world), world)
+            full_seg, _ = gather_slabs(seg, None, slab_ranges(plan, sx, world), world, max_label)
             return full_seg, probs, x_range
         if return_device_tensors == 'full':                  # whole (seg, probabilities) on every rank's device
-            return gather_slabs(seg, probs, slab_ranges(plan, sx, world), world)
+            return gather_slabs(seg, probs, slab_ranges(plan, sx, world), world, max_label)
         if return_device_tensors:
             return seg, probs, x_range
-        seg, probs = gather_slabs(seg, probs, slab_ranges(plan, sx, world), world)
+        seg, probs = gather_slabs(seg, probs, slab_ranges(plan, sx, world), world, max_label)
     elif return_device_tensors == 'mask':
         return seg, probs, (0, sx.stop - sx.start)
     elif return_device_tensors:
@@ -395,7 +398,7 @@ def _all_gather_padded(t, ranges, axis, world, via_host):
     return full
 
 
-def gather_slabs(seg, probs, ranges, world):
+def gather_slabs(seg, probs, ranges, world, max_label=None):
     """the per-rank slabs -> the whole (seg, probs) on every rank (API mode).  Either may be None: callers that classify after their own
     resampling only need the probabilities, the benchmark's gathered variant only the mask (uint8: 134 MB for 512^3 instead of 25 GB of
     47-channel probabilities).  One all_gather per tensor on padded slabs; the row ranges come from the plan (slab_ranges), not from
@@ -405,7 +408,9 @@ def gather_slabs(seg, probs, ranges, world):
     via_host = ref.is_cuda and dist.get_backend() == 'gloo'
     full_seg = full_probs = None
     if seg is not None:
-        small = seg.dtype in (torch.int32, torch.int64) and (seg.numel() == 0 or int(seg.max()) < 256)      # labels fit a byte: 4x less traffic
+        # labels fit a byte: 4x less traffic.  The wire type must be the SAME on every rank of the collective, so it is decided from
+        # `max_label` (num_classes - 1 resp. max(regions_class_order): a property of the job, passed by predict_3D), never from a rank's own slab
+        small = seg.dtype in (torch.int32, torch.int64) and max_label is not None and int(max_label) < 256
         s8 = seg.to(torch.uint8) if small else seg
         full_seg = _all_gather_padded(s8.contiguous(), ranges, 0, world, via_host).to(seg.dtype)
     if probs is not None:

@@ -139,6 +139,7 @@ class FusedTrainStep:
         self.ws = None
         self.reducer = GradAllReducer(self.eng) if ddp else None
         self.head_params, self.head_opt = None, None
+        self.last_logits = None      # full-resolution logits (NCDHW view of the engine's NDHWC buffer) of the latest forward
 
     def set_head_optimizer(self, params, lr=3e-3, weight_decay=3e-5):
         """Heads-only phase of the fine-tuning trainers (reference nnUNetTrainerV2_warmup.py:119-132): AdamW(amsgrad) on `params`
@@ -190,8 +191,10 @@ class FusedTrainStep:
             with torch.no_grad():
                 outs = eng.forward(data, need_grad=False, all_heads=True)
                 res = self.loss_fn([o.permute(0, 4, 1, 2, 3) for o in outs], *loss_args)
+                self.last_logits = outs[0].permute(0, 4, 1, 2, 3)       # online evaluation reads THIS forward's output, like the reference
             return res
         leaves, res = self.forward_loss(data, loss_args)
+        self.last_logits = leaves[0].detach()
         loss = res[0] if isinstance(res, (tuple, list)) else res
         loss.backward()
         dl = [None if l.grad is None else l.grad.permute(0, 2, 3, 4, 1).contiguous() for l in leaves]

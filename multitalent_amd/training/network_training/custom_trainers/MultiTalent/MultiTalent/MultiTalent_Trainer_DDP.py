@@ -143,7 +143,8 @@ class MultiTalent_trainer_ddp(nnUNetTrainerV2_DDP):
         largs = self.loss_args(data_dict)
         l, ce, dc = self.train_step(data, *largs, do_backprop=do_backprop)
         if run_online_evaluation:
-            self.run_online_evaluation(None, largs[0], largs[1], data=data)
+            # the output of the SAME forward pass (reference :355-357), not a second one
+            self.run_online_evaluation([self.train_step.last_logits], largs[0], largs[1])
         return l.detach().cpu().numpy(), ce.detach().cpu().numpy(), dc.detach().cpu().numpy()
 
     def run_online_evaluation(self, output, target, valid_regions, data=None):

@@ -570,7 +570,8 @@ class nnUNetTrainerV2(nnUNetTrainer):
         res = self.train_step(data, *largs, do_backprop=do_backprop)
         l = res[0] if isinstance(res, tuple) else res
         if run_online_evaluation:
-            self.run_online_evaluation(None, largs[0], data=data)
+            # the output of the SAME forward pass (nnUNetTrainerV2.py:256-258), not a second one
+            self.run_online_evaluation([self.train_step.last_logits], largs[0])
         return l.detach().cpu().numpy()
 
     def on_epoch_end(self):

@@ -305,6 +305,27 @@ def test_bench_two_ranks_self_validation_on_one_gpu(extra):
         assert line['comm']['loss_finite']
 
 
+def test_bench_headline_survives_a_failing_also_leg():
+    """First contact of the N > 1 default run: the headline line is printed BEFORE the other configs run, and an
+    exception inside any `also` entry becomes {"error": ...} under its name in the complete line instead of losing the job's output."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-roofline'],
+                         capture_output=True, text=True, timeout=1200,
+                         env=dict(os.environ, MT_BENCH_ONE_GPU='1', MT_BENCH_INJECT_ALSO_FAILURE='all'))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 2, out.stdout[-2000:]
+    first, last = lines
+    assert isinstance(first['also'], str) and first['value'] == last['value'] and first['n_gpus'] == 2
+    assert last['comm']['params_identical_on_all_ranks'] and last['comm']['ms_per_step_over_ranks_before_barrier']['max'] >= \
+        last['comm']['ms_per_step_over_ranks_before_barrier']['min'] > 0
+    assert set(last['also']) >= {'task100', 'resenc_bf16', 'infer_512_nomirror'}
+    assert all('injected failure' in e['error'] for e in last['also'].values()), last['also']
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL)")
 @pytest.mark.parametrize("extra", [[], ['--workload', 'task100'], ['--workload', 'infer', '--mirror', '0', '--volume', '160', '256', '256']])
 def test_bench_two_ranks_smoke(extra):

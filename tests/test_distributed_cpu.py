@@ -195,8 +195,13 @@ def _gather(rank, world):
         a, b = ranges[rank]
         seg, probs = gather_slabs(full_s[a:b].clone(), full_p[:, a:b].clone(), ranges, world)
         assert torch.equal(seg, full_s) and seg.dtype == torch.int32 and torch.equal(probs, full_p)
-        seg2, none = gather_slabs(full_s[a:b].clone(), None, ranges, world)
+        seg2, none = gather_slabs(full_s[a:b].clone(), None, ranges, world, max_label=4)        # byte wire format, decided by the job
         assert none is None and torch.equal(seg2, full_s)
+        # labels >= 256 on ONE rank only — the wire type comes from max_label (rank-invariant), not from the rank's slab
+        big = full_s.clone()
+        big[ranges[world - 1][0]:ranges[world - 1][1]] += 300
+        seg3, _ = gather_slabs(big[a:b].clone(), None, ranges, world, max_label=304)
+        assert torch.equal(seg3, big)
         # exchange_slabs: partial aggregates of this rank's tiles -> the owned slab == the slab of the full sum
         C = 2
         tot_a, tot_n = torch.zeros((C, X, Y, Z)), torch.zeros((X, Y, Z))

@@ -820,6 +820,9 @@ def test_multitalent_loss_kernels_flat_and_strided(dev, B, C, V, wide):
     (47, 6000, [(1 << 23) - 1, (1 << 24) - 1, (1 << 47) - 1]),               # 23 (sparse), 24 and 47 (flat form inside the same launch)
     (47, 3001, [0b1011 << 10, 0b1 << 40]),                                   # V * C not a multiple of 4: the dword backward
     (5, 1236, [0b10001, 0b00100]),
+    (1, 4096, [0b1, 0b0, 0b1]),                                              # a single channel must not take the quad-unwrapping backward
+    (2, 4096, [0b01, 0b11, 0b10]),
+    (3, 4096, [0b101, 0b010, 0b111]),
 ])
 def test_multitalent_loss_few_valid_regions(dev, C, V, masks):
     """round 4: mt_loss_fwd_sparse_kernel / mt_loss_bwd_wide_kernel (a sample carries the regions of its dataset only) against the formula of
