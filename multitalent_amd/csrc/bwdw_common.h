@@ -1,0 +1,23 @@
+// Parameter blocks shared by the backward-weight translation units (conv_lds.hip plans and reduces; bwdw_tr16.hip holds a kernel family).
+#pragma once
+#include "mt_common.h"
+
+struct ConvChunk { short src, c0, ck, cglob; };
+
+#define BW_CK 16
+struct BwdWParams {
+  mt_conv3d_t c;      // X geometry (src), conv geometry; Do/Ho/Wo = Y dims
+  mt_src_t y;         // Y source (C = Cout)
+  int TD, TH, TW;     // spatial tile (TW % 4 == 0)
+  int tilesD, tilesH, tilesW, ntiles_total;
+  int nchunks, ntaps, ncot, nsg;
+  int nsg_cap, nunits, nseg, dseg;   // marching kernel: units = (sample, h-tile, w-tile, D segment of dseg planes)
+  int cw;             // conv_bwdw_fast_kernel: cout tiles per workgroup (1 | 2 | 4; grid.y = ceil(ncot / cw))
+  float* part;        // [chunk][cot][sg][tap][16][32]
+  ConvChunk chunk[MT_MAX_CHUNKS];
+};
+
+typedef __bf16 bwb_bf16x8 __attribute__((ext_vector_type(8)));
+
+// bwdw_tr16.hip: direct bf16 backward-weight of 3x3x3 (KD = 3) / 1x3x3 (KD = 1) stride-1 convolutions fed by LDS transpose reads
+int mt_launch_bwdw_tr16(const BwdWParams& P, int KD, int xdt, hipStream_t st);

@@ -16,11 +16,10 @@
 //  * epilogue adds bias, writes NDHWC (optionally into two destinations = split of a concat
 //    gradient, optionally accumulating) and emits per-block (sum, sumsq) partials for InstanceNorm.
 #include "mt_common.h"
+#include "bwdw_common.h"
 #include <cstring>
 #include <stdlib.h>
 #include <type_traits>
-
-struct ConvChunk { short src, c0, ck, cglob; };
 
 struct ConvKParams {
   mt_conv3d_t c;
@@ -2343,6 +2342,7 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
 
 static int g_bwdw_bf16 = -1;       // -1: read MT_BWDW_BF16 (default 1): bf16 Winograd backward-weight kernel when mt_conv3d_t.mma == 1
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
+static int g_bwdw_tr16 = -1;       // -1: read MT_BWDW_TR16 (default 1): direct bf16 backward-weight fed by LDS transpose reads (conv_bwdw_tr16_kernel) instead of the bf16 Winograd marching kernel
 static int g_bwdw_cw = -1;         // -1: read MT_BWDW_CW (default 4): most cout tiles per workgroup of the tiled backward-weight kernels (1 | 2 | 4; + 100: also on small problems)
 static std::atomic<int> g_wino_waves{8};       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
 static std::atomic<int> g_wino_persist{1};     // 8-wave kernel: 1 persistent over spatial tiles (conv_wino8p_kernel), 0 one tile per workgroup, n > 1: at most n workers
@@ -2361,6 +2361,7 @@ extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "bwdw_bf16") == 0) { g_bwdw_bf16 = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bf16_persist") == 0) { g_bf16_persist = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_cw") == 0) { g_bwdw_cw = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "bwdw_tr16") == 0) { g_bwdw_tr16 = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
 }
@@ -3122,19 +3123,7 @@ extern "C" int mt_pack_conv_weights(const float* w, float* dst, size_t* packed_f
 // A workgroup owns (ci chunk, 32 couts) and walks a strided list of spatial tiles, keeping all taps'
 // accumulators in registers (taps are dealt round-robin to the 4 waves); it writes ONE partial per
 // workgroup, reduced deterministically by bwdw_reduce_kernel straight into the torch weight layout.
-struct BwdWParams {
-  mt_conv3d_t c;      // X geometry (src), conv geometry; Do/Ho/Wo = Y dims
-  mt_src_t y;         // Y source (C = Cout)
-  int TD, TH, TW;     // spatial tile (TW % 4 == 0)
-  int tilesD, tilesH, tilesW, ntiles_total;
-  int nchunks, ntaps, ncot, nsg;
-  int nsg_cap, nunits, nseg, dseg;   // marching kernel: units = (sample, h-tile, w-tile, D segment of dseg planes)
-  int cw;             // conv_bwdw_fast_kernel: cout tiles per workgroup (1 | 2 | 4; grid.y = ceil(ncot / cw))
-  float* part;        // [chunk][cot][sg][tap][16][32]
-  ConvChunk chunk[MT_MAX_CHUNKS];
-};
 
-#define BW_CK 16
 #ifndef BW_ABL
 #define BW_ABL 0   // compile-time timing ablations of the fast backward-weight kernel: 1 skip X staging, 2 skip Y, 8 skip MFMA
 #endif
@@ -3969,6 +3958,40 @@ static bool bwdw_use_bf16_133(const mt_conv3d_t* p) {       // 1x3x3 stride-1 ba
   return g_bwdw_bf16 && p->mma == 1 && p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 &&
          p->PD == 0 && p->PH == 1 && p->PW == 1 && p->Wo > 16 && p->Ho >= 2 && p->Do >= 1 && conv_fast_vec(p) == 2;
 }
+// conv_bwdw_tr16_kernel (bwdw_tr16.inc): 3x3x3 / 1x3x3 stride-1, 16-bit X (lazy activations or plain), bf16 dY without affine, Wo > 16.
+// ysrc == nullptr: geometry + X only (workspace query).
+static bool bwdw_use_tr16(const mt_conv3d_t* p, const mt_src_t* ysrc) {
+  if (g_bwdw_tr16 < 0) { const char* e = getenv("MT_BWDW_TR16"); g_bwdw_tr16 = e ? atoi(e) : 1; }
+  if (!g_bwdw_tr16 || p->mma != 1 || p->N > 16) return false;                 // (BWT_MAXN samples in the kernel's activation table)
+  if (!(bwdw_use_bf16(p) || bwdw_use_bf16_133(p))) return false;              // the geometries / slopes / alignments of the kernels it replaces
+  const int xdt = conv_src_dtype(p);
+  if (xdt != MT_F16 && xdt != MT_BF16) return false;
+  if (ysrc != nullptr && (ysrc->dtype != MT_BF16 || ysrc->scale != nullptr || (ysrc->cs & 1) || (((uintptr_t)ysrc->ptr) & 3))) return false;
+  for (int i = 0; i < p->nsrc; ++i)
+    if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 2.0 >= 2147483648.0) return false;
+  if ((double)p->Do * p->Ho * p->Wo * (ysrc ? ysrc->cs : p->Cout) * 2.0 >= 2147483648.0) return false;
+  return true;
+}
+// workgroups per (cout tile, chunk pair): one per CU over all pairs, never more than (column, plane) pairs
+static int bwdw_tr16_nsg(const mt_conv3d_t* p, int nchunks) {
+  const int pairs = mt_cdiv(p->Cout, 32) * ((nchunks + 1) / 2);
+  const long T = (long)p->N * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 32) * p->Do;
+  long nsg = (mt_device_cus(mt_current_device()) + pairs - 1) / pairs;
+  if (nsg > T) nsg = T;
+  if (g_bwdw_tr16 > 1 && nsg > g_bwdw_tr16) nsg = g_bwdw_tr16;      // tests: few workgroups, so that a range spans columns on small volumes
+  return nsg < 1 ? 1 : (int)nsg;
+}
+static void bwdw_tr16_plan(const mt_conv3d_t* p, BwdWParams* P) {
+  P->TD = 1; P->TH = 4; P->TW = 32;
+  P->tilesD = p->Do; P->tilesH = mt_cdiv(p->Ho, 4); P->tilesW = mt_cdiv(p->Wo, 32);
+  P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N;
+  P->ntaps = p->KD * 9;
+  P->nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, BW_CK, P->chunk);
+  P->ncot = mt_cdiv(p->Cout, 32);
+  P->cw = 1;
+  P->nsg = P->nsg_cap = P->nchunks > 0 ? bwdw_tr16_nsg(p, P->nchunks) : 1;
+  P->nunits = 0; P->nseg = 1; P->dseg = p->Do;
+}
 // conv_bwdw_fast_kernel (fp32 storage on both sides) / conv_bwdw_fast16_kernel with several cout tiles per workgroup (channel-pair
 // staging; the geometries launch_bwdw_fast / launch_bwdw_fast16 instantiate them for): 4 when the cout tiles divide by 4, else 2, else 1.  MT_BWDW_CW=1 switches it off.
 static int bwdw_fast_cw(const mt_conv3d_t* p, int ntiles_total, int nchunks) {
@@ -4171,6 +4194,11 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
       }
     }
   }
+  if (bwdw_use_tr16(p, nullptr)) {
+    BwdWParams F; bwdw_tr16_plan(p, &F);
+    const size_t tr = (size_t)F.nchunks * F.ncot * F.nsg * F.ntaps * 512 * sizeof(float);
+    if (F.nchunks > 0 && tr > generic) generic = tr;
+  }
   if (bwdw_is_stem(p, nullptr)) {
     const size_t stem = (size_t)mt_cdiv(p->Cout, 32) * BW_STEM_WGS * 27 * 512 * sizeof(float);
     if (stem > generic) generic = stem;
@@ -4190,6 +4218,7 @@ extern "C" int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_s
   const int geo = use_fast ? bwdw_fast_geo(p, ysrc) : -1;
   if (geo < 0) { snprintf(buf, n, "conv_bwdw_kernel"); return MT_OK; }
   if (use_fast && bwdw_use_gemm(p, ysrc)) { snprintf(buf, n, "bwdw_gemm_kernel"); return MT_OK; }
+  if ((geo == 0 || geo == 6) && bwdw_use_tr16(p, ysrc)) { snprintf(buf, n, "conv_bwdw_tr16_kernel<%d, %d>", p->KD, conv_src_dtype(p)); return MT_OK; }
   if (geo == 0) {
     if (bwdw_use_bf16(p)) snprintf(buf, n, (conv_src_dtype(p) > 0 && ysrc->dtype == MT_BF16 && bwdw_staged()) ? "conv_bwdw_wino_bf16s_kernel<3, %d, %d>" : "conv_bwdw_wino_bf16_kernel<3, %d, %d>", conv_src_dtype(p), ysrc->dtype);
     else if (bwdw_use_wino(p)) snprintf(buf, n, "conv_bwdw_wino_kernel<2>");
@@ -4281,7 +4310,9 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     const bool cw_ok = (bwdw_fast16_ok(p, ysrc) || (xdt == MT_F32 && ysrc->dtype == MT_F32)) &&
                        !(geo == 0 && bwdw_use_march(p) && !(bwdw_use_wino(p) && !bwdw_use_bf16(p) && xdt == MT_F32 && ysrc->dtype == MT_F32)) &&
                        !(geo == 6 && bwdw_use_bf16_133(p));
-    bwdw_fast_plan(p, &P, cw_ok);
+    const bool tr16 = (geo == 0 || geo == 6) && bwdw_use_tr16(p, ysrc);
+    if (tr16) bwdw_tr16_plan(p, &P);
+    else bwdw_fast_plan(p, &P, cw_ok);
     MT_REQUIRE(P.nchunks > 0, "bwd_weight: too many channel chunks");
     const size_t need = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need) { mt_set_error("bwd_weight: workspace %zu < %zu", workspace_bytes, need); return MT_EWORKSPACE; }
@@ -4291,6 +4322,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     int rc = MT_EINVAL;
     switch (geo) {
       case 0: {
+        if (tr16) { rc = mt_launch_bwdw_tr16(P, 3, xdt, st); break; }
         if (bwdw_use_bf16(p)) {
           const dim3 g3(P.nsg, P.ncot, P.nchunks);
           const bool yb = ysrc->dtype == MT_BF16;
@@ -4357,6 +4389,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
       case 7: rc = launch_bwdw_fast<1, 1, 1, 2, 2, 2>(P, vec, st); break;
       case 8: rc = launch_bwdw_fast<1, 1, 1, 1, 2, 2>(P, vec, st); break;
       case 6:
+        if (tr16) { rc = mt_launch_bwdw_tr16(P, 1, xdt, st); break; }
         if (bwdw_use_bf16_133(p)) {
           const dim3 g3(P.nsg, P.ncot, P.nchunks);
           const bool yb = ysrc->dtype == MT_BF16;

@@ -399,19 +399,91 @@ def test_bwdw_wino_bf16_storage_bitexact(dev, Cin, Cout, shape, k, xb, yb):
     sc, sh = torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g)
     dy = rbf(torch.randn((N,) + shape + (Cout,), generator=g))
     res = []
-    for xdt, ydt in ((torch.float32, torch.float32), (xb if xb is not None else torch.float32, torch.bfloat16 if yb else torch.float32)):
-        a = ops.Act(x.to(dev).to(xdt), scale=sc.to(dev), shift=sh.to(dev), slope=0.01)
-        y = ops.Act(dy.to(dev).to(ydt))
-        p = ops.fill_conv([a], geom, Cout, mma=1)
-        assert ops.conv_bwd_weight_io_supported(p, y)
-        assert ops.conv_bwd_weight_kernel_name(p, y).startswith('conv_bwdw_wino_bf16'), ops.conv_bwd_weight_kernel_name(p, y)
-        dw = torch.full((Cout, Cin) + k, float('nan'), device=dev)
-        ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
-        ops.conv3d_bwd_weight(p, y, dw, ops.conv_weight_strides(dw), False, ws)
-        torch.cuda.synchronize()
-        res.append(dw)
+    ops.set_option('bwdw_tr16', 0)          # (16-bit X with bf16 dY is served by conv_bwdw_tr16_kernel by default: test_bwdw_tr16_vs_host)
+    try:
+        for xdt, ydt in ((torch.float32, torch.float32), (xb if xb is not None else torch.float32, torch.bfloat16 if yb else torch.float32)):
+            a = ops.Act(x.to(dev).to(xdt), scale=sc.to(dev), shift=sh.to(dev), slope=0.01)
+            y = ops.Act(dy.to(dev).to(ydt))
+            p = ops.fill_conv([a], geom, Cout, mma=1)
+            assert ops.conv_bwd_weight_io_supported(p, y)
+            assert ops.conv_bwd_weight_kernel_name(p, y).startswith('conv_bwdw_wino_bf16'), ops.conv_bwd_weight_kernel_name(p, y)
+            dw = torch.full((Cout, Cin) + k, float('nan'), device=dev)
+            ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
+            ops.conv3d_bwd_weight(p, y, dw, ops.conv_weight_strides(dw), False, ws)
+            torch.cuda.synchronize()
+            res.append(dw)
+    finally:
+        ops.set_option('bwdw_tr16', 1)
     assert torch.isfinite(res[1]).all()
     assert torch.equal(res[0], res[1]), float((res[0] - res[1]).abs().max())
+
+
+def _bwdw_host(xs, dy, k, pad):
+    """dW of a stride-1 convolution in float64 from already activated / rounded operands: xs [N, D, H, W, Cin], dy [N, D, H, W, Cout]."""
+    import torch.nn.functional as F
+    x = torch.cat(xs, -1).permute(0, 4, 1, 2, 3).double().requires_grad_(False)
+    g = dy.permute(0, 4, 1, 2, 3).double()
+    w = torch.zeros((g.shape[1], x.shape[1]) + tuple(k), dtype=torch.float64, requires_grad=True)
+    F.conv3d(x, w, None, 1, pad).backward(g)
+    return w.grad
+
+
+@pytest.mark.parametrize("cins,Cout,shape,k,lazy,cap", [
+    ((32,), 32, (6, 12, 64), (3, 3, 3), True, 1),
+    ((30,), 60, (5, 10, 40), (3, 3, 3), True, 1),          # ragged column (h 10 = 2.5 tiles, w 40 = 1.25 tiles), channel tails
+    ((30,), 30, (4, 12, 64), (1, 3, 3), True, 1),          # residual encoder stage 0
+    ((30, 30), 30, (7, 9, 35), (3, 3, 3), True, 5),        # two sources (decoder concat), five workgroups: ranges cut columns anywhere
+    ((48,), 32, (3, 8, 33), (3, 3, 3), False, 3),          # three chunks (the last pair is half empty), plain (not lazy) source
+    ((60,), 30, (9, 16, 48), (1, 3, 3), True, 7),
+    ((32,), 32, (12, 4, 32), (3, 3, 3), True, 2),          # one column per sample, two workgroups: every segment boundary inside a column
+])
+@pytest.mark.parametrize("xdt", [torch.float16, torch.bfloat16])
+def test_bwdw_tr16_vs_host(dev, cins, Cout, shape, k, lazy, cap, xdt):
+    """conv_bwdw_tr16_kernel (round 5: the direct bf16 backward-weight fed by ds_read_b64_tr_b16) against float64 autograd on the operands the
+    kernel multiplies: X activated in fp32 (one fma, LeakyReLU) and rounded ONCE to bf16, dY bf16, fp32 accumulation -> 2e-4 of max|dW|
+    (an fp32-ulp difference of the host's fma may flip the bf16 rounding of single elements).  `cap` > 1 limits the number of workgroups
+    (mt_set_option bwdw_tr16) so that one workgroup's (column, plane) range spans several columns and starts / ends inside columns."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31 + sum(cins) + Cout)
+    N = 2
+    pad = tuple((kk - 1) // 2 for kk in k)
+    geom = ops.ConvGeom(shape, k, (1, 1, 1), pad)
+    C = sum(cins)
+    buf = rbf(1.5 * torch.randn((N,) + shape + (C + 2,), generator=g), xdt)            # the sources are channel slices of a wider buffer
+    dy = rbf(torch.randn((N,) + shape + (Cout,), generator=g))
+    xd = buf.to(dev).to(xdt)
+    srcs, hx, c0 = [], [], 0
+    for ci in cins:
+        sl = buf[..., c0:c0 + ci]
+        if lazy:
+            sc, sh = torch.rand((N, ci), generator=g) + 0.5, torch.randn((N, ci), generator=g)
+            srcs.append(ops.Act(xd, c0, ci, scale=sc.to(dev), shift=sh.to(dev), slope=0.01))
+            t = torch.addcmul(sh[:, None, None, None, :], sl, sc[:, None, None, None, :])
+            hx.append(rbf(torch.maximum(t, t * 0.01)))
+        else:
+            srcs.append(ops.Act(xd, c0, ci))
+            hx.append(rbf(sl))
+        c0 += ci
+    y = ops.Act(dy.to(dev).to(torch.bfloat16))
+    p = ops.fill_conv(srcs, geom, Cout, mma=1)
+    ops.set_option('bwdw_tr16', cap)
+    try:
+        assert ops.conv_bwd_weight_io_supported(p, y)
+        name = ops.conv_bwd_weight_kernel_name(p, y)
+        assert name.startswith('conv_bwdw_tr16_kernel<%d' % k[0]), name
+        dw = torch.full((Cout, C) + k, float('nan'), device=dev)
+        ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
+        ops.conv3d_bwd_weight(p, y, dw, ops.conv_weight_strides(dw), False, ws)
+        dw2 = dw.clone()
+        ops.conv3d_bwd_weight(p, y, dw2, ops.conv_weight_strides(dw2), True, ws)          # accumulate: 2 dW
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option('bwdw_tr16', 1)
+    ref = _bwdw_host(hx, dy, k, pad)
+    err = float((dw.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert torch.isfinite(dw).all() and err < 2e-4, err
+    assert torch.equal(dw2, 2 * dw)
+
 
 
 def test_unsupported_storage_types_are_refused(dev):
