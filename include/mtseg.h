@@ -159,27 +159,26 @@ int mt_conv3d_io_supported(const mt_conv3d_t* p);
 int mt_conv3d_bwd_data_strided_io_supported(const mt_conv3d_t* p);
 int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_src_t* ysrc);
 /* Runtime options (tests, A/B measurements): "conv_wino" = 0 direct kernels only, 1 Winograd where the grid fills the chip
- * (default, also MT_CONV_WINO), 2 Winograd wherever the geometry is eligible; "wino_waves" 8 | 4; "wino_persist" 1 | 0 | n (8-wave
- * kernel: persistent over spatial tiles (default; n > 1: at most n workers per output-channel tile) or one tile per workgroup); "bwdw_wino" 0 | 1;
- * "conv_bf16" (problems with mma == 1) = 0 never, 1 where the grid fills the chip (default), 2 wherever eligible;
- * "bwdw_bf16" 0 | 1; "bf16_persist" 0 (default) | 1: conv_bf16p_kernel (persistent, wave-specialised) for 16-bit storage (also MT_BF16_PERSIST). */
+ * (default, also MT_CONV_WINO), 2 Winograd wherever the geometry is eligible; "wino_persist" 1 | n (persistent Winograd kernel: n > 1 = at
+ * most n workers per output-channel tile); "bwdw_wino" 0 | 1; "conv_bf16" (problems with mma == 1) = 0 never, 1 where the grid fills the
+ * chip (default), 2 wherever eligible; "bwdw_tr16" 1 (default) | 0 | n: conv_bwdw_tr16_kernel for 16-bit X with bf16 dY (0: cast + the fp32
+ * kernels; n > 1: at most n workgroups per (cout tile, chunk pair) — tests); "bwdw_cw" (below). */
 int mt_set_option(const char* name, int value);
 /* Process-wide tuning knobs.  mt_set_option and the environment variables below choose BETWEEN KERNELS THAT COMPUTE THE SAME
  * RESULT (to fp32 rounding); they are the only mutable state of the library (atomics: setting one while other threads launch is
  * safe, it simply takes effect for later launches on every device).  Per-DEVICE one-time setup (raising a kernel's dynamic-LDS
  * limit, the CU count that sizes persistent grids) is keyed by the current HIP device, so one process may drive several GPUs.
  * Environment, read once at first use (0 disables the named kernel family and falls back to the generic one unless noted):
- *   MT_CONV_WINO (0|1|2), MT_WINO_WAVES (4|8), MT_WINO_PERSIST (0|1|n), MT_BWDW_WINO, MT_BWDW_MARCH, MT_BWDW_FAST, MT_BWDW_TALL,
- *   MT_CONV_BF16 (0|1|2), MT_BWDW_BF16, MT_STRIDED_BF16, MT_CONV_FASTV2, MT_CONV_RT, MT_CONV_STEM, MT_CONV_TAPSPLIT,
+ *   MT_CONV_WINO (0|1|2), MT_WINO_PERSIST (1|n), MT_BWDW_WINO, MT_BWDW_MARCH, MT_BWDW_FAST, MT_BWDW_TALL,
+ *   MT_CONV_BF16 (0|1|2), MT_BWDW_TR16, MT_STRIDED_BF16, MT_CONV_FASTV2, MT_CONV_RT, MT_CONV_STEM, MT_CONV_TAPSPLIT,
  *   MT_CONV_FAST133, MT_CONV_GATHER, MT_CONV_VEC1 (1: dword staging loads),
  *   MT_PW_VEC / MT_GATHER_VEC (1|2|4: floats per load instruction of pw_fast_kernel / conv_gather_kernel; default 4 = 16-byte
  *   buffer loads on dword-aligned addresses, see mt_probe_device), MT_PW_HEAD (0: the 33..64-channel 1x1x1 heads on pw_fast_kernel
  *   instead of pw_head_kernel; also the narrow-head kernels), MT_PW_WIDE (0: dword stores in the transposed-conv epilogue), MT_PW_SPLIT8 (0: all
- *   eight taps of a 2x2x2 transposed conv in one workgroup), MT_WINO_DMA (1: conv_wino8d_kernel), MT_PACK_BLOCKS (workgroups per descriptor of mt_pack_batched,
+ *   eight taps of a 2x2x2 transposed conv in one workgroup), MT_PACK_BLOCKS (workgroups per descriptor of mt_pack_batched,
  *   default 1024), MT_HEAD_BWD_WIDE, MT_CONV_CFG / MT_BF16_CFG (force a tile configuration), MT_CONV_STAGGER, MT_CONV_DBG (debugging).
- *   Round 4 (mixed precision): MT_BWDW_STAGED (0: conv_bwdw_wino_bf16_kernel with per-thread gathers instead of the LDS-staged
- *   conv_bwdw_wino_bf16s_kernel), MT_BWDW_GEMM (0: the low-resolution backward-weight on the fp32 marching kernel instead of
- *   im2col + bf16 GEMM), MT_BWDW_FAST16 (0: the tiled backward-weight geometries keep fp32 products in mixed precision), MT_BF16_PERSIST (1: conv_bf16p_kernel), MT_BWDW_MARCH16 (0: the strided stage convs' backward-weight on the tiled
+ *   Mixed precision: MT_BWDW_GEMM (0: the low-resolution backward-weight on the fp32 marching kernel instead of
+ *   im2col + bf16 GEMM), MT_BWDW_FAST16 (0: the tiled backward-weight geometries keep fp32 products in mixed precision), MT_BWDW_MARCH16 (0: the strided stage convs' backward-weight on the tiled
  *   kernel), MT_PACK_TILED (0: per-item weight packing), MT_LOSS_SPARSE (0: the flat MultiTalent loss kernels for every sample),
  *   MT_GATHER_BF16 (0: fp32 products in the backward-data of the transposed convs), MT_PW_M16 (0: fp32 products in the pointwise kernels
  *   whatever mt_pointwise_t.mma says — the weights must then be packed with layout 1), MT_INORM_SMALL (0: three launches for the InstanceNorm backward of small tensors instead of one).

@@ -2288,44 +2288,12 @@ static int launch_bf16_t(const mt_conv3d_t* p, hipStream_t st) {
   MT_CHECK_LAUNCH("conv3d_bf16");
   return MT_OK;
 }
-static std::atomic<int> g_bf16_persist{-1};     // -1: read MT_BF16_PERSIST (default 0); option "bf16_persist"
-static bool bf16_persist() {           // 1: conv_bf16p_kernel (persistent, wave-specialised; measured SLOWER: DESIGN.md 3.3) for 16-bit storage
-  int use = g_bf16_persist.load();
-  if (use < 0) { const char* e = getenv("MT_BF16_PERSIST"); use = e ? atoi(e) : 0; g_bf16_persist = use; }
-  return use != 0;
-}
-template <int MW, int RH, int TD, int KD, int XS, int OS, int MTY>
-static int launch_bf16p_t(const mt_conv3d_t* p, hipStream_t st) {
-  ConvKParams P;
-  P.c = *p;
-  if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
-  constexpr int TH = (32 / MW) * RH, TW = MW;
-  P.tilesD = mt_cdiv(p->Do, TD); P.tilesH = mt_cdiv(p->Ho, TH); P.tilesW = mt_cdiv(p->Wo, TW);
-  P.nsb = P.tilesD * P.tilesH * P.tilesW;
-  P.ntaps = KD * 9; P.dbg = 0; P.stagger = 0;
-  P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
-  MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
-  const size_t ldsb = bf16p_lds_bytes<MW, RH, TD, KD>();
-  const long items = (long)P.nsb * p->N * mt_cdiv(p->Cout, 32);
-  int G = mt_device_cus(mt_current_device());           // one workgroup (12 waves) per CU
-  if (G > items) G = (int)items;
-  auto kfn = conv_bf16p_kernel<MW, RH, TD, KD, XS, OS, MTY>;
-  if (ldsb > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
-  }
-  hipLaunchKernelGGL(kfn, dim3((unsigned)G), dim3(64 * (BF16P_NC + 4)), ldsb, st, P);
-  MT_CHECK_LAUNCH("conv3d_bf16p");
-  return MT_OK;
-}
 static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
   // NT = 2 (64 output channels per workgroup) measured slower: 0.197 vs 0.179 ms on 64->64 @ 24x96x96; 8 waves: no gain
   // storage: all fp32 (bf16 matrix type), all bf16 (backward-data over gradients) or all fp16 (forward over activations: fp16 matrix
   // type); 16-bit sources are read as 8-byte groups of four channels, 16-bit destinations written as channel-pair dwords
   const int sd = conv_src_dtype(p);
   MT_REQUIRE(sd >= 0 && sd == p->odtype, "conv3d: conv_bf16_kernel takes ONE storage type on all operands (ask mt_conv3d_io_supported)");
-  if (cfg == 0 && bf16_persist() && sd == MT_F16) return p->KD == 1 ? launch_bf16p_t<32, 4, 4, 1, MT_F16, MT_F16, MT_F16>(p, st) : launch_bf16p_t<32, 4, 4, 3, MT_F16, MT_F16, MT_F16>(p, st);
-  if (cfg == 0 && bf16_persist() && sd == MT_BF16) return p->KD == 1 ? launch_bf16p_t<32, 4, 4, 1, MT_BF16, MT_BF16, MT_BF16>(p, st) : launch_bf16p_t<32, 4, 4, 3, MT_BF16, MT_BF16, MT_BF16>(p, st);
 #define MT_BF_CASE(I_, MW_, RH_, TD_, NW_)                                                   \
   if (cfg == I_) {                                                                           \
     if (sd == MT_F16) return p->KD == 1 ? launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 1, MT_F16, MT_F16, MT_F16>(p, st) : launch_bf16_t<MW_, RH_, TD_, 4, 1, NW_, 3, MT_F16, MT_F16, MT_F16>(p, st); \
@@ -2340,54 +2308,42 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
   return MT_EINVAL;
 }
 
-static int g_bwdw_bf16 = -1;       // -1: read MT_BWDW_BF16 (default 1): bf16 Winograd backward-weight kernel when mt_conv3d_t.mma == 1
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
 static int g_bwdw_tr16 = -1;       // -1: read MT_BWDW_TR16 (default 1): direct bf16 backward-weight fed by LDS transpose reads (conv_bwdw_tr16_kernel) instead of the bf16 Winograd marching kernel
 static int g_bwdw_cw = -1;         // -1: read MT_BWDW_CW (default 4): most cout tiles per workgroup of the tiled backward-weight kernels (1 | 2 | 4; + 100: also on small problems)
-static std::atomic<int> g_wino_waves{8};       // 4: conv_wino_kernel, 8: conv_wino8_kernel (two waves per SIMD)
-static std::atomic<int> g_wino_persist{1};     // 8-wave kernel: 1 persistent over spatial tiles (conv_wino8p_kernel), 0 one tile per workgroup, n > 1: at most n workers
-#ifndef WINO_DMA_DEFAULT
-#define WINO_DMA_DEFAULT 0
-#endif
-static std::atomic<int> g_wino_dma{-1};        // persistent kernel with LDS-DMA patch staging (conv_wino8d_kernel): -1 read MT_WINO_DMA (default 1)
+static std::atomic<int> g_wino_persist{1};     // conv_wino8p_kernel: n > 1 = at most n workers per output-channel tile (tests: few workers, many tiles each)
 static std::atomic<int> g_wino_mode{-1};       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
 extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "conv_wino") == 0) { g_wino_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_wino") == 0) { g_bwdw_wino = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "wino_waves") == 0) { g_wino_waves = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "wino_persist") == 0) { g_wino_persist = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "wino_dma") == 0) { g_wino_dma = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "conv_bf16") == 0) { g_bf16_mode = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "bwdw_bf16") == 0) { g_bwdw_bf16 = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "bf16_persist") == 0) { g_bf16_persist = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_cw") == 0) { g_bwdw_cw = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_tr16") == 0) { g_bwdw_tr16 = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
 }
+// Packed patch geometry of the persistent kernel: a task's linear offset (ld*Hi + lh)*Wi + lw with ld, lh <= 5 and lw <= 17 lives
+// in bits 0-19 of a table entry, so its maximum (5*Hi + 5)*Wi + 17 must stay below 2^20 (beyond that the offset would spill into
+// the ld bits); larger planes take the direct kernels.
+static bool wino_persist_geometry_ok(const mt_conv3d_t* p) { return (5.0 * p->Hi + 5.0) * p->Wi + 17.0 < 1048576.0; }
 static bool conv_wino_ok(const mt_conv3d_t* p) {
   if (g_wino_mode < 0) {
     const char* e = getenv("MT_CONV_WINO"); g_wino_mode = e ? atoi(e) : 1;
-    const char* w = getenv("MT_WINO_WAVES"); if (w) g_wino_waves = atoi(w);
     const char* pe = getenv("MT_WINO_PERSIST"); if (pe) g_wino_persist = atoi(pe);
   }
-  if (g_wino_dma < 0) { const char* de = getenv("MT_WINO_DMA"); g_wino_dma = de ? atoi(de) : WINO_DMA_DEFAULT; }
   const int use = g_wino_mode;
   if (!use) return false;
-  if (p->Cin < 16 || conv_fast_vec(p) != 2) return false;
+  if (p->Cin < 16 || conv_fast_vec(p) != 2 || !wino_persist_geometry_ok(p)) return false;
   if (p->csplit < p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs1 * 4.0 >= 2147483648.0) return false;
   if (mt_cdiv(p->src[0].C, WCK) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, WCK) : 0) > MT_MAX_CHUNKS) return false;
   if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return false;
   const long wgs = (long)p->N * mt_cdiv(p->Do, 4) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 16) * mt_cdiv(p->Cout, 32);
   return wgs >= 256 || use == 2;          // MT_CONV_WINO=2 forces it (tests on small shapes)
 }
-// Packed patch geometry of the persistent kernel: a task's linear offset (ld*Hi + lh)*Wi + lw with ld, lh <= 5 and lw <= 17 lives
-// in bits 0-19 of a table entry, so its maximum (5*Hi + 5)*Wi + 17 must stay below 2^20 (beyond that the offset would spill into
-// the ld bits); larger planes run the one-tile-per-workgroup kernel.
-static bool wino_persist_geometry_ok(const mt_conv3d_t* p) { return (5.0 * p->Hi + 5.0) * p->Wi + 17.0 < 1048576.0; }
 // mt_bwd_stats_t is implemented in the epilogue of the persistent register-staged Winograd kernel (conv_wino8p_kernel)
 static bool wino_serves_bwd_stats(const mt_conv3d_t* p) {
-  return g_wino_waves == 8 && g_wino_persist && wino_persist_geometry_ok(p) && g_wino_dma <= 0;
+  return wino_persist_geometry_ok(p);
 }
 static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
   MT_REQUIRE(p->bstats.y == nullptr || (wino_serves_bwd_stats(p) && p->stats_part != nullptr && p->bstats.mean && p->bstats.rstd &&
@@ -2401,71 +2357,31 @@ static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
   P.ntaps = 27; P.dbg = 0; P.stagger = 0;
   P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, WCK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks for the Winograd kernel (Cin=%d)", p->Cin);
-  const size_t ldsb = (size_t)(W_RAWF + W_VF) * sizeof(float);
   const int devid = mt_current_device();
-  static std::atomic<uint64_t> attr_set{0};
-  if (mt_device_pending(attr_set, devid)) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ldsb, hipGetErrorString(e)); return MT_EHIP; }
-    mt_mark_device_done(attr_set, devid);
-  }
-  dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
-  if (g_wino_waves == 8) {
-    const size_t l8 = (size_t)(2 * W_RAWF + W_VF) * sizeof(float);
-    static std::atomic<uint64_t> attr8{0};
-    if (mt_device_pending(attr8, devid)) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv_wino8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l8);
+  const size_t l8 = (size_t)(2 * W_RAWF + W_VF) * sizeof(float) + 11 * 256 * 4;          // two raw patches + V + the patch-geometry table
+  // one resident workgroup per CU (126 KiB of LDS each): NW workers per output-channel tile walk over the spatial tiles
+  const int T = P.nsb * p->N, nct = mt_cdiv(p->Cout, 32);
+  int nw = mt_device_cus(devid) / nct; if (nw < 1) nw = 1; if (nw > T) nw = T;
+  if (g_wino_persist > 1 && nw > g_wino_persist) nw = g_wino_persist;       // tests: few workers, many tiles each
+  if (p->bstats.y != nullptr) {
+    static std::atomic<uint64_t> attrb{0};
+    if (mt_device_pending(attrb, devid)) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv_wino8pb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l8);
       if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", l8, hipGetErrorString(e)); return MT_EHIP; }
-      mt_mark_device_done(attr8, devid);
+      mt_mark_device_done(attrb, devid);
     }
-    if (g_wino_persist && wino_persist_geometry_ok(p)) {
-      static std::atomic<uint64_t> attrp{0};
-      if (mt_device_pending(attrp, devid)) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wino8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(l8 + 11 * 256 * 4));
-        if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", l8, hipGetErrorString(e)); return MT_EHIP; }
-        mt_mark_device_done(attrp, devid);
-      }
-      const int ncu = mt_device_cus(devid);
-      if (g_wino_dma > 0) {
-        const size_t ld = (size_t)(WD_NRAW * WD_RB + W_VF) * sizeof(float);
-        static std::atomic<uint64_t> attrd{0};
-        if (mt_device_pending(attrd, devid)) {
-          hipError_t e = hipFuncSetAttribute((const void*)conv_wino8d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ld);
-          if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", ld, hipGetErrorString(e)); return MT_EHIP; }
-          mt_mark_device_done(attrd, devid);
-        }
-        const int T = P.nsb * p->N, nct = mt_cdiv(p->Cout, 32);
-        int nw = ncu / nct; if (nw < 1) nw = 1; if (nw > T) nw = T;
-        if (g_wino_persist > 1 && nw > g_wino_persist) nw = g_wino_persist;
-        hipLaunchKernelGGL(conv_wino8d_kernel, dim3((unsigned)nw, (unsigned)nct, 1), dim3(512), ld, st, P);
-        MT_CHECK_LAUNCH("conv3d_wino8d");
-        return MT_OK;
-      }
-      // one resident workgroup per CU (126 KiB of LDS each): NW workers per output-channel tile walk over the spatial tiles
-      const int T = P.nsb * p->N, nct = mt_cdiv(p->Cout, 32);
-      int nw = ncu / nct; if (nw < 1) nw = 1; if (nw > T) nw = T;
-      if (g_wino_persist > 1 && nw > g_wino_persist) nw = g_wino_persist;       // tests: few workers, many tiles each
-      if (p->bstats.y != nullptr) {
-        static std::atomic<uint64_t> attrb{0};
-        if (mt_device_pending(attrb, devid)) {
-          hipError_t e = hipFuncSetAttribute((const void*)conv_wino8pb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(l8 + 11 * 256 * 4));
-          if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", l8, hipGetErrorString(e)); return MT_EHIP; }
-          mt_mark_device_done(attrb, devid);
-        }
-        hipLaunchKernelGGL(conv_wino8pb_kernel, dim3((unsigned)nw, (unsigned)nct, 1), dim3(512), l8 + 11 * 256 * 4, st, P);
-        MT_CHECK_LAUNCH("conv3d_wino8pb");
-        return MT_OK;
-      }
-      hipLaunchKernelGGL(conv_wino8p_kernel, dim3((unsigned)nw, (unsigned)nct, 1), dim3(512), l8 + 11 * 256 * 4, st, P);   // + the patch-geometry table
-      MT_CHECK_LAUNCH("conv3d_wino8p");
-      return MT_OK;
-    }
-    hipLaunchKernelGGL(conv_wino8_kernel, grid, dim3(512), l8, st, P);
-    MT_CHECK_LAUNCH("conv3d_wino8");
+    hipLaunchKernelGGL(conv_wino8pb_kernel, dim3((unsigned)nw, (unsigned)nct, 1), dim3(512), l8, st, P);
+    MT_CHECK_LAUNCH("conv3d_wino8pb");
     return MT_OK;
   }
-  hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), ldsb, st, P);
-  MT_CHECK_LAUNCH("conv3d_wino");
+  static std::atomic<uint64_t> attrp{0};
+  if (mt_device_pending(attrp, devid)) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wino8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l8);
+    if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", l8, hipGetErrorString(e)); return MT_EHIP; }
+    mt_mark_device_done(attrp, devid);
+  }
+  hipLaunchKernelGGL(conv_wino8p_kernel, dim3((unsigned)nw, (unsigned)nct, 1), dim3(512), l8, st, P);
+  MT_CHECK_LAUNCH("conv3d_wino8p");
   return MT_OK;
 }
 
@@ -2608,10 +2524,6 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   if (pl.kind == CONV_BF16) {
     // the instance launch_bf16 picks, as the profiler prints it: <MW, RH, TD, VEC, NT, NW, KD, XS, OS, MTY>
     const int sd = conv_src_dtype(p);
-    if (sd > 0 && i == 0 && bf16_persist()) {     // (the 4x4x32 tile only) <MW, RH, TD, KD, XS, OS, MTY>
-      snprintf(buf, n, "conv_bf16p_kernel<%d, %d, %d, %d, %d, %d, %d>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, p->KD, sd, sd, sd == MT_F16 ? MT_F16 : MT_BF16);
-      return MT_OK;
-    }
     snprintf(buf, n, "conv_bf16_kernel<%d, %d, %d, %d, 1, 4, %d, %d, %d, %d>", kBfCfgs[i].MW, kBfCfgs[i].RH, kBfCfgs[i].TD, sd > 0 ? 4 : conv_bf16_vec(p), p->KD,
              sd > 0 ? sd : 0, sd > 0 ? sd : 0, sd == MT_F16 ? MT_F16 : MT_BF16);
     return MT_OK;
@@ -2629,7 +2541,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   else if (pl.kind == CONV_STEM)
     snprintf(buf, n, "conv_stem_kernel<%d>", p->odtype);
   else if (pl.kind == CONV_WINO)
-    snprintf(buf, n, g_wino_waves == 8 ? ((g_wino_persist && wino_persist_geometry_ok(p)) ? (g_wino_dma > 0 ? "conv_wino8d_kernel" : (p->bstats.y != nullptr ? "conv_wino8pb_kernel" : "conv_wino8p_kernel")) : "conv_wino8_kernel") : "conv_wino_kernel");
+    snprintf(buf, n, p->bstats.y != nullptr ? "conv_wino8pb_kernel" : "conv_wino8p_kernel");
   else if (pl.kind == CONV_FAST_STRIDED)
   {
     const int sd = conv_src_dtype(p);
@@ -3886,7 +3798,6 @@ __global__ __launch_bounds__(256) void conv_bwdw_stem_kernel(const BwdWParams P)
 }
 
 #include "bwdw_wino.inc"
-#include "bwdw_bf16.inc"
 static int conv_src_dtype(const mt_conv3d_t* p);
 #include "bwdw_gemm.inc"
 #include "bwdw_fast16.inc"
@@ -3942,28 +3853,16 @@ static bool bwdw_use_wino(const mt_conv3d_t* p) {
     if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
   return g_bwdw_wino && bwdw_use_march(p) && p->Wo > 16 && p->Ho >= 2 && conv_fast_vec(p) == 2;
 }
-static bool bwdw_staged() {        // MT_BWDW_STAGED=0: the register-fed bf16 Winograd backward-weight kernel also for 16-bit operands
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_BWDW_STAGED"); use = e ? atoi(e) : 1; }
-  return use != 0;
-}
-static bool bwdw_use_bf16(const mt_conv3d_t* p) {
-  if (g_bwdw_bf16 < 0) { const char* e = getenv("MT_BWDW_BF16"); g_bwdw_bf16 = e ? atoi(e) : 1; }
-  return g_bwdw_bf16 && p->mma == 1 && bwdw_use_wino(p);
-}
-static bool bwdw_use_bf16_133(const mt_conv3d_t* p) {       // 1x3x3 stride-1 backward-weight on the bf16 Winograd marching kernel
-  if (g_bwdw_bf16 < 0) { const char* e = getenv("MT_BWDW_BF16"); g_bwdw_bf16 = e ? atoi(e) : 1; }
-  for (int i = 0; i < p->nsrc; ++i)          // (the staged kernel applies LeakyReLU as max(t, slope * t))
-    if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
-  return g_bwdw_bf16 && p->mma == 1 && p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 &&
-         p->PD == 0 && p->PH == 1 && p->PW == 1 && p->Wo > 16 && p->Ho >= 2 && p->Do >= 1 && conv_fast_vec(p) == 2;
-}
-// conv_bwdw_tr16_kernel (bwdw_tr16.inc): 3x3x3 / 1x3x3 stride-1, 16-bit X (lazy activations or plain), bf16 dY without affine, Wo > 16.
+// conv_bwdw_tr16_kernel (bwdw_tr16.hip): 3x3x3 / 1x3x3 stride-1, 16-bit X (lazy activations or plain), bf16 dY without affine, Wo > 16.
 // ysrc == nullptr: geometry + X only (workspace query).
 static bool bwdw_use_tr16(const mt_conv3d_t* p, const mt_src_t* ysrc) {
   if (g_bwdw_tr16 < 0) { const char* e = getenv("MT_BWDW_TR16"); g_bwdw_tr16 = e ? atoi(e) : 1; }
   if (!g_bwdw_tr16 || p->mma != 1 || p->N > 16) return false;                 // (BWT_MAXN samples in the kernel's activation table)
-  if (!(bwdw_use_bf16(p) || bwdw_use_bf16_133(p))) return false;              // the geometries / slopes / alignments of the kernels it replaces
+  const bool g333 = bwdw_use_march(p) && p->PH == 1 && p->PW == 1;
+  const bool g133 = p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 0 && p->PH == 1 && p->PW == 1 && p->Do >= 1;
+  if (!(g333 || g133) || !(p->dilD == 1 && p->dilH == 1 && p->dilW == 1) || !(p->Wo > 16 && p->Ho >= 2) || conv_fast_vec(p) != 2) return false;
+  for (int i = 0; i < p->nsrc; ++i)          // (its X path applies LeakyReLU as max(t, slope * t))
+    if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
   const int xdt = conv_src_dtype(p);
   if (xdt != MT_F16 && xdt != MT_BF16) return false;
   if (ysrc != nullptr && (ysrc->dtype != MT_BF16 || ysrc->scale != nullptr || (ysrc->cs & 1) || (((uintptr_t)ysrc->ptr) & 3))) return false;
@@ -4022,14 +3921,13 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = 
   P->ncot = mt_cdiv(p->Cout, 32);
   P->cw = allow_cw ? bwdw_fast_cw(p, P->ntiles_total, P->nchunks) : 1;
   // fp32 Winograd marching kernel: two cout tiles per workgroup where the cout tiles pair up and a workgroup still gets >= 12 planes
-  if (allow_cw && bwdw_use_wino(p) && !bwdw_use_bf16(p) && conv_src_dtype(p) == MT_F32) {
+  if (allow_cw && bwdw_use_wino(p) && conv_src_dtype(p) == MT_F32) {
     if (g_bwdw_cw < 0) { const char* e = getenv("MT_BWDW_CW"); g_bwdw_cw = e ? atoi(e) : 4; }
     const long planes = (long)p->N * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 32) * p->Do;
     if ((g_bwdw_cw % 100) >= 2 && P->ncot % 2 == 0 && (g_bwdw_cw >= 100 || planes * P->nchunks * (P->ncot / 2) >= 3072)) P->cw = 2;
   }
   int pairs = P->nchunks * mt_cdiv(P->ncot, P->cw); if (pairs < 1) pairs = 1;
   int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
-  if ((bwdw_use_march(p) && bwdw_use_bf16(p)) || bwdw_use_bf16_133(p)) nsg = (512 + pairs - 1) / pairs;      // 64 KiB ring: two workgroups per CU
   // conv_bwdw_fast16_kernel with few taps (transposed-conv weights, 1x1x1): <= 180 registers and <= 49 KiB of LDS — two workgroups per CU
   if (p->mma == 1 && p->src[0].dtype != MT_F32 && P->ntaps <= 8 && !bwdw_use_march(p)) nsg = (512 + pairs - 1) / pairs;
   P->nsg_cap = nsg;
@@ -4037,11 +3935,6 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = 
   if (nsg < 1) nsg = 1;
   P->nsg = nsg;
   P->nunits = 0; P->nseg = 1; P->dseg = p->Do;
-  if (bwdw_use_bf16_133(p)) {
-    P->TH = 4; P->TW = 32; P->tilesH = mt_cdiv(p->Ho, 4); P->tilesW = mt_cdiv(p->Wo, 32);
-    P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N;
-    bwdw_march_plan(p, P);
-  }
   if (bwdw_march16_geo(p)) bwdw_march_plan(p, P);      // conv_bwdw_march16_kernel: columns x D segments (tile 4 x 32: Wo > 16)
   if (bwdw_use_march(p)) {
     static int tall = -1;
@@ -4220,14 +4113,9 @@ extern "C" int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_s
   if (use_fast && bwdw_use_gemm(p, ysrc)) { snprintf(buf, n, "bwdw_gemm_kernel"); return MT_OK; }
   if ((geo == 0 || geo == 6) && bwdw_use_tr16(p, ysrc)) { snprintf(buf, n, "conv_bwdw_tr16_kernel<%d, %d>", p->KD, conv_src_dtype(p)); return MT_OK; }
   if (geo == 0) {
-    if (bwdw_use_bf16(p)) snprintf(buf, n, (conv_src_dtype(p) > 0 && ysrc->dtype == MT_BF16 && bwdw_staged()) ? "conv_bwdw_wino_bf16s_kernel<3, %d, %d>" : "conv_bwdw_wino_bf16_kernel<3, %d, %d>", conv_src_dtype(p), ysrc->dtype);
-    else if (bwdw_use_wino(p)) snprintf(buf, n, "conv_bwdw_wino_kernel<2>");
+    if (bwdw_use_wino(p)) snprintf(buf, n, "conv_bwdw_wino_kernel<2>");
     else if (bwdw_use_march(p)) snprintf(buf, n, "conv_bwdw_march_kernel<3, 3, 1, 1>");
     else snprintf(buf, n, bwdw_fast16_ok(p, ysrc) ? "conv_bwdw_fast16_kernel<3, 3, 3, 1, 1, 1>" : "conv_bwdw_fast_kernel<3, 3, 3, 1, 1, 1>");
-    return MT_OK;
-  }
-  if (geo == 6 && bwdw_use_bf16_133(p)) {
-    snprintf(buf, n, (conv_src_dtype(p) > 0 && ysrc->dtype == MT_BF16 && bwdw_staged()) ? "conv_bwdw_wino_bf16s_kernel<1, %d, %d>" : "conv_bwdw_wino_bf16_kernel<1, %d, %d>", conv_src_dtype(p), ysrc->dtype);
     return MT_OK;
   }
   static const char* kGeo[9] = {"", "3, 3, 3, 2, 2, 2", "3, 3, 3, 1, 2, 2", "2, 2, 2, 2, 2, 2", "1, 2, 2, 1, 2, 2", "1, 1, 1, 1, 1, 1",
@@ -4253,7 +4141,7 @@ extern "C" int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_
   const int geo = bwdw_fast_geo(p, ysrc);
   if (geo < 0) return 0;
   if (bwdw_use_gemm(p, ysrc)) return 1;                        // im2col + GEMM: every storage type on either side
-  if ((geo == 0 && bwdw_use_bf16(p)) || (geo == 6 && bwdw_use_bf16_133(p))) return ydt != MT_F16 ? 1 : 0;   // bf16 Winograd marching kernels
+  if ((geo == 0 || geo == 6) && bwdw_use_tr16(p, ysrc)) return 1;                                              // conv_bwdw_tr16_kernel: 16-bit X, bf16 dY
   if (bwdw_fast16_ok(p, ysrc) && !(geo == 0 && bwdw_use_march(p))) return 1;   // conv_bwdw_fast16_kernel (mixed precision, bf16 products)
   if (geo == 0) return 0;                                     // fp32 Winograd / marching kernels: fp32 storage only
   // conv_bwdw_fast_kernel (strided 3x3x3, transposed-conv weights, 1x1x1, 1x3x3): 16-bit X as channel pairs
@@ -4308,8 +4196,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
   if (geo >= 0) {
     // several cout tiles per workgroup: conv_bwdw_fast_kernel with fp32 storage on both sides, conv_bwdw_fast16_kernel and its marching form
     const bool cw_ok = (bwdw_fast16_ok(p, ysrc) || (xdt == MT_F32 && ysrc->dtype == MT_F32)) &&
-                       !(geo == 0 && bwdw_use_march(p) && !(bwdw_use_wino(p) && !bwdw_use_bf16(p) && xdt == MT_F32 && ysrc->dtype == MT_F32)) &&
-                       !(geo == 6 && bwdw_use_bf16_133(p));
+                       !(geo == 0 && bwdw_use_march(p) && !(bwdw_use_wino(p) && xdt == MT_F32 && ysrc->dtype == MT_F32));
     const bool tr16 = (geo == 0 || geo == 6) && bwdw_use_tr16(p, ysrc);
     if (tr16) bwdw_tr16_plan(p, &P);
     else bwdw_fast_plan(p, &P, cw_ok);
@@ -4323,35 +4210,6 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     switch (geo) {
       case 0: {
         if (tr16) { rc = mt_launch_bwdw_tr16(P, 3, xdt, st); break; }
-        if (bwdw_use_bf16(p)) {
-          const dim3 g3(P.nsg, P.ncot, P.nchunks);
-          const bool yb = ysrc->dtype == MT_BF16;
-          if (yb && xdt != MT_F32 && bwdw_staged()) {       // 16-bit X and dY: raw planes staged through LDS with 16-byte loads
-            auto kfn = xdt == MT_F16 ? conv_bwdw_wino_bf16s_kernel<3, MT_F16, MT_BF16> : conv_bwdw_wino_bf16s_kernel<3, MT_BF16, MT_BF16>;
-            static std::atomic<uint64_t> attr_s[2];
-            const int devid = mt_current_device();
-            std::atomic<uint64_t>& at = attr_s[xdt == MT_F16 ? 0 : 1];
-            if (mt_device_pending(at, devid)) {
-              hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWS_LDS_BYTES);
-              if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
-              mt_mark_device_done(at, devid);
-            }
-            hipLaunchKernelGGL(kfn, g3, dim3(256), BWS_LDS_BYTES, st, P);
-            MT_CHECK_LAUNCH("conv_bwdw_wino_bf16s");
-            rc = MT_OK;
-            break;
-          }
-#define MT_BWB(XS_) do { if (yb) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, XS_, MT_BF16>), g3, dim3(256), BWB_LDS_BYTES, st, P); \
-                         else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3, XS_, MT_F32>), g3, dim3(256), BWB_LDS_BYTES, st, P); } while (0)
-          if (xdt == MT_F16) MT_BWB(MT_F16);
-          else if (xdt == MT_BF16) MT_BWB(MT_BF16);
-          else if (yb) MT_BWB(MT_F32);
-#undef MT_BWB
-          else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<3>), g3, dim3(256), BWB_LDS_BYTES, st, P);
-          MT_CHECK_LAUNCH("conv_bwdw_wino_bf16");
-          rc = MT_OK;
-          break;
-        }
         if (bwdw_use_wino(p)) {
           const size_t ldsb = (size_t)BWW_LDS_FLOATS * sizeof(float);
           static std::atomic<uint64_t> attr{0};
@@ -4390,35 +4248,6 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
       case 8: rc = launch_bwdw_fast<1, 1, 1, 1, 2, 2>(P, vec, st); break;
       case 6:
         if (tr16) { rc = mt_launch_bwdw_tr16(P, 1, xdt, st); break; }
-        if (bwdw_use_bf16_133(p)) {
-          const dim3 g3(P.nsg, P.ncot, P.nchunks);
-          const bool yb = ysrc->dtype == MT_BF16;
-          if (yb && xdt != MT_F32 && bwdw_staged()) {       // 16-bit X and dY: raw planes staged through LDS with 16-byte loads
-            auto kfn = xdt == MT_F16 ? conv_bwdw_wino_bf16s_kernel<1, MT_F16, MT_BF16> : conv_bwdw_wino_bf16s_kernel<1, MT_BF16, MT_BF16>;
-            static std::atomic<uint64_t> attr_s[2];
-            const int devid = mt_current_device();
-            std::atomic<uint64_t>& at = attr_s[xdt == MT_F16 ? 0 : 1];
-            if (mt_device_pending(at, devid)) {
-              hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWS_LDS_BYTES);
-              if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
-              mt_mark_device_done(at, devid);
-            }
-            hipLaunchKernelGGL(kfn, g3, dim3(256), BWS_LDS_BYTES, st, P);
-            MT_CHECK_LAUNCH("conv_bwdw_wino_bf16s");
-            rc = MT_OK;
-            break;
-          }
-#define MT_BWB(XS_) do { if (yb) hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, XS_, MT_BF16>), g3, dim3(256), BWB_LDS_BYTES, st, P); \
-                         else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1, XS_, MT_F32>), g3, dim3(256), BWB_LDS_BYTES, st, P); } while (0)
-          if (xdt == MT_F16) MT_BWB(MT_F16);
-          else if (xdt == MT_BF16) MT_BWB(MT_BF16);
-          else if (yb) MT_BWB(MT_F32);
-#undef MT_BWB
-          else hipLaunchKernelGGL((conv_bwdw_wino_bf16_kernel<1>), g3, dim3(256), BWB_LDS_BYTES, st, P);
-          MT_CHECK_LAUNCH("conv_bwdw_wino_bf16<1>");
-          rc = MT_OK;
-          break;
-        }
         rc = launch_bwdw_fast<1, 3, 3, 1, 1, 1>(P, vec, st);
         break;
     }

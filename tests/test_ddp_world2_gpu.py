@@ -216,7 +216,8 @@ def _sharded_inference(rank, world, dev):
         ref_p, ref_s = z['mt/probs_m%d' % int(mirror)], z['mt/seg_m%d' % int(mirror)]
         assert np.abs(ps - ref_p).max() < 1e-4
         from mask_check import check_masks
-        check_masks(segs, ref_s, ps, ref_p, [3, 1, 4, 2, 5], 1e-4, 'tile-sharded predict_3D rank %d/%d mirror=%d' % (rank, world, int(mirror)))
+        check_masks(segs, ref_s, ps, ref_p, [3, 1, 4, 2, 5], 1e-4, 'tile-sharded predict_3D rank %d/%d mirror=%d' % (rank, world, int(mirror)),
+                    key='tile-sharded predict_3D world %d mirror=%d' % (world, int(mirror)))
     return worst
 
 

@@ -418,9 +418,9 @@ def test_conv_bf16_1x3x3(dev, N, Cin, Cout, shape):
     (30, 30, (3, 5, 20), True),       # odd H (half tile), channel tails
 ])
 def test_conv_bwd_weight_bf16_mixed_precision(dev, Cin, Cout, shape, lazy):
-    """conv_bwdw_wino_bf16_kernel (mt_conv3d_t.mma = 1): Winograd-domain operands rounded to bf16, fp32 accumulation and output
-    transform.  Against the exact fp32 weight gradient of autograd: 1e-2 of the largest entry (observed ~3e-3; the rounding of
-    B^T X B and A dY A^T is not restated on the CPU); the accumulating form (dW += ...) is checked on top."""
+    """mt_conv3d_t.mma = 1 with FP32 storage on both sides (the MT_BF16_STORAGE=0 experiment mode): since round 5 these launches take the
+    fp32 backward-weight kernels (the bf16 Winograd marching kernels are gone; 16-bit storage is served by conv_bwdw_tr16_kernel,
+    tests/test_storage_bf16_gpu.py::test_bwdw_tr16_vs_host).  Against autograd, the accumulating form (dW += ...) on top."""
     ops = _ops()
     g = torch.Generator().manual_seed(14)
     N = 2
@@ -443,12 +443,12 @@ def test_conv_bwd_weight_bf16_mixed_precision(dev, Cin, Cout, shape, lazy):
     torch.cuda.synchronize()
     got = dw.cpu() - base
     err = relerr(got, w.grad)
-    assert 1e-5 < err < 1e-2, err          # > 1e-5: the bf16 kernel really ran (the fp32 kernels reach 2e-5 only on other shapes)
+    assert err < 1e-4, err
 
 
 @pytest.mark.parametrize("Cin,Cout,shape", [(30, 30, (5, 9, 37)), (32, 64, (3, 8, 40)), (16, 30, (1, 6, 20))])
 def test_conv_bwd_weight_bf16_1x3x3(dev, Cin, Cout, shape):
-    """conv_bwdw_wino_bf16_kernel<1>: 1x3x3 weight gradient (residual encoder stage 0) vs autograd, 1e-2 of the largest entry."""
+    """1x3x3 weight gradient (residual encoder stage 0) with mma = 1 and fp32 storage: the fp32 tiled kernel since round 5; vs autograd."""
     ops = _ops()
     g = torch.Generator().manual_seed(15)
     N = 2
@@ -465,7 +465,7 @@ def test_conv_bwd_weight_bf16_1x3x3(dev, Cin, Cout, shape):
     ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
     torch.cuda.synchronize()
     err = relerr(dw.cpu(), w.grad)
-    assert 1e-5 < err < 1e-2, err
+    assert err < 1e-4, err
 
 
 @pytest.mark.parametrize("Cin,Cout,base,so,extra", [
@@ -599,19 +599,15 @@ def test_ds_label_pyramid_on_device(dev):
     (2, 20, 16, (8, 8, 32), False),         # odd chunk count (8,8,4): the persistent kernel's pairs end in a phantom chunk
     (1, 24, 32, (6, 9, 20), True),          # 3 + 3 chunks: the middle pair straddles the two sources
 ])
-@pytest.mark.parametrize("waves", [8, 4, 803, 800, 810, 813])
+@pytest.mark.parametrize("waves", [8, 803])
 def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
-    """conv_wino_kernel (3D Winograd F(2x2x2,3x3x3)) forced on small shapes: forward with lazy inputs + statistics, and the
+    """conv_wino8p_kernel (3D Winograd F(2x2x2,3x3x3)) forced on small shapes: forward with lazy inputs + statistics, and the
     flipped-weight backward-data form with two destinations; vs F.conv3d / autograd (tolerance 1e-5: +-1 and 1/2 transforms)."""
     ops = _ops()
     ops.set_option('conv_wino', 2)
-    # 8: the persistent wave-specialised kernel (default: one worker per CU, here one tile each), 803: the same with only 3 workers per
-    # output-channel tile (every worker walks over several tiles: cross-tile pipeline, ragged last iteration), 800: the one-tile-per-
-    # workgroup 8-wave kernel, 4: the four-wave kernel
-    # 810 / 813: the persistent kernel with LDS-DMA patch staging (conv_wino8d_kernel), one tile per worker / three workers
-    ops.set_option('wino_waves', 8 if waves >= 8 else 4)
-    ops.set_option('wino_persist', {8: 1, 803: 3, 800: 0, 4: 1, 810: 1, 813: 3}[waves])
-    ops.set_option('wino_dma', 1 if waves in (810, 813) else 0)
+    # 8: one worker per CU (here one tile each), 803: only 3 workers per output-channel tile (every worker walks over several tiles:
+    # cross-tile pipeline, ragged last iteration)
+    ops.set_option('wino_persist', {8: 1, 803: 3}[waves])
     try:
         g = torch.Generator().manual_seed(21)
         srcs = [torch.randn((N, Cin) + shape, generator=g)]
@@ -653,9 +649,7 @@ def test_conv_winograd(dev, N, Cin, Cout, shape, two_src, waves):
         assert relerr(to_ncdhw(got), x.grad) < 1e-5
     finally:
         ops.set_option('conv_wino', 1)
-        ops.set_option('wino_waves', 8)
         ops.set_option('wino_persist', 1)
-        ops.set_option('wino_dma', -1)
 
 
 @pytest.mark.parametrize("N,Cin,Cout,shape,two_src", [
@@ -916,10 +910,10 @@ def test_device_probe_and_per_device_setup(dev):
     assert _lib._probed[0] == arch
 
 
-@pytest.mark.parametrize("Wi,kernel", [(522, 'conv_wino8p_kernel'), (524, 'conv_wino8_kernel')])
+@pytest.mark.parametrize("Wi,kernel", [(522, 'conv_wino8p_kernel'), (524, 'conv_fast_kernel')])
 def test_winograd_plane_near_the_packed_offset_limit(dev, Wi, kernel):
     """Persistent Winograd kernel: a task's linear offset (ld*Hi + lh)*Wi + lw (ld, lh <= 5, lw <= 17) is packed into 20 bits.
-    Hi = 400: Wi = 522 is the largest even width that fits ((5*400+5)*522+17 < 2^20), Wi = 524 must run the one-tile-per-workgroup
+    Hi = 400: Wi = 522 is the largest even width that fits ((5*400+5)*522+17 < 2^20), Wi = 524 must take a direct
     kernel (the old guard 5*Hi*Wi < 2^20 let it through and the offset spilled into the ld bits).  Both against F.conv3d."""
     ops = _ops()
     Hi, D, cin, cout = 400, 4, 16, 32
@@ -931,7 +925,7 @@ def test_winograd_plane_near_the_packed_offset_limit(dev, Wi, kernel):
     try:
         xa = ops.Act(to_ndhwc(x).to(dev))
         p = ops.fill_conv([xa], ops.ConvGeom((D, Hi, Wi), (3, 3, 3), (1, 1, 1), (1, 1, 1)), cout)
-        assert ops.conv_kernel_name(p) == kernel, ops.conv_kernel_name(p)
+        assert ops.conv_kernel_name(p).startswith(kernel), ops.conv_kernel_name(p)
         out, _ = run_conv(dev, [x], w, b, (1, 1, 1), (1, 1, 1))
         ref = F.conv3d(x, w, b, padding=1)
         assert relerr(to_ncdhw(out.cpu()), ref) < 2e-5

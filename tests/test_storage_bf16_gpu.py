@@ -193,12 +193,9 @@ def _conv_pair(dev, srcs, lazy, w, bias, geom, split=None, accumulate=False, sta
     (32, 60, (8, 16, 64), (3, 3, 3), False, 30, True),             # backward-data shape: two destinations, accumulate
     (64, 64, (8, 16, 32), (3, 3, 3), False, None, True),
 ])
-@pytest.mark.parametrize("persist", [0, 1])
-def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, split, acc, persist):
-    """persist = 1: conv_bf16p_kernel (the opt-in persistent wave-specialised form) serves the 16-bit launch"""
+def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, split, acc):
     ops = _ops()
     ops.set_option('conv_bf16', 2)
-    ops.set_option('bf16_persist', persist)
     try:
         g = torch.Generator().manual_seed(5)
         N = 2
@@ -213,7 +210,7 @@ def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, s
         w = torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))
         b = torch.randn(Cout, generator=g)
         f32, b16, names = _conv_pair(dev, srcs, lazy, w, b, geom, split=split, accumulate=acc, stats=not acc)
-        assert names[0].startswith('conv_bf16_kernel') and names[1].startswith('conv_bf16p_kernel' if (persist and names[0].startswith('conv_bf16_kernel<32, 4, 4,')) else 'conv_bf16_kernel'), names      # (the persistent form exists for the 4x4x32 tile)
+        assert names[0].startswith('conv_bf16_kernel') and names[1].startswith('conv_bf16_kernel'), names
         assert b16[0].dtype == torch.bfloat16
         assert torch.equal(b16[0], f32[0].to(torch.bfloat16)), float((b16[0].float() - f32[0]).abs().max())
         if split is not None:
@@ -226,7 +223,6 @@ def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, s
             assert torch.allclose(s[..., 1], (o * o).sum((1, 2, 3)), rtol=1e-4)
     finally:
         ops.set_option('conv_bf16', 1)
-        ops.set_option('bf16_persist', 0)
 
 
 def _host_conv_16(srcs, lazy, w, b, stride, pad, dt):
@@ -385,37 +381,6 @@ def test_strided_stage_conv_bf16_storage_bitexact(dev, Cin, Cout, shape, stride,
                 dt, int(bad.sum()), idx[:, 1].unique().tolist()[:12], idx[:, 2].unique().tolist()[:20], idx[:, 3].unique().tolist()[:40], idx[:, 4].unique().tolist()[:40]))
     assert torch.equal(res[torch.bfloat16], res[torch.float32].to(torch.bfloat16)), \
         float((res[torch.bfloat16].float() - res[torch.float32]).abs().max())
-
-
-@pytest.mark.parametrize("Cin,Cout,shape,k", [(32, 32, (6, 12, 64), (3, 3, 3)), (30, 60, (5, 10, 40), (3, 3, 3)), (30, 30, (4, 12, 64), (1, 3, 3))])
-@pytest.mark.parametrize("xb,yb", [(torch.float16, True), (torch.bfloat16, True), (torch.float16, False), (None, True)])
-def test_bwdw_wino_bf16_storage_bitexact(dev, Cin, Cout, shape, k, xb, yb):
-    ops = _ops()
-    g = torch.Generator().manual_seed(8)
-    N = 2
-    pad = tuple((kk - 1) // 2 for kk in k)
-    geom = ops.ConvGeom(shape, k, (1, 1, 1), pad)
-    x = rbf(torch.randn((N,) + shape + (Cin,), generator=g), xb if xb is not None else torch.bfloat16)
-    sc, sh = torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g)
-    dy = rbf(torch.randn((N,) + shape + (Cout,), generator=g))
-    res = []
-    ops.set_option('bwdw_tr16', 0)          # (16-bit X with bf16 dY is served by conv_bwdw_tr16_kernel by default: test_bwdw_tr16_vs_host)
-    try:
-        for xdt, ydt in ((torch.float32, torch.float32), (xb if xb is not None else torch.float32, torch.bfloat16 if yb else torch.float32)):
-            a = ops.Act(x.to(dev).to(xdt), scale=sc.to(dev), shift=sh.to(dev), slope=0.01)
-            y = ops.Act(dy.to(dev).to(ydt))
-            p = ops.fill_conv([a], geom, Cout, mma=1)
-            assert ops.conv_bwd_weight_io_supported(p, y)
-            assert ops.conv_bwd_weight_kernel_name(p, y).startswith('conv_bwdw_wino_bf16'), ops.conv_bwd_weight_kernel_name(p, y)
-            dw = torch.full((Cout, Cin) + k, float('nan'), device=dev)
-            ws = torch.empty(ops.conv3d_bwd_weight_workspace(p) // 4 + 16, device=dev)
-            ops.conv3d_bwd_weight(p, y, dw, ops.conv_weight_strides(dw), False, ws)
-            torch.cuda.synchronize()
-            res.append(dw)
-    finally:
-        ops.set_option('bwdw_tr16', 1)
-    assert torch.isfinite(res[1]).all()
-    assert torch.equal(res[0], res[1]), float((res[0] - res[1]).abs().max())
 
 
 def _bwdw_host(xs, dy, k, pad):
