@@ -44,6 +44,9 @@ __device__ __forceinline__ int mt_xcd_remap(int bid, int nblk) {
 // wait (s_waitcnt vmcnt) and fence themselves.
 typedef __attribute__((ext_vector_type(4))) int mt_i32x4;
 __device__ __forceinline__ void mt_lds_dma16(mt_i32x4 rsrc, int voff, unsigned lds_addr) {
+  // (descriptor and LDS address must be wave-uniform: forced into scalar registers)
+  rsrc = mt_i32x4{__builtin_amdgcn_readfirstlane(rsrc[0]), __builtin_amdgcn_readfirstlane(rsrc[1]), __builtin_amdgcn_readfirstlane(rsrc[2]), __builtin_amdgcn_readfirstlane(rsrc[3])};
+  lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
 }
 
