@@ -338,6 +338,21 @@ int mt_softmax_dice_ce_fwd(const float* logits, int cs, const float* target, int
 int mt_softmax_dice_ce_bwd(const float* logits, int cs, const float* target, int B, long V, int C,
                            const float* gstats /* [B][C][4], slot (b,0,0) = dLoss/dce_sum[b] */,
                            float* dlogits, int dcs, mt_stream_t stream);
+/* The loss combination on top of the per-level statistics, value and gradient in one launch (the reference forms it with a few
+ * dozen autograd operations on [B, C] tensors: MultiTalent_Trainer_DDP.py:598-623; dice_loss.py:150-183 + deep_supervision.py:37-42;
+ * nnUNetTrainerV2_DDP.py:262-282).  stats [L][B][C][4] as written by the *_fwd calls of the L levels; dice [L][B][C][dice_stride] =
+ * (tp, fp, fn, ...) the Dice ratios are formed from: stats + 1 with stride 4, or the sum of the statistics over ranks with stride 3.
+ *   loss = sum_l ce_coef[l] * sum_{b, c in CE set} stats[l,b,c,0]  -  sum_l dice_coef[l] * sum_entries r,
+ *   r = (2 tp + smooth_num) / max(2 tp + fp + fn + smooth_den + den_eps, clamp_min)   over channels c >= c0,
+ * flags: MT_LOSS_CE_ALL_CHANNELS (else channel 0 carries the level's CE sum), MT_LOSS_DICE_OVER_BATCH (tp / fp / fn summed over b
+ * before the ratio).  ce_coef, dice_coef: device vectors [L].  out3 = (loss, CE part, Dice part); gstats [L][B][C][4] =
+ * dLoss/d(local stats), the argument of the *_bwd calls; its Dice part is multiplied by dice_grad_scale (the world size when `dice`
+ * is the sum over ranks: the backward of the reference's all-gather sums the ranks' identical gradients, distributed.py:63-73). */
+#define MT_LOSS_CE_ALL_CHANNELS 1
+#define MT_LOSS_DICE_OVER_BATCH 2
+int mt_loss_combine(const float* stats, const float* dice, int dice_stride, int L, int B, int C, const float* ce_coef,
+                    const float* dice_coef, int flags, int c0, float smooth_num, float smooth_den, float den_eps, float clamp_min,
+                    float dice_grad_scale, float* out3, float* gstats, mt_stream_t stream);
 
 /* ---- optimizer (nnUNetTrainerV2.py:166-170; clip MultiTalent_Trainer_DDP.py:352,362) --------- */
 int mt_sumsq(const float* x, long n, float* out /* [1], overwritten */, void* ws, size_t ws_bytes,

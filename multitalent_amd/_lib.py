@@ -115,6 +115,7 @@ SIGNATURES = {
     'mt_hard_stats_workspace': (_sz, [_i, _i]),
     'mt_softmax_dice_ce_fwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _sz, _vp]),
     'mt_softmax_dice_ce_bwd': (_i, [_vp, _i, _vp, _i, _l, _i, _vp, _vp, _i, _vp]),
+    'mt_loss_combine': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
     'mt_sumsq': (_i, [_vp, _l, _vp, _vp, _sz, _vp]),
     'mt_sumsq_workspace': (_sz, [_l]),
     'mt_sgd_nesterov': (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _vp, _f, _vp]),

@@ -584,3 +584,73 @@ extern "C" int mt_softmax_dice_ce_bwd(const float* logits, int cs, const float* 
   MT_CHECK_LAUNCH("softmax_dice_ce_bwd");
   return MT_OK;
 }
+
+// ---- the few-hundred-float loss combination on top of the statistics, forward AND backward in one launch ---------------------
+// loss = sum_l ( ce_coef[l] * sum_{(b,c) in CE set} stats[l,b,c,0]  -  dice_coef[l] * sum_{entries} r ),
+// r = (2 tp + smooth_num) / max(2 tp + fp + fn + smooth_den + den_eps, clamp_min), over the channels c >= c0; with
+// MT_LOSS_DICE_OVER_BATCH the statistics are summed over b before the ratio (batch_dice of dice_loss.py:150-160).  Covers
+// MultiTalent_Trainer_DDP.py:598-623 (clamp 1e-7, no smooth, every (b, c) entry), dice_loss.py:180-183 + deep_supervision.py:37-42
+// and nnUNetTrainerV2_DDP.py:262-282.  `dice` = the statistics the ratios are formed from ([L][B][C][dice_stride], tp/fp/fn first):
+// the local ones (stats + 1, stride 4) or their sum over ranks (stride 3); gstats = dLoss/d(local stats), what the per-level
+// backward kernels take; gscale multiplies the Dice part of it (the world size when `dice` is the sum over ranks: the reference's
+// all-gather sums the ranks' identical gradients in its backward, distributed.py:63-73).  One workgroup: L * B * C <= a few thousand entries.
+__global__ __launch_bounds__(256) void loss_combine_kernel(const float* __restrict__ stats, const float* __restrict__ dice, int ds,
+                                                           int L, int B, int C, const float* __restrict__ ce_coef,
+                                                           const float* __restrict__ dice_coef, int flags, int c0,
+                                                           float sn, float sd, float eps, float clamp_min, float gscale,
+                                                           float* __restrict__ out3, float* __restrict__ gstats) {
+  __shared__ double red[2][256];
+  const int tid = threadIdx.x;
+  const bool all_c = flags & 1, over_b = flags & 2;
+  double ce = 0.0, dc = 0.0;
+  const int nE = L * B * C;
+  for (int e = tid; e < nE; e += 256) {
+    const int l = e / (B * C), c = e % C;
+    const bool in = all_c || c == 0;
+    const float k = in ? ce_coef[l] : 0.f;
+    gstats[(long)e * 4] = k;
+    if (in) ce += (double)k * (double)stats[(long)e * 4];
+    if (c < c0) { gstats[(long)e * 4 + 1] = 0.f; gstats[(long)e * 4 + 2] = 0.f; gstats[(long)e * 4 + 3] = 0.f; }
+  }
+  const int nb = over_b ? B : 1, Bo = over_b ? 1 : B, Cd = C - c0;
+  const int nI = L * Bo * Cd;
+  for (int i = tid; i < nI; i += 256) {
+    const int l = i / (Bo * Cd), bo = (i / Cd) % Bo, c = c0 + i % Cd;
+    float T = 0.f, F = 0.f, N = 0.f;
+    for (int b = 0; b < nb; ++b) {
+      const float* p = dice + ((long)(l * B + bo + b) * C + c) * ds;
+      T += p[0]; F += p[1]; N += p[2];
+    }
+    const float num = 2.f * T + sn;
+    const float raw = 2.f * T + F + N + sd + eps;
+    const bool pass = raw >= clamp_min;
+    const float den = pass ? raw : clamp_min;
+    const float inv = 1.f / den;
+    const float k = dice_coef[l];
+    dc += (double)k * (double)(num * inv);
+    const float gden = pass ? -num * inv * inv : 0.f;
+    const float gT = -k * gscale * (2.f * inv + 2.f * gden), gF = -k * gscale * gden;
+    for (int b = 0; b < nb; ++b) {
+      float* g = gstats + ((long)(l * B + bo + b) * C + c) * 4;
+      g[1] = gT; g[2] = gF; g[3] = gF;
+    }
+  }
+  red[0][tid] = ce; red[1][tid] = dc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { out3[0] = (float)(red[0][0] - red[1][0]); out3[1] = (float)red[0][0]; out3[2] = (float)red[1][0]; }
+}
+
+extern "C" int mt_loss_combine(const float* stats, const float* dice, int dice_stride, int L, int B, int C, const float* ce_coef,
+                               const float* dice_coef, int flags, int c0, float smooth_num, float smooth_den, float den_eps,
+                               float clamp_min, float dice_grad_scale, float* out3, float* gstats, mt_stream_t stream) {
+  MT_REQUIRE(stats && dice && ce_coef && dice_coef && out3 && gstats && L > 0 && B > 0 && C > 0 && c0 >= 0 && c0 < C && dice_stride >= 3,
+             "loss_combine: bad args");
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, dice, dice_stride, L, B, C, ce_coef, dice_coef,
+                     flags, c0, smooth_num, smooth_den, den_eps, clamp_min, dice_grad_scale, out3, gstats);
+  MT_CHECK_LAUNCH("loss_combine");
+  return MT_OK;
+}

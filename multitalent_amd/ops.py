@@ -497,6 +497,17 @@ def softmax_dice_ce_bwd(logits, target, gstats, dlogits):
                                                   C.c_void_p(dlogits.data_ptr()), dlogits.cs, _stream()), 'softmax_dice_ce_bwd')
 
 
+LOSS_CE_ALL_CHANNELS, LOSS_DICE_OVER_BATCH = 1, 2
+
+
+def loss_combine(stats, dice, dice_stride, ce_coef, dice_coef, flags, c0, smooth_num, smooth_den, den_eps, clamp_min, out3, gstats, dice_grad_scale=1.0):
+    """stats / gstats [L, B, C, 4]; dice = data pointer tensor of the (tp, fp, fn) the ratios are formed from (see mtseg.h)."""
+    L, B, Cn = stats.shape[:3]
+    _lib.check(_lib.load().mt_loss_combine(_ptr(stats), C.c_void_p(dice.data_ptr()), int(dice_stride), L, B, Cn, _ptr(ce_coef),
+                                           _ptr(dice_coef), int(flags), int(c0), float(smooth_num), float(smooth_den), float(den_eps),
+                                           float(clamp_min), float(dice_grad_scale), _ptr(out3), _ptr(gstats), _stream()), 'loss_combine')
+
+
 def sumsq(x, out, ws):
     _lib.check(_lib.load().mt_sumsq(_ptr(x), x.numel(), _ptr(out), _ptr(ws), ws.numel() * ws.element_size(), _stream()), 'sumsq')
 

@@ -14,6 +14,19 @@ def _active():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def active():
+    return _active()
+
+
+def world_size():
+    return dist.get_world_size() if _active() else 1
+
+
+def all_reduce_sum(t):
+    """Plain (no autograd) in-place SUM over ranks: the fused loss step's exchange of the Dice statistics."""
+    return _all_reduce_sum(t)
+
+
 def _all_reduce_sum(t):
     """in-place SUM over ranks of a small tensor.  RCCL ('nccl') reduces device tensors directly; under gloo (CPU tests, or two
     ranks sharing one GPU in the single-GPU test box) a device tensor travels through the host — transport only, a few KB."""

@@ -2,8 +2,11 @@
 forward -> loss -> backward (+ DDP gradient all-reduce overlapped with backward) -> clip_grad_norm_(12) ->
 SGD-Nesterov step, all on the HIP engine with flat parameter / gradient / momentum buffers.
 
-The network forward/backward bypass torch autograd entirely (engine.forward / engine.backward); autograd is only
-used for the few-hundred-float loss combination on top of the fused statistics kernels."""
+The network forward/backward bypass torch autograd entirely (engine.forward / engine.backward), and so does the loss when it offers
+`fused_step` (statistics kernels -> mt_loss_combine -> backward kernels); autograd only runs for a loss callable without it or for
+the cases `fused_step` declines (few-hundred-float combination on top of the fused statistics kernels)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -139,6 +142,7 @@ class FusedTrainStep:
         self.ws = None
         self.reducer = GradAllReducer(self.eng) if ddp else None
         self.head_params, self.head_opt = None, None
+        self.fused_loss = os.environ.get('MT_FUSED_LOSS', '1') != '0'      # 0: always the autograd form of the loss (A/B, tests)
         self.last_logits = None      # full-resolution logits (NCDHW view of the engine's NDHWC buffer) of the latest forward
 
     def set_head_optimizer(self, params, lr=3e-3, weight_decay=3e-5):
@@ -177,12 +181,14 @@ class FusedTrainStep:
             self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
             self.ws = torch.empty(ops.sumsq_workspace(self.eng.flat.numel()) // 4 + 16, dtype=torch.float32, device=dev)
 
-    def forward_loss(self, data, loss_args):
-        eng = self.eng
-        outs = eng.forward(data, need_grad=True, all_heads=True)
+    def _loss_on(self, outs, loss_args):
         leaves = [o.permute(0, 4, 1, 2, 3).requires_grad_(True) for o in outs]
         res = self.loss_fn(leaves, *loss_args)
         return leaves, res
+
+    def forward_loss(self, data, loss_args):
+        """Forward + the loss in its autograd form (any callable with the reference's compute_loss signature)."""
+        return self._loss_on(self.eng.forward(data, need_grad=True, all_heads=True), loss_args)
 
     def __call__(self, data, *loss_args, do_backprop=True):
         """Returns whatever loss_fn returns (loss first if a tuple), detached device tensors (no host sync)."""
@@ -193,11 +199,19 @@ class FusedTrainStep:
                 res = self.loss_fn([o.permute(0, 4, 1, 2, 3) for o in outs], *loss_args)
                 self.last_logits = outs[0].permute(0, 4, 1, 2, 3)       # online evaluation reads THIS forward's output, like the reference
             return res
-        leaves, res = self.forward_loss(data, loss_args)
-        self.last_logits = leaves[0].detach()
-        loss = res[0] if isinstance(res, (tuple, list)) else res
-        loss.backward()
-        dl = [None if l.grad is None else l.grad.permute(0, 2, 3, 4, 1).contiguous() for l in leaves]
+        outs = eng.forward(data, need_grad=True, all_heads=True)
+        # value + dLoss/dlogits straight from the loss kernels (mt_loss_combine) when the loss offers it: no autograd graph over
+        # the [L, B, C] glue; None = a case only the autograd form covers
+        fused = self.loss_fn.fused_step(outs, *loss_args) if self.fused_loss and hasattr(self.loss_fn, 'fused_step') else None
+        if fused is not None:
+            res, dl = fused
+            self.last_logits = outs[0].permute(0, 4, 1, 2, 3)
+        else:
+            leaves, res = self._loss_on(outs, loss_args)
+            self.last_logits = leaves[0].detach()
+            loss = res[0] if isinstance(res, (tuple, list)) else res
+            loss.backward()
+            dl = [None if l.grad is None else l.grad.permute(0, 2, 3, 4, 1).contiguous() for l in leaves]
         if self.reducer is not None:
             self.reducer.begin()
             eng.grad_ready_hook = self.reducer.ready

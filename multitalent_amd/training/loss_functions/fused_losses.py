@@ -162,6 +162,38 @@ class MultiTalentLoss(nn.Module):
         return total_ce - total_dc, total_ce, total_dc
 
 
+    def fused_step(self, outs, target, valid_regions):
+        """Value AND dLoss/dlogits of `forward` without autograd (the training step's path): per level one statistics pass, ONE
+        combination launch (mt_loss_combine: value + gradient of the [L, B, C] arithmetic the reference spells as ~40 autograd
+        operations), per level one backward pass.  outs = the engine's NDHWC logits of every level.
+        Returns ((total, ce, dc), [dlogits NDHWC])."""
+        dev = outs[0].device
+        valid, lut = self._masks(valid_regions, dev)
+        acts = [Act(o) for o in outs]
+        L, B, Cn = len(acts), acts[0].N, acts[0].C
+        st = torch.empty((L, B, Cn, 4), dtype=torch.float32, device=dev)
+        tg = []
+        for i, a in enumerate(acts):
+            t = _target_flat(target[i])
+            tg.append(t)
+            ops.multitalent_loss_fwd(a, t, valid, lut, st[i], _workspace(dev, ops.loss_workspace(a.N, a.V, a.C)))
+        dice, stride, gscale = st.view(-1)[1:], 4, 1.0
+        if self.batch_dice and distributed_utils.active():
+            dice, stride = distributed_utils.all_reduce_sum(st[..., 1:].contiguous()), 3
+            gscale = float(distributed_utils.world_size())
+        w = _const(self.ds_loss_weights[:L], dev)
+        ce_coef = _const([self.ds_loss_weights[i] / tg[i].shape[1] for i in range(L)], dev)
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        g = torch.empty_like(st)
+        ops.loss_combine(st, dice, stride, ce_coef, w, ops.LOSS_CE_ALL_CHANNELS, 0, 0.0, 0.0, 0.0, 1e-7, out3, g, dice_grad_scale=gscale)
+        dl = []
+        for i, a in enumerate(acts):
+            d = torch.empty_like(outs[i])
+            ops.multitalent_loss_bwd(a, tg[i], valid, lut, g[i], Act(d))
+            dl.append(d)
+        return (out3[0], out3[1], out3[2]), dl
+
+
 class DC_and_CE_DS_loss(nn.Module):
     """MultipleOutputLoss2(DC_and_CE_loss({'batch_dice', 'smooth': 1e-5, 'do_bg': False}, {}), weights)
     (nnUNetTrainer.py:108, nnUNetTrainerV2.py:78-90) fused per level.  `ddp=True` reproduces
@@ -229,3 +261,35 @@ class DC_and_CE_DS_loss(nn.Module):
         else:
             dc = ((2 * tp + self.smooth) / (2 * tp + fp + fn + self.smooth + 1e-8)).mean((1, 2))
         return (w * (ce - dc)).sum()
+
+    def fused_step(self, outs, target):
+        """As MultiTalentLoss.fused_step.  Returns None where the autograd form has to run: levels of different (B, C), or the DDP
+        variant's batch Dice over ranks (numerator / denominator gathered, nnUNetTrainerV2_DDP.py:267-270)."""
+        active = [i for i in range(len(outs)) if i == 0 or self.ds_loss_weights[i] != 0]
+        acts = {i: Act(outs[i]) for i in active}
+        if len({(a.N, a.C) for a in acts.values()}) != 1 or (self.ddp and self.batch_dice and distributed_utils.active()):
+            return None
+        dev = outs[0].device
+        a0 = acts[active[0]]
+        L, B, Cn = len(active), a0.N, a0.C
+        st = torch.empty((L, B, Cn, 4), dtype=torch.float32, device=dev)
+        tg = {}
+        for k, i in enumerate(active):
+            t = _target_flat(target[i])
+            tg[i] = t
+            ops.softmax_dice_ce_fwd(acts[i], t, st[k], _workspace(dev, ops.loss_workspace(B, acts[i].V, Cn)))
+        c0 = 0 if self.do_bg else 1
+        over_b = self.batch_dice and not self.ddp                  # nnUNetTrainerV2_DDP.compute_loss keeps [B, C-1] entries
+        count = (Cn - c0) * (1 if over_b else B)
+        ce_coef = _const([self.ds_loss_weights[i] / (B * tg[i].shape[1]) for i in active], dev)
+        dice_coef = _const([self.ds_loss_weights[i] / count for i in active], dev)
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        g = torch.empty_like(st)
+        ops.loss_combine(st, st.view(-1)[1:], 4, ce_coef, dice_coef, ops.LOSS_DICE_OVER_BATCH if over_b else 0, c0, self.smooth,
+                         self.smooth, 0.0 if self.ddp else 1e-8, -3.0e38, out3, g)
+        dl = [None] * len(outs)
+        for k, i in enumerate(active):
+            d = torch.empty_like(outs[i])
+            ops.softmax_dice_ce_bwd(acts[i], tg[i], g[k], Act(d))
+            dl[i] = d
+        return out3[0], dl
