@@ -3889,6 +3889,14 @@ static bool bwdw_use_march(const mt_conv3d_t* p) {
 }
 static void bwdw_march_plan(const mt_conv3d_t* p, BwdWParams* P);
 static int conv_fast_vec(const mt_conv3d_t* p);
+// the same kernel with KD = 1: the 1x3x3 stride-1 layers of the residual encoder's first stage (no depth halo, any Do)
+static bool bwdw_use_wino133(const mt_conv3d_t* p) {
+  if (g_bwdw_wino < 0) { const char* e = getenv("MT_BWDW_WINO"); g_bwdw_wino = e ? atoi(e) : 1; }
+  for (int i = 0; i < p->nsrc; ++i)
+    if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
+  return g_bwdw_wino && p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 0 && p->PH == 1 &&
+         p->PW == 1 && p->Wo > 16 && p->Ho >= 2 && conv_fast_vec(p) == 2 && conv_src_dtype(p) == MT_F32;
+}
 static bool bwdw_use_wino(const mt_conv3d_t* p) {
   if (g_bwdw_wino < 0) { const char* e = getenv("MT_BWDW_WINO"); g_bwdw_wino = e ? atoi(e) : 1; }
   // (its X path applies LeakyReLU as max(t, slope * t): lazy sources need 0 <= slope <= 1)
@@ -3954,7 +3962,7 @@ static int bwdw_fast_cw(const mt_conv3d_t* p, int ntiles_total, int nchunks) {
   return cw;
 }
 // plan for the fast kernel: tile 1 x TH x TW with (TH,TW) = (4,32) or (8,16)
-static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = false) {
+static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = false, bool f32_both = false) {
   const bool wide = p->Wo > 16;
   P->TD = 1; P->TH = wide ? 4 : 8; P->TW = wide ? 32 : 16;
   P->tilesD = p->Do; P->tilesH = mt_cdiv(p->Ho, P->TH); P->tilesW = mt_cdiv(p->Wo, P->TW);
@@ -3964,21 +3972,27 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = 
   P->ncot = mt_cdiv(p->Cout, 32);
   P->cw = allow_cw ? bwdw_fast_cw(p, P->ntiles_total, P->nchunks) : 1;
   // fp32 Winograd marching kernel: two cout tiles per workgroup where the cout tiles pair up and a workgroup still gets >= 12 planes
-  if (allow_cw && bwdw_use_wino(p) && conv_src_dtype(p) == MT_F32) {
+  if (allow_cw && (bwdw_use_wino(p) || (f32_both && bwdw_use_wino133(p))) && conv_src_dtype(p) == MT_F32) {
     if (g_bwdw_cw < 0) { const char* e = getenv("MT_BWDW_CW"); g_bwdw_cw = e ? atoi(e) : 4; }
     const long planes = (long)p->N * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 32) * p->Do;
+    P->cw = 1;                              // (bwdw_fast_cw answers for conv_bwdw_fast_kernel)
     if ((g_bwdw_cw % 100) >= 2 && P->ncot % 2 == 0 && (g_bwdw_cw >= 100 || planes * P->nchunks * (P->ncot / 2) >= 3072)) P->cw = 2;
   }
   int pairs = P->nchunks * mt_cdiv(P->ncot, P->cw); if (pairs < 1) pairs = 1;
   int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
   // conv_bwdw_fast16_kernel with few taps (transposed-conv weights, 1x1x1): <= 180 registers and <= 49 KiB of LDS — two workgroups per CU
   if (p->mma == 1 && p->src[0].dtype != MT_F32 && P->ntaps <= 8 && !bwdw_use_march(p)) nsg = (512 + pairs - 1) / pairs;
+  if (allow_cw && f32_both && bwdw_use_wino133(p)) nsg = (512 + pairs - 1) / pairs;       // conv_bwdw_wino_kernel<2, CW, 1>: 64 KiB of LDS, two per CU
   P->nsg_cap = nsg;
   if (nsg > P->ntiles_total) nsg = P->ntiles_total;
   if (nsg < 1) nsg = 1;
   P->nsg = nsg;
   P->nunits = 0; P->nseg = 1; P->dseg = p->Do;
   if (bwdw_march16_geo(p)) bwdw_march_plan(p, P);      // conv_bwdw_march16_kernel: columns x D segments (tile 4 x 32: Wo > 16)
+  if (allow_cw && f32_both && bwdw_use_wino133(p)) {   // conv_bwdw_wino_kernel<2, CW, 1>: columns x D segments
+    P->TH = 4; P->TW = 32; P->tilesH = mt_cdiv(p->Ho, 4); P->tilesW = mt_cdiv(p->Wo, 32); P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N;
+    bwdw_march_plan(p, P);
+  }
   if (bwdw_use_march(p)) {
     static int tall = -1;
     if (tall < 0) { const char* e = getenv("MT_BWDW_TALL"); tall = e ? atoi(e) : 1; }
@@ -4032,6 +4046,33 @@ static int launch_bwdw_march(const BwdWParams& P, int vec, int yv, hipStream_t s
 #undef MT_BW_LAUNCH_T
 #undef MT_BW_LAUNCH
   MT_CHECK_LAUNCH("conv_bwdw_march");
+  return MT_OK;
+}
+
+// conv_bwdw_wino_kernel<2, CW, KD>: one or two cout tiles per workgroup (BwdWParams::cw), KD = 3 | 1
+template <int KD>
+static int launch_bwdw_wino(const BwdWParams& P, hipStream_t st) {
+  const size_t ldsb = (size_t)BWW_LDS_FLOATS * sizeof(float) / (KD == 3 ? 1 : 2);      // ring of 4 (KD = 3) / 2 (KD = 1) planes
+  const int devid = mt_current_device();
+  MT_REQUIRE(P.cw == 1 || P.cw == 2, "bwd_weight: %d cout tiles per workgroup in the Winograd kernel", P.cw);
+  if (P.cw == 2) {
+    static std::atomic<uint64_t> attr2{0};
+    if (mt_device_pending(attr2, devid)) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv_bwdw_wino_kernel<2, 2, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+      if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
+      mt_mark_device_done(attr2, devid);
+    }
+    hipLaunchKernelGGL((conv_bwdw_wino_kernel<2, 2, KD>), dim3(P.nsg, P.ncot / 2, P.nchunks), dim3(256), ldsb, st, P);
+  } else {
+    static std::atomic<uint64_t> attr{0};
+    if (mt_device_pending(attr, devid)) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv_bwdw_wino_kernel<2, 1, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+      if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
+      mt_mark_device_done(attr, devid);
+    }
+    hipLaunchKernelGGL((conv_bwdw_wino_kernel<2, 1, KD>), dim3(P.nsg, P.ncot, P.nchunks), dim3(256), ldsb, st, P);
+  }
+  MT_CHECK_LAUNCH("conv_bwdw_wino");
   return MT_OK;
 }
 
@@ -4123,7 +4164,7 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
   size_t generic = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
   {
     for (int cwp = 0; cwp < 2; ++cwp) {          // with and without several cout tiles per workgroup (decided with dY's type at launch)
-      BwdWParams F; bwdw_fast_plan(p, &F, cwp == 1);
+      BwdWParams F; bwdw_fast_plan(p, &F, cwp == 1, cwp == 1);
       if (F.nchunks > 0) {
         const size_t fast = (size_t)F.nchunks * F.ncot * F.nsg * F.ntaps * 512 * sizeof(float);
         if (fast > generic) generic = fast;
@@ -4161,6 +4202,7 @@ extern "C" int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_s
     else snprintf(buf, n, bwdw_fast16_ok(p, ysrc) ? "conv_bwdw_fast16_kernel<3, 3, 3, 1, 1, 1>" : "conv_bwdw_fast_kernel<3, 3, 3, 1, 1, 1>");
     return MT_OK;
   }
+  if (geo == 6 && bwdw_use_wino133(p) && ysrc->dtype == MT_F32) { snprintf(buf, n, "conv_bwdw_wino_kernel<2, KD = 1>"); return MT_OK; }
   static const char* kGeo[9] = {"", "3, 3, 3, 2, 2, 2", "3, 3, 3, 1, 2, 2", "2, 2, 2, 2, 2, 2", "1, 2, 2, 1, 2, 2", "1, 1, 1, 1, 1, 1",
                                 "1, 3, 3, 1, 1, 1", "1, 1, 1, 2, 2, 2", "1, 1, 1, 1, 2, 2"};
   if (geo > 8) return MT_EINVAL;
@@ -4240,9 +4282,10 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     // several cout tiles per workgroup: conv_bwdw_fast_kernel with fp32 storage on both sides, conv_bwdw_fast16_kernel and its marching form
     const bool cw_ok = (bwdw_fast16_ok(p, ysrc) || (xdt == MT_F32 && ysrc->dtype == MT_F32)) &&
                        !(geo == 0 && bwdw_use_march(p) && !(bwdw_use_wino(p) && xdt == MT_F32 && ysrc->dtype == MT_F32));
+    const bool f32_both = xdt == MT_F32 && ysrc->dtype == MT_F32;
     const bool tr16 = (geo == 0 || geo == 6) && bwdw_use_tr16(p, ysrc);
     if (tr16) bwdw_tr16_plan(p, &P);
-    else bwdw_fast_plan(p, &P, cw_ok);
+    else bwdw_fast_plan(p, &P, cw_ok, f32_both);
     MT_REQUIRE(P.nchunks > 0, "bwd_weight: too many channel chunks");
     const size_t need = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
     if (workspace == nullptr || workspace_bytes < need) { mt_set_error("bwd_weight: workspace %zu < %zu", workspace_bytes, need); return MT_EWORKSPACE; }
@@ -4253,31 +4296,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
     switch (geo) {
       case 0: {
         if (tr16) { rc = mt_launch_bwdw_tr16(P, 3, xdt, st); break; }
-        if (bwdw_use_wino(p)) {
-          const size_t ldsb = (size_t)BWW_LDS_FLOATS * sizeof(float);
-          static std::atomic<uint64_t> attr{0};
-          const int devid = mt_current_device();
-          if (mt_device_pending(attr, devid)) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv_bwdw_wino_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-            if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
-            mt_mark_device_done(attr, devid);
-          }
-          if (P.cw == 2) {
-            static std::atomic<uint64_t> attr2{0};
-            if (mt_device_pending(attr2, devid)) {
-              hipError_t e = hipFuncSetAttribute((const void*)conv_bwdw_wino_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-              if (e != hipSuccess) { mt_set_error("bwd_weight: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return MT_EHIP; }
-              mt_mark_device_done(attr2, devid);
-            }
-            hipLaunchKernelGGL((conv_bwdw_wino_kernel<2, 2>), dim3(P.nsg, P.ncot / 2, P.nchunks), dim3(256), ldsb, st, P);
-          } else {
-            MT_REQUIRE(P.cw == 1, "bwd_weight: %d cout tiles per workgroup in the Winograd kernel", P.cw);
-            hipLaunchKernelGGL((conv_bwdw_wino_kernel<2, 1>), dim3(P.nsg, P.ncot, P.nchunks), dim3(256), ldsb, st, P);
-          }
-          MT_CHECK_LAUNCH("conv_bwdw_wino");
-          rc = MT_OK;
-          break;
-        }
+        if (bwdw_use_wino(p)) { rc = launch_bwdw_wino<3>(P, st); break; }
         const int yv = ((ysrc->cs & 1) || (p->Cout & 1) || (((uintptr_t)ysrc->ptr) & 7)) ? 1 : 2;
         rc = bwdw_use_march(p) ? launch_bwdw_march<3, 3, 1, 1>(P, vec, yv, st) : launch_bwdw_fast<3, 3, 3, 1, 1, 1>(P, vec, st);
         break;
@@ -4291,6 +4310,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
       case 8: rc = launch_bwdw_fast<1, 1, 1, 1, 2, 2>(P, vec, st); break;
       case 6:
         if (tr16) { rc = mt_launch_bwdw_tr16(P, 1, xdt, st); break; }
+        if (cw_ok && f32_both && bwdw_use_wino133(p)) { rc = launch_bwdw_wino<1>(P, st); break; }
         rc = launch_bwdw_fast<1, 3, 3, 1, 1, 1>(P, vec, st);
         break;
     }

@@ -296,6 +296,53 @@ def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
         assert relerr(dw2.cpu(), w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("cins,Cout,shape,lazy", [
+    ((32,), 32, (5, 8, 64), True),           # the residual encoder's stage-0 block: one cout tile, two cin chunks
+    ((32, 32), 32, (3, 9, 40), True),        # decoder concat 64 -> 32: two sources, odd H (half tile), ragged W
+    ((30,), 30, (1, 5, 20), False),          # a single plane, channel tails
+    ((24,), 70, (7, 6, 33), False),          # three cout tiles, more planes than ring slots
+])
+def test_conv_bwd_weight_winograd_1x3x3(dev, cins, Cout, shape, lazy):
+    """conv_bwdw_wino_kernel<2, CW, KD = 1>: F(3x3, 2x2) backward-weight of the 1x3x3 stride-1 convolutions (residual encoder stage 0,
+    generic_modular_residual_UNet.py:69-71) against host autograd and against the direct tiled kernel it replaces (bwdw_wino = 0)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    N, k = 2, (1, 3, 3)
+    xs, acts, hosts = [], [], []
+    for ci in cins:
+        x = torch.randn((N, ci) + shape, generator=g)
+        if lazy:
+            sc, sh = torch.rand((N, ci), generator=g) + 0.5, torch.randn((N, ci), generator=g) * 0.3
+            hosts.append(F.leaky_relu(x * sc[:, :, None, None, None] + sh[:, :, None, None, None], 0.01))
+            acts.append(ops.Act(to_ndhwc(x).to(dev), scale=sc.to(dev), shift=sh.to(dev), slope=0.01))
+        else:
+            hosts.append(x)
+            acts.append(ops.Act(to_ndhwc(x).to(dev)))
+    Cin = sum(cins)
+    w = (torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * 9)).requires_grad_(True)
+    y = F.conv3d(torch.cat(hosts, 1), w, None, stride=1, padding=(0, 1, 1))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    ya = ops.Act(to_ndhwc(dy).to(dev))
+    p = ops.fill_conv(acts, ops.ConvGeom(shape, k, (1, 1, 1), (0, 1, 1)), Cout)
+    assert ops.conv_bwd_weight_kernel_name(p, ya) == 'conv_bwdw_wino_kernel<2, KD = 1>'
+    res = {}
+    try:
+        for mode in (1, 0):
+            ops.set_option('bwdw_wino', mode)
+            ws = torch.full((max(ops.conv3d_bwd_weight_workspace(p) // 4, 1),), float('nan'), device=dev)
+            dw = torch.full(w.shape, float('nan'), device=dev)
+            ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
+            ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), True, ws)       # accumulate: twice the gradient
+            torch.cuda.synchronize()
+            res[mode] = dw.cpu()
+            assert relerr(res[mode], 2 * w.grad) < 2e-5, mode
+    finally:
+        ops.set_option('bwdw_wino', 1)
+    assert ops.conv_bwd_weight_kernel_name(p, ya) == 'conv_bwdw_wino_kernel<2, KD = 1>'
+    assert relerr(res[1], res[0]) < 2e-5
+
+
 @pytest.mark.parametrize("Cin,Cout,shape,k,stride,lazy", [
     (30, 60, (6, 12, 68), (3, 3, 3), (2, 2, 2), False),      # two cout tiles -> 2 per workgroup, tile 4 x 32, ragged in W
     (30, 120, (6, 12, 34), (3, 3, 3), (2, 2, 2), True),      # four -> 4 per workgroup, lazily activated X
