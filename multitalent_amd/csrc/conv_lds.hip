@@ -1039,10 +1039,13 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
 // is 4x shorter and the grid 4x larger; the four accumulator tiles are summed through LDS in a fixed order (deterministic).
 // BF = true (mixed precision): bf16 LDS image and one v_mfma_f32_32x32x16_bf16 per tap instead of eight fp32 MFMAs.
 // XS / OS / MTY (BF only): storage types of the source / destination and the matrix type, as in conv_bf16_kernel.
-template <int VEC, bool BF = false, int XS = MT_F32, int OS = MT_F32, int MTY = MT_BF16>
+// SD / SH / SW (round 5): the same kernel for the strided 3x3x3 stage convs whose standard tiling (conv_fast_strided_kernel, 2x4x8
+// outputs x 64 channels) yields fewer workgroups than the chip has CUs — 240 -> 320 @ 6x24x24 -> 3x12x12 is 120 workgroups of 15
+// chunks x 216 MFMAs, the bottleneck's 320 -> 320 stride (1,2,2) 40 of 20 (generic_UNet.py:263-278).
+template <int VEC, bool BF = false, int XS = MT_F32, int OS = MT_F32, int MTY = MT_BF16, int SD = 1, int SH = 1, int SW = 1>
 __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P) {
   static_assert(BF || (XS == MT_F32 && OS == MT_F32), "16-bit storage is served by the 16-bit matrix path");
-  constexpr int TD = 2, TH = 4, TW = 4, LD = TD + 2, LH = TH + 2, LW = TW + 2;
+  constexpr int TD = 2, TH = 4, TW = 4, LD = (TD - 1) * SD + 3, LH = (TH - 1) * SH + 3, LW = (TW - 1) * SW + 3;
   constexpr int LWP = BF ? bstage_lwp<LD, LH, LW, VEC, 4>() : stage_lwp<LD, LH, LW, VEC>();
   constexpr int PITCH = BF ? BFP : FCKP;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
   // M tile row li -> voxel (dm, r, col) = (li>>4, (li>>2)&3, li&3)
-  const int abase = (((li >> 4) * LH + ((li >> 2) & 3)) * LWP + (li & 3)) * PITCH + lhalf * (BF ? 4 : 8);
+  const int abase = (((li >> 4) * SD * LH + ((li >> 2) & 3) * SH) * LWP + (li & 3) * SW) * PITCH + lhalf * (BF ? 4 : 8);
 
   f32x16 acc;
 #pragma unroll
@@ -1065,7 +1068,7 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
     const ConvChunk cc = P.chunk[ch];
     __syncthreads();
     if constexpr (BF) {
-      mt_stage_bf16<LD, LH, LW, VEC, 4, XS, MTY>((unsigned*)lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+      mt_stage_bf16<LD, LH, LW, VEC, 4, XS, MTY>((unsigned*)lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
       __syncthreads();
       const unsigned* ldsu = (const unsigned*)lds;
       const unsigned* wl = (const unsigned*)c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 256) + lane * 4;
@@ -1082,7 +1085,7 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
       continue;
     }
     const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
-    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 - 1, oh0 - 1, ow0 - 1, lane, wave);
+    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
     __syncthreads();
     // this wave's taps: wave, wave+4, ... (7 or 6 of them); the next tap's fragments are fetched behind the current MFMAs
     f32x4 a[2][2], b[2][2];
@@ -1971,6 +1974,9 @@ static bool conv_is_133(const mt_conv3d_t* p);
 static int conv_bf16_cfg(const mt_conv3d_t* p);
 static bool strided_use_bf16(const mt_conv3d_t* p);
 static int conv_matrix_type(const mt_conv3d_t* p);
+static int conv_src_dtype(const mt_conv3d_t* p);
+static int conv_fast_vec(const mt_conv3d_t* p);
+static int g_tapsplit = -1;         // -1: read MT_CONV_TAPSPLIT (default 1); 0 off, 2: the strided form also on well-filled grids (tests)
 static ConvPlan conv_plan(const mt_conv3d_t* p) {
   static int use_v2 = -1, use_rt = -1;
   if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
@@ -1990,8 +1996,8 @@ static ConvPlan conv_plan(const mt_conv3d_t* p) {
   if (conv_is_fast(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0) {
     pl.kind = CONV_FAST;
     // low-resolution stages: fewer than two workgroups per CU -> split the taps over the waves instead
-    static int use_ts = -1;
-    if (use_ts < 0) { const char* e = getenv("MT_CONV_TAPSPLIT"); use_ts = e ? atoi(e) : 1; }
+    if (g_tapsplit < 0) { const char* e = getenv("MT_CONV_TAPSPLIT"); g_tapsplit = e ? atoi(e) : 1; }
+    const int use_ts = g_tapsplit;
     int TD, TH, TW; cfg_tile(kCfgs[pl.cfg], &TD, &TH, &TW);
     const long wgs = (long)p->N * mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW) * mt_cdiv(p->Cout, 32);
     if (use_ts && wgs < 300 && p->csplit >= p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 < 2147483648.0) pl.kind = CONV_TAPSPLIT;
@@ -2002,7 +2008,16 @@ static ConvPlan conv_plan(const mt_conv3d_t* p) {
     if (use133 < 0) { const char* e = getenv("MT_CONV_FAST133"); use133 = e ? atoi(e) : 1; }
     if (use133) { pl.kind = CONV_FAST; return pl; }
   }
-  if (use_rt && conv_fast_strided_ok(p)) { pl.kind = CONV_FAST_STRIDED; pl.cfg = 0; return pl; }
+  if (use_rt && conv_fast_strided_ok(p)) {
+    pl.kind = CONV_FAST_STRIDED; pl.cfg = 0;
+    // fewer workgroups than CUs in the 2x4x8 x 64-channel tiling: one 32-voxel tile x 32 channels per workgroup, taps over the waves
+    if (g_tapsplit < 0) { const char* e = getenv("MT_CONV_TAPSPLIT"); g_tapsplit = e ? atoi(e) : 1; }
+    const long wgs = (long)p->N * mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 8) * mt_cdiv(p->Cout, 64);
+    const int sd = conv_src_dtype(p);
+    const bool inst = strided_use_bf16(p) ? mt_is16(sd) && (p->odtype == sd || p->odtype == MT_F32) : (sd == MT_F32 && p->odtype == MT_F32 && conv_fast_vec(p) == 2);
+    if (g_tapsplit && (wgs < 256 || g_tapsplit >= 2) && inst) pl.kind = CONV_TAPSPLIT;
+    return pl;
+  }
   if (use_rt && conv_rt_ok(p)) {
     const int i = pick_rt_cfg(p);
     if (i >= 0) { pl.kind = CONV_RT; pl.cfg = i; return pl; }
@@ -2178,7 +2193,25 @@ static int launch_tapsplit(const mt_conv3d_t* p, hipStream_t st) {
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d)", p->Cin);
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
   const size_t red = (size_t)4 * 16 * 64 * sizeof(float);
-  if (strided_use_bf16(p)) {               // same eligibility: mma == 1, >= 16 even channels, aligned sources
+  if (p->SH == 2) {                        // strided stage convs (conv_plan: fp32 with 8-byte channel pairs, or 16-bit storage)
+    const int sd = conv_src_dtype(p);
+#define MT_TS_STRIDED(SD_)                                                                                                           \
+    do {                                                                                                                             \
+      constexpr int LD_ = SD_ + 3, LH_ = 9, LW_ = 9;                                                                                 \
+      if (strided_use_bf16(p)) {                                                                                                     \
+        size_t l = bstage_lds_bytes<LD_, LH_, LW_, 4, 4>(); if (l < red) l = red;                                                    \
+        if (sd == MT_F16 && p->odtype == MT_F16) hipLaunchKernelGGL((conv_tapsplit_kernel<4, true, MT_F16, MT_F16, MT_F16, SD_, 2, 2>), grid, dim3(256), l, st, P);       \
+        else if (sd == MT_F16) hipLaunchKernelGGL((conv_tapsplit_kernel<4, true, MT_F16, MT_F32, MT_F16, SD_, 2, 2>), grid, dim3(256), l, st, P);                        \
+        else if (p->odtype == MT_BF16) hipLaunchKernelGGL((conv_tapsplit_kernel<4, true, MT_BF16, MT_BF16, MT_BF16, SD_, 2, 2>), grid, dim3(256), l, st, P);             \
+        else hipLaunchKernelGGL((conv_tapsplit_kernel<4, true, MT_BF16, MT_F32, MT_BF16, SD_, 2, 2>), grid, dim3(256), l, st, P);                                        \
+      } else {                                                                                                                       \
+        size_t l = stage_lds_bytes<LD_, LH_, LW_, 2>(); if (l < red) l = red;                                                        \
+        hipLaunchKernelGGL((conv_tapsplit_kernel<2, false, MT_F32, MT_F32, MT_BF16, SD_, 2, 2>), grid, dim3(256), l, st, P);         \
+      }                                                                                                                              \
+    } while (0)
+    if (p->SD == 2) MT_TS_STRIDED(2); else MT_TS_STRIDED(1);
+#undef MT_TS_STRIDED
+  } else if (strided_use_bf16(p)) {        // same eligibility: mma == 1, >= 16 even channels, aligned sources
     const int sd = conv_src_dtype(p);
     if (sd == MT_F32) {
       size_t l = bstage_lds_bytes<4, 6, 6, 2, 4>(); if (l < red) l = red;
@@ -2358,6 +2391,7 @@ extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "bwdw_cw") == 0) { g_bwdw_cw = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_tr16") == 0) { g_bwdw_tr16 = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "conv_march16") == 0) { g_march16 = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "conv_tapsplit") == 0) { g_tapsplit = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
 }
@@ -2577,7 +2611,9 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   else if (pl.kind == CONV_TAPSPLIT)
   {
     const int sd = conv_src_dtype(p);
-    if (strided_use_bf16(p) && sd > 0) snprintf(buf, n, "conv_tapsplit_kernel<4, true, %d, %d, %d>", sd, p->odtype == sd ? sd : 0, sd == MT_F16 ? MT_F16 : MT_BF16);
+    if (p->SH == 2 && strided_use_bf16(p)) snprintf(buf, n, "conv_tapsplit_kernel<4, true, %d, %d, %d, %d, 2, 2>", sd, p->odtype == sd ? sd : 0, sd == MT_F16 ? MT_F16 : MT_BF16, p->SD);
+    else if (p->SH == 2) snprintf(buf, n, "conv_tapsplit_kernel<2, false, 0, 0, 1, %d, 2, 2>", p->SD);
+    else if (strided_use_bf16(p) && sd > 0) snprintf(buf, n, "conv_tapsplit_kernel<4, true, %d, %d, %d>", sd, p->odtype == sd ? sd : 0, sd == MT_F16 ? MT_F16 : MT_BF16);
     else snprintf(buf, n, strided_use_bf16(p) ? "conv_tapsplit_kernel<%d, true, 0, 0, 1>" : "conv_tapsplit_kernel<%d, false, 0, 0, 1>", conv_fast_vec(p));
   }
   else if (pl.kind == CONV_STEM)

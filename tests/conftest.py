@@ -33,3 +33,4 @@ def _fresh_matrix_mode():
     lib = sys.modules.get('multitalent_amd._lib')
     if mod is not None and lib is not None and getattr(lib, '_lib', None) is not None:
         mod.set_option('bwdw_cw', 4)
+        mod.set_option('conv_tapsplit', 1)

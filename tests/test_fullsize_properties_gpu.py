@@ -73,9 +73,9 @@ def conv_bwd_weight(ops, x, g, w_shape, geom):
     (60, 30, (48, 192, 192), (1, 1, 1), 'conv_fast_kernel'),         # decoder stage 0, two chunks per source
     (1, 30, (48, 192, 192), (1, 1, 1), 'conv_stem_kernel'),          # stem
     (30, 60, (48, 192, 192), (2, 2, 2), 'conv_fast_strided_kernel'), # first strided stage
-    (240, 320, (6, 24, 24), (2, 2, 2), 'conv_fast_strided_kernel'),
+    (240, 320, (6, 24, 24), (2, 2, 2), 'conv_tapsplit_kernel'),      # 120 workgroups in the strided tiling: taps split over the waves
     (320, 320, (3, 12, 12), (1, 1, 1), 'conv_tapsplit_kernel'),      # low-resolution stage
-    (320, 320, (3, 12, 12), (1, 2, 2), 'conv_fast_strided_kernel'),  # bottleneck
+    (320, 320, (3, 12, 12), (1, 2, 2), 'conv_tapsplit_kernel'),      # bottleneck
 ])
 def test_adjoint_identity_and_linearity_at_full_size(dev, Cin, Cout, shape, stride, kernel):
     ops = _ops()

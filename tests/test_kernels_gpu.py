@@ -116,6 +116,45 @@ def test_conv_fwd(dev, N, Cin, Cout, shape, k, stride):
     assert np.allclose(s[..., 1].numpy(), (ref.double() ** 2).sum((2, 3, 4)).numpy(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("N,cins,Cout,shape,stride,lazy", [
+    (2, (240,), 320, (6, 24, 24), (2, 2, 2), True),       # the 120-workgroup stage conv of the benchmark networks
+    (2, (320,), 320, (3, 12, 12), (1, 2, 2), True),       # bottleneck, 40 workgroups in the standard tiling
+    (1, (30,), 60, (6, 12, 34), (2, 2, 2), False),        # ragged tiles in every direction
+    (2, (24, 16), 70, (5, 9, 11), (2, 2, 2), True),       # odd extents, two sources, three cout tiles with a tail
+    (1, (40,), 33, (3, 7, 9), (1, 2, 2), False),
+])
+def test_conv_tapsplit_strided(dev, N, cins, Cout, shape, stride, lazy):
+    """conv_tapsplit_kernel<2, false, 0, 0, 1, SD, 2, 2>: the strided 3x3x3 stage convs on under-filled grids with the taps split over
+    the waves, against F.conv3d (fp32) and against conv_fast_strided_kernel (option conv_tapsplit = 0), statistics included."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    xs = [torch.randn((N, ci) + shape, generator=g) for ci in cins]
+    lz = [(torch.rand((N, ci), generator=g) + 0.5, torch.randn((N, ci), generator=g) * 0.3, 0.01) for ci in cins] if lazy else None
+    Cin = sum(cins)
+    w = torch.randn((Cout, Cin, 3, 3, 3), generator=g) / np.sqrt(Cin * 27)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv3d(ref_inputs(xs, lz), w, b, stride=stride, padding=1)
+    geom = ops.ConvGeom(shape, (3, 3, 3), stride, (1, 1, 1))
+    probe = ops.fill_conv([ops.Act(torch.empty((N,) + shape + (ci,), device=dev)) for ci in cins], geom, Cout,
+                          out0=ops.Act(torch.empty((N,) + tuple(geom.out) + (Cout,), device=dev)))
+    res = {}
+    try:
+        for mode, kernel in ((1, 'conv_tapsplit_kernel<2, false, 0, 0, 1, %d, 2, 2>' % stride[0]), (0, 'conv_fast_strided_kernel')):
+            ops.set_option('conv_tapsplit', mode)
+            assert ops.conv_kernel_name(probe).startswith(kernel), ops.conv_kernel_name(probe)
+            out, part = run_conv(dev, xs, w, b, stride, (1, 1, 1), lazy=lz, stats=True)
+            got = to_ncdhw(out.cpu())
+            assert relerr(got, ref) < 1e-5, mode
+            sums = part.cpu().double().sum(1)
+            V = ref[0, 0].numel()
+            assert np.allclose(sums[..., 0].numpy(), ref.double().sum((2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3 * np.sqrt(V))
+            assert np.allclose(sums[..., 1].numpy(), (ref.double() ** 2).sum((2, 3, 4)).numpy(), rtol=1e-4)
+            res[mode] = got
+    finally:
+        ops.set_option('conv_tapsplit', 1)
+    assert relerr(res[1], res[0]) < 1e-5
+
+
 def test_conv_fwd_two_lazy_sources(dev):
     """concat(tconv output [identity], skip [InstanceNorm+LeakyReLU on load]) -> conv, generic_UNet.py:392."""
     g = torch.Generator().manual_seed(2)

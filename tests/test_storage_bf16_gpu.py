@@ -259,12 +259,19 @@ def test_forward_convs_fp16_storage(dev, Cin, Cout, shape, k, stride, two, odt):
     tapsplit = k == (3, 3, 3) and stride == (1, 1, 1) and shape[2] <= 12
     ops.set_option('conv_bf16', 1 if tapsplit else 2)          # 2: the 16-bit matrix kernel also on the small grids of this test
     try:
-        _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit)
+        if stride == (1, 1, 1):
+            _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit)
+        else:
+            # strided stage convs: the tap-split form these small grids take by default, and conv_fast_strided_kernel
+            for ts, prefix in ((1, 'conv_tapsplit_kernel<4, true, 2, %d, 2, %d, 2, 2>' % (2 if odt == torch.float16 else 0, stride[0])), (0, 'conv_fast_strided_kernel')):
+                ops.set_option('conv_tapsplit', ts)
+                _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, False, prefix)
     finally:
         ops.set_option('conv_bf16', 1)
+        ops.set_option('conv_tapsplit', 1)
 
 
-def _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit):
+def _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit, prefix=None):
     ops = _ops()
     g = torch.Generator().manual_seed(21)
     N = 2
@@ -290,6 +297,7 @@ def _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit):
     name = ops.conv_kernel_name(p)
     assert ops.conv_io_supported(p), name
     assert ops.conv_pack_layout(p) == 4, (name, ops.conv_pack_layout(p))                 # fp16 weight fragments
+    assert prefix is None or name.startswith(prefix), (name, prefix)
     wd = w.to(dev).contiguous()
     wp = ops.pack_conv_weights(wd, acts[0].C, acts[1].C if two else 0, Cout, k, ops.conv_weight_strides(wd), False, ops.conv_ck(p), layout=4)
     p.wpack = wp.data_ptr()
@@ -384,6 +392,7 @@ def test_conv_march16_vs_host(dev, Cin, Cout, shape, k, two, cap, H):
 def test_strided_stage_conv_bf16_storage_bitexact(dev, Cin, Cout, shape, stride, out_bf16):
     """forward strided 3x3x3 (bf16 source; bf16 or fp32 destination) and its one-launch backward-data (dY bf16 or fp32, dX bf16)."""
     ops = _ops()
+    ops.set_option('conv_tapsplit', 0)           # this test is about conv_fast_strided_kernel (grids this small take the tap-split form by default)
     g = torch.Generator().manual_seed(6)
     N = 2
     geom = ops.ConvGeom(shape, (3, 3, 3), stride, (1, 1, 1))
