@@ -178,8 +178,8 @@ def roofline_from_groups(groups, nrep, precision):
     out = {"kernel": name, "launches_per_step": g["n"] // nrep, "avg_launch_ms": round(g["ms"] / g["n"], 4),
            "algorithmic_gflop_per_launch": round(g["flops"] / g["n"] / 1e9, 2),
            "algorithmic_bytes_per_launch": int(g["bytes"] / g["n"]), "traffic": None}
-    if 'tr16' in name or 'march16' in name:
-        # 16-bit backward-weight / register-weight forward: 654 FLOP/B algorithmic at 60 -> 60 channels (K = 27 taps x both channel
+    if 'tr16' in name:
+        # 16-bit direct backward-weight: 654 FLOP/B algorithmic at 60 -> 60 channels (K = 27 taps x both channel
         # counts against two 2-byte tensors), above the dense 16-bit machine balance of 312: priced against the 16-bit MFMA peak
         out.update({"bound": "mfma", "achieved": round(alg_tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(alg_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "hbm_gbs_algorithmic": round(g["bytes"] / sec / 1e9, 1),

@@ -164,8 +164,7 @@ int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_src_t* ysrc
  * chip (default), 2 wherever eligible; "bwdw_tr16" 1 (default) | 0 | n: conv_bwdw_tr16_kernel for 16-bit X with bf16 dY (0: cast + the fp32
  * kernels; n > 1: at most n workgroups per (cout tile, chunk pair) — tests); "bwdw_cw" (below); "conv_tapsplit" 1 (default) | 0 | 2:
  * conv_tapsplit_kernel on under-filled grids — stride-1 3x3x3 convs below 300 workgroups, strided stage convs below 256 (0: the full-tile
- * kernels; 2: the strided form wherever eligible); "conv_march16" 0 (default) | 1 | n: conv_march16_kernel for the 16-bit stride-1
- * convolutions of <= 64 input channels (n > 1: at most n workgroups per cout tile); "bwdw_wino" 1 | 0: the F(3x3, 2x2) backward-weight
+ * kernels; 2: the strided form wherever eligible); "bwdw_wino" 1 | 0: the F(3x3, 2x2) backward-weight
  * kernels (3x3x3 and 1x3x3). */
 int mt_set_option(const char* name, int value);
 /* Process-wide tuning knobs.  mt_set_option and the environment variables below choose BETWEEN KERNELS THAT COMPUTE THE SAME
@@ -174,7 +173,7 @@ int mt_set_option(const char* name, int value);
  * limit, the CU count that sizes persistent grids) is keyed by the current HIP device, so one process may drive several GPUs.
  * Environment, read once at first use (0 disables the named kernel family and falls back to the generic one unless noted):
  *   MT_CONV_WINO (0|1|2), MT_WINO_PERSIST (1|n), MT_BWDW_WINO, MT_BWDW_MARCH, MT_BWDW_FAST, MT_BWDW_TALL,
- *   MT_CONV_BF16 (0|1|2), MT_BWDW_TR16, MT_CONV_MARCH16, MT_STRIDED_BF16, MT_CONV_FASTV2, MT_CONV_RT, MT_CONV_STEM, MT_CONV_TAPSPLIT,
+ *   MT_CONV_BF16 (0|1|2), MT_BWDW_TR16, MT_STRIDED_BF16, MT_CONV_FASTV2, MT_CONV_RT, MT_CONV_STEM, MT_CONV_TAPSPLIT,
  *   MT_CONV_FAST133, MT_CONV_GATHER, MT_CONV_VEC1 (1: dword staging loads),
  *   MT_PW_VEC / MT_GATHER_VEC (1|2|4: floats per load instruction of pw_fast_kernel / conv_gather_kernel; default 4 = 16-byte
  *   buffer loads on dword-aligned addresses, see mt_probe_device), MT_PW_HEAD (0: the 33..64-channel 1x1x1 heads on pw_fast_kernel

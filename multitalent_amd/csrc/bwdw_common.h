@@ -1,5 +1,5 @@
-// Parameter blocks shared by the convolution translation units (conv_lds.hip plans, dispatches and reduces; bwdw_tr16.hip and
-// conv_march16.hip each hold one kernel family of the mixed-precision mode).
+// Parameter blocks shared by the convolution translation units (conv_lds.hip plans, dispatches and reduces; bwdw_tr16.hip holds one
+// kernel family of the mixed-precision mode).
 #pragma once
 #include "mt_common.h"
 
@@ -31,8 +31,3 @@ typedef __bf16 bwb_bf16x8 __attribute__((ext_vector_type(8)));
 
 // bwdw_tr16.hip: direct bf16 backward-weight of 3x3x3 (KD = 3) / 1x3x3 (KD = 1) stride-1 convolutions fed by LDS transpose reads
 int mt_launch_bwdw_tr16(const BwdWParams& P, int KD, int xdt, hipStream_t st);
-
-// conv_march16.hip: 3x3x3 (KD = 3) / 1x3x3 (KD = 1) stride-1 convolution over 16-bit sources (forward over fp16 activations, backward-data
-// over bf16 gradients), at most 64 input channels, marching along D with the weights in registers.  nwg = workgroups per cout tile.
-int mt_launch_conv_march16(const ConvKParams& P, int nwg, hipStream_t st);
-int mt_conv_march16_lds_bytes(int npairs);

@@ -2038,15 +2038,12 @@ extern "C" int mt_conv3d_pack_layout(const mt_conv3d_t* p) {      // layout argu
   if ((k == CONV_FAST_STRIDED || k == CONV_TAPSPLIT) && strided_use_bf16(p)) return l16;
   return k == CONV_WINO ? 2 : k == CONV_BF16 ? l16 : 1;
 }
-static bool conv_march16_ok(const mt_conv3d_t* p);
-static int conv_march16_nwg(const mt_conv3d_t* p);
 extern "C" int mt_conv3d_stats_blocks(const mt_conv3d_t* p) {
   const ConvPlan pl = conv_plan(p);
   if (pl.cfg < 0) return -1;
   if (pl.kind == CONV_FAST_STRIDED) return mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 8);
   if (pl.kind == CONV_TAPSPLIT) return mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 4);
   if (pl.kind == CONV_WINO) return mt_cdiv(p->Do, 4) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 16);
-  if (pl.kind == CONV_BF16 && conv_march16_ok(p)) return conv_march16_nwg(p);
   if (pl.kind == CONV_BF16) { int TD, TH, TW; cfg_tile(kBfCfgs[pl.cfg], &TD, &TH, &TW); return mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW); }
   int TD, TH, TW; cfg_tile(kCfgs[pl.cfg], &TD, &TH, &TW);
   return mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW);
@@ -2287,48 +2284,6 @@ static int conv_bf16_cfg(const mt_conv3d_t* p) {
   if (wgs < 256 && use != 2) return -1;          // low-resolution stages stay on the fp32 latency-oriented kernels
   return best;
 }
-// conv_march16_kernel (conv_march16.hip): the CONV_BF16 problems with 16-bit storage on all operands, at most 64 input channels, one
-// destination, no accumulation, Wo > 16.  option "conv_march16" / MT_CONV_MARCH16 (default 0 = conv_bf16_kernel — see DESIGN 3.3 for the
-// measurements —; 1: on; n > 1: on, at most n workgroups per cout tile — tests)
-static int g_march16 = -1;
-static bool conv_march16_ok(const mt_conv3d_t* p) {
-  if (g_march16 < 0) { const char* e = getenv("MT_CONV_MARCH16"); g_march16 = e ? atoi(e) : 0; }
-  if (!g_march16 || p->mma != 1) return false;
-  const int sd = conv_src_dtype(p);
-  if (!mt_is16(sd) || p->odtype != sd || !conv_out_pairs_ok(p)) return false;
-  if (p->csplit < p->Cout || p->accumulate || p->osD > 0 || p->bstats.y != nullptr) return false;
-  if (!(p->KH == 3 && p->KW == 3 && (p->KD == 3 || p->KD == 1) && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PH == 1 && p->PW == 1 &&
-        p->PD == (p->KD == 3 ? 1 : 0) && p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
-  if (p->N > 16 || p->Wo <= 16 || p->Ho < 2) return false;
-  const int nch = mt_cdiv(p->src[0].C, 16) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, 16) : 0);
-  if (nch > 4) return false;
-  for (int i = 0; i < p->nsrc; ++i) {
-    if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 2.0 >= 2147483648.0) return false;
-    if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
-  }
-  if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 2.0 >= 2147483648.0) return false;
-  return true;
-}
-static int conv_march16_nwg(const mt_conv3d_t* p) {
-  const long T = (long)p->N * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 32) * p->Do;
-  long n = mt_device_cus(mt_current_device()) / mt_cdiv(p->Cout, 32);
-  if (n < 1) n = 1;
-  if (n > T) n = T;
-  if (g_march16 > 1 && n > g_march16) n = g_march16;
-  return (int)n;
-}
-static int launch_march16(const mt_conv3d_t* p, hipStream_t st) {
-  ConvKParams P;
-  P.c = *p;
-  if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
-  P.tilesD = p->Do; P.tilesH = mt_cdiv(p->Ho, 4); P.tilesW = mt_cdiv(p->Wo, 32);
-  P.ntaps = p->KD * 9; P.dbg = 0; P.stagger = 0;
-  P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
-  MT_REQUIRE(P.nchunks > 0 && P.nchunks <= 4, "conv3d (march16): %d chunks", P.nchunks);
-  const int nwg = conv_march16_nwg(p);
-  P.nsb = nwg;                                     // statistics partials: one row per (sample, workgroup)
-  return mt_launch_conv_march16(P, nwg, st);
-}
 static bool strided_use_bf16(const mt_conv3d_t* p) {      // forward strided stage convs in mixed precision
   if (g_bf16_mode < 0) { const char* e = getenv("MT_CONV_BF16"); g_bf16_mode = e ? atoi(e) : 1; }
   static int use = -1;
@@ -2390,7 +2345,6 @@ extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "conv_bf16") == 0) { g_bf16_mode = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_cw") == 0) { g_bwdw_cw = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_tr16") == 0) { g_bwdw_tr16 = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "conv_march16") == 0) { g_march16 = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "conv_tapsplit") == 0) { g_tapsplit = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
@@ -2593,10 +2547,6 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   const ConvPlan pl = conv_plan(p);
   const int i = pl.cfg;
   if (i < 0) return MT_EINVAL;
-  if (pl.kind == CONV_BF16 && conv_march16_ok(p)) {
-    snprintf(buf, n, "conv_march16_kernel<%d, %d, %d>", p->KD, (mt_cdiv(p->src[0].C, 16) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, 16) : 0) + 1) / 2, conv_src_dtype(p));
-    return MT_OK;
-  }
   if (pl.kind == CONV_BF16) {
     // the instance launch_bf16 picks, as the profiler prints it: <MW, RH, TD, VEC, NT, NW, KD, XS, OS, MTY>
     const int sd = conv_src_dtype(p);
@@ -2678,7 +2628,6 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
              "(ask mt_conv3d_io_supported, convert with mt_cast)", p->src[0].dtype, p->nsrc == 2 ? p->src[1].dtype : -1, p->odtype);
   MT_REQUIRE(p->bstats.y == nullptr || pl.kind == CONV_WINO, "conv3d: bstats set on a problem whose kernel does not compute them "
              "(ask mt_conv3d_bwd_stats_supported)");
-  if (pl.kind == CONV_BF16 && conv_march16_ok(p)) return launch_march16(p, (hipStream_t)stream);
   if (pl.kind == CONV_BF16) return launch_bf16(p, i, (hipStream_t)stream);
   const ConvCfg& g = kCfgs[i];
   hipStream_t st = (hipStream_t)stream;

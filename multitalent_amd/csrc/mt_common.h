@@ -39,17 +39,6 @@ __device__ __forceinline__ int mt_xcd_remap(int bid, int nblk) {
   return base + idx;
 }
 
-// one LDS-DMA instruction (`buffer_load_dwordx4 ... lds`): lane l's 16 bytes at buffer offset `voff` -> LDS byte address lds_addr + 16 l.
-// M0 is written in the same statement that reads it; the compiler neither counts this load (vmcnt) nor sees its LDS write: callers
-// wait (s_waitcnt vmcnt) and fence themselves.
-typedef __attribute__((ext_vector_type(4))) int mt_i32x4;
-__device__ __forceinline__ void mt_lds_dma16(mt_i32x4 rsrc, int voff, unsigned lds_addr) {
-  // (descriptor and LDS address must be wave-uniform: forced into scalar registers)
-  rsrc = mt_i32x4{__builtin_amdgcn_readfirstlane(rsrc[0]), __builtin_amdgcn_readfirstlane(rsrc[1]), __builtin_amdgcn_readfirstlane(rsrc[2]), __builtin_amdgcn_readfirstlane(rsrc[3])};
-  lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
-}
-
 __device__ __forceinline__ float mt_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // ---- 16-bit storage (MT_BF16, MT_F16): widening is exact, narrowing rounds to nearest-even (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32).

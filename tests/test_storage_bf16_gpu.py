@@ -320,73 +320,6 @@ def _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit, pre
         assert name.startswith('conv_tapsplit_kernel'), name
 
 
-@pytest.mark.parametrize("Cin,Cout,shape,k,two", [
-    (32, 32, (8, 16, 64), (3, 3, 3), False),
-    (30, 60, (9, 14, 70), (3, 3, 3), False),           # ragged column, channel tails, two cout tiles
-    (30, 30, (6, 20, 40), (1, 3, 3), False),           # residual encoder stage 0
-    (60, 30, (8, 16, 64), (3, 3, 3), True),            # two sources, two chunk pairs
-    (48, 32, (5, 8, 33), (3, 3, 3), False),            # three chunks: the second pair is half empty
-    (60, 60, (7, 12, 48), (1, 3, 3), False),
-])
-@pytest.mark.parametrize("cap", [1, 3, 7])
-@pytest.mark.parametrize("H", [torch.float16, torch.bfloat16])
-def test_conv_march16_vs_host(dev, Cin, Cout, shape, k, two, cap, H):
-    """conv_march16_kernel (round 5: weights in registers, register window of three output planes, LDS-DMA input ring) against the host
-    restatement (operands and output rounded where the kernel rounds them, float64 sums), with statistics of the stored values.
-    cap > 1 limits the workgroups per cout tile, so that a workgroup's (column, plane) range spans columns / samples and starts and ends
-    inside columns."""
-    ops = _ops()
-    ops.set_option('conv_bf16', 2)
-    ops.set_option('conv_march16', cap)
-    try:
-        g = torch.Generator().manual_seed(3 + Cin + Cout)
-        N = 2
-        pad = tuple((kk - 1) // 2 for kk in k)
-        geom = ops.ConvGeom(shape, k, (1, 1, 1), pad)
-        if two:
-            srcs = [rbf(torch.randn((N,) + shape + (Cin // 2,), generator=g), H), rbf(torch.randn((N,) + shape + (Cin // 2,), generator=g), H)]
-            lazy = [None, (torch.rand((N, Cin // 2), generator=g) + 0.5, torch.randn((N, Cin // 2), generator=g), 0.01)]
-        else:
-            srcs = [rbf(torch.randn((N,) + shape + (Cin,), generator=g), H)]
-            lazy = [(torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)]
-        w = torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))
-        b = torch.randn(Cout, generator=g)
-        acts, keep = [], []
-        for sx, lz in zip(srcs, lazy):
-            buf = sx.to(dev).to(H)
-            keep.append(buf)
-            acts.append(ops.Act(buf) if lz is None else ops.Act(buf, scale=lz[0].to(dev), shift=lz[1].to(dev), slope=lz[2]))
-        out = torch.full((N,) + tuple(geom.out) + (Cout,), float('nan'), device=dev).to(H)
-        bd = b.to(dev)
-        p = ops.fill_conv(acts, geom, Cout, out0=ops.Act(out), bias=bd, mma=1)
-        name = ops.conv_kernel_name(p)
-        assert name.startswith('conv_march16_kernel<%d, %d' % (k[0], 1 if Cin <= 32 else 2)), name
-        assert ops.conv_io_supported(p)
-        lay = ops.conv_pack_layout(p)
-        assert lay == (4 if H == torch.float16 else 3)
-        wd = w.to(dev).contiguous()
-        wp = ops.pack_conv_weights(wd, acts[0].C, acts[1].C if two else 0, Cout, k, ops.conv_weight_strides(wd), False, ops.conv_ck(p), layout=lay)
-        p.wpack = wp.data_ptr()
-        part = torch.full((N, ops.conv_stats_blocks(p), Cout, 2), float('nan'), device=dev)
-        p.stats_part = part.data_ptr()
-        ops.conv3d_fwd(p)
-        torch.cuda.synchronize()
-    finally:
-        ops.set_option('conv_bf16', 1)
-        ops.set_option('conv_march16', 0)
-    ref = _host_conv_16(srcs, lazy, w, b, (1, 1, 1), pad, H)
-    got = out.float().cpu()
-    assert torch.isfinite(got).all()
-    tol = (2.0 ** -10 if H == torch.float16 else 2.0 ** -7) * float(ref.abs().max())
-    assert float((got - ref).abs().max()) < 4 * tol + 2e-3, (name, float((got - ref).abs().max()), tol)
-    assert float(((got - ref).abs() > tol).float().mean()) < 2e-3, name
-    o = out.float().double()
-    sm = part.double().sum(1)
-    assert torch.isfinite(sm).all()
-    assert torch.allclose(sm[..., 0], o.sum((1, 2, 3)), rtol=1e-4, atol=1e-3 * o[0, ..., 0].numel() ** 0.5)
-    assert torch.allclose(sm[..., 1], (o * o).sum((1, 2, 3)), rtol=1e-4)
-
-
 @pytest.mark.parametrize("Cin,Cout,shape,stride", [(30, 60, (8, 18, 34), (2, 2, 2)), (32, 64, (6, 16, 32), (1, 2, 2))])
 @pytest.mark.parametrize("out_bf16", [True, False])
 def test_strided_stage_conv_bf16_storage_bitexact(dev, Cin, Cout, shape, stride, out_bf16):

@@ -15,6 +15,6 @@ for tag in ('pmcA', 'pmcB'):
             k = r['Kernel_Name'][:40]
             agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         for k, d in agg.items():
-            if 'tr16' in k or 'march16' in k or 'conv_bf16' in k:
+            if 'tr16' in k or 'conv_bf16' in k:
                 print(tag, k, {c: int(v) for c, v in d.items()})
 PY
