@@ -1919,6 +1919,99 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   }
 }
 
+// The same backward-data on UNDER-FILLED grids (round 5): dY of 3x12x12 or 3x6x6 positions is 96 / 80 workgroups of 20 serial
+// chunks x 216 MFMAs in the tiling above.  Here a workgroup owns ONE 32-position M tile (2 x 4 x 4 dY positions) x 32 dX channels
+// and its four waves split the K of every chunk — wave w multiplies the channel pairs 2w, 2w + 1 of the chunk's eight, for all 27
+// taps into all NC class tiles —, so the grid is 3-4 x larger and a wave's chain 4 x shorter; the four partial tiles of a class are
+// summed through LDS in a fixed order (deterministic), class by class.  fp32 storage, 8-byte channel pairs.
+template <int SD, int SH, int SW>
+__global__ __launch_bounds__(256) void conv_bwdd_strided_ks_kernel(const ConvKParams P) {
+  constexpr int TD = 2, TH = 4, TW = 4;
+  constexpr int LD = TD + (SD == 2 ? 1 : 2), LH = TH + (SH == 2 ? 1 : 2), LW = TW + (SW == 2 ? 1 : 2);
+  constexpr int NC = SD * SH * SW, LWP = stage_lwp<LD, LH, LW, 2>();
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const mt_conv3d_t& c = P.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lhalf = lane >> 5;
+  int ntile, td, th, tw, nb;
+  mt_tile_coords<1>(mt_block_decode(ntile), P.tilesD, P.tilesH, P.tilesW, td, th, tw, nb);
+  const int md0 = td * TD, mh0 = th * TH, mw0 = tw * TW;
+  // M row li -> dY position (li >> 4, (li >> 2) & 3, li & 3); the lane's eight channels of a chunk start at lhalf * 8, this wave's two
+  // at + 2 wave (the MFMA pairs channel lhalf * 8 + k of both lane halves)
+  const int abase = (((li >> 4) * LH + ((li >> 2) & 3)) * LWP + (li & 3)) * FCKP + lhalf * 8 + 2 * wave;
+
+  f32x16 acc[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
+
+  for (int ch = 0; ch < P.nchunks; ++ch) {
+    const ConvChunk cc = P.chunk[ch];
+    // this wave's share of the chunk's weight fragments ([tap][group 2][lane 64][4]: group wave >> 1, floats 2 (wave & 1), + 1): all 27
+    // requested before the staging, consumed behind its barrier
+    const float* wl = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + (wave >> 1) * 256 + lane * 4 + 2 * (wave & 1);
+    float2 b[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) b[t] = *(const float2*)(wl + t * 512);
+    __syncthreads();
+    mt_stage_fast2<LD, LH, LW, 2>(lds, c, cc, nb, md0 - (SD == 1 ? 1 : 0), mh0 - (SH == 1 ? 1 : 0), mw0 - (SW == 1 ? 1 : 0), lane, wave);
+    __syncthreads();
+    float2 a[2];
+    {
+      constexpr int o0 = ((bd_off<SD>(0) * LH + bd_off<SH>(0)) * LWP + bd_off<SW>(0)) * FCKP;
+      a[0] = *(const float2*)(lds + abase + o0);
+    }
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      if (t + 1 < 27) {
+        const int t1 = t + 1;
+        const int o1 = ((bd_off<SD>(t1 / 9) * LH + bd_off<SH>((t1 / 3) % 3)) * LWP + bd_off<SW>(t1 % 3)) * FCKP;
+        a[t1 & 1] = *(const float2*)(lds + abase + o1);
+      }
+      const int q = (bd_par<SD>(t / 9) * SH + bd_par<SH>((t / 3) % 3)) * SW + bd_par<SW>(t % 3);
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1].x, b[t].x, acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1].y, b[t].y, acc[q], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: class by class, the four waves' tiles summed in a fixed order; wave w finishes accumulator registers 4w .. 4w + 3
+  // = M rows jj + 8 w + 4 lhalf; class (pd, ph, pw) of dY position m lands at dX[S m + par]
+  const int co = ntile * 32 + li;
+  const bool covalid = co < c.Cout;
+  const int ocs = c.ocs0;
+  const size_t out_sample = (size_t)c.OD * c.OH * c.OW;
+  __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out0 + (size_t)nb * out_sample * ocs), 0, (int)(out_sample * ocs * 4), 0x00020000);
+  float* red = lds;                                        // [wave][16][64] floats = 16 KiB
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    const int pd = q / (SH * SW), ph = (q / SW) % SH, pw = q % SW;
+    int off[4];
+    float prev[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int iv = jj + 8 * wave + 4 * lhalf;
+      const int xd = (md0 + (iv >> 4)) * SD + pd, xh = (mh0 + ((iv >> 2) & 3)) * SH + ph, xw = (mw0 + (iv & 3)) * SW + pw;
+      const bool ok = covalid && xd < c.OD && xh < c.OH && xw < c.OW;
+      off[jj] = ok ? (((xd * c.OH + xh) * c.OW + xw) * ocs + co) * 4 : (int)0x80000000;
+      prev[jj] = 0.f;
+      if (c.accumulate) prev[jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, off[jj], 0, 0));
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[(wave * 16 + j) * 64 + lane] = acc[q][j];
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const float* rp = red + (wave * 4 + jj) * 64 + lane;
+      const float v = (((rp[0] + rp[16 * 64]) + rp[32 * 64]) + rp[48 * 64]) + prev[jj];
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rd, off[jj], 0, 0);
+    }
+    __syncthreads();
+  }
+}
+
 #include "conv_wino.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -2697,6 +2790,16 @@ extern "C" int mt_conv3d_bwd_data_strided_io_supported(const mt_conv3d_t* p) {
   // dX bf16 (channel-pair dwords: even Cin / stride, dword-aligned base) from dY bf16 or fp32
   return (p->odtype == MT_BF16 && !(p->Cin & 1) && !(p->ocs0 & 1) && !(((uintptr_t)p->out0) & 3)) ? 1 : 0;
 }
+// conv_bwdd_strided_ks_kernel: fp32 on both sides, 8-byte channel pairs, fewer workgroups than CUs in the 2 x 4 x 16 tiling
+// (option "conv_tapsplit" / MT_CONV_TAPSPLIT = 0: never; 2: wherever the types fit)
+static bool bwdd_strided_use_ks(const mt_conv3d_t* p) {
+  if (g_tapsplit < 0) { const char* e = getenv("MT_CONV_TAPSPLIT"); g_tapsplit = e ? atoi(e) : 1; }
+  const mt_src_t& s0 = p->src[0];
+  if (!g_tapsplit || bwdd_strided_use_bf16(p) || s0.dtype != MT_F32 || p->odtype != MT_F32) return false;
+  if ((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7)) return false;
+  const long wgs = (long)p->N * mt_cdiv(mt_cdiv(p->Di, p->SD), 2) * mt_cdiv(mt_cdiv(p->Hi, 2), 4) * mt_cdiv(mt_cdiv(p->Wi, 2), 16) * mt_cdiv(p->Cin, 32);
+  return wgs < 256 || g_tapsplit >= 2;
+}
 template <int SD, int SH, int SW>
 static int launch_bwdd_strided(const mt_conv3d_t* p, hipStream_t st) {
   constexpr int TD = 2, TH = 4, TW = 16;
@@ -2718,6 +2821,15 @@ static int launch_bwdd_strided(const mt_conv3d_t* p, hipStream_t st) {
   const mt_src_t& s0 = p->src[0];
   const bool v2 = !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7));
   MT_REQUIRE(mt_conv3d_bwd_data_strided_io_supported(p), "bwd_data_strided: storage types not taken by the kernel that serves this problem (ask mt_conv3d_bwd_data_strided_io_supported)");
+  if (bwdd_strided_use_ks(p)) {           // under-filled grid: one 2 x 4 x 4 tile per workgroup, the chunk's K split over the waves
+    constexpr int KLD = 2 + (SD == 2 ? 1 : 2), KLH = 4 + 1, KLW = 4 + 1;
+    P.tilesH = mt_cdiv(gH, 4); P.tilesW = mt_cdiv(gW, 4);
+    P.nsb = P.tilesD * P.tilesH * P.tilesW;
+    size_t l = stage_lds_bytes<KLD, KLH, KLW, 2>(); if (l < (size_t)4 * 16 * 64 * sizeof(float)) l = (size_t)4 * 16 * 64 * sizeof(float);
+    hipLaunchKernelGGL((conv_bwdd_strided_ks_kernel<SD, SH, SW>), dim3((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cin, 32), 1), dim3(256), l, st, P);
+    MT_CHECK_LAUNCH("conv_bwdd_strided_ks");
+    return MT_OK;
+  }
   if (bwdd_strided_use_bf16(p)) {
     if (s0.dtype == MT_BF16 && p->odtype == MT_BF16)
       hipLaunchKernelGGL((conv_bwdd_strided_kernel<SD, SH, SW, 4, true, MT_BF16, MT_BF16>), grid, dim3(256), (bstage_lds_bytes<LD, LH, LW, 4, 4>()), st, P);
@@ -2745,6 +2857,7 @@ extern "C" int mt_conv3d_bwd_data_strided_kernel_name(const mt_conv3d_t* p, char
   if (p == nullptr || buf == nullptr || n == 0 || !mt_conv3d_bwd_data_strided_supported(p)) return MT_EINVAL;
   const mt_src_t& s0 = p->src[0];
   const bool v2 = !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7));
+  if (bwdd_strided_use_ks(p)) { snprintf(buf, n, "conv_bwdd_strided_ks_kernel<%d, 2, 2>", p->SD); return MT_OK; }
   if (bwdd_strided_use_bf16(p)) {
     if (s0.dtype == MT_BF16 && p->odtype == MT_BF16) snprintf(buf, n, "conv_bwdd_strided_kernel<%d, 2, 2, 4, true, 1, 1>", p->SD);
     else snprintf(buf, n, "conv_bwdd_strided_kernel<%d, 2, 2, 2, true, 0, %d>", p->SD, p->odtype == MT_BF16 ? 1 : 0);

@@ -214,6 +214,8 @@ def test_conv_bwd_data_parity_classes(dev, Cin, Cout, shape, k, stride, pad):
     (30, 60, (6, 12, 32), (1, 2, 2), False),
     (64, 33, (5, 9, 40), (1, 2, 2), True),
     (17, 20, (3, 5, 7), (2, 2, 2), False),
+    (240, 320, (6, 24, 24), (2, 2, 2), True),      # the benchmark networks' under-filled layers
+    (320, 320, (3, 12, 12), (1, 2, 2), True),
 ])
 @pytest.mark.parametrize("mma", [0, 1])
 def test_conv_bwd_data_strided_one_launch(dev, Cin, Cout, shape, stride, acc, mma):
@@ -250,12 +252,23 @@ def test_conv_bwd_data_strided_one_launch(dev, Cin, Cout, shape, stride, acc, mm
     assert lay == (3 if (mma and Cout >= 16 and Cout % 2 == 0) else 1)
     wp = ops.pack_conv_weights(wd, Cout, 0, Cin, k, ops.conv_weight_strides(wd, as_bwd_data=True), False, 16, layout=lay)
     p.wpack = wp.data_ptr()
-    ops.conv3d_bwd_data_strided(p)
-    torch.cuda.synchronize()
-    got = to_ncdhw(dx.cpu())
-    if acc:
-        got = got - to_ncdhw(base)
-    assert relerr(got, x.grad) < (1e-4 if lay == 3 else (2e-2 if mma else 1e-5))
+    # grids this small take conv_bwdd_strided_ks_kernel (one tile per workgroup, K split over the waves) where the types fit;
+    # option conv_tapsplit = 0: the full-tile kernel
+    names = set()
+    try:
+        for ts in (1, 0):
+            ops.set_option('conv_tapsplit', ts)
+            names.add(ops.conv_bwd_data_strided_kernel_name(p).split('<')[0])
+            dx.copy_(base.to(dev))
+            ops.conv3d_bwd_data_strided(p)
+            torch.cuda.synchronize()
+            got = to_ncdhw(dx.cpu())
+            if acc:
+                got = got - to_ncdhw(base)
+            assert relerr(got, x.grad) < (1e-4 if lay == 3 else (2e-2 if mma else 1e-5)), ts
+    finally:
+        ops.set_option('conv_tapsplit', 1)
+    assert names == ({'conv_bwdd_strided_ks_kernel', 'conv_bwdd_strided_kernel'} if (lay == 1 and Cout % 2 == 0) else {'conv_bwdd_strided_kernel'}), names
 
 
 @pytest.mark.parametrize("Cin,Cout,shape,k,stride", [
