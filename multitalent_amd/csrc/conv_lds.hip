@@ -1042,6 +1042,9 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
 // SD / SH / SW (round 5): the same kernel for the strided 3x3x3 stage convs whose standard tiling (conv_fast_strided_kernel, 2x4x8
 // outputs x 64 channels) yields fewer workgroups than the chip has CUs — 240 -> 320 @ 6x24x24 -> 3x12x12 is 120 workgroups of 15
 // chunks x 216 MFMAs, the bottleneck's 320 -> 320 stride (1,2,2) 40 of 20 (generic_UNet.py:263-278).
+#ifndef TS_ABL
+#define TS_ABL 0      // timing ablations of the fp32 path: 1 skip the staging, 2 every weight fragment from the same cached 14 KiB, 4 skip the MFMAs
+#endif
 template <int VEC, bool BF = false, int XS = MT_F32, int OS = MT_F32, int MTY = MT_BF16, int SD = 1, int SH = 1, int SW = 1>
 __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P) {
   static_assert(BF || (XS == MT_F32 && OS == MT_F32), "16-bit storage is served by the 16-bit matrix path");
@@ -1084,8 +1087,8 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
         if (i < 6 || wave < 3) acc = mt_mfma16<MTY>(fa[i], fb[i], acc);
       continue;
     }
-    const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
-    mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
+    const float* wlane = c.wpack + ((TS_ABL & 2) ? (size_t)0 : (size_t)(ntile * P.nchunks + ch) * (27 * 512)) + lane * 4;
+    if (!(TS_ABL & 1)) mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
     __syncthreads();
     // this wave's taps: wave, wave+4, ... (7 or 6 of them); the next tap's fragments are fetched behind the current MFMAs
     f32x4 a[2][2], b[2][2];
@@ -1105,6 +1108,7 @@ __global__ __launch_bounds__(256) void conv_tapsplit_kernel(const ConvKParams P)
         b[(i + 1) & 1][0] = *(const f32x4*)(wlane + tt * 512);   b[(i + 1) & 1][1] = *(const f32x4*)(wlane + tt * 512 + 256);
       }
       if (i < 6 || wave < 3) {                             // only wave 3 lacks a 7th tap (wave-uniform)
+        if (TS_ABL & 4) { acc[0] += a[i & 1][0][0] + a[i & 1][1][3] + b[i & 1][0][1] + b[i & 1][1][2]; continue; }
 #pragma unroll
         for (int kp = 0; kp < 8; ++kp)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i & 1][kp >> 2][kp & 3], b[i & 1][kp >> 2][kp & 3], acc, 0, 0, 0);
