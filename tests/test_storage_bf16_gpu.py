@@ -271,13 +271,13 @@ def test_forward_convs_fp16_storage(dev, Cin, Cout, shape, k, stride, two, odt):
         ops.set_option('conv_tapsplit', 1)
 
 
-def _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit, prefix=None):
+def _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit, prefix=None, H=torch.float16):
     ops = _ops()
     g = torch.Generator().manual_seed(21)
     N = 2
     pad = tuple((kk - 1) // 2 for kk in k)
     geom = ops.ConvGeom(shape, k, stride, pad)
-    H = torch.float16
+    lay = 4 if H == torch.float16 else 3                        # fp16 / bf16 weight fragments
     if two:
         srcs = [rbf(torch.randn((N,) + shape + (Cin // 2,), generator=g), H), rbf(torch.randn((N,) + shape + (Cin // 2,), generator=g), H)]
         lazy = [None, (torch.rand((N, Cin // 2), generator=g) + 0.5, torch.randn((N, Cin // 2), generator=g), 0.01)]
@@ -296,10 +296,10 @@ def _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit, pre
     p = ops.fill_conv(acts, geom, Cout, out0=ops.Act(out), bias=bd, mma=1)
     name = ops.conv_kernel_name(p)
     assert ops.conv_io_supported(p), name
-    assert ops.conv_pack_layout(p) == 4, (name, ops.conv_pack_layout(p))                 # fp16 weight fragments
+    assert ops.conv_pack_layout(p) == lay, (name, ops.conv_pack_layout(p))
     assert prefix is None or name.startswith(prefix), (name, prefix)
     wd = w.to(dev).contiguous()
-    wp = ops.pack_conv_weights(wd, acts[0].C, acts[1].C if two else 0, Cout, k, ops.conv_weight_strides(wd), False, ops.conv_ck(p), layout=4)
+    wp = ops.pack_conv_weights(wd, acts[0].C, acts[1].C if two else 0, Cout, k, ops.conv_weight_strides(wd), False, ops.conv_ck(p), layout=lay)
     p.wpack = wp.data_ptr()
     part = torch.zeros((N, ops.conv_stats_blocks(p), Cout, 2), device=dev)
     p.stats_part = part.data_ptr()
@@ -308,7 +308,7 @@ def _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit, pre
     ref = _host_conv_16(srcs, lazy, w, b, stride, pad, H)
     got = out.float().cpu()
     assert torch.isfinite(got).all()
-    tol = (2.0 ** -10 if odt == H else 1e-4) * float(ref.abs().max())
+    tol = ((2.0 ** -10 if H == torch.float16 else 2.0 ** -7) if odt == H else 1e-4) * float(ref.abs().max())
     # (the activation t = x * scale + shift is an fma on the device: an fp16 rounding boundary crossed by it shows as one input ulp)
     assert float((got - ref).abs().max()) < 4 * tol + 2e-3, (name, float((got - ref).abs().max()), tol)
     assert float(((got - ref).abs() > tol).float().mean()) < 2e-3, name
@@ -318,6 +318,22 @@ def _forward_conv_fp16(dev, Cin, Cout, shape, k, stride, two, odt, tapsplit, pre
     assert torch.allclose(sm[..., 1], (o * o).sum((1, 2, 3)), rtol=1e-4)
     if tapsplit:
         assert name.startswith('conv_tapsplit_kernel'), name
+
+
+@pytest.mark.parametrize("Cin,Cout,shape,stride,odt", [
+    (30, 60, (8, 18, 34), (2, 2, 2), torch.bfloat16),
+    (32, 70, (6, 16, 32), (1, 2, 2), torch.float32),
+])
+def test_strided_tapsplit_bf16_storage(dev, Cin, Cout, shape, stride, odt):
+    """the strided tap-split kernel over bf16 sources (bf16 products; bf16 or fp32 destination) against the host restatement — the
+    instances the fp16 cases of test_forward_convs_fp16_storage do not reach."""
+    ops = _ops()
+    ops.set_option('conv_bf16', 2)
+    try:
+        prefix = 'conv_tapsplit_kernel<4, true, 1, %d, 1, %d, 2, 2>' % (1 if odt == torch.bfloat16 else 0, stride[0])
+        _forward_conv_fp16(dev, Cin, Cout, shape, (3, 3, 3), stride, False, odt, False, prefix, H=torch.bfloat16)
+    finally:
+        ops.set_option('conv_bf16', 1)
 
 
 @pytest.mark.parametrize("Cin,Cout,shape,stride", [(30, 60, (8, 18, 34), (2, 2, 2)), (32, 64, (6, 16, 32), (1, 2, 2))])
