@@ -61,10 +61,15 @@ extern "C" int mt_inorm_finalize(const float* part, int N, int nsb, int C, doubl
 #ifndef MT_VB_BLOCKS
 #define MT_VB_BLOCKS 512      // target workgroups per sample below full resolution (256 / 1024 measured no better: tools/build_norm_variant.sh)
 #endif
+#ifndef MT_VB_MIN
+#define MT_VB_MIN 32
+#endif
 __host__ __device__ static inline int mt_vb(long V) {
   if (V >= 2048L * MT_VB_BLOCKS) return 2048;
-  long vb = ((V + MT_VB_BLOCKS - 1) / MT_VB_BLOCKS + 63) / 64 * 64;
-  return vb < 128 ? 128 : (int)vb;
+  long vb = ((V + MT_VB_BLOCKS - 1) / MT_VB_BLOCKS + 31) / 32 * 32;
+  // (the low-resolution tensors, V < 64 K voxels: MT_VB_MIN voxels per workgroup — at 128 a 6 x 12 x 12 tensor was 7 workgroups per
+  // sample walking ten dependent load rounds each)
+  return vb < MT_VB_MIN ? MT_VB_MIN : (int)vb;
 }
 static inline int nb_blocks(long V) { return mt_cdiv(V, (long)mt_vb(V)); }
 
@@ -368,12 +373,15 @@ struct InBwdSmall {
   long V; int C, N;
   float* dgamma; float* dbeta; float* dbias;
 };
+// 256 .. 1024 threads (round 5): a sample's voxels in as few dependent load rounds as possible — at 256 threads a 6 x 12 x 12 tensor
+// was four rounds per pass, two passes, per sample
 template <int VEC, int AT, int GT>
-__global__ __launch_bounds__(256) void inorm_bwd_small_kernel(const InBwdSmall P) {
+__global__ __launch_bounds__(1024) void inorm_bwd_small_kernel(const InBwdSmall P) {
   static_assert(mt_ebytes<AT>() == mt_ebytes<GT>(), "one vector index addresses both tensors");
-  __shared__ double redd[4][2 * VEC];
+  __shared__ double redd[16][2 * VEC];
   __shared__ float msh[2 * VEC];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int NT = blockDim.x, NWV = NT >> 6;
   const int grp = blockIdx.x, G = P.C / VEC;
   float ga[VEC], be[VEC];
 #pragma unroll
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_small_kernel(const InBwdSmall P
     float a0[VEC], a1[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-    for (long v = t; v < P.V; v += 256) {
+    for (long v = t; v < P.V; v += NT) {
       float gv[VEC], yv[VEC];
       mt_ldv<VEC, GT>(gp, (size_t)(v * G + grp), gv);
       mt_ldv<VEC, AT>(yp, (size_t)(v * G + grp), yv);
@@ -411,7 +419,8 @@ __global__ __launch_bounds__(256) void inorm_bwd_small_kernel(const InBwdSmall P
     }
     __syncthreads();
     if (t < 2 * VEC) {
-      const double s = (redd[0][t] + redd[1][t]) + (redd[2][t] + redd[3][t]);
+      double s = 0.0;
+      for (int w = 0; w < NWV; ++w) s += redd[w][t];           // fixed order
       msh[t] = (float)(s / (double)P.V);
       if (t & 1) tB += s; else tA += s;         // thread 2e: A of channel e, thread 2e + 1: B
     }
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_small_kernel(const InBwdSmall P
     float d0[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) d0[e] = 0.f;
-    for (long v = t; v < P.V; v += 256) {
+    for (long v = t; v < P.V; v += NT) {
       float gv[VEC], yv[VEC], out[VEC];
       mt_ldv<VEC, GT>(gp, (size_t)(v * G + grp), gv);
       mt_ldv<VEC, AT>(yp, (size_t)(v * G + grp), yv);
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(256) void inorm_bwd_small_kernel(const InBwdSmall P
         if (lane == 0) redd[wave][e] = (double)s0;
       }
       __syncthreads();
-      if (t < VEC) tD += (redd[0][t] + redd[1][t]) + (redd[2][t] + redd[3][t]);
+      if (t < VEC) { double s = 0.0; for (int w = 0; w < NWV; ++w) s += redd[w][t]; tD += s; }
     }
     __syncthreads();                             // redd / msh are rewritten for the next sample
   }
@@ -511,9 +520,10 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
     S.g = g; S.y = y; S.mean = mean; S.rstd = rstd; S.gamma = gamma; S.beta = beta; S.slope = slope; S.V = V; S.C = C; S.N = N;
     S.dgamma = dgamma; S.dbeta = dbeta; S.dbias = dbias;
     const dim3 grid(C / svec);
-    if (gdtype == MT_F32) hipLaunchKernelGGL((inorm_bwd_small_kernel<4, MT_F32, MT_F32>), grid, dim3(256), 0, st, S);
-    else if (ydtype == MT_F16) hipLaunchKernelGGL((inorm_bwd_small_kernel<8, MT_F16, MT_BF16>), grid, dim3(256), 0, st, S);
-    else hipLaunchKernelGGL((inorm_bwd_small_kernel<8, MT_BF16, MT_BF16>), grid, dim3(256), 0, st, S);
+    const dim3 blk(V > 768 ? 1024 : V > 512 ? 768 : V > 256 ? 512 : 256);
+    if (gdtype == MT_F32) hipLaunchKernelGGL((inorm_bwd_small_kernel<4, MT_F32, MT_F32>), grid, blk, 0, st, S);
+    else if (ydtype == MT_F16) hipLaunchKernelGGL((inorm_bwd_small_kernel<8, MT_F16, MT_BF16>), grid, blk, 0, st, S);
+    else hipLaunchKernelGGL((inorm_bwd_small_kernel<8, MT_BF16, MT_BF16>), grid, blk, 0, st, S);
     MT_CHECK_LAUNCH("inorm_lrelu_bwd(small)");
     return MT_OK;
   }
