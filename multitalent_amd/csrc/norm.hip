@@ -466,7 +466,9 @@ __global__ __launch_bounds__(1024) void inorm_bwd_small_kernel(const InBwdSmall 
   }
   if (t < VEC && P.dbias != nullptr) P.dbias[grp * VEC + t] = (float)tD;
 }
-#define INORM_SMALL_MAX 16384        // voxels over the batch
+#define INORM_SMALL_MAX 2048         // voxels over the batch.  (16384 through round 4: at 2 x 12x24x24 x 256 the one-launch kernel — C / 8 workgroups
+                                     // streaming the whole tensor — takes 115 us where the three launches take 31, tools/bench_norm_small.py; at 2 x 6x12x12 they tie,
+                                     // at 2 x 3x6x6 it is 11 against 20 us)
 extern "C" size_t mt_inorm_bwd_workspace(int N, long V, int C) {
   const size_t nvb = (size_t)nb_blocks(V);
   return ((size_t)N * nvb * C * 3 + (size_t)N * C * 2) * sizeof(float);
