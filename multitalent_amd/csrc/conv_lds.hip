@@ -4028,7 +4028,9 @@ static bool bwdw_use_tr16(const mt_conv3d_t* p, const mt_src_t* ysrc) {
 static int bwdw_tr16_nsg(const mt_conv3d_t* p, int nchunks) {
   const int pairs = mt_cdiv(p->Cout, 32) * ((nchunks + 1) / 2);
   const long T = (long)p->N * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 32) * p->Do;
-  long nsg = (mt_device_cus(mt_current_device()) + pairs - 1) / pairs;
+  // (rounded DOWN: one workgroup fits a CU, so 8 pairs x ceil(256 / 120) = 360 workgroups were two rounds for 104 of them — twice a
+  // workgroup's time — where 240 workgroups of 1.5x the work take 1.5x)
+  long nsg = mt_device_cus(mt_current_device()) / pairs;
   if (nsg > T) nsg = T;
   if (g_bwdw_tr16 > 1 && nsg > g_bwdw_tr16) nsg = g_bwdw_tr16;      // tests: few workgroups, so that a range spans columns on small volumes
   return nsg < 1 ? 1 : (int)nsg;
@@ -4081,10 +4083,13 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = 
     if ((g_bwdw_cw % 100) >= 2 && P->ncot % 2 == 0 && (g_bwdw_cw >= 100 || planes * P->nchunks * (P->ncot / 2) >= 3072)) P->cw = 2;
   }
   int pairs = P->nchunks * mt_cdiv(P->ncot, P->cw); if (pairs < 1) pairs = 1;
-  int nsg = (256 + pairs - 1) / pairs;          // one workgroup per CU (up to 216 accumulator registers per wave)
+  // one workgroup per CU (up to 216 accumulator registers per wave), rounded DOWN: 60 pairs x ceil(256 / 60) = 300 workgroups are two
+  // rounds for 44 of them (240 -> 240 @ 6x24x24), 60 x 4 = 240 are one round of 1.25x the work
+  int nsg = 256 / pairs;
   // conv_bwdw_fast16_kernel with few taps (transposed-conv weights, 1x1x1): <= 180 registers and <= 49 KiB of LDS — two workgroups per CU
-  if (p->mma == 1 && p->src[0].dtype != MT_F32 && P->ntaps <= 8 && !bwdw_use_march(p)) nsg = (512 + pairs - 1) / pairs;
-  if (allow_cw && f32_both && bwdw_use_wino133(p)) nsg = (512 + pairs - 1) / pairs;       // conv_bwdw_wino_kernel<2, CW, 1>: 64 KiB of LDS, two per CU
+  if (p->mma == 1 && p->src[0].dtype != MT_F32 && P->ntaps <= 8 && !bwdw_use_march(p)) nsg = 512 / pairs;
+  if (allow_cw && f32_both && bwdw_use_wino133(p)) nsg = 512 / pairs;       // conv_bwdw_wino_kernel<2, CW, 1>: 64 KiB of LDS, two per CU
+  if (nsg < 1) nsg = 1;
   P->nsg_cap = nsg;
   if (nsg > P->ntiles_total) nsg = P->ntiles_total;
   if (nsg < 1) nsg = 1;
