@@ -75,19 +75,23 @@ def oracle_two_precisions(run):
     return run(torch.float32), run(torch.float64)
 
 
+ENTRY_BOUND = 0.03       # largest entry error of a gradient tensor, as a fraction of the tensor's largest exact entry
+
+
 def compare(tag, logits, loss, grads, o32, o64, logit_tol=1e-3, loss_tol=1e-3):
     """Logits and loss: within 1e-3 of the fp32 oracle (north_star's tolerance; observed ~3e-5).
     Gradients: at this size the fp32 oracle ITSELF is 1e-3 .. 8e-3 (of a tensor's largest entry) away from the exact gradient:
     a LeakyReLU decision of a voxel within rounding of zero flips and changes that voxel's gradient hundredfold — at the 3x12x12
     stages one flipped voxel moves a weight-gradient entry by ~5 % of its typical size — and InstanceNorm backward subtracts means
     of 1.8 M-voxel sums.  So the truth is the fp64 oracle, and the HIP path is held to: per parameter tensor relative L2 error
-    < 1e-2 (tensors whose exact gradient is not numerically zero), largest entry error < 0.1 max|g_64| + 1e-4 G (G = largest
+    < 1e-2 (tensors whose exact gradient is not numerically zero), largest entry error < 0.03 max|g_64| + 1e-4 G (G = largest
     gradient entry of the network; the second term is the noise floor of gradients that are mathematically ZERO — the bias of every
-    conv that feeds an InstanceNorm: 1e-19 in fp64, 1e-10 noise in both fp32 paths), globally relative L2 < max(5e-3, 2x the fp32
-    torch oracle's own error) and 1 - cos < max(1e-5, 4x the oracle's).
+    conv that feeds an InstanceNorm: 1e-19 in fp64, 1e-10 noise in both fp32 paths), globally relative L2 < max(2e-3, 1.6x the fp32
+    torch oracle's own error) and 1 - cos < max(1e-5, 4x the oracle's).  (Round 5: tightened from 0.1 max|g| and max(5e-3, 2x); measured
+    1.51e-3 against the oracle's 0.96e-3 on Task009, 0.87e-3 / 0.81e-3 on Task100, 5.0e-3 / 3.3e-3 on the residual encoder.)
     The HIP path normalises with ONE fma per element, t = y * (gamma rstd) + (beta - mu gamma rstd) (DESIGN.md §2 "lazy activations");
     rounding that per-channel offset to fp32 is a coherent 1-ulp perturbation: the same formula emulated inside the fp32 torch
-    oracle raises ITS relative L2 gradient error from 0.9e-3 to 2.4e-3 (measured, Task009 network) — the HIP path measures 2.1e-3."""
+    oracle raises ITS relative L2 gradient error from 0.9e-3 to 2.4e-3 (measured, Task009 network) — the HIP path measures 1.5e-3 on this test's batch (2.1e-3 on the batch of tools/diag_fullsize_grads.py)."""
     sd32, out32, l32 = o32
     sd64, out64, l64 = o64
     for i, (a, b) in enumerate(zip(logits, out32)):
@@ -107,7 +111,7 @@ def compare(tag, logits, loss, grads, o32, o64, logit_tol=1e-3, loss_tol=1e-3):
         # relative L2 only for tensors with a gradient worth the name (rms >= 1e-3 G): the norm biases of the 3x6x6 stage have
         # max|g| = 3e-4 G, and there 2e-5 G of backpropagated rounding noise is 6 % "relative" (r3: all five resenc outputs weighted)
         l2t = float((g.double() - t).norm() / t.norm()) if float(t.norm()) > 1e-3 * G * t.numel() ** 0.5 else 0.0
-        rows.append((max(err / (0.1 * mx + 1e-4 * G), l2t / 1e-2), err, cerr, mx, n))
+        rows.append((max(err / (ENTRY_BOUND * mx + 1e-4 * G), l2t / 1e-2), err, cerr, mx, n))
         ga.append(g.double().reshape(-1)); gt.append(t.reshape(-1)); gc.append(c.reshape(-1))
     rows.sort(reverse=True)
     ga, gt, gc = torch.cat(ga), torch.cat(gt), torch.cat(gc)
@@ -117,10 +121,10 @@ def compare(tag, logits, loss, grads, o32, o64, logit_tol=1e-3, loss_tol=1e-3):
     for r in rows[:6]:
         print("   %.2f of bound: max err %.2e (cpu32 %.2e), max|g| %.2e  %s" % r)
     assert rows[0][0] < 1.0, "%s: gradient of %s exceeds its bound by a factor %.2f" % (tag, rows[0][4], rows[0][0])
-    # global: within 5e-3 / cos 0.99999 — or, where the fp32 torch oracle itself is that far from the exact gradient (resenc with all
-    # five levels weighted: torch-CPU 3.3e-3, HIP 5.4e-3), within 2x of what the reference's own arithmetic achieves
+    # global: within 2e-3 / cos 0.99999 — or, where the fp32 torch oracle itself is that far from the exact gradient (resenc with all
+    # five levels weighted: torch-CPU 3.3e-3, HIP 5.0e-3), within 1.6x of what the reference's own arithmetic achieves
     cosc = float((gc * gt).sum() / (gc.norm() * gt.norm()))
-    assert l2 < max(5e-3, 2.0 * l2c) and (1.0 - cos) < max(1e-5, 4.0 * (1.0 - cosc)), (tag, l2, l2c, cos, cosc)
+    assert l2 < max(2e-3, 1.6 * l2c) and (1.0 - cos) < max(1e-5, 4.0 * (1.0 - cosc)), (tag, l2, l2c, cos, cosc)
     return rows[0]
 
 
