@@ -136,7 +136,7 @@ extern "C" int mt_inorm_lrelu_apply(const float* y, int ycs, const float* scale,
   ApplyParams P{y, ycs, scale, shift, slope, res, rcs, rscale, rshift, rslope, out, ocs, V, C};
   if (ycs == C && ocs == C && (res == nullptr || rcs == C)) {
     const int vec = dense_vec(C, V * C, dtype, {y, out, res});
-    if (vec > 0) return launch_apply_fast(P, N, dtype, vec, stream);
+    if (vec > 0 && C / vec <= 256) return launch_apply_fast(P, N, dtype, vec, stream);
   }
   hipLaunchKernelGGL(inorm_apply_kernel, dim3(nb_blocks(V), N), dim3(256), 0, (hipStream_t)stream, P, dtype);
   MT_CHECK_LAUNCH("inorm_lrelu_apply");
@@ -579,71 +579,111 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const LBwdParams P) {
   }
 }
 
-// ---- dense fast paths of the two element-wise kernels above (every operand contiguous, cs == C, C % VEC == 0): one thread
-// moves VEC consecutive channels of a voxel per iteration with 16/8-byte accesses; the per-(n, c) scale/shift come from a
-// small table read through the cache.  HBM-bound: apply = 2-3 streams, lrelu_bwd = 3-5 streams.
+// ---- dense fast paths of the two element-wise kernels above (every operand contiguous, cs == C, C % VEC == 0, C / VEC <= 256): the
+// mapping of inorm_bwd_fast_kernel — thread t keeps the VEC channels of group t % G for all its voxels (A = (256 / G) G active
+// threads, a block's range a multiple of A), so the per-(n, c) scale / shift are registers loaded once and an iteration is NF_UNROLL
+// independent 16 / 8 / 4-byte accesses per stream.  (Through round 4 a thread walked the flat element index: one 64-bit modulo and
+// up to 4 VEC table loads through the vector memory path per iteration — 2.8 TB/s at 30 channels where inorm_bwd_fast_kernel moves
+// 5.4.)  HBM-bound: apply = 2-3 streams, lrelu_bwd = 3-5 streams.
+struct DenseGeo { long nvec; int G, A, nblk; };
 template <int VEC, int AT>
-__global__ __launch_bounds__(256) void inorm_apply_fast_kernel(const ApplyParams P, long per_sample) {
-  const int n = blockIdx.y;
-  const size_t sb = (size_t)n * per_sample * mt_ebytes<AT>();         // bytes
-  const char* yp = (const char*)P.y + sb;
-  const char* rp = P.res ? (const char*)P.res + sb : nullptr;
-  char* op = (char*)P.out + sb;
+__global__ __launch_bounds__(256) void inorm_apply_fast_kernel(const ApplyParams P, const DenseGeo D) {
+  const int n = blockIdx.y, t = threadIdx.x;
+  if (t >= D.A) return;
+  const int grp = t % D.G;
   const bool has_res = P.res != nullptr;
-  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC; i < per_sample; i += (long)gridDim.x * 256 * VEC) {
-    const int c = (int)(i % P.C);
-    float y[VEC], r[VEC], o[VEC];
-    mt_ldv<VEC, AT>(yp, (size_t)(i / VEC), y);
-    if (has_res) mt_ldv<VEC, AT>(rp, (size_t)(i / VEC), r);
+  float sc[VEC], sh[VEC], rsc[VEC], rsh[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float sc = P.scale ? P.scale[(size_t)n * P.C + c + e] : 1.f, sh = P.scale ? P.shift[(size_t)n * P.C + c + e] : 0.f;
-      float t = fmaf(y[e], sc, sh);
-      if (has_res) {
-        const float rsc = P.rscale ? P.rscale[(size_t)n * P.C + c + e] : 1.f, rsh = P.rscale ? P.rshift[(size_t)n * P.C + c + e] : 0.f;
-        t += mt_lrelu(fmaf(r[e], rsc, rsh), P.rslope);
-      }
-      o[e] = mt_lrelu(t, P.slope);
+  for (int e = 0; e < VEC; ++e) {
+    const size_t k = (size_t)n * P.C + grp * VEC + e;
+    sc[e] = P.scale ? P.scale[k] : 1.f; sh[e] = P.scale ? P.shift[k] : 0.f;
+    rsc[e] = (has_res && P.rscale) ? P.rscale[k] : 1.f; rsh[e] = (has_res && P.rscale) ? P.rshift[k] : 0.f;
+  }
+  const long per = ((D.nvec + D.nblk - 1) / D.nblk + D.A - 1) / D.A * D.A;
+  const long lo = (long)blockIdx.x * per;
+  long hi = lo + per; if (hi > D.nvec) hi = D.nvec;
+  const size_t sb = (size_t)n * D.nvec * VEC * mt_ebytes<AT>();        // bytes
+  const char* yp = (const char*)P.y + sb;
+  const char* rp = has_res ? (const char*)P.res + sb : nullptr;
+  char* op = (char*)P.out + sb;
+  for (long i0 = lo + t; i0 < hi; i0 += (long)D.A * NF_UNROLL) {
+    float y[NF_UNROLL][VEC], r[NF_UNROLL][VEC];
+#pragma unroll
+    for (int u = 0; u < NF_UNROLL; ++u) {
+      const long i = i0 + (long)u * D.A;
+      if (i < hi) { mt_ldv<VEC, AT>(yp, (size_t)i, y[u]); if (has_res) mt_ldv<VEC, AT>(rp, (size_t)i, r[u]); }
     }
-    mt_stv<VEC, AT>(op, (size_t)(i / VEC), o);
+#pragma unroll
+    for (int u = 0; u < NF_UNROLL; ++u) {
+      const long i = i0 + (long)u * D.A;
+      if (i < hi) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float tt = fmaf(y[u][e], sc[e], sh[e]);
+          if (has_res) tt += mt_lrelu(fmaf(r[u][e], rsc[e], rsh[e]), P.rslope);
+          o[e] = mt_lrelu(tt, P.slope);
+        }
+        mt_stv<VEC, AT>(op, (size_t)i, o);
+      }
+    }
   }
 }
 
 template <int VEC, int AT, int GT>
-__global__ __launch_bounds__(256) void lrelu_bwd_fast_kernel(const LBwdParams P, long per_sample) {
+__global__ __launch_bounds__(256) void lrelu_bwd_fast_kernel(const LBwdParams P, const DenseGeo D) {
   static_assert(mt_ebytes<AT>() == mt_ebytes<GT>(), "one vector index addresses all tensors");
-  const int n = blockIdx.y;
-  const size_t sb = (size_t)n * per_sample * mt_ebytes<GT>();
+  const int n = blockIdx.y, t = threadIdx.x;
+  if (t >= D.A) return;
+  const int grp = t % D.G;
+  const bool has2 = P.y2 != nullptr;
+  float sc[VEC], sh[VEC], sc2[VEC], sh2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const size_t k = (size_t)n * P.C + grp * VEC + e;
+    sc[e] = P.scale ? P.scale[k] : 1.f; sh[e] = P.scale ? P.shift[k] : 0.f;
+    sc2[e] = (has2 && P.scale2) ? P.scale2[k] : 1.f; sh2[e] = (has2 && P.scale2) ? P.shift2[k] : 0.f;
+  }
+  const long per = ((D.nvec + D.nblk - 1) / D.nblk + D.A - 1) / D.A * D.A;
+  const long lo = (long)blockIdx.x * per;
+  long hi = lo + per; if (hi > D.nvec) hi = D.nvec;
+  const size_t sb = (size_t)n * D.nvec * VEC * mt_ebytes<GT>();
   const char* yp = (const char*)P.y + sb;
-  const char* y2p = P.y2 ? (const char*)P.y2 + sb : nullptr;
+  const char* y2p = has2 ? (const char*)P.y2 + sb : nullptr;
   char* gp = (char*)P.g + sb;
   char* cp = P.gcopy ? (char*)P.gcopy + sb : nullptr;
-  const bool has2 = P.y2 != nullptr;
-  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC; i < per_sample; i += (long)gridDim.x * 256 * VEC) {
-    const int c = (int)(i % P.C);
-    float y[VEC], y2[VEC], g[VEC];
-    mt_ldv<VEC, AT>(yp, (size_t)(i / VEC), y);
-    mt_ldv<VEC, GT>(gp, (size_t)(i / VEC), g);
-    if (has2) mt_ldv<VEC, AT>(y2p, (size_t)(i / VEC), y2);
+  for (long i0 = lo + t; i0 < hi; i0 += (long)D.A * NF_UNROLL) {
+    float y[NF_UNROLL][VEC], y2[NF_UNROLL][VEC], g[NF_UNROLL][VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float sc = P.scale ? P.scale[(size_t)n * P.C + c + e] : 1.f, sh = P.scale ? P.shift[(size_t)n * P.C + c + e] : 0.f;
-      float t = fmaf(y[e], sc, sh);
-      if (has2) {
-        const float sc2 = P.scale2 ? P.scale2[(size_t)n * P.C + c + e] : 1.f, sh2 = P.scale2 ? P.shift2[(size_t)n * P.C + c + e] : 0.f;
-        t += mt_lrelu(fmaf(y2[e], sc2, sh2), P.slope2);
-      }
-      g[e] = t > 0.f ? g[e] : g[e] * P.slope;
+    for (int u = 0; u < NF_UNROLL; ++u) {
+      const long i = i0 + (long)u * D.A;
+      if (i < hi) { mt_ldv<VEC, AT>(yp, (size_t)i, y[u]); mt_ldv<VEC, GT>(gp, (size_t)i, g[u]); if (has2) mt_ldv<VEC, AT>(y2p, (size_t)i, y2[u]); }
     }
-    mt_stv<VEC, GT>(gp, (size_t)(i / VEC), g);
-    if (cp) mt_stv<VEC, GT>(cp, (size_t)(i / VEC), g);
+#pragma unroll
+    for (int u = 0; u < NF_UNROLL; ++u) {
+      const long i = i0 + (long)u * D.A;
+      if (i < hi) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float tt = fmaf(y[u][e], sc[e], sh[e]);
+          if (has2) tt += mt_lrelu(fmaf(y2[u][e], sc2[e], sh2[e]), P.slope2);
+          g[u][e] = tt > 0.f ? g[u][e] : g[u][e] * P.slope;
+        }
+        mt_stv<VEC, GT>(gp, (size_t)i, g[u]);
+        if (cp) mt_stv<VEC, GT>(cp, (size_t)i, g[u]);
+      }
+    }
   }
 }
 
+static DenseGeo dense_geo(long V, int C, int vec) {
+  DenseGeo D;
+  D.nvec = V * C / vec; D.G = C / vec; D.A = (256 / D.G) * D.G; D.nblk = nb_blocks(V);
+  return D;
+}
 static int launch_apply_fast(const ApplyParams& P, int N, int dtype, int vec, mt_stream_t stream) {
-  const long per = P.V * P.C;
-  int blocks = (int)((per / vec + 255) / 256); if (blocks > 8192) blocks = 8192;
-  const dim3 grid(blocks, N);
+  const DenseGeo per = dense_geo(P.V, P.C, vec);
+  const dim3 grid(per.nblk, N);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MT_F32) {
     if (vec == 4) hipLaunchKernelGGL((inorm_apply_fast_kernel<4, MT_F32>), grid, dim3(256), 0, st, P, per);
@@ -662,7 +702,7 @@ static int launch_apply_fast(const ApplyParams& P, int N, int dtype, int vec, mt
   return MT_OK;
 }
 template <int AT, int GT>
-static void launch_lrelu_bwd_fast(const LBwdParams& P, dim3 grid, int vec, long per, hipStream_t st) {
+static void launch_lrelu_bwd_fast(const LBwdParams& P, dim3 grid, int vec, const DenseGeo per, hipStream_t st) {
   if constexpr (AT == MT_F32) {
     if (vec == 4) hipLaunchKernelGGL((lrelu_bwd_fast_kernel<4, AT, GT>), grid, dim3(256), 0, st, P, per);
     else if (vec == 2) hipLaunchKernelGGL((lrelu_bwd_fast_kernel<2, AT, GT>), grid, dim3(256), 0, st, P, per);
@@ -680,11 +720,10 @@ extern "C" int mt_lrelu_bwd(float* g, int gcs, const float* y, int ycs, const fl
   MT_REQUIRE(g && y && N > 0 && V > 0 && C > 0 && mt_dtype_ok(gdtype) && mt_dtype_ok(ydtype), "lrelu_bwd: bad args");
   LBwdParams P{g, gcs, y, ycs, scale, shift, slope, y2, y2cs, scale2, shift2, slope2, gcopy, gcopycs, V, C, gdtype, ydtype};
   if (gcs == C && ycs == C && (y2 == nullptr || y2cs == C) && (gcopy == nullptr || gcopycs == C) && V * C < (1L << 40) && ag_fast(ydtype, gdtype)) {
-    const long per = V * C;
-    const int vec = dense_vec(C, per, gdtype, {g, y, y2, gcopy});
-    if (vec > 0) {
-      int blocks = (int)((per / vec + 255) / 256); if (blocks > 8192) blocks = 8192;
-      MT_AG_SWITCH(ydtype, gdtype, (launch_lrelu_bwd_fast<AT, GT>(P, dim3(blocks, N), vec, per, (hipStream_t)stream)), (void)0);
+    const int vec = dense_vec(C, V * C, gdtype, {g, y, y2, gcopy});
+    if (vec > 0 && C / vec <= 256) {
+      const DenseGeo geo = dense_geo(V, C, vec);
+      MT_AG_SWITCH(ydtype, gdtype, (launch_lrelu_bwd_fast<AT, GT>(P, dim3(geo.nblk, N), vec, geo, (hipStream_t)stream)), (void)0);
       MT_CHECK_LAUNCH("lrelu_bwd_fast");
       return MT_OK;
     }

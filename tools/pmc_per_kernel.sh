@@ -1,9 +1,9 @@
-# HBM traffic of every kernel of the bench step, per kernel name: separate FETCH_SIZE / WRITE_SIZE passes over
-# bench.py (no other trace domain beside --kernel-trace), joined with the serialised kernel durations of tools/profile_r4.sh
-# -> gpurun_out/pmc_r4/pmc_per_kernel.json : {workload: {kernel: {launches, fetch_kb, write_kb, avg_us, hbm_gbs, frac_of_8TBs}}}
-# usage: bash tools/pmc_per_kernel_r4.sh [tags...]      tags as in tools/profile_r4.sh (their *_kernel_stats.csv must exist)
+# HBM traffic of every kernel of the bench step, per kernel name : separate FETCH_SIZE / WRITE_SIZE passes over
+# bench.py (no other trace domain beside --kernel-trace), joined with the serialised kernel durations of tools/profile_r5.sh
+# -> gpurun_out/pmc_r5/pmc_per_kernel.json : {workload: {kernel: {launches, fetch_kb, write_kb, avg_us, hbm_gbs, frac_of_8TBs}}}
+# usage: bash tools/pmc_per_kernel.sh [tags...]      tags as in tools/profile_r5.sh (their *_kernel_stats.csv must exist)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_r4
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_r5
 mkdir -p $O
 export MT_BWDW_STREAMS=0
 TAGS=${@:-task009_fp32 task009_bf16 resenc_bf16}
@@ -22,7 +22,7 @@ for t in $TAGS; do
 done
 python - $TAGS <<'PY'
 import csv, json, os, sys, collections
-R = os.environ['GRAFT_REPO_ROOT']; O = R + '/gpurun_out/pmc_r4'
+R = os.environ['GRAFT_REPO_ROOT']; O = R + '/gpurun_out/pmc_r5'
 out = {}
 for t in sys.argv[1:]:
     agg = collections.defaultdict(lambda: {'n': 0, 'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})
@@ -36,7 +36,7 @@ for t in sys.argv[1:]:
             agg[k][c] += float(r['Counter_Value'])
             if c == 'FETCH_SIZE': agg[k]['n'] += 1
     dur = {}
-    sf = R + '/gpurun_out/prof_r4/%s_kernel_stats.csv' % t
+    sf = R + '/gpurun_out/prof_r5/%s_kernel_stats.csv' % t
     if os.path.exists(sf):
         for r in csv.DictReader(open(sf)):
             dur[r['Name']] = float(r['AverageNs']) / 1e3
