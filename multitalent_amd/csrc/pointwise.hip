@@ -1309,13 +1309,37 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_b_kernel(const HeadBwdRed
 // dY[v][co] and dbias[co] = sum_v dY[v][co] in registers over the thread's voxels, reduced over the wave by DPP shuffles and over
 // the workgroup through LDS in a fixed order; one partial row per workgroup, summed in fp64 by head_narrow_reduce_kernel.
 #define HN_BLOCKS 1024
+// a lane's row of CIN channels in the wave's LDS image (rows are only 8- / 4-byte aligned: 120 / 60 bytes apart)
+template <int CIN, int ST>
+__device__ __forceinline__ void hn_row_from_lds(const char* row, float (&x)[CIN + 2]) {
+  if constexpr (ST == MT_F32) {
+#pragma unroll
+    for (int q = 0; q < CIN / 2; ++q) { const float2 t = *(const float2*)(row + q * 8); x[2 * q] = t.x; x[2 * q + 1] = t.y; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < CIN / 2; ++q) { const unsigned d = *(const unsigned*)(row + q * 4); x[2 * q] = mt_lo16<ST>(d); x[2 * q + 1] = mt_hi16<ST>(d); }
+  }
+}
+template <int CIN, int ST>
+__device__ __forceinline__ void hn_row_to_lds(char* row, const float (&x)[CIN + 2]) {
+  if constexpr (ST == MT_F32) {
+#pragma unroll
+    for (int q = 0; q < CIN / 2; ++q) { float2 t; t.x = x[2 * q]; t.y = x[2 * q + 1]; *(float2*)(row + q * 8) = t; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < CIN / 2; ++q) *(unsigned*)(row + q * 4) = mt_pk16<ST>(x[2 * q], x[2 * q + 1]);
+  }
+}
 template <int CIN, int NCO, int XS = MT_F32, int OS = MT_F32>
 __global__ __launch_bounds__(256) void head_bwd_narrow_kernel(const HeadBwdParams P) {
+  static_assert(CIN % 2 == 0, "channel pairs");
+  __shared__ __attribute__((aligned(16))) float hn_img[4 * 64 * CIN];          // one [64 voxels][CIN] image per wave (fp32-sized)
   constexpr int XE = mt_ebytes<XS>(), OE = mt_ebytes<OS>();
   constexpr int NP = NCO * CIN + NCO;                       // partial sums per thread: dW rows, then dbias
   __shared__ __attribute__((aligned(16))) float sw[NCO][CIN + 2], ssc[CIN + 2], ssh[CIN + 2];
   __shared__ float red[4][NP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const mt_src_t& S = P.x;
   const bool aff = S.scale != nullptr;
   const float slope = aff ? S.slope : 1.f;
@@ -1339,13 +1363,55 @@ __global__ __launch_bounds__(256) void head_bwd_narrow_kernel(const HeadBwdParam
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)S.ptr + (size_t)nb * xs * XE), 0, (int)(xs * XE), 0x00020000);
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)P.dx + (size_t)nb * xs * OE), 0, (int)(xs * OE), 0x00020000);
     const float* dyp = P.dy + (size_t)nb * P.V * P.dycs;
-    for (long v = b * 256 + tid; v < P.V; v += per_sample_blocks * 256) {
+    // Rows through LDS (round 5).  A thread owns a voxel and needs its CIN channels as registers, but a row-per-lane access is 64
+    // pieces at 120-byte (60-byte) strides per instruction: 3.3 TB/s.  The rows of a wave's 64 consecutive voxels are ONE contiguous
+    // block of 64 * CIN elements, so the wave moves it as 16-byte pieces (lane l: pieces l, l + 64, ...) through a wave-private LDS
+    // image of the same linear layout, and every lane reads / writes its own row there.
+    constexpr int ROWX = CIN * XE, ROWO = CIN * OE;            // bytes per row
+    constexpr int NPX = 64 * ROWX / 16, NPO = 64 * ROWO / 16;  // 16-byte pieces of a wave's block
+    char* const img = (char*)hn_img + wave * (64 * CIN * 4);
+    for (long v0 = b * 256 + wave * 64; v0 < P.V; v0 += per_sample_blocks * 256) {
+      const long v = v0 + lane;
+      const bool vok = v < P.V;
       float x[CIN + 2], old[CIN + 2], dy[NCO];
-      pw_load_row<CIN, XS>(ra, (int)(v * (CIN * XE)), x);
-      const int o = (int)(v * (CIN * OE));
-      if (P.accumulate_dx) pw_load_row<CIN, OS>(rx, o, old);
+      {
+        uint4 pc[(NPX + 63) / 64];
 #pragma unroll
-      for (int co = 0; co < NCO; ++co) dy[co] = co < P.Cout ? dyp[v * P.dycs + co] : 0.f;
+        for (int k = 0; k < (NPX + 63) / 64; ++k) {
+          const int p = k * 64 + lane;
+          pc[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ra, p < NPX ? (int)(v0 * ROWX) + p * 16 : (int)0x80000000, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < (NPX + 63) / 64; ++k) {
+          const int p = k * 64 + lane;
+          if (p < NPX) *(uint4*)(img + p * 16) = pc[k];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        hn_row_from_lds<CIN, XS>(img + lane * ROWX, x);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (P.accumulate_dx) {
+        uint4 pc[(NPO + 63) / 64];
+#pragma unroll
+        for (int k = 0; k < (NPO + 63) / 64; ++k) {
+          const int p = k * 64 + lane;
+          pc[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, p < NPO ? (int)(v0 * ROWO) + p * 16 : (int)0x80000000, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < (NPO + 63) / 64; ++k) {
+          const int p = k * 64 + lane;
+          if (p < NPO) *(uint4*)(img + p * 16) = pc[k];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        hn_row_from_lds<CIN, OS>(img + lane * ROWO, old);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int co = 0; co < NCO; ++co) dy[co] = (vok && co < P.Cout) ? dyp[v * P.dycs + co] : 0.f;      // (a lane past the sample adds nothing)
       float dx[CIN + 2];
 #pragma unroll
       for (int ci = 0; ci < CIN; ++ci) {
@@ -1361,7 +1427,19 @@ __global__ __launch_bounds__(256) void head_bwd_narrow_kernel(const HeadBwdParam
       }
 #pragma unroll
       for (int co = 0; co < NCO; ++co) part[NCO * CIN + co] += dy[co];
-      pw_store_row<CIN, OS>(rx, o, dx);
+      hn_row_to_lds<CIN, OS>(img + lane * ROWO, dx);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < (NPO + 63) / 64; ++k) {
+        const int p = k * 64 + lane;
+        if (p < NPO) {                                         // (pieces past the sample's last row: beyond num_records, dropped)
+          const uint4 q = *(const uint4*)(img + p * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, q), rx, (int)(v0 * ROWO) + p * 16, 0, 0);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
     }
   }
   // wave reduction (fixed butterfly), then the four waves through LDS in wave order
