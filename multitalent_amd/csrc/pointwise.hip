@@ -1114,11 +1114,19 @@ struct HeadBwdParams {
   float* part; int nwaves; long ntiles;
 };
 // XS: storage type of the head's input x (fp32 | fp16 | bf16); OS: of dX (fp32 | bf16).  dY (the loss gradient) is fp32.
-template <int NCI, int XS = MT_F32, int OS = MT_F32>
+// ST (round 5, dense tensors: x.cs == dxcs == Cin, dycs == Cout): the tile's dY block [32][Cout] and x block [32][Cin] are ONE
+// contiguous run each — staged into a wave-private LDS image as coalesced 16-byte pieces, operands read from there, dX leaves the
+// same way.  Without it a tile costs 70 vector-memory instructions (6 row-per-lane b128 loads, 48 two-voxel gathers of 128-376
+// bytes, 16 two-row stores) for 56 MFMAs: 10.5 k cycles per tile against 3.6 k of matrix time.
+template <int NCI, int XS = MT_F32, int OS = MT_F32, bool ST = false>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
   constexpr int XE = mt_ebytes<XS>(), OE = mt_ebytes<OS>();
+  constexpr int HB_WF = 2048 + 1024 * NCI;                   // floats of a wave's image: dY [32][<= 64], x / dX [32][<= 32 NCI]
+  __shared__ __attribute__((aligned(16))) float hb_img[ST ? 4 * HB_WF : 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const idy = hb_img + (ST ? wave * HB_WF : 0);
+  float* const ixf = idy + (ST ? 2048 : 0);                  // x block (storage type XS), afterwards the dX tile in fp32
   const int li = lane & 31, lhalf = lane >> 5;
   const int gw = blockIdx.x * 4 + wave;
   const mt_src_t& S = P.x;
@@ -1170,6 +1178,35 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
     const long bv = m0 + li;
     const bool vok = bv < P.V;
     const int yoff = vok ? (int)((bv * P.dycs + 8 * lhalf) * 4) : (int)0x80000000;
+    if constexpr (ST) {
+      const int ybytes = 32 * P.Cout * 4, xbytes = 32 * P.Cin * XE;
+      const int ybase = (int)(m0 * P.Cout * 4), xbase = (int)(m0 * P.Cin * XE);
+      uint4 py[8], px[4 * NCI];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int o = (k * 64 + lane) * 16;
+        py[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ry, o < ybytes ? ybase + o : (int)0x80000000, 0, 0));
+      }
+#pragma unroll
+      for (int k = 0; k < 4 * NCI; ++k) {
+        const int o = (k * 64 + lane) * 16;
+        px[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, o < xbytes ? xbase + o : (int)0x80000000, 0, 0));
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();                         // the previous tile's dX pieces have left the image
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int o = (k * 64 + lane) * 16;
+        if (o < ybytes) *(uint4*)((char*)idy + o) = py[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4 * NCI; ++k) {
+        const int o = (k * 64 + lane) * 16;
+        if (o < xbytes) *(uint4*)((char*)ixf + o) = px[k];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
     f32x16 ax[NCI];
 #pragma unroll
     for (int t = 0; t < NCI; ++t)
@@ -1179,10 +1216,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
     for (int ch = 0; ch < 4; ++ch) {
       if (ch < nchunks) {
         float xa[8];
+        if constexpr (ST) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xa[e] = idy[li * P.Cout + ch * 16 + 8 * lhalf + e];      // (rows past the sample were staged as zeros)
+        } else {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, yoff + (ch * 16 + g * 4) * 4, 0, 0));
           xa[4 * g] = v[0]; xa[4 * g + 1] = v[1]; xa[4 * g + 2] = v[2]; xa[4 * g + 3] = v[3];
+        }
         }
         const int cb = ch * 16 + 8 * lhalf;                        // a row's tail runs into the next voxel's first channels: zero them
         if (cb + 8 > P.Cout) {
@@ -1210,7 +1252,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
         const int ci = t * 32 + li;
         const int o = (in && ci < P.Cin) ? (int)((v * S.cs + ci) * XE) : (int)0x80000000;
         float raw;
-        if constexpr (XS == MT_F32) raw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        if constexpr (ST) {
+          const int ei = (2 * s2 + lhalf) * P.Cin + ci;
+          if constexpr (XS == MT_F32) raw = (ci < P.Cin) ? ixf[ei] : 0.f;
+          else raw = (ci < P.Cin) ? mt_from16<XS>(((const unsigned short*)ixf)[ei]) : 0.f;
+        } else if constexpr (XS == MT_F32) raw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
         else raw = mt_from16<XS>(__builtin_amdgcn_raw_buffer_load_b16(rx, o, 0, 0));
         const float tt = fmaf(raw, xsc[t], xsh[t]);
         av[t] = in ? fmaxf(tt, tt * slope) : 0.f;
@@ -1220,7 +1266,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
       for (int n = 0; n < 2; ++n) {
         const int co = n * 32 + li;
         const int o = (in && co < P.Cout) ? (int)((v * P.dycs + co) * 4) : (int)0x80000000;
-        bvv[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, o, 0, 0));
+        if constexpr (ST) bvv[n] = (in && co < P.Cout) ? idy[(2 * s2 + lhalf) * P.Cout + co] : 0.f;
+        else bvv[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, o, 0, 0));
       }
       (void)vo;
 #pragma unroll
@@ -1229,6 +1276,45 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
         for (int n = 0; n < 2; ++n) aw[t][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bvv[n], aw[t][n], 0, 0, 0);
     }
     // ---- store dX (C layout: lane = input channel column, registers = voxel rows)
+    if constexpr (ST) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();                         // every lane has read its x operands: the region becomes the fp32 dX tile
+#pragma unroll
+      for (int t = 0; t < NCI; ++t) {
+        const int ci = t * 32 + li;
+        if (ci < P.Cin) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) ixf[((j & 3) + 8 * (j >> 2) + 4 * lhalf) * P.Cin + ci] = ax[t][j];
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      const int dbytes = 32 * P.Cin * OE, dbase = (int)(m0 * P.Cin * OE);
+#pragma unroll
+      for (int k = 0; k < 4 * NCI; ++k) {
+        const int o = (k * 64 + lane) * 16;                    // byte offset of this lane's 16-byte piece inside the tile's dX block
+        if (o < dbytes) {
+          if constexpr (OS == MT_F32) {
+            f32x4 v = *(const f32x4*)((const char*)ixf + o);
+            if (P.accumulate_dx) {
+              const f32x4 old = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, dbase + o, 0, 0));
+              v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rd, dbase + o, 0, 0);
+          } else {
+            const f32x4 v0 = *(const f32x4*)((const char*)ixf + 2 * o), v1 = *(const f32x4*)((const char*)ixf + 2 * o + 16);
+            float e[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (P.accumulate_dx) {
+              const uint4 old = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rd, dbase + o, 0, 0));
+              e[0] += mt_lo16<OS>(old.x); e[1] += mt_hi16<OS>(old.x); e[2] += mt_lo16<OS>(old.y); e[3] += mt_hi16<OS>(old.y);
+              e[4] += mt_lo16<OS>(old.z); e[5] += mt_hi16<OS>(old.z); e[6] += mt_lo16<OS>(old.w); e[7] += mt_hi16<OS>(old.w);
+            }
+            uint4 q; q.x = mt_pk16<OS>(e[0], e[1]); q.y = mt_pk16<OS>(e[2], e[3]); q.z = mt_pk16<OS>(e[4], e[5]); q.w = mt_pk16<OS>(e[6], e[7]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, q), rd, dbase + o, 0, 0);
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int t = 0; t < NCI; ++t) {
       const int ci = t * 32 + li;
@@ -1536,10 +1622,14 @@ extern "C" int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, 
   P.nwaves = head_bwd_waves(N, V); P.ntiles = (long)N * ((V + 31) / 32);
   const int nci = (Cin + 31) / 32;
   hipStream_t st = (hipStream_t)stream;
-#define HB(NCI_) do { if (xs == MT_F16) hipLaunchKernelGGL((head_bwd_kernel<NCI_, MT_F16, MT_BF16>), dim3(P.nwaves / 4), dim3(256), 0, st, P);          \
-                      else if (xs == MT_BF16) hipLaunchKernelGGL((head_bwd_kernel<NCI_, MT_BF16, MT_BF16>), dim3(P.nwaves / 4), dim3(256), 0, st, P);   \
-                      else hipLaunchKernelGGL((head_bwd_kernel<NCI_>), dim3(P.nwaves / 4), dim3(256), 0, st, P); } while (0)
-  if (nci == 1) HB(1); else HB(2);
+  static int staged = -1;                   // MT_HEAD_BWD_STAGED=0: operands straight from global memory also for dense tensors
+  if (staged < 0) { const char* e = getenv("MT_HEAD_BWD_STAGED"); staged = e ? atoi(e) : 1; }
+  const bool dense = staged && x->cs == Cin && dxcs == Cin && dycs == Cout && (mt_is16(xs) ? (Cin % 2) == 0 : true);
+#define HB(NCI_, ST_) do { if (xs == MT_F16) hipLaunchKernelGGL((head_bwd_kernel<NCI_, MT_F16, MT_BF16, ST_>), dim3(P.nwaves / 4), dim3(256), 0, st, P);          \
+                      else if (xs == MT_BF16) hipLaunchKernelGGL((head_bwd_kernel<NCI_, MT_BF16, MT_BF16, ST_>), dim3(P.nwaves / 4), dim3(256), 0, st, P);   \
+                      else hipLaunchKernelGGL((head_bwd_kernel<NCI_, MT_F32, MT_F32, ST_>), dim3(P.nwaves / 4), dim3(256), 0, st, P); } while (0)
+  if (dense) { if (nci == 1) HB(1, true); else HB(2, true); }
+  else { if (nci == 1) HB(1, false); else HB(2, false); }
 #undef HB
   MT_CHECK_LAUNCH("head_bwd");
   HeadBwdReduce R;

@@ -961,8 +961,13 @@ def test_multitalent_loss_few_valid_regions(dev, C, V, masks):
                                                         (2, 60, 47, 777, False, True, True), (1, 64, 5, 4096, True, False, True), (3, 8, 64, 33, True, False, True),
                                                         (2, 30, 2, 48 * 20 * 21 + 5, True, False, True), (1, 32, 3, 1000, False, True, True),
                                                         (2, 30, 4, 777, True, True, False), (3, 32, 1, 4099, True, False, True)])
-def test_head_bwd_fused(dev, N, Cin, Cout, V, lazy, acc, bias):
-    """mt_head_bwd: dX, dW and dbias of a 1x1x1 head in one pass vs autograd of F.conv3d on the activated input (fp64)."""
+@pytest.mark.parametrize("sliced", [False, True])
+def test_head_bwd_fused(dev, N, Cin, Cout, V, lazy, acc, bias, sliced):
+    """mt_head_bwd: dX, dW and dbias of a 1x1x1 head in one pass vs autograd of F.conv3d on the activated input (fp64).
+    sliced: x is a channel slice of a wider buffer — the wide heads then fetch their operands straight from global memory instead of
+    through the staged LDS image of the dense case."""
+    if sliced and (Cout <= 4 and Cin in (30, 32)):
+        pytest.skip("the narrow form takes dense tensors only; its slice falls to the same wide kernel as the other cases")
     ops = _ops()
     g = torch.Generator().manual_seed(Cin * 100 + Cout)
     x = torch.randn((N, V, 1, 1, Cin), generator=g)
@@ -971,8 +976,14 @@ def test_head_bwd_fused(dev, N, Cin, Cout, V, lazy, acc, bias):
     w = torch.randn((Cout, Cin, 1, 1, 1), generator=g) / np.sqrt(Cin)
     dy = torch.randn((N, V, 1, 1, Cout), generator=g)
     dx0 = torch.randn((N, V, 1, 1, Cin), generator=g)
-    xd = x.to(dev)
-    a = ops.Act(xd, scale=sc.to(dev), shift=sh.to(dev), slope=0.01) if lazy else ops.Act(xd)
+    if sliced:
+        xw = torch.full((N, V, 1, 1, Cin + 6), float('nan'))
+        xw[..., 2:2 + Cin] = x
+        xd = xw.to(dev)
+        a = ops.Act(xd, 2, Cin, scale=sc.to(dev), shift=sh.to(dev), slope=0.01) if lazy else ops.Act(xd, 2, Cin)
+    else:
+        xd = x.to(dev)
+        a = ops.Act(xd, scale=sc.to(dev), shift=sh.to(dev), slope=0.01) if lazy else ops.Act(xd)
     wd = w.to(dev).contiguous()
     wb = ops.pack_conv_weights(wd, Cout, 0, Cin, (1, 1, 1), ops.conv_weight_strides(wd, as_bwd_data=True), False, ops.POINTWISE_CK)
     dxd = dx0.to(dev).clone()
