@@ -166,11 +166,13 @@ class MultiTalentLoss(nn.Module):
         """Value AND dLoss/dlogits of `forward` without autograd (the training step's path): per level one statistics pass, ONE
         combination launch (mt_loss_combine: value + gradient of the [L, B, C] arithmetic the reference spells as ~40 autograd
         operations), per level one backward pass.  outs = the engine's NDHWC logits of every level.
-        Returns ((total, ce, dc), [dlogits NDHWC])."""
+        Returns ((total, ce, dc), [dlogits NDHWC]), or None where only the autograd form applies."""
         dev = outs[0].device
         valid, lut = self._masks(valid_regions, dev)
         acts = [Act(o) for o in outs]
         L, B, Cn = len(acts), acts[0].N, acts[0].C
+        if any((a.N, a.C) != (B, Cn) for a in acts):
+            return None                      # (levels of different (B, C): the autograd form)
         st = torch.empty((L, B, Cn, 4), dtype=torch.float32, device=dev)
         tg = []
         for i, a in enumerate(acts):
