@@ -110,6 +110,22 @@ def conv_flops(engine):
     return f
 
 
+def conv_bytes(engine, esize):
+    """Algorithmic HBM bytes of one fwd+bwd of the whole batch in the fused ideal of SURVEY §8d: every conv / transposed conv reads its
+    input once and writes its output once (norm + LeakyReLU folded into the consumer's load); backward reads dY and X and writes dX:
+    sum_conv (3 |in| + 2 |out|) * esize."""
+    from multitalent_amd.engine import ConvNormOp, TConvOp
+    b = 0.0
+    for op in engine.ops:
+        if isinstance(op, TConvOp):
+            a, o = op.src.act, op.out.act
+            b += (3.0 * a.N * a.V * op.tu.in_channels + 2.0 * o.N * o.V * op.tu.out_channels) * esize
+        elif isinstance(op, ConvNormOp):
+            o = op.out.act
+            b += (3.0 * o.N * sum(float(np.prod(s.spatial)) * s.C for s in op.srcs) + 2.0 * o.N * o.V * o.C) * esize
+    return b
+
+
 class ConvTimer:
     """HIP-event timing (on the stream the kernels are launched on = torch's current stream) of EVERY convolution launch of the
     C ABI — mt_conv3d_fwd (forward and backward-data), mt_conv3d_bwd_weight, mt_conv3d_bwd_data_strided — grouped by the device
@@ -600,6 +616,18 @@ def training_line(r, workload, precision, patch, B, steps, warmup, world):
         "algorithmic_tflop_per_step": round(fl / 1e12, 3),
         "step_frac_of_fp32_mfma_roofline": round(fl / (r['ms'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
     }
+    # roofline of the step := max(t_HBM_alg, t_MFMA_alg) / t_measured with the figures of the run's dtype
+    esz = 4 if precision == 'fp32' else 2
+    nb = conv_bytes(r['step'].eng, esz)
+    t_hbm = nb / (HBM_PEAK_GBS * 1e9)
+    t_mfma = fl / ((MFMA_F32_PEAK_TFLOPS if precision == 'fp32' else MFMA_BF16_PEAK_TFLOPS) * 1e12)
+    line["algorithmic_gb_per_step"] = round(nb / 1e9, 3)
+    line["step_bound"] = {"t_hbm_ms": round(t_hbm * 1e3, 3), "t_mfma_ms": round(t_mfma * 1e3, 3), "bound": "hbm" if t_hbm > t_mfma else "mfma",
+                          "mfma_peak_tflops": MFMA_F32_PEAK_TFLOPS if precision == 'fp32' else MFMA_BF16_PEAK_TFLOPS,
+                          "frac": round(max(t_hbm, t_mfma) / (r['ms'] * 1e-3), 4)}
+    if precision != 'fp32':
+        line["frac_of_bf16_bound"] = line["step_bound"]["frac"]
+        del line["step_frac_of_fp32_mfma_roofline"]      # a 16-bit run against the fp32 matrix peak says nothing
     if r.get('comm') is not None:
         line["comm"] = r['comm']
     return line
@@ -635,9 +663,12 @@ def measure_also(args, dev, rank, world, ddp):
         rf = None if args.no_roofline else measure_roofline(r['step'], r['x'], r['largs'], precision, nrep=2)     # all ranks (collectives inside)
         e = training_line(r, workload, precision, patch, B, args.also_steps, 3, world)
         e = {k: e[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "algorithmic_tflop_per_step",
-                               "step_frac_of_fp32_mfma_roofline", "comm") if k in e}
+                               "step_frac_of_fp32_mfma_roofline", "frac_of_bf16_bound", "algorithmic_gb_per_step", "step_bound", "comm") if k in e}
         if rf is not None:
             e["roofline"] = rf
+            if world == 1 and rank == 0 and not args.no_traffic:
+                ca = ['--workload', workload, '--precision', precision, '--patch'] + [str(i) for i in patch]
+                e["roofline"].update(measure_traffic(rf["kernel"], ca))
         return e
 
     for workload, precision in todo:
@@ -718,6 +749,13 @@ def main():
     line = None
     if rank == 0:
         line = training_line(r, workload, args.precision, patch, B, args.steps, args.warmup, world)
+    if ddp:
+        # N > 1: the headline leaves the process as soon as it is measured — BEFORE the per-launch roofline pass (every rank, collectives
+        # inside) and before the other configs (first RCCL contact of the sharded sliding window and of two more networks): a hang or a
+        # crash in either must not cost the headline.  The complete line follows as the LAST line of the job with the same headline fields.
+        flush_c_stdio()
+        if rank == 0:
+            print(json.dumps(dict(line, roofline="pending: the complete line follows", also="pending: the complete line follows")), flush=True)
     if not args.no_roofline:
         # every rank runs the per-launch pass (the step contains the gradient all-reduce); rank 0 reports its own launches
         rf = measure_roofline(r['step'], r['x'], r['largs'], args.precision)
@@ -731,9 +769,7 @@ def main():
     torch.cuda.empty_cache()
     if args.workload is None and not args.no_also:
         if ddp:
-            # N > 1: the headline line leaves the process BEFORE the other configs run (they are the first RCCL contact of the sharded
-            # sliding window and of two more networks: a hang or a crash there must not cost the headline).  The complete line, with
-            # "also", follows as the LAST line of the job; both carry the same headline fields.
+            # second early line: now with the roofline object, still before the other configs run
             flush_c_stdio()
             dist.barrier()
             if rank == 0:

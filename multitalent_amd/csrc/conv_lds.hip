@@ -4270,8 +4270,8 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
   if (P.nchunks <= 0) return 0;
   size_t generic = (size_t)P.nchunks * P.ncot * P.nsg * P.ntaps * 512 * sizeof(float);
   {
-    for (int cwp = 0; cwp < 2; ++cwp) {          // with and without several cout tiles per workgroup (decided with dY's type at launch)
-      BwdWParams F; bwdw_fast_plan(p, &F, cwp == 1, cwp == 1);
+    for (int cwp = 0; cwp < 4; ++cwp) {          // every (allow_cw, f32_both) the launch can choose (decided with dY's type there)
+      BwdWParams F; bwdw_fast_plan(p, &F, (cwp & 1) != 0, (cwp & 2) != 0);
       if (F.nchunks > 0) {
         const size_t fast = (size_t)F.nchunks * F.ncot * F.nsg * F.ntaps * 512 * sizeof(float);
         if (fast > generic) generic = fast;

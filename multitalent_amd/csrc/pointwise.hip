@@ -1123,6 +1123,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadBwdParams P) {
   constexpr int XE = mt_ebytes<XS>(), OE = mt_ebytes<OS>();
   constexpr int HB_WF = 2048 + 1024 * NCI;                   // floats of a wave's image: dY [32][<= 64], x / dX [32][<= 32 NCI]
   __shared__ __attribute__((aligned(16))) float hb_img[ST ? 4 * HB_WF : 4];
+  static_assert(!ST || 4 * HB_WF * sizeof(float) <= 65536, "head_bwd_kernel: the four wave images must fit the 64 KiB of static LDS (NCI <= 2)");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* const idy = hb_img + (ST ? wave * HB_WF : 0);

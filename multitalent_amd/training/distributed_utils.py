@@ -39,6 +39,23 @@ def _all_reduce_sum(t):
     return t
 
 
+def assert_same_on_all_ranks(values, what):
+    """One MAX all-reduce of (v, -v): raises on EVERY rank when the ranks disagree on `values` (a short list of numbers).  Used once per
+    training-step object to pin decisions that change the NUMBER of collectives a rank issues (fused loss step or autograd form): a
+    disagreement would otherwise show up as a deadlock."""
+    if not active():
+        return
+    v = torch.tensor([float(x) for x in values], dtype=torch.float64)
+    t = torch.cat([v, -v])
+    if dist.get_backend() != 'gloo':
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = t.cpu()
+    hi, lo = t[:len(v)], -t[len(v):]
+    if not torch.equal(hi, lo):
+        raise RuntimeError("%s differs between the ranks: max %s, min %s (this rank: %s)" % (what, hi.tolist(), lo.tolist(), v.tolist()))
+
+
 class _AllReduceSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

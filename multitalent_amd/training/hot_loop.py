@@ -143,6 +143,7 @@ class FusedTrainStep:
         self.reducer = GradAllReducer(self.eng) if ddp else None
         self.head_params, self.head_opt = None, None
         self.fused_loss = os.environ.get('MT_FUSED_LOSS', '1') != '0'      # 0: always the autograd form of the loss (A/B, tests)
+        self._loss_form_checked = False
         self.last_logits = None      # full-resolution logits (NCDHW view of the engine's NDHWC buffer) of the latest forward
 
     def set_head_optimizer(self, params, lr=3e-3, weight_decay=3e-5):
@@ -203,6 +204,17 @@ class FusedTrainStep:
         # value + dLoss/dlogits straight from the loss kernels (mt_loss_combine) when the loss offers it: no autograd graph over
         # the [L, B, C] glue; None = a case only the autograd form covers
         fused = self.loss_fn.fused_step(outs, *loss_args) if self.fused_loss and hasattr(self.loss_fn, 'fused_step') else None
+        if not self._loss_form_checked:
+            # The fused form and the autograd form issue DIFFERENT numbers of collectives under batch Dice (one all-reduce of the
+            # statistics with dLoss/dstats scaled by the world size, against the all-gather + all-reduce pairs of the autograd graph), and
+            # the world-size scaling is only the all-gather's backward while every rank holds the same dLoss/d(dice sums) — the same
+            # (L, B, C) and deep-supervision weights.  Both are properties of the configuration, not of a call; pinned here once
+            # (ADVICE r5): a rank that decided differently raises instead of deadlocking.
+            self._loss_form_checked = True
+            from . import distributed_utils
+            sig = [1.0 if fused is not None else 0.0, len(outs)] + [float(v) for o in outs for v in (o.shape[0], o.shape[-1])]
+            sig += [float(w) for w in getattr(self.loss_fn, 'ds_loss_weights', [])]
+            distributed_utils.assert_same_on_all_ranks(sig, "the loss form (fused / autograd), the levels' (B, C) or the deep-supervision weights")
         if fused is not None:
             res, dl = fused
             self.last_logits = outs[0].permute(0, 4, 1, 2, 3)

@@ -114,7 +114,10 @@ def test_hip_mixed_mode_within_the_reference_autocast_deviation(dev, tag):
         assert abs(a - float(b)) <= 1.5 * float(d) + 2e-5 * max(1.0, abs(float(b)))
     # backward: within 1.5x the reference's fp16-autocast gradient deviation
     assert gl2 <= 1.5 * r16['grad_l2'] and (1.0 - gcos) <= 1.5 * (1.0 - r16['grad_cos']), (gl2, gcos, r16)
-    # and against the autocast outputs themselves: two approximations of the same exact answer
+    # and against the autocast outputs themselves.  Two approximations of one exact answer with (nearly) independent rounding errors of
+    # at most 1.5 r and r lie sqrt(1.5^2 + 1) r = 1.8 r apart; the triangle inequality (2.5 r) would hold for ANY pair that passed the
+    # checks above and could never fail
     for i, a in enumerate(logits):
         b = z['%s/fp16/out%d' % (tag, i)]
-        assert float(np.linalg.norm(a - b) / np.linalg.norm(b)) <= ll2[i] + r16['logits'][i] + 1e-6
+        d = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        assert d <= 1.8 * r16['logits'][i] + 1e-5, "level %d: HIP mixed vs the reference's fp16-autocast logits %.3e, the autocast's own deviation %.3e" % (i, d, r16['logits'][i])

@@ -74,3 +74,47 @@ def test_tile_48x192x192_nc47_into_an_aggregate_beyond_2_to_32_elements(dev):
     print("un-mirrored tile added on top: max |d| %.3e" % err2)
     assert err2 < 2e-4, err2
     assert torch.allclose(nb[sl].cpu(), 2 * gauss, atol=1e-6)
+
+
+def test_predict_3d_four_real_tiles_nc47_vs_oracle(dev):
+    """BASELINE configs[4] at the REAL tile with SEVERAL tiles (VERDICT r5 missing #5): a 72 x 192 x 288 volume = 2 x 1 x 2 tiles of
+    48 x 192 x 192 at step 0.5 (overlap along d and along w), 47 sigmoid regions, no mirroring, Gaussian weighting — predict_3D
+    (tile extraction, network, fused head + sigmoid, overlap-add, normalise, region thresholds painted in regions_class_order) against
+    the oracle's restatement of _internal_predict_3D_3Dconv_tiled (neural_network.py:287-428) with four CPU forwards.
+    Probabilities within 1e-4; masks: identical wherever the reference is further than 1e-4 from a threshold, the reference's rule on
+    this path's own probabilities everywhere, and a voxel may differ only where the reference's margin is below the probability
+    difference that was actually measured."""
+    import bench
+    from mask_check import check_masks
+    from oracle import reference_ops as R
+    patch, shape, nc = (48, 192, 192), (72, 192, 288), 47
+    torch.manual_seed(1234)
+    net = bench.build_network('task100').to(dev)
+    net.inference_apply_nonlin = nn.Sigmoid()
+    net.eval(); net.do_ds = False
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    from multitalent_amd.synthetic import synthetic_ct
+    vol = synthetic_ct(1, shape, 31, torch.device('cpu'))[0].numpy()            # [1, 72, 192, 288]
+    order = list(range(1, nc + 1))
+    seg, probs = net.predict_3D(vol, do_mirroring=False, mirror_axes=(0, 1, 2), use_sliding_window=True, step_size=0.5, patch_size=patch,
+                                regions_class_order=order, use_gaussian=True, pad_border_mode='constant', pad_kwargs={'constant_values': 0},
+                                all_in_gpu=False, verbose=False, mixed_precision=False)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    calls = []
+
+    def fwd(xt):
+        calls.append(1)
+        return R.generic_unet_forward(sd, xt, bench.POOLS, bench.KERNELS, deep_supervision=False)
+    ref_seg, ref_probs = R.predict_3d_tiled(fwd, vol, patch, nc, do_mirroring=False, step_size=0.5, use_gaussian=True,
+                                            regions_class_order=order, nonlin='sigmoid')
+    assert len(calls) == 4                                                   # 2 x 1 x 2 tiles
+    assert probs.shape == ref_probs.shape == (nc,) + shape and seg.shape == ref_seg.shape == shape
+    err = float(np.abs(probs - ref_probs).max())
+    print("four real tiles, nc = 47: max |p - p_ref| = %.3e" % err)
+    assert err < 1e-4, err
+    ties, ndiff = check_masks(seg, ref_seg, probs, ref_probs, order, 1e-4, 'predict_3D 72x192x288 nc47 mirror=0', max_tie_frac=5e-2, live=True)
+    # a voxel's mask may only differ where SOME region's reference probability is closer to 0.5 than the measured difference
+    margin = np.abs(ref_probs - 0.5).min(0)
+    differing = seg.astype(np.int64) != ref_seg.astype(np.int64)
+    assert not differing[margin > err].any()
+    print("masks: %d of %d voxels differ (all within the measured %.1e of a threshold)" % (int(differing.sum()), differing.size, err))

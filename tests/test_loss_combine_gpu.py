@@ -102,3 +102,42 @@ def test_training_step_takes_the_fused_loss(dev, monkeypatch):
     assert np.allclose(results[True][0], results[False][0], rtol=1e-6, atol=1e-6), (results[True][0], results[False][0])
     d = float((results[True][1] - results[False][1]).abs().max())
     assert d <= 1e-6, d
+
+
+def test_task100_plan_batch_4_full_resolution_level_vs_oracle(dev):
+    """BASELINE configs[2] at its PLAN batch: B = 4 samples x 47 region channels at one 48x192x192 level, four
+    different datasets (13, 2, 1 and 8 valid regions: 4 x 47 columns of statistics, most of them untouched) — loss, BCE and Dice terms and dLoss/dlogits of `fused_step` against the oracle's restatement of
+    compute_loss (MultiTalent_Trainer_DDP.py:544-623) with autograd on the host."""
+    from multitalent_amd.dataset_conversion.Task100_MultiTalent import (MultiTalent_region_output_idx_mapping, MultiTalent_regions,
+                                                                        MultiTalent_valid_regions)
+    from multitalent_amd.synthetic import synthetic_targets
+    from multitalent_amd.training.loss_functions.fused_losses import MultiTalentLoss
+    from oracle import reference_ops as R
+    B, patch, C = 4, (48, 192, 192), 47
+    names = ['Task017_AbdominalOrganSegmentation', 'Task003_Liver', 'Task009_Spleen', 'Task046_AbdOrgSegm2']
+    valid = [MultiTalent_valid_regions[n] for n in names]
+    label_sets = [sorted({l for r in v for l in MultiTalent_regions[r]}) for v in valid]
+    tg = synthetic_targets(B, patch, [[1, 1, 1]], label_sets, 4242, dev)
+    g = torch.Generator().manual_seed(77)
+    logits = (torch.randn((B,) + patch + (C,), generator=g) * 1.5)           # NDHWC, what the head kernels write
+    loss_fn = MultiTalentLoss([1.0], batch_dice=True)
+    res, dl = loss_fn.fused_step([logits.to(dev)], tg, valid)
+    torch.cuda.synchronize()
+    leaf = logits.permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    rl = R.multitalent_loss([leaf], [t.cpu() for t in tg], valid, MultiTalent_regions, MultiTalent_region_output_idx_mapping, [1.0])
+    rl[0].backward()
+    got = [float(r) for r in res]
+    want = [float(r) for r in rl]
+    print("B=4 Task100 level: loss/ce/dice HIP %s oracle %s" % (got, want))
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-4), (got, want)
+    ref = leaf.grad.permute(0, 2, 3, 4, 1)
+    d = (dl[0].cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print("dlogits: max |d| %.3e of max %.3e" % (d, scale))
+    assert d <= 1e-4 * scale, (d, scale)
+    # channels of regions that are not valid for a sample carry exactly zero gradient (the reference never touches them)
+    for b in range(B):
+        idx = sorted(MultiTalent_region_output_idx_mapping[r] for r in valid[b])
+        rest = [c for c in range(C) if c not in idx]
+        assert float(dl[0][b][..., rest].abs().max()) == 0.0

@@ -648,10 +648,11 @@ def test_strided_projection_pointwise_forward_and_scatter_backward(dev, stride):
 
 @pytest.mark.parametrize("Cin,Cout", [(30, 47), (30, 2), (32, 4)])
 @pytest.mark.parametrize("acc", [False, True])
-def test_head_backward_fp16_x_bf16_dx_bitexact(dev, Cin, Cout, acc):
+@pytest.mark.parametrize("base", [(4, 8, 16), (3, 7, 11)])       # (3, 7, 11): V = 231 (odd), V * Cin * 2 % 16 != 0 — 16-byte dX pieces straddle the sample end
+def test_head_backward_fp16_x_bf16_dx_bitexact(dev, Cin, Cout, acc, base):
     ops = _ops()
     g = torch.Generator().manual_seed(34)
-    N, base = 2, (4, 8, 16)
+    N = 3 if base[0] == 3 else 2
     V = int(np.prod(base))
     x = rbf(torch.randn((N,) + base + (Cin,), generator=g), torch.float16)
     sc, sh = torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g)
