@@ -768,7 +768,7 @@ def main():
     del r
     torch.cuda.empty_cache()
     if args.workload is None and not args.no_also:
-        if ddp:
+        if ddp and not args.no_roofline:
             # second early line: now with the roofline object, still before the other configs run
             flush_c_stdio()
             dist.barrier()

@@ -320,7 +320,7 @@ def test_bench_headline_survives_a_failing_also_leg():
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 2, out.stdout[-2000:]
     first, last = lines
-    assert isinstance(first['also'], str) and first['value'] == last['value'] and first['n_gpus'] == 2
+    assert isinstance(first['also'], str) and isinstance(first['roofline'], str) and first['value'] == last['value'] and first['n_gpus'] == 2
     assert last['comm']['params_identical_on_all_ranks'] and last['comm']['ms_per_step_over_ranks_before_barrier']['max'] >= \
         last['comm']['ms_per_step_over_ranks_before_barrier']['min'] > 0
     assert set(last['also']) >= {'task100', 'resenc_bf16', 'infer_512_nomirror'}
