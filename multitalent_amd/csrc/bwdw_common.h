@@ -31,3 +31,16 @@ typedef __bf16 bwb_bf16x8 __attribute__((ext_vector_type(8)));
 
 // bwdw_tr16.hip: direct bf16 backward-weight of 3x3x3 (KD = 3) / 1x3x3 (KD = 1) stride-1 convolutions fed by LDS transpose reads
 int mt_launch_bwdw_tr16(const BwdWParams& P, int KD, int xdt, hipStream_t st);
+
+// conv_x16.hip: persistent stride-1 3x3x3 (KD = 3) / 1x3x3 (KD = 1) convolution with ONE 16-bit storage type on all operands (fp16 forward,
+// bf16 backward-data); weights in pack layout 4 / 3; items = (spatial 4x4x32 tile, 32-channel cout tile), nwg persistent workgroups
+struct X16Params {
+  mt_conv3d_t c;
+  int tilesD, tilesH, tilesW, nsb;
+  int nchunks, ncot, nitems, nwg;
+  int npairs;                         // chunk pairs: two consecutive 16-channel chunks of one source (64 bytes of a voxel), or a single chunk (-1)
+  short pair[MT_MAX_CHUNKS][2];
+  ConvChunk chunk[MT_MAX_CHUNKS];
+};
+int mt_conv_x16_workgroups(int nitems);
+int mt_launch_conv_x16(const X16Params& P, int KD, int dt, hipStream_t st);

@@ -2430,6 +2430,48 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
   return MT_EINVAL;
 }
 
+// conv_x16_kernel (conv_x16.hip): the CONV_BF16 problems on the 4 x 4 x 32 tile with ONE 16-bit storage type on all operands and one
+// destination — persistent workgroups, weight fragments in LDS, register prefetch of the next (tile, chunk) step, 16-byte stores.
+// option "conv_x16" / MT_CONV_X16: 1 (default) | 0 = conv_bf16_kernel everywhere | n > 1: at most n workgroups (tests: several tiles each)
+static int g_x16 = -1;
+static bool conv_x16_ok(const mt_conv3d_t* p, int cfg) {
+  if (g_x16 < 0) { const char* e = getenv("MT_CONV_X16"); g_x16 = e ? atoi(e) : 1; }
+  if (!g_x16 || cfg != 0 || p->mma != 1) return false;
+  const int sd = conv_src_dtype(p);
+  if (!mt_is16(sd) || p->odtype != sd || !conv_out_pairs_ok(p)) return false;
+  if (p->csplit < p->Cout || p->osD > 0 || p->bstats.y != nullptr) return false;
+  if (!(p->KH == 3 && p->KW == 3 && (p->KD == 3 || p->KD == 1) && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PH == 1 && p->PW == 1 &&
+        p->PD == (p->KD == 3 ? 1 : 0) && p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
+  for (int i = 0; i < p->nsrc; ++i) {
+    if ((double)p->Di * p->Hi * p->Wi * p->src[i].cs * 2.0 >= 2147483648.0) return false;
+    if ((p->src[i].cs & 1) || (((uintptr_t)p->src[i].ptr) & 3)) return false;
+    if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
+  }
+  if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 2.0 >= 2147483648.0) return false;
+  if ((long)p->N * mt_cdiv(p->Do, 4) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 32) * mt_cdiv(p->Cout, 32) >= 2147483647L) return false;
+  return true;
+}
+static int launch_x16(const mt_conv3d_t* p, hipStream_t st) {
+  X16Params P;
+  P.c = *p;
+  if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
+  P.tilesD = mt_cdiv(p->Do, 4); P.tilesH = mt_cdiv(p->Ho, 4); P.tilesW = mt_cdiv(p->Wo, 32);
+  P.nsb = P.tilesD * P.tilesH * P.tilesW;
+  P.ncot = mt_cdiv(p->Cout, 32);
+  P.nitems = p->N * P.nsb * P.ncot;
+  P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, FCK, P.chunk);
+  MT_REQUIRE(P.nchunks > 0, "conv3d (x16): too many channel chunks (Cin=%d)", p->Cin);
+  P.npairs = 0;
+  for (int i = 0; i < P.nchunks; ++P.npairs) {
+    const bool two = i + 1 < P.nchunks && P.chunk[i + 1].src == P.chunk[i].src && P.chunk[i + 1].c0 == P.chunk[i].c0 + 16;
+    P.pair[P.npairs][0] = (short)i; P.pair[P.npairs][1] = (short)(two ? i + 1 : -1);
+    i += two ? 2 : 1;
+  }
+  P.nwg = mt_conv_x16_workgroups(P.nitems);
+  if (g_x16 > 1 && P.nwg > g_x16) P.nwg = g_x16;
+  return mt_launch_conv_x16(P, p->KD, conv_src_dtype(p), st);
+}
+
 static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
 static int g_bwdw_tr16 = -1;       // -1: read MT_BWDW_TR16 (default 1): direct bf16 backward-weight fed by LDS transpose reads (conv_bwdw_tr16_kernel) instead of the bf16 Winograd marching kernel
 static int g_bwdw_cw = -1;         // -1: read MT_BWDW_CW (default 4): most cout tiles per workgroup of the tiled backward-weight kernels (1 | 2 | 4; + 100: also on small problems)
@@ -2443,6 +2485,7 @@ extern "C" int mt_set_option(const char* name, int value) {
   if (name != nullptr && strcmp(name, "bwdw_cw") == 0) { g_bwdw_cw = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "bwdw_tr16") == 0) { g_bwdw_tr16 = value; return MT_OK; }
   if (name != nullptr && strcmp(name, "conv_tapsplit") == 0) { g_tapsplit = value; return MT_OK; }
+  if (name != nullptr && strcmp(name, "conv_x16") == 0) { g_x16 = value; return MT_OK; }
   mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
   return MT_EINVAL;
 }
@@ -2644,6 +2687,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   const ConvPlan pl = conv_plan(p);
   const int i = pl.cfg;
   if (i < 0) return MT_EINVAL;
+  if (pl.kind == CONV_BF16 && conv_x16_ok(p, i)) { snprintf(buf, n, "conv_x16_kernel<%d, %d>", p->KD, conv_src_dtype(p)); return MT_OK; }
   if (pl.kind == CONV_BF16) {
     // the instance launch_bf16 picks, as the profiler prints it: <MW, RH, TD, VEC, NT, NW, KD, XS, OS, MTY>
     const int sd = conv_src_dtype(p);
@@ -2725,6 +2769,7 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
              "(ask mt_conv3d_io_supported, convert with mt_cast)", p->src[0].dtype, p->nsrc == 2 ? p->src[1].dtype : -1, p->odtype);
   MT_REQUIRE(p->bstats.y == nullptr || pl.kind == CONV_WINO, "conv3d: bstats set on a problem whose kernel does not compute them "
              "(ask mt_conv3d_bwd_stats_supported)");
+  if (pl.kind == CONV_BF16 && conv_x16_ok(p, i)) return launch_x16(p, (hipStream_t)stream);
   if (pl.kind == CONV_BF16) return launch_bf16(p, i, (hipStream_t)stream);
   const ConvCfg& g = kCfgs[i];
   hipStream_t st = (hipStream_t)stream;

@@ -196,6 +196,7 @@ def _conv_pair(dev, srcs, lazy, w, bias, geom, split=None, accumulate=False, sta
 def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, split, acc):
     ops = _ops()
     ops.set_option('conv_bf16', 2)
+    ops.set_option('conv_x16', 0)              # conv_bf16_kernel itself (the one-destination 16-bit problems take conv_x16_kernel by default)
     try:
         g = torch.Generator().manual_seed(5)
         N = 2
@@ -223,6 +224,84 @@ def test_conv_bf16_kernel_bf16_storage_bitexact(dev, Cin, Cout, shape, k, two, s
             assert torch.allclose(s[..., 1], (o * o).sum((1, 2, 3)), rtol=1e-4)
     finally:
         ops.set_option('conv_bf16', 1)
+        ops.set_option('conv_x16', 1)
+
+
+@pytest.mark.parametrize("H", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Cin,Cout,shape,k,two,acc,nwg", [
+    (32, 32, (8, 16, 64), (3, 3, 3), False, False, 2),           # two workgroups walk 16 items each: the prefetch across tile boundaries
+    (30, 60, (11, 14, 90), (3, 3, 3), False, False, 3),          # ragged tiles in d, h and w; 14-channel tail chunk; 28-channel tail cout tile
+    (30, 30, (8, 20, 60), (1, 3, 3), False, False, 1000),        # 1x3x3 (residual encoder stage 0); 60-byte voxel rows (12-byte tail pieces)
+    (60, 30, (8, 16, 64), (3, 3, 3), True, False, 5),            # two sources (decoder: up | skip), one of them plain
+    (64, 64, (8, 16, 32), (3, 3, 3), False, True, 2),            # accumulate (gradient of a skip connection)
+    (30, 30, (7, 9, 40), (3, 3, 3), False, True, 1000),          # accumulate on ragged tiles
+    (48, 36, (4, 8, 32), (3, 3, 3), False, False, 1000),         # three chunks (a pair and a single); 4-channel tail cout tile (8-byte tail pieces)
+    (32, 34, (4, 8, 32), (1, 3, 3), False, False, 2),            # 2-channel tail cout tile (4-byte tail pieces)
+])
+def test_conv_x16_kernel(dev, Cin, Cout, shape, k, two, acc, nwg, H):
+    """conv_x16_kernel (persistent, weights in LDS, register prefetch, 16-byte stores) against (a) the host restatement of the 16-bit
+    arithmetic and (b) conv_bf16_kernel on the same buffers: same operands, same products, fp32 sums in a different tap order — the
+    stored 16-bit values agree except for rare one-ulp differences; statistics are those of the values as stored.  `nwg` caps the
+    number of persistent workgroups so that a workgroup walks several (tile, cout tile) items across sample boundaries."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    N = 2
+    pad = tuple((kk - 1) // 2 for kk in k)
+    geom = ops.ConvGeom(shape, k, (1, 1, 1), pad)
+    lay = 4 if H == torch.float16 else 3
+    if two:
+        srcs = [rbf(torch.randn((N,) + shape + (Cin // 2,), generator=g), H), rbf(torch.randn((N,) + shape + (Cin // 2,), generator=g), H)]
+        lazy = [None, (torch.rand((N, Cin // 2), generator=g) + 0.5, torch.randn((N, Cin // 2), generator=g), 0.01)]
+    else:
+        srcs = [rbf(torch.randn((N,) + shape + (Cin,), generator=g), H)]
+        lazy = [(torch.rand((N, Cin), generator=g) + 0.5, torch.randn((N, Cin), generator=g), 0.01)] if not acc else [None]
+    w = torch.randn((Cout, Cin) + k, generator=g) / np.sqrt(Cin * np.prod(k))
+    b = torch.randn(Cout, generator=g) if not acc else None
+    prev = rbf(torch.randn((N,) + tuple(geom.out) + (Cout,), generator=g), H)
+    acts, keep = [], []
+    for sx, lz in zip(srcs, lazy):
+        buf = sx.to(dev).to(H)
+        keep.append(buf)
+        acts.append(ops.Act(buf) if lz is None else ops.Act(buf, scale=lz[0].to(dev), shift=lz[1].to(dev), slope=lz[2]))
+    bd = b.to(dev) if b is not None else None
+    wd = w.to(dev).contiguous()
+    outs = {}
+    ops.set_option('conv_bf16', 2)
+    try:
+        for mode in (1 if nwg >= 1000 else nwg, 0):             # conv_x16: 1 = on, n > 1 = on with at most n workgroups, 0 = conv_bf16_kernel
+            ops.set_option('conv_x16', mode)
+            out = (prev.to(dev) if acc else torch.full(prev.shape, float('nan'))).to(dev).to(H)
+            p = ops.fill_conv(acts, geom, Cout, out0=ops.Act(out), bias=bd, accumulate=acc, mma=1)
+            name = ops.conv_kernel_name(p)
+            assert name.startswith('conv_x16_kernel<%d' % k[0] if mode else 'conv_bf16_kernel'), name
+            assert ops.conv_io_supported(p) and ops.conv_pack_layout(p) == lay
+            wp = ops.pack_conv_weights(wd, acts[0].C, acts[1].C if two else 0, Cout, k, ops.conv_weight_strides(wd), False, ops.conv_ck(p), layout=lay)
+            p.wpack = wp.data_ptr()
+            part = torch.zeros((N, ops.conv_stats_blocks(p), Cout, 2), device=dev)
+            p.stats_part = part.data_ptr()
+            ops.conv3d_fwd(p)
+            torch.cuda.synchronize()
+            outs[bool(mode)] = (out.float().cpu(), part.double().sum(1).cpu())
+    finally:
+        ops.set_option('conv_bf16', 1)
+        ops.set_option('conv_x16', 1)
+    got, st = outs[True]
+    old, st_old = outs[False]
+    assert torch.isfinite(got).all()
+    ulp = 2.0 ** -10 if H == torch.float16 else 2.0 ** -7
+    ref = _host_conv_16(srcs, lazy, w, b, (1, 1, 1), pad, H)
+    if acc:
+        ref = ref + prev
+    tol = ulp * float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 4 * tol + 2e-3, float((got - ref).abs().max())
+    assert float(((got - ref).abs() > tol).float().mean()) < 2e-3
+    # against conv_bf16_kernel: at most one ulp apart, and almost everywhere identical
+    d = (got - old).abs()
+    assert float(d.max()) <= 2 * ulp * float(old.abs().max()), float(d.max())
+    assert float((d > 0).float().mean()) < 0.02, float((d > 0).float().mean())
+    o = got.double()
+    assert torch.allclose(st[..., 0], o.sum((1, 2, 3)), rtol=1e-4, atol=1e-3 * o[0, ..., 0].numel() ** 0.5)
+    assert torch.allclose(st[..., 1], (o * o).sum((1, 2, 3)), rtol=1e-4)
 
 
 def _host_conv_16(srcs, lazy, w, b, stride, pad, dt):
