@@ -2432,11 +2432,17 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
 
 // conv_x16_kernel (conv_x16.hip): the CONV_BF16 problems on the 4 x 4 x 32 tile with ONE 16-bit storage type on all operands and one
 // destination — persistent workgroups, weight fragments in LDS, register prefetch of the next (tile, chunk) step, 16-byte stores.
-// option "conv_x16" / MT_CONV_X16: 1 (default) | 0 = conv_bf16_kernel everywhere | n > 1: at most n workgroups (tests: several tiles each)
+// option "conv_x16" / MT_CONV_X16: 1 (default) = where it measured faster than conv_bf16_kernel (one cout tile, or >= 8 channel chunks:
+// tools/bench_fwd16.py) | 0 = conv_bf16_kernel everywhere | n > 1: wherever eligible, at most n workgroups (tests: several tiles
+// per workgroup; 4096 = no cap)
 static int g_x16 = -1;
 static bool conv_x16_ok(const mt_conv3d_t* p, int cfg) {
   if (g_x16 < 0) { const char* e = getenv("MT_CONV_X16"); g_x16 = e ? atoi(e) : 1; }
   if (!g_x16 || cfg != 0 || p->mma != 1) return false;
+  if (g_x16 == 1) {
+    const int nch = mt_cdiv(p->src[0].C, FCK) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, FCK) : 0);
+    if (p->Cout > 32 && nch < 8) return false;
+  }
   const int sd = conv_src_dtype(p);
   if (!mt_is16(sd) || p->odtype != sd || !conv_out_pairs_ok(p)) return false;
   if (p->csplit < p->Cout || p->osD > 0 || p->bstats.y != nullptr) return false;
@@ -2468,6 +2474,7 @@ static int launch_x16(const mt_conv3d_t* p, hipStream_t st) {
     i += two ? 2 : 1;
   }
   P.nwg = mt_conv_x16_workgroups(P.nitems);
+  { static int stg = -1; if (stg < 0) { const char* e = getenv("MT_X16_STAGGER"); stg = e ? atoi(e) : 0; } P.stagger = stg; }
   if (g_x16 > 1 && P.nwg > g_x16) P.nwg = g_x16;
   return mt_launch_conv_x16(P, p->KD, conv_src_dtype(p), st);
 }

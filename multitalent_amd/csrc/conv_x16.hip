@@ -345,6 +345,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long ts_last = __builtin_amdgcn_s_memtime();
 #endif
+  // Co-resident workgroups that start together stay in phase (same code, same step time): both stage, both multiply, both store at the
+  // same moments and the phases ADD.  The second resident of a CU (launch order: eight XCDs round-robin, 32 CUs each) starts late by
+  // P.stagger x 8k cycles — a fraction of a tile period — and keeps that offset for the whole (persistent) kernel.
+  if (P.stagger > 0 && ((blockIdx.x >> 3) >> 5) & 1)
+    for (int k = 0; k < P.stagger; ++k) __builtin_amdgcn_s_sleep(127);
   X16Geo cur, nxt;
   decode(it0, cur);
   nxt = cur;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         X16_STAMP(7)
         if (!(X16_ABL & 2)) convert(cur, ch, ra[sub], rh[sub]);
         X16_STAMP(0)
-        if (!(X16_ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's weight fragments have landed (LDS-DMA)
+        if (!(X16_ABL & 16)) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this step's weight fragments have landed (LDS-DMA).  The BUILTIN, not inline asm: the compiler's wait-count pass must see it, or it drains vmcnt again in front of every later LDS read that might alias the DMA (it did: four times per epilogue, each time waiting for the stores just issued)
         __syncthreads();
         X16_STAMP(1)
         if (ends_pair) {

@@ -268,7 +268,7 @@ def test_conv_x16_kernel(dev, Cin, Cout, shape, k, two, acc, nwg, H):
     outs = {}
     ops.set_option('conv_bf16', 2)
     try:
-        for mode in (1 if nwg >= 1000 else nwg, 0):             # conv_x16: 1 = on, n > 1 = on with at most n workgroups, 0 = conv_bf16_kernel
+        for mode in (4096 if nwg >= 1000 else nwg, 0):          # conv_x16: n > 1 = wherever eligible with at most n workgroups (4096: no cap), 0 = conv_bf16_kernel
             ops.set_option('conv_x16', mode)
             out = (prev.to(dev) if acc else torch.full(prev.shape, float('nan'))).to(dev).to(H)
             p = ops.fill_conv(acts, geom, Cout, out0=ops.Act(out), bias=bd, accumulate=acc, mma=1)

@@ -17,6 +17,8 @@ LAYERS = [  # (cins, cout, shape, k)
     ((120,), 120, (24, 48, 48), (3, 3, 3)),
     ((60, 60), 60, (48, 96, 96), (3, 3, 3)),
     ((240,), 240, (12, 24, 24), (3, 3, 3)),
+    ((32,), 32, (48, 192, 192), (3, 3, 3)),
+    ((64,), 64, (48, 96, 96), (3, 3, 3)),
 ]
 ap_acc = None
 ap = argparse.ArgumentParser()
@@ -47,7 +49,7 @@ for li, (cins, cout, shape, k) in enumerate(LAYERS):
         byts = 2.0 * N * shape[0] * shape[1] * shape[2] * (C + cout)
         res = {}
         for mode in a.modes:
-            ops.set_option('conv_x16', mode)
+            ops.set_option('conv_x16', 4096 if mode else 0)        # 4096: conv_x16_kernel wherever eligible (1 = the dispatcher's rule)
             out = torch.zeros((N,) + tuple(geom.out) + (cout,), device=dev, dtype=H)
             p = ops.fill_conv(srcs, geom, cout, out0=ops.Act(out), bias=b, mma=1, accumulate=bool(a.acc and dtn == 'bf16'))
             name = ops.conv_kernel_name(p)
