@@ -144,6 +144,15 @@ class FusedTrainStep:
         self.head_params, self.head_opt = None, None
         self.fused_loss = os.environ.get('MT_FUSED_LOSS', '1') != '0'      # 0: always the autograd form of the loss (A/B, tests)
         self._loss_form_checked = False
+        # MT_STEP_GRAPH=1 (default 0): the steady-state step — the same ~450 launches on two streams every iteration — is captured once as a
+        # HIP graph per (shapes, hyper-parameters) and replayed: the host enqueues one graph instead of hundreds of launches.  Bit-identical
+        # to the eager step (tests/test_step_graph_gpu.py), but on ROCm 7.2 the replay is SLOWER than the eager enqueue it replaces
+        # [measured, round 6: Task009 fp32 29.74 -> 31.49 ms, residual encoder mixed 21.61 -> 23.14, Task009 mixed 10.72 -> 11.90]: the graph
+        # executor loses more between dependent nodes than the host's 7 % of idle time it removes.  Kept opt-in.  Single process, fused SGD only.
+        self.use_graph = os.environ.get('MT_STEP_GRAPH', '0') == '1'
+        self._graph = None
+        self._eager_seen = {}            # graph key -> eager steps run with it (planning, packing programs and buffers exist before a capture)
+        self._eager_steps = 0
         self.last_logits = None      # full-resolution logits (NCDHW view of the engine's NDHWC buffer) of the latest forward
 
     def set_head_optimizer(self, params, lr=3e-3, weight_decay=3e-5):
@@ -200,6 +209,64 @@ class FusedTrainStep:
                 res = self.loss_fn([o.permute(0, 4, 1, 2, 3) for o in outs], *loss_args)
                 self.last_logits = outs[0].permute(0, 4, 1, 2, 3)       # online evaluation reads THIS forward's output, like the reference
             return res
+        if self._graphable(data):
+            done = self._graph_step(data, loss_args)
+            if done is not None:
+                return done
+        self._eager_steps += 1
+        return self._train_step(data, loss_args)
+
+    # ---- HIP graph of the steady-state step -----------------------------------------------------------------------------------
+    def _graphable(self, data):
+        return (self.use_graph and data.is_cuda and self.reducer is None and self.head_opt is None and not self.first
+                and self.fused_loss and hasattr(self.loss_fn, 'static_args') and not torch.cuda.is_current_stream_capturing())
+
+    def invalidate_graph(self):
+        self._graph = None
+
+    def _graph_step(self, data, loss_args):
+        """Replay (or capture, then replay) the graph of one training step.  The graph reads its inputs from STATIC tensors (the batch and
+        the loss arguments are copied into them: device-to-device, a few MB) and leaves the loss values in static tensors that the next
+        call overwrites.  Anything that changes what the step launches — shapes, precision, learning rate (a kernel argument), the
+        engine's stream setup — is part of the key; a new key captures a new graph (the poly schedule: once per epoch)."""
+        eng = self.eng
+        sa = self.loss_fn.static_args(*loss_args)
+        if sa is None:
+            return None
+        tensors, rebuild, skey = sa
+        key = (tuple(data.shape), data.dtype, tuple((tuple(t.shape), t.dtype) for t in tensors), skey, float(self.lr), float(self.wd), float(self.mom),
+               float(self.max_norm), eng.mma, eng.bwdw_streams, eng._planned, eng.flat.data_ptr())
+        g = self._graph
+        if (g is None or g['key'] != key) and self._eager_seen.get(key, 0) < 2:
+            self._eager_seen[key] = self._eager_seen.get(key, 0) + 1        # (a new shape plans, allocates and uploads tables: not capturable)
+            return None
+        if g is None or g['key'] != key:
+            sx = data.clone()
+            st = [t.clone() for t in tensors]
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    res = self._train_step(sx, rebuild(st))
+            except Exception as ex:            # noqa: BLE001 — a step that cannot be captured runs eagerly, loudly, from now on
+                import sys
+                sys.stderr.write("multitalent_amd: HIP graph capture of the training step failed (%s: %s); running eagerly\n" % (type(ex).__name__, str(ex)[:300]))
+                self.use_graph = False
+                self._graph = None
+                torch.cuda.synchronize()
+                return None
+            g = self._graph = {'key': key, 'graph': graph, 'x': sx, 't': st, 'res': res, 'logits': self.last_logits}
+        else:
+            g['x'].copy_(data)
+            for a, b in zip(g['t'], tensors):
+                a.copy_(b)
+        g['graph'].replay()
+        self.last_logits = g['logits']
+        eng.mark_params_dirty()
+        return g['res']
+
+    def _train_step(self, data, loss_args):
+        eng = self.eng
         outs = eng.forward(data, need_grad=True, all_heads=True)
         # value + dLoss/dlogits straight from the loss kernels (mt_loss_combine) when the loss offers it: no autograd graph over
         # the [L, B, C] glue; None = a case only the autograd form covers

@@ -168,7 +168,10 @@ class MultiTalentLoss(nn.Module):
         operations), per level one backward pass.  outs = the engine's NDHWC logits of every level.
         Returns ((total, ce, dc), [dlogits NDHWC]), or None where only the autograd form applies."""
         dev = outs[0].device
-        valid, lut = self._masks(valid_regions, dev)
+        if isinstance(valid_regions, torch.Tensor):        # the per-sample region masks as a device tensor (static_args: the captured step)
+            valid, lut = valid_regions, self._masks([], dev)[1]
+        else:
+            valid, lut = self._masks(valid_regions, dev)
         acts = [Act(o) for o in outs]
         L, B, Cn = len(acts), acts[0].N, acts[0].C
         if any((a.N, a.C) != (B, Cn) for a in acts):
@@ -194,6 +197,18 @@ class MultiTalentLoss(nn.Module):
             ops.multitalent_loss_bwd(a, tg[i], valid, lut, g[i], Act(d))
             dl.append(d)
         return (out3[0], out3[1], out3[2]), dl
+
+
+    def static_args(self, target, valid_regions):
+        """For the HIP-graph form of the training step (hot_loop.FusedTrainStep): (device tensors that change from step to step, a function
+        that rebuilds fused_step's arguments from static copies of them, a hashable key of everything else).  The valid regions travel as
+        their mask tensor."""
+        if distributed_utils.active():
+            return None
+        tg = list(target)
+        dev = tg[0].device
+        valid = self._masks(valid_regions, dev)[0]
+        return tg + [valid], (lambda ts: (ts[:-1], ts[-1])), ('mt', len(tg), self.batch_dice, tuple(self.ds_loss_weights))
 
 
 class DC_and_CE_DS_loss(nn.Module):
@@ -295,3 +310,10 @@ class DC_and_CE_DS_loss(nn.Module):
             ops.softmax_dice_ce_bwd(acts[i], tg[i], g[k], Act(d))
             dl[i] = d
         return out3[0], dl
+
+    def static_args(self, target):
+        """As MultiTalentLoss.static_args: the targets are the only per-step tensors."""
+        if self.ddp and distributed_utils.active():
+            return None
+        tg = list(target)
+        return tg, (lambda ts: (ts,)), ('dcce', len(tg), self.batch_dice, self.do_bg, self.ddp, float(self.smooth), tuple(self.ds_loss_weights))
