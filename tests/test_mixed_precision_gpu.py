@@ -54,8 +54,8 @@ def test_bf16_mode_uses_the_bf16_kernel_and_tracks_fp32(dev):
             step = FusedTrainStep(net, DC_and_CE_DS_loss(w, batch_dice=False), lr=1e-2)
             losses = [float(step(x, tg)) for _ in range(3)]
             res[mode] = ([o.detach().cpu() for o in out], float(loss.detach()), grads, losses, names)
-        assert not any(n.startswith('conv_bf16') for n in res['fp32'][4])
-        assert sum(n.startswith('conv_bf16') for n in res['bf16'][4]) >= 5, res['bf16'][4]      # every Cin >= 16 3x3x3 stride-1 conv
+        assert not any(n.startswith(('conv_bf16', 'conv_x16')) for n in res['fp32'][4])
+        assert sum(n.startswith(('conv_bf16', 'conv_x16')) for n in res['bf16'][4]) >= 5, res['bf16'][4]      # every Cin >= 16 3x3x3 stride-1 conv
         for a, b in zip(res['bf16'][0], res['fp32'][0]):
             assert float((a - b).abs().max()) < 3e-2 * float(b.abs().max())
         assert abs(res['bf16'][1] - res['fp32'][1]) < 1e-2
