@@ -306,6 +306,29 @@ def test_bench_two_ranks_self_validation_on_one_gpu(extra):
         assert line['comm']['loss_finite']
 
 
+@pytest.mark.parametrize("extra", [['--patch', '16', '64', '64', '--batch', '1'],
+                                   ['--workload', 'infer', '--mirror', '0', '--volume', '96', '384', '384']])
+def test_bench_eight_ranks_on_one_gpu(extra):
+    """World size 8 end to end (VERDICT r5 #8c) with all ranks on cuda:0 and gloo as the transport: the gradient buckets of 8 ranks
+    (bucket boundaries, mean over 8, bit-identical parameters afterwards) on a reduced patch, and the sliding window's shard_plan /
+    exchange_slabs / gather_slabs with 27 tiles over 8 ranks (uneven shares, padded slabs) equal to the unsharded result."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--no-also', '--no-roofline'] + extra,
+                         capture_output=True, text=True, timeout=1800, env=dict(os.environ, MT_BENCH_ONE_GPU='1'))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 8 and line['value'] > 0 and 'comm' in line, line
+    if 'infer' in extra:
+        assert line['sharded_equals_unsharded']['ok'], line['sharded_equals_unsharded']
+        assert line['config']['tiles'] == 27
+    else:
+        assert line['comm']['world'] == 8 and line['comm']['params_identical_on_all_ranks'] and line['comm']['param_checksum_spread_over_ranks'] == 0.0, line['comm']
+        assert line['comm']['loss_finite']
+
+
 def test_bench_headline_survives_a_failing_also_leg():
     """First contact of the N > 1 default run: the headline line is printed BEFORE the other configs run, and an
     exception inside any `also` entry becomes {"error": ...} under its name in the complete line instead of losing the job's output."""

@@ -192,7 +192,7 @@ def test_task009_fullsize_forward_loss_backward_vs_oracle(dev):
             lb, lossb, gb = hip_forward_backward(net, DC_and_CE_DS_loss(w, batch_dice=False), x, (tg,))
         mixed_vs_reference_autocast('task009', 'task009', lb, lossb, gb, o32, o64)
         assert any(n.startswith('conv_bwdw_tr16_kernel<3') for n in names16['bwdw']), names16['bwdw']
-        assert sum(n.startswith('conv_bf16') for n in names16['fwd']) >= 10, names16['fwd']
+        assert sum(n.startswith(('conv_bf16', 'conv_x16')) for n in names16['fwd']) >= 10, names16['fwd']
     finally:
         net.engine().set_precision('fp32')
         ops.set_mma(0)
@@ -307,7 +307,7 @@ def _resenc_fp32_and_bf16(dev):
     del grads, logits
     torch.cuda.empty_cache()
     _, _, _, _, _, lb, lossb, gb, nb = _resenc(dev, 'bf16')
-    assert sum(n.startswith('conv_bf16') for n in nb['fwd']) >= 20, nb['fwd']
+    assert sum(n.startswith(('conv_bf16', 'conv_x16')) for n in nb['fwd']) >= 20, nb['fwd']
     assert any(n.startswith('conv_bwdw_tr16_kernel<3') for n in nb['bwdw']) and any(n.startswith('conv_bwdw_tr16_kernel<1') for n in nb['bwdw']), nb['bwdw']
     assert any(n.startswith('bwdw_gemm_kernel') for n in nb['bwdw'])                      # the low-resolution stages
     mixed_vs_reference_autocast('resenc', 'resenc', lb, lossb, gb, o32, o64)
