@@ -35,7 +35,9 @@ extern "C" {
 #define MT_EHIP (-3)    /* HIP runtime error on launch */
 #define MT_EUNSUPPORTED (-4) /* the device is not the one this library is built for (gfx950) */
 
-#define MT_ABI_VERSION 3   /* 2: storage dtypes (mt_src_t.dtype, odtype fields, dtype arguments of the streaming kernels, mt_cast); 3: mt_pointwise_t.mma + mt_pointwise_pack_layout */
+#define MT_ABI_VERSION 4   /* 2: storage dtypes (mt_src_t.dtype, odtype fields, dtype arguments of the streaming kernels, mt_cast); 3: mt_pointwise_t.mma + mt_pointwise_pack_layout;
+                            * 4: kernel selection is a FIELD of the problem (mt_conv3d_t.select / max_workgroups): mt_set_option and every MT_* environment
+                            *    switch of the library are gone — no process-wide state besides per-device caches of immutable properties */
 #define MT_MAX_CHUNKS 64
 
 /* Storage type of an activation / gradient tensor in HBM.  fp32 is the parity path.  The mixed-precision mode (the reference's
@@ -111,7 +113,28 @@ typedef struct {
   int32_t odtype;             /* MT_F32 | MT_BF16 | MT_F16: element type of out0 / out1 (ocs0 / ocs1 count elements); statistics are taken from
                                  the values as stored */
   mt_bwd_stats_t bstats;      /* bstats.y != NULL: fused first pass of the NEXT InstanceNorm backward (see mt_bwd_stats_t) */
+  uint32_t select;            /* ABI 4: kernel selection of THIS problem, 2-bit fields MT_SEL_* (0 = the library's policy everywhere).  The queries
+                                 (mt_conv3d_ck, _pack_layout, _stats_blocks, _kernel_name, *_io_supported, *_workspace) and the launch must see the same value. */
+  int32_t max_workgroups;     /* ABI 4: > 0 caps the workers of the persistent kernels (conv_wino8p: per output-channel tile; conv_x16, conv_bwdw_tr16: total)
+                                 — tests make a worker walk several tiles of a small problem; 0 = fill the chip */
 } mt_conv3d_t;
+
+/* mt_conv3d_t.select: which kernel FAMILIES may serve the problem.  All families compute the same convolution (fp32: to rounding of the
+ * summation order; mma == 1: the 16-bit matrix kernels round the operands); the policy (MT_SEL_DEFAULT) takes a specialised kernel where
+ * its grid fills the chip.  Tests force a family on small shapes (MT_SEL_FORCE) or exclude it (MT_SEL_OFF) to compare two kernels on the
+ * same problem; the A/B tools do the same over whole steps. */
+#define MT_SEL_DEFAULT 0u
+#define MT_SEL_OFF 1u
+#define MT_SEL_FORCE 2u
+#define MT_SEL_WINO 0        /* shift: Winograd F(2x2x2, 3x3x3) forward / backward-data (conv_wino8p_kernel) */
+#define MT_SEL_M16 2         /* 16-bit matrix kernels of mma == 1 problems (conv_bf16_kernel, conv_x16_kernel; OFF = the fp32 kernels) */
+#define MT_SEL_X16 4         /* conv_x16_kernel among them (DEFAULT: where it measured faster; FORCE: wherever eligible) */
+#define MT_SEL_TAPSPLIT 6    /* conv_tapsplit_kernel on under-filled grids (FORCE: the strided form also on well-filled grids) */
+#define MT_SEL_BWDW_WINO 8   /* F(3x3, 2x2) backward-weight kernels (3x3x3 and 1x3x3) */
+#define MT_SEL_BWDW_TR16 10  /* conv_bwdw_tr16_kernel (16-bit X, bf16 dY) */
+#define MT_SEL_BWDW_CW 12    /* cout tiles per workgroup of the tiled backward-weight kernels: 0 = up to 4 where a workgroup walks enough tiles,
+                                1 = one, 2 = at most two, 3 = up to 4 also on small problems */
+#define MT_SEL_GET(sel, shift) (((sel) >> (shift)) & 3u)
 
 const char* mt_last_error(void);
 int mt_abi_version(void);
@@ -158,41 +181,17 @@ int mt_conv3d_bwd_data_strided_pack_layout(const mt_conv3d_t* p); /* `layout` of
 int mt_conv3d_io_supported(const mt_conv3d_t* p);
 int mt_conv3d_bwd_data_strided_io_supported(const mt_conv3d_t* p);
 int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_src_t* ysrc);
-/* Runtime options (tests, A/B measurements): "conv_wino" = 0 direct kernels only, 1 Winograd where the grid fills the chip
- * (default, also MT_CONV_WINO), 2 Winograd wherever the geometry is eligible; "wino_persist" 1 | n (persistent Winograd kernel: n > 1 = at
- * most n workers per output-channel tile); "bwdw_wino" 0 | 1; "conv_bf16" (problems with mma == 1) = 0 never, 1 where the grid fills the
- * chip (default), 2 wherever eligible; "bwdw_tr16" 1 (default) | 0 | n: conv_bwdw_tr16_kernel for 16-bit X with bf16 dY (0: cast + the fp32
- * kernels; n > 1: at most n workgroups per (cout tile, chunk pair) — tests); "bwdw_cw" (below); "conv_tapsplit" 1 (default) | 0 | 2:
- * conv_tapsplit_kernel on under-filled grids — stride-1 3x3x3 convs below 300 workgroups, strided stage convs below 256 (0: the full-tile
- * kernels; 2: the strided form wherever eligible); "bwdw_wino" 1 | 0: the F(3x3, 2x2) backward-weight
- * kernels (3x3x3 and 1x3x3). */
-int mt_set_option(const char* name, int value);
-/* Process-wide tuning knobs.  mt_set_option and the environment variables below choose BETWEEN KERNELS THAT COMPUTE THE SAME
- * RESULT (to fp32 rounding); they are the only mutable state of the library (atomics: setting one while other threads launch is
- * safe, it simply takes effect for later launches on every device).  Per-DEVICE one-time setup (raising a kernel's dynamic-LDS
- * limit, the CU count that sizes persistent grids) is keyed by the current HIP device, so one process may drive several GPUs.
- * Environment, read once at first use (0 disables the named kernel family and falls back to the generic one unless noted):
- *   MT_CONV_WINO (0|1|2), MT_WINO_PERSIST (1|n), MT_BWDW_WINO, MT_BWDW_MARCH, MT_BWDW_FAST, MT_BWDW_TALL,
- *   MT_CONV_BF16 (0|1|2), MT_BWDW_TR16, MT_STRIDED_BF16, MT_CONV_FASTV2, MT_CONV_RT, MT_CONV_STEM, MT_CONV_TAPSPLIT,
- *   MT_CONV_FAST133, MT_CONV_GATHER, MT_CONV_VEC1 (1: dword staging loads),
- *   MT_PW_VEC / MT_GATHER_VEC (1|2|4: floats per load instruction of pw_fast_kernel / conv_gather_kernel; default 4 = 16-byte
- *   buffer loads on dword-aligned addresses, see mt_probe_device), MT_PW_HEAD (0: the 33..64-channel 1x1x1 heads on pw_fast_kernel
- *   instead of pw_head_kernel; also the narrow-head kernels), MT_PW_WIDE (0: dword stores in the transposed-conv epilogue), MT_PW_SPLIT8 (0: all
- *   eight taps of a 2x2x2 transposed conv in one workgroup), MT_PACK_BLOCKS (workgroups per descriptor of mt_pack_batched,
- *   default 1024), MT_HEAD_BWD_WIDE, MT_CONV_CFG / MT_BF16_CFG (force a tile configuration), MT_CONV_STAGGER, MT_CONV_DBG (debugging).
- *   Mixed precision: MT_BWDW_GEMM (0: the low-resolution backward-weight on the fp32 marching kernel instead of
- *   im2col + bf16 GEMM), MT_BWDW_FAST16 (0: the tiled backward-weight geometries keep fp32 products in mixed precision), MT_BWDW_MARCH16 (0: the strided stage convs' backward-weight on the tiled
- *   kernel), MT_PACK_TILED (0: per-item weight packing), MT_LOSS_SPARSE (0: the flat MultiTalent loss kernels for every sample),
- *   MT_GATHER_BF16 (0: fp32 products in the backward-data of the transposed convs), MT_PW_M16 (0: fp32 products in the pointwise kernels
- *   whatever mt_pointwise_t.mma says — the weights must then be packed with layout 1), MT_INORM_SMALL (0: three launches for the InstanceNorm backward of small tensors instead of one).
- *   MT_BWDW_CW / option "bwdw_cw" (4 | 2 | 1: most cout tiles per workgroup of the tiled backward-weight kernels conv_bwdw_fast_kernel (fp32 storage),
- *   conv_bwdw_fast16_kernel and conv_bwdw_march16_kernel — a wave then takes one cout tile and 4 / 2 of the tile's k-step blocks, so that the staged
- *   X tile feeds 4 / 2 times the MFMAs — and of conv_bwdw_wino_kernel (at most 2: a wave takes 16 output channels and both tile rows);
- *   + 100 (104 | 102): also where a workgroup would walk fewer than six tiles / twelve planes).
- * The HOST side above this ABI (multitalent_amd/engine.py, inference/, bench.py) reads: MT_BF16_STORAGE (0: fp32 storage in mixed
- * precision), MT_ACT_STORAGE (fp16 | bf16), MT_BF16_MIN_VOXELS, MT_PW_STRIDED (0: strided 1x1x1 projections on conv_rt_kernel),
- * MT_BWDW_STREAMS, MT_FUSE_NORM_BWD, MT_HEAD_BWD_FUSED, MT_INFER_FUSED_HEAD, MT_INFER_MIXED, MT_PACK_SPLIT, MT_IO_DEBUG (1: print
- * every launch that needed an mt_cast), MT_FORCE_REDUCER, MT_BENCH_ONE_GPU (bench.py: all ranks on cuda:0 over gloo), MT_LIB_VARIANT.
+
+/* State.  The library keeps NO mutable process-wide state (ABI 4): which kernel serves a problem is a function of the problem struct
+ * alone (geometry, storage types, mma, select, max_workgroups), launches are re-entrant across host threads and streams, and memory
+ * (outputs, workspaces, statistics partials) is caller-owned.  What it caches is immutable per DEVICE: a kernel's raised dynamic-LDS
+ * limit and the CU count that sizes persistent grids, keyed by the current HIP device (one process may drive several GPUs).
+ * Rounds 1 - 5 had 39 MT_* environment switches and mt_set_option in here; the A/Bs they served are closed, the losing
+ * kernels are deleted or unreachable, and the families tests still compare are the MT_SEL_* fields above.
+ * The HOST side above this ABI (multitalent_amd/engine.py, ops.py, inference/, bench.py) has its own knobs: MT_BF16_STORAGE (0: fp32
+ * storage in mixed precision), MT_ACT_STORAGE (fp16 | bf16), MT_BF16_MIN_VOXELS, MT_BWDW_STREAMS, MT_FUSED_LOSS, MT_STEP_GRAPH, MT_IO_DEBUG
+ * (1: print every launch that needed an mt_cast), MT_SELECT ("x16=off,wino=force,...": default mt_conv3d_t.select of the process, for A/B
+ * runs of whole steps), MT_FORCE_REDUCER, MT_BENCH_ONE_GPU (bench.py: all ranks on cuda:0 over gloo), MT_LIB_VARIANT.
  * Which workgroup computes which tile (block id -> XCD -> tile order) is a compile-time choice (-DMT_TILE_ORDER=0 builds
  * the round-2 order for A/B measurements); results do not depend on it. */
 

@@ -41,7 +41,7 @@ class mt_conv3d_t(C.Structure):
                 ('OD', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32),
                 ('osD', C.c_int32), ('osH', C.c_int32), ('osW', C.c_int32),
                 ('ooD', C.c_int32), ('ooH', C.c_int32), ('ooW', C.c_int32), ('mma', C.c_int32), ('odtype', C.c_int32),
-                ('bstats', mt_bwd_stats_t)]
+                ('bstats', mt_bwd_stats_t), ('select', C.c_uint32), ('max_workgroups', C.c_int32)]
 
 
 class mt_pointwise_t(C.Structure):
@@ -57,7 +57,7 @@ class mt_pointwise_t(C.Structure):
 
 
 MT_F32, MT_BF16, MT_F16 = 0, 1, 2
-MT_ABI_VERSION = 3
+MT_ABI_VERSION = 4
 
 _vp, _i, _l, _f, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
 _P = C.POINTER
@@ -78,7 +78,6 @@ SIGNATURES = {
     'mt_conv3d_bwd_data_strided_supported': (_i, [_P(mt_conv3d_t)]),
     'mt_downsample_seg_nearest': (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     'mt_gaussian_blur_axis': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    'mt_set_option': (_i, [C.c_char_p, _i]),
     'mt_conv3d_pack_layout': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_bwd_data_strided_pack_layout': (_i, [_P(mt_conv3d_t)]),
     'mt_conv3d_kernel_name': (_i, [_P(mt_conv3d_t), C.c_char_p, _sz]),

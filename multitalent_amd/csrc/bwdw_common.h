@@ -38,7 +38,6 @@ struct X16Params {
   mt_conv3d_t c;
   int tilesD, tilesH, tilesW, nsb;
   int nchunks, ncot, nitems, nwg;
-  int stagger;                        // start delay of a CU's second resident workgroup, units of 8 128 cycles (s_sleep 127)
   int npairs;                         // chunk pairs: two consecutive 16-channel chunks of one source (64 bytes of a voxel), or a single chunk (-1)
   short pair[MT_MAX_CHUNKS][2];
   ConvChunk chunk[MT_MAX_CHUNKS];

@@ -2038,8 +2038,7 @@ static size_t cfg_lds(const ConvCfg& g, const mt_conv3d_t* p) {
 }
 // choose the tile shape with the least padded work that fits LDS; prefer >=2 workgroups per CU
 static int pick_cfg(const mt_conv3d_t* p) {
-  static int force = -2;
-  if (force == -2) { const char* e = getenv("MT_CONV_CFG"); force = e ? atoi(e) : -1; }
+  constexpr int force = -1;
   if (force >= 0 && cfg_lds(kCfgs[force], p) <= 160 * 1024) return force;
   int best = -1; double bestcost = 1e300;
   for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i) {
@@ -2073,11 +2072,10 @@ static bool strided_use_bf16(const mt_conv3d_t* p);
 static int conv_matrix_type(const mt_conv3d_t* p);
 static int conv_src_dtype(const mt_conv3d_t* p);
 static int conv_fast_vec(const mt_conv3d_t* p);
-static int g_tapsplit = -1;         // -1: read MT_CONV_TAPSPLIT (default 1); 0 off, 2: the strided form also on well-filled grids (tests)
+// mt_conv3d_t.select field as the legacy three-way switch: 0 = never this family, 1 = the library's policy, 2 = wherever eligible
+static inline int mt_sel3(const mt_conv3d_t* p, int shift) { const unsigned v = MT_SEL_GET(p->select, shift); return v == MT_SEL_OFF ? 0 : v == MT_SEL_FORCE ? 2 : 1; }
 static ConvPlan conv_plan(const mt_conv3d_t* p) {
-  static int use_v2 = -1, use_rt = -1;
-  if (use_v2 < 0) { const char* e = getenv("MT_CONV_FASTV2"); use_v2 = e ? atoi(e) : 1; }
-  if (use_rt < 0) { const char* e = getenv("MT_CONV_RT"); use_rt = e ? atoi(e) : 1; }
+  constexpr int use_v2 = 1, use_rt = 1;
   ConvPlan pl; pl.kind = CONV_GENERIC; pl.cfg = pick_cfg(p);
   if (p->mma == 1) {                      // bf16 matrix inputs where the bf16 kernel serves the problem; fp32 kernels elsewhere
     const int bc = conv_bf16_cfg(p);
@@ -2085,30 +2083,27 @@ static ConvPlan conv_plan(const mt_conv3d_t* p) {
   }
   if (conv_is_fast(p) && use_v2 && p->osD <= 0 && p->nsrc == 1 && p->Cin == 1 && p->csplit >= p->Cout &&
       (double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 < 2147483648.0) {
-    static int use_stem = -1;
-    if (use_stem < 0) { const char* e = getenv("MT_CONV_STEM"); use_stem = e ? atoi(e) : 1; }
+    constexpr int use_stem = 1;
     if (use_stem) { pl.kind = CONV_STEM; pl.cfg = 0; return pl; }
   }
   if (conv_is_fast(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0 && conv_wino_ok(p)) { pl.kind = CONV_WINO; return pl; }
   if (conv_is_fast(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0) {
     pl.kind = CONV_FAST;
     // low-resolution stages: fewer than two workgroups per CU -> split the taps over the waves instead
-    if (g_tapsplit < 0) { const char* e = getenv("MT_CONV_TAPSPLIT"); g_tapsplit = e ? atoi(e) : 1; }
-    const int use_ts = g_tapsplit;
+    const int use_ts = mt_sel3(p, MT_SEL_TAPSPLIT);
     int TD, TH, TW; cfg_tile(kCfgs[pl.cfg], &TD, &TH, &TW);
     const long wgs = (long)p->N * mt_cdiv(p->Do, TD) * mt_cdiv(p->Ho, TH) * mt_cdiv(p->Wo, TW) * mt_cdiv(p->Cout, 32);
     if (use_ts && wgs < 300 && p->csplit >= p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 < 2147483648.0) pl.kind = CONV_TAPSPLIT;
     return pl;
   }
   if (conv_is_133(p) && use_v2 && pl.cfg >= 0 && pl.cfg <= 2 && p->osD <= 0 && p->Cin >= 8) {      // compile-time taps instead of conv_rt
-    static int use133 = -1;
-    if (use133 < 0) { const char* e = getenv("MT_CONV_FAST133"); use133 = e ? atoi(e) : 1; }
+    constexpr int use133 = 1;
     if (use133) { pl.kind = CONV_FAST; return pl; }
   }
   if (use_rt && conv_fast_strided_ok(p)) {
     pl.kind = CONV_FAST_STRIDED; pl.cfg = 0;
     // fewer workgroups than CUs in the 2x4x8 x 64-channel tiling: one 32-voxel tile x 32 channels per workgroup, taps over the waves
-    if (g_tapsplit < 0) { const char* e = getenv("MT_CONV_TAPSPLIT"); g_tapsplit = e ? atoi(e) : 1; }
+    const int g_tapsplit = mt_sel3(p, MT_SEL_TAPSPLIT);
     const long wgs = (long)p->N * mt_cdiv(p->Do, 2) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 8) * mt_cdiv(p->Cout, 64);
     const int sd = conv_src_dtype(p);
     const bool inst = strided_use_bf16(p) ? mt_is16(sd) && (p->odtype == sd || p->odtype == MT_F32) : (sd == MT_F32 && p->odtype == MT_F32 && conv_fast_vec(p) == 2);
@@ -2176,8 +2171,7 @@ static bool conv_is_fast(const mt_conv3d_t* p) {
 
 // FAST v2 eligibility: FAST geometry + 8-byte alignment of every source for the 2-channel staging loads
 static int conv_fast_vec(const mt_conv3d_t* p) {
-  static int force1 = -1;
-  if (force1 < 0) { const char* e = getenv("MT_CONV_VEC1"); force1 = e ? atoi(e) : 0; }
+  constexpr int force1 = 0;
   if (force1) return 1;
   for (int i = 0; i < p->nsrc; ++i) {
     const mt_src_t& s = p->src[i];
@@ -2356,16 +2350,13 @@ static bool conv_is_133(const mt_conv3d_t* p) {
   return true;
 }
 // ---- bf16 matrix inputs (conv_bf16.inc)
-static int g_bf16_mode = -1;       // -1: read MT_CONV_BF16 (default 1); 0 never; 1 where the grid fills the chip; 2 wherever eligible
 static int conv_bf16_cfg(const mt_conv3d_t* p) {
-  if (g_bf16_mode < 0) { const char* e = getenv("MT_CONV_BF16"); g_bf16_mode = e ? atoi(e) : 1; }
-  const int use = g_bf16_mode;
+  const int use = mt_sel3(p, MT_SEL_M16);       // 0 never; 1 where the grid fills the chip; 2 wherever eligible
   if (!use || !(conv_is_fast(p) || conv_is_133(p)) || p->osD > 0 || p->Cin < 16 || conv_fast_vec(p) != 2) return -1;
   if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return -1;            // 31-bit store offsets per sample
   if (p->csplit < p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs1 * 4.0 >= 2147483648.0) return -1;
   if (mt_cdiv(p->src[0].C, FCK) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, FCK) : 0) > MT_MAX_CHUNKS) return -1;
-  static int force = -2;
-  if (force == -2) { const char* e = getenv("MT_BF16_CFG"); force = e ? atoi(e) : -1; }
+  constexpr int force = -1;
   int best = -1; double bestcost = 1e300;
   for (int i = 0; i < (int)(sizeof(kBfCfgs) / sizeof(kBfCfgs[0])); ++i) {
     int TD, TH, TW; cfg_tile(kBfCfgs[i], &TD, &TH, &TW);
@@ -2382,9 +2373,8 @@ static int conv_bf16_cfg(const mt_conv3d_t* p) {
   return best;
 }
 static bool strided_use_bf16(const mt_conv3d_t* p) {      // forward strided stage convs in mixed precision
-  if (g_bf16_mode < 0) { const char* e = getenv("MT_CONV_BF16"); g_bf16_mode = e ? atoi(e) : 1; }
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_STRIDED_BF16"); use = e ? atoi(e) : 1; }
+  const int g_bf16_mode = mt_sel3(p, MT_SEL_M16);
+  constexpr int use = 1;
   return use && g_bf16_mode && p->mma == 1 && p->Cin >= 16 && conv_fast_vec(p) == 2;
 }
 static int conv_bf16_vec(const mt_conv3d_t*) { return 2; }    // 16-byte staging loads measured slower (0.409 vs 0.372 ms on 32->32)
@@ -2432,12 +2422,11 @@ static int launch_bf16(const mt_conv3d_t* p, int cfg, hipStream_t st) {
 
 // conv_x16_kernel (conv_x16.hip): the CONV_BF16 problems on the 4 x 4 x 32 tile with ONE 16-bit storage type on all operands and one
 // destination — persistent workgroups, weight fragments in LDS, register prefetch of the next (tile, chunk) step, 16-byte stores.
-// option "conv_x16" / MT_CONV_X16: 1 (default) = where it measured faster than conv_bf16_kernel (one cout tile, or >= 8 channel chunks:
-// tools/bench_fwd16.py) | 0 = conv_bf16_kernel everywhere | n > 1: wherever eligible, at most n workgroups (tests: several tiles
-// per workgroup; 4096 = no cap)
-static int g_x16 = -1;
+// mt_conv3d_t.select MT_SEL_X16: default = where it measured faster than conv_bf16_kernel (one cout tile, or >= 8 channel chunks:
+// tools/bench_fwd16.py) | OFF = conv_bf16_kernel everywhere | FORCE: wherever eligible; max_workgroups caps the persistent grid
+// (tests: several tiles per workgroup)
 static bool conv_x16_ok(const mt_conv3d_t* p, int cfg) {
-  if (g_x16 < 0) { const char* e = getenv("MT_CONV_X16"); g_x16 = e ? atoi(e) : 1; }
+  const int g_x16 = mt_sel3(p, MT_SEL_X16);
   if (!g_x16 || cfg != 0 || p->mma != 1) return false;
   if (g_x16 == 1) {
     const int nch = mt_cdiv(p->src[0].C, FCK) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, FCK) : 0);
@@ -2474,38 +2463,18 @@ static int launch_x16(const mt_conv3d_t* p, hipStream_t st) {
     i += two ? 2 : 1;
   }
   P.nwg = mt_conv_x16_workgroups(P.nitems);
-  { static int stg = -1; if (stg < 0) { const char* e = getenv("MT_X16_STAGGER"); stg = e ? atoi(e) : 0; } P.stagger = stg; }
-  if (g_x16 > 1 && P.nwg > g_x16) P.nwg = g_x16;
+  if (p->max_workgroups > 0 && P.nwg > p->max_workgroups) P.nwg = p->max_workgroups;
   return mt_launch_conv_x16(P, p->KD, conv_src_dtype(p), st);
 }
 
-static int g_bwdw_wino = -1;       // -1: read MT_BWDW_WINO (default 1); Winograd backward-weight kernel
-static int g_bwdw_tr16 = -1;       // -1: read MT_BWDW_TR16 (default 1): direct bf16 backward-weight fed by LDS transpose reads (conv_bwdw_tr16_kernel) instead of the bf16 Winograd marching kernel
-static int g_bwdw_cw = -1;         // -1: read MT_BWDW_CW (default 4): most cout tiles per workgroup of the tiled backward-weight kernels (1 | 2 | 4; + 100: also on small problems)
-static std::atomic<int> g_wino_persist{1};     // conv_wino8p_kernel: n > 1 = at most n workers per output-channel tile (tests: few workers, many tiles each)
-static std::atomic<int> g_wino_mode{-1};       // -1: read MT_CONV_WINO (default 1); 0 off; 1 where the grid fills the chip; 2 wherever eligible
-extern "C" int mt_set_option(const char* name, int value) {
-  if (name != nullptr && strcmp(name, "conv_wino") == 0) { g_wino_mode = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "bwdw_wino") == 0) { g_bwdw_wino = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "wino_persist") == 0) { g_wino_persist = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "conv_bf16") == 0) { g_bf16_mode = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "bwdw_cw") == 0) { g_bwdw_cw = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "bwdw_tr16") == 0) { g_bwdw_tr16 = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "conv_tapsplit") == 0) { g_tapsplit = value; return MT_OK; }
-  if (name != nullptr && strcmp(name, "conv_x16") == 0) { g_x16 = value; return MT_OK; }
-  mt_set_error("set_option: unknown option '%s'", name ? name : "(null)");
-  return MT_EINVAL;
-}
 // Packed patch geometry of the persistent kernel: a task's linear offset (ld*Hi + lh)*Wi + lw with ld, lh <= 5 and lw <= 17 lives
 // in bits 0-19 of a table entry, so its maximum (5*Hi + 5)*Wi + 17 must stay below 2^20 (beyond that the offset would spill into
 // the ld bits); larger planes take the direct kernels.
+// MT_SEL_BWDW_CW as the legacy value: most cout tiles per workgroup (1 | 2 | 4), + 100 = also where a workgroup walks few tiles
+static inline int mt_bwdw_cw(const mt_conv3d_t* p) { const unsigned v = MT_SEL_GET(p->select, MT_SEL_BWDW_CW); return v == 1 ? 1 : v == 2 ? 2 : v == 3 ? 104 : 4; }
 static bool wino_persist_geometry_ok(const mt_conv3d_t* p) { return (5.0 * p->Hi + 5.0) * p->Wi + 17.0 < 1048576.0; }
 static bool conv_wino_ok(const mt_conv3d_t* p) {
-  if (g_wino_mode < 0) {
-    const char* e = getenv("MT_CONV_WINO"); g_wino_mode = e ? atoi(e) : 1;
-    const char* pe = getenv("MT_WINO_PERSIST"); if (pe) g_wino_persist = atoi(pe);
-  }
-  const int use = g_wino_mode;
+  const int use = mt_sel3(p, MT_SEL_WINO);
   if (!use) return false;
   if (p->Cin < 16 || conv_fast_vec(p) != 2 || !wino_persist_geometry_ok(p)) return false;
   if (p->csplit < p->Cout && (double)p->Do * p->Ho * p->Wo * p->ocs1 * 4.0 >= 2147483648.0) return false;
@@ -2535,7 +2504,7 @@ static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
   // one resident workgroup per CU (126 KiB of LDS each): NW workers per output-channel tile walk over the spatial tiles
   const int T = P.nsb * p->N, nct = mt_cdiv(p->Cout, 32);
   int nw = mt_device_cus(devid) / nct; if (nw < 1) nw = 1; if (nw > T) nw = T;
-  if (g_wino_persist > 1 && nw > g_wino_persist) nw = g_wino_persist;       // tests: few workers, many tiles each
+  if (p->max_workgroups > 0 && nw > p->max_workgroups) nw = p->max_workgroups;       // tests: few workers, many tiles each
   if (p->bstats.y != nullptr) {
     static std::atomic<uint64_t> attrb{0};
     if (mt_device_pending(attrb, devid)) {
@@ -2560,8 +2529,7 @@ static int launch_wino(const mt_conv3d_t* p, hipStream_t st) {
 
 // kernel == stride, pad 0, one plain destination, no statistics: every output owns its input block (conv_gather_kernel)
 static bool conv_gather_ok(const mt_conv3d_t* p) {
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_CONV_GATHER"); use = e ? atoi(e) : 1; }
+  constexpr int use = 1;
   if (!use || p->nsrc != 1 || p->csplit < p->Cout || p->osD > 0 || p->stats_part != nullptr) return false;
   if (!(p->KD == p->SD && p->KH == p->SH && p->KW == p->SW && p->PD == 0 && p->PH == 0 && p->PW == 0)) return false;
   if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
@@ -2569,8 +2537,7 @@ static bool conv_gather_ok(const mt_conv3d_t* p) {
   return true;
 }
 static bool gather_use_bf16(const mt_conv3d_t* p) {          // mixed precision: a bf16 gradient without a lazy activation
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_GATHER_BF16"); use = e ? atoi(e) : 1; }
+  constexpr int use = 1;
   return use && p->mma == 1 && p->src[0].dtype == MT_BF16 && p->src[0].scale == nullptr && !(p->src[0].cs & 1) && !(((uintptr_t)p->src[0].ptr) & 3);
 }
 static int launch_gather(const mt_conv3d_t* p, hipStream_t st) {
@@ -2585,8 +2552,7 @@ static int launch_gather(const mt_conv3d_t* p, hipStream_t st) {
   dim3 grid((unsigned)(P.nsb * p->N), (unsigned)mt_cdiv(p->Cout, 32), 1);
   const mt_src_t& S = p->src[0];
   // 16-byte loads at any alignment (dword-aligned dwordx4 buffer loads are legal and range-checked per dword: tools/ubench/oob128.hip)
-  static int force_vec = -1;
-  if (force_vec < 0) { const char* e = getenv("MT_GATHER_VEC"); force_vec = e ? atoi(e) : 0; }
+  constexpr int force_vec = 0;
   int vec = 4;
   if (force_vec == 1 || force_vec == 2) vec = force_vec;
   if (vec == 2 && !((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0)) vec = 1;
@@ -2668,11 +2634,9 @@ static int launch_conv(const mt_conv3d_t* p, const ConvCfg& g, hipStream_t st) {
   P.nchunks = mt_build_chunks(p->src[0].C, p->nsrc == 2 ? p->src[1].C : 0, CK, P.chunk);
   MT_REQUIRE(P.nchunks > 0, "conv3d: too many channel chunks (Cin=%d, ck=%d)", p->Cin, CK);
   {
-    static int stagger_env = -1;
-    if (stagger_env < 0) { const char* e = getenv("MT_CONV_STAGGER"); stagger_env = e ? atoi(e) : 0; }
+    constexpr int stagger_env = 0;
     P.stagger = stagger_env;
-    static int dbg_env = -1;
-    if (dbg_env < 0) { const char* e = getenv("MT_CONV_DBG"); dbg_env = e ? atoi(e) : 0; }
+    constexpr int dbg_env = 0;
     P.dbg = dbg_env;
   }
   const size_t ldsb = cfg_lds(g, p);
@@ -2832,9 +2796,8 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
 // mt_conv3d_bwd_data_strided: see include/mtseg.h.  p carries the FORWARD geometry (Di.. = X dims, Do.. = Y dims, K = 3,
 // S in {(2,2,2), (1,2,2)}, P = 1); src[0] = dY (C = Cout of the conv), out0 = dX (Cin channels).
 static bool bwdd_strided_use_bf16(const mt_conv3d_t* p) {          // p = FORWARD geometry, src[0] = dY
-  if (g_bf16_mode < 0) { const char* e = getenv("MT_CONV_BF16"); g_bf16_mode = e ? atoi(e) : 1; }
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_STRIDED_BF16"); use = e ? atoi(e) : 1; }
+  const int g_bf16_mode = mt_sel3(p, MT_SEL_M16);
+  constexpr int use = 1;
   const mt_src_t& s0 = p->src[0];
   return use && g_bf16_mode && p->mma == 1 && p->Cout >= 16 && !((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & (mt_is16(s0.dtype) ? 3 : 7)));
 }
@@ -2849,7 +2812,7 @@ extern "C" int mt_conv3d_bwd_data_strided_io_supported(const mt_conv3d_t* p) {
 // conv_bwdd_strided_ks_kernel: fp32 on both sides, 8-byte channel pairs, fewer workgroups than CUs in the 2 x 4 x 16 tiling
 // (option "conv_tapsplit" / MT_CONV_TAPSPLIT = 0: never; 2: wherever the types fit)
 static bool bwdd_strided_use_ks(const mt_conv3d_t* p) {
-  if (g_tapsplit < 0) { const char* e = getenv("MT_CONV_TAPSPLIT"); g_tapsplit = e ? atoi(e) : 1; }
+  const int g_tapsplit = mt_sel3(p, MT_SEL_TAPSPLIT);
   const mt_src_t& s0 = p->src[0];
   if (!g_tapsplit || bwdd_strided_use_bf16(p) || s0.dtype != MT_F32 || p->odtype != MT_F32) return false;
   if ((s0.cs & 1) || (s0.C & 1) || (((uintptr_t)s0.ptr) & 7)) return false;
@@ -3183,8 +3146,7 @@ static int pack_fill(PackParams& P, size_t* packed_floats, const float* w, float
   P.has_tm = tapmap != nullptr;
   for (int d = 0; d < 3; ++d) { P.tb[d] = tapmap ? tapmap[2 * d] : 0; P.ts[d] = tapmap ? tapmap[2 * d + 1] : 1; }
   P.s_ci = s_ci; P.s_co = s_co; P.s_kd = s_kd; P.s_kh = s_kh; P.s_kw = s_kw;
-  static int tiled = -1;
-  if (tiled < 0) { const char* e = getenv("MT_PACK_TILED"); tiled = e ? atoi(e) : 1; }
+  constexpr int tiled = 1;
   P.contig = (tiled && tapmap == nullptr && ck <= 16 && KD * KH * KW <= 27 && s_kw == 1 && s_kh == KW && s_kd == (long)KH * KW && s_ci == (long)KD * KH * KW) ? 1 : 0;
   return MT_OK;
 }
@@ -3198,8 +3160,7 @@ extern "C" int mt_pack_desc_fill(void* desc, const float* w, float* dst, int C0,
 // workgroups per descriptor of the batched packing: the launch lasts as long as its LARGEST descriptor (a 320 x 320 x 27 layer is 2.8 M
 // scattered 4-byte reads), so that one needs the whole chip; the small descriptors' surplus workgroups exit at once
 static unsigned g_pack_blocks() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MT_PACK_BLOCKS"); v = e ? atoi(e) : 1024; if (v < 1) v = 1; }
+  constexpr int v = 1024;
   return (unsigned)v;
 }
 extern "C" int mt_pack_batched(const void* descs_device, int n, mt_stream_t stream) {
@@ -4027,8 +3988,7 @@ static int bwdw_fast_geo(const mt_conv3d_t* p, const mt_src_t* y) {
 static bool bwdw_is_fast(const mt_conv3d_t* p, const mt_src_t* y) { return bwdw_fast_geo(p, y) >= 0; }
 #define BW_STEM_WGS 512
 static bool bwdw_is_stem(const mt_conv3d_t* p, const mt_src_t* y) {
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_CONV_STEM"); use = e ? atoi(e) : 1; }
+  constexpr int use = 1;
   if (!use || p->nsrc != 1 || p->Cin != 1 || p->src[0].C != 1) return false;
   if (!(p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 1 && p->PH == 1 && p->PW == 1)) return false;
   if (!(p->dilD == 1 && p->dilH == 1 && p->dilW == 1)) return false;
@@ -4037,22 +3997,21 @@ static bool bwdw_is_stem(const mt_conv3d_t* p, const mt_src_t* y) {
   return true;
 }
 static bool bwdw_use_march(const mt_conv3d_t* p) {
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_BWDW_MARCH"); use = e ? atoi(e) : 1; }
+  constexpr int use = 1;
   return use && p->KD == 3 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 1 && p->Do >= 3;
 }
 static void bwdw_march_plan(const mt_conv3d_t* p, BwdWParams* P);
 static int conv_fast_vec(const mt_conv3d_t* p);
 // the same kernel with KD = 1: the 1x3x3 stride-1 layers of the residual encoder's first stage (no depth halo, any Do)
 static bool bwdw_use_wino133(const mt_conv3d_t* p) {
-  if (g_bwdw_wino < 0) { const char* e = getenv("MT_BWDW_WINO"); g_bwdw_wino = e ? atoi(e) : 1; }
+  const int g_bwdw_wino = mt_sel3(p, MT_SEL_BWDW_WINO);
   for (int i = 0; i < p->nsrc; ++i)
     if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
   return g_bwdw_wino && p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 0 && p->PH == 1 &&
          p->PW == 1 && p->Wo > 16 && p->Ho >= 2 && conv_fast_vec(p) == 2 && conv_src_dtype(p) == MT_F32;
 }
 static bool bwdw_use_wino(const mt_conv3d_t* p) {
-  if (g_bwdw_wino < 0) { const char* e = getenv("MT_BWDW_WINO"); g_bwdw_wino = e ? atoi(e) : 1; }
+  const int g_bwdw_wino = mt_sel3(p, MT_SEL_BWDW_WINO);
   // (its X path applies LeakyReLU as max(t, slope * t): lazy sources need 0 <= slope <= 1)
   for (int i = 0; i < p->nsrc; ++i)
     if (p->src[i].scale != nullptr && !(p->src[i].slope >= 0.f && p->src[i].slope <= 1.f)) return false;
@@ -4061,7 +4020,7 @@ static bool bwdw_use_wino(const mt_conv3d_t* p) {
 // conv_bwdw_tr16_kernel (bwdw_tr16.hip): 3x3x3 / 1x3x3 stride-1, 16-bit X (lazy activations or plain), bf16 dY without affine, Wo > 16.
 // ysrc == nullptr: geometry + X only (workspace query).
 static bool bwdw_use_tr16(const mt_conv3d_t* p, const mt_src_t* ysrc) {
-  if (g_bwdw_tr16 < 0) { const char* e = getenv("MT_BWDW_TR16"); g_bwdw_tr16 = e ? atoi(e) : 1; }
+  const int g_bwdw_tr16 = mt_sel3(p, MT_SEL_BWDW_TR16);
   if (!g_bwdw_tr16 || p->mma != 1 || p->N > 16) return false;                 // (BWT_MAXN samples in the kernel's activation table)
   const bool g333 = bwdw_use_march(p) && p->PH == 1 && p->PW == 1;
   const bool g133 = p->KD == 1 && p->KH == 3 && p->KW == 3 && p->SD == 1 && p->SH == 1 && p->SW == 1 && p->PD == 0 && p->PH == 1 && p->PW == 1 && p->Do >= 1;
@@ -4084,7 +4043,7 @@ static int bwdw_tr16_nsg(const mt_conv3d_t* p, int nchunks) {
   // workgroup's time — where 240 workgroups of 1.5x the work take 1.5x)
   long nsg = mt_device_cus(mt_current_device()) / pairs;
   if (nsg > T) nsg = T;
-  if (g_bwdw_tr16 > 1 && nsg > g_bwdw_tr16) nsg = g_bwdw_tr16;      // tests: few workgroups, so that a range spans columns on small volumes
+  if (p->max_workgroups > 0 && nsg > p->max_workgroups) nsg = p->max_workgroups;      // tests: few workgroups, so that a range spans columns on small volumes
   return nsg < 1 ? 1 : (int)nsg;
 }
 static void bwdw_tr16_plan(const mt_conv3d_t* p, BwdWParams* P) {
@@ -4101,7 +4060,7 @@ static void bwdw_tr16_plan(const mt_conv3d_t* p, BwdWParams* P) {
 // conv_bwdw_fast_kernel (fp32 storage on both sides) / conv_bwdw_fast16_kernel with several cout tiles per workgroup (channel-pair
 // staging; the geometries launch_bwdw_fast / launch_bwdw_fast16 instantiate them for): 4 when the cout tiles divide by 4, else 2, else 1.  MT_BWDW_CW=1 switches it off.
 static int bwdw_fast_cw(const mt_conv3d_t* p, int ntiles_total, int nchunks) {
-  if (g_bwdw_cw < 0) { const char* e = getenv("MT_BWDW_CW"); g_bwdw_cw = e ? atoi(e) : 4; }
+  const int g_bwdw_cw = mt_bwdw_cw(p);
   const int cap = g_bwdw_cw % 100;
   const bool force = g_bwdw_cw >= 100;          // 104 / 102: without the tiles-per-workgroup condition below (tests on small volumes)
   if (cap < 2 || conv_src_dtype(p) < 0 || conv_fast_vec(p) != 2) return 1;
@@ -4129,7 +4088,7 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = 
   P->cw = allow_cw ? bwdw_fast_cw(p, P->ntiles_total, P->nchunks) : 1;
   // fp32 Winograd marching kernel: two cout tiles per workgroup where the cout tiles pair up and a workgroup still gets >= 12 planes
   if (allow_cw && (bwdw_use_wino(p) || (f32_both && bwdw_use_wino133(p))) && conv_src_dtype(p) == MT_F32) {
-    if (g_bwdw_cw < 0) { const char* e = getenv("MT_BWDW_CW"); g_bwdw_cw = e ? atoi(e) : 4; }
+    const int g_bwdw_cw = mt_bwdw_cw(p);
     const long planes = (long)p->N * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 32) * p->Do;
     P->cw = 1;                              // (bwdw_fast_cw answers for conv_bwdw_fast_kernel)
     if ((g_bwdw_cw % 100) >= 2 && P->ncot % 2 == 0 && (g_bwdw_cw >= 100 || planes * P->nchunks * (P->ncot / 2) >= 3072)) P->cw = 2;
@@ -4153,8 +4112,7 @@ static void bwdw_fast_plan(const mt_conv3d_t* p, BwdWParams* P, bool allow_cw = 
     bwdw_march_plan(p, P);
   }
   if (bwdw_use_march(p)) {
-    static int tall = -1;
-    if (tall < 0) { const char* e = getenv("MT_BWDW_TALL"); tall = e ? atoi(e) : 1; }
+    constexpr int tall = 1;
     if (bwdw_use_wino(p)) { P->TH = 4; P->TW = 32; P->tilesH = mt_cdiv(p->Ho, 4); P->tilesW = mt_cdiv(p->Wo, 32); P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N; }
     else if (tall && wide && p->Ho >= 8) { P->TH = 8; P->tilesH = mt_cdiv(p->Ho, 8); P->ntiles_total = P->tilesD * P->tilesH * P->tilesW * p->N; }
     bwdw_march_plan(p, P);
@@ -4348,8 +4306,7 @@ extern "C" size_t mt_conv3d_bwd_weight_workspace(const mt_conv3d_t* p) {
 
 extern "C" int mt_conv3d_bwd_weight_kernel_name(const mt_conv3d_t* p, const mt_src_t* ysrc, char* buf, size_t n) {
   if (p == nullptr || ysrc == nullptr || buf == nullptr || n == 0) return MT_EINVAL;
-  const char* e = getenv("MT_BWDW_FAST");
-  const int use_fast = e ? atoi(e) : 1;
+  constexpr int use_fast = 1;
   if (use_fast && bwdw_is_stem(p, ysrc)) { snprintf(buf, n, "conv_bwdw_stem_kernel<%d>", ysrc->dtype); return MT_OK; }
   const int geo = use_fast ? bwdw_fast_geo(p, ysrc) : -1;
   if (geo < 0) { snprintf(buf, n, "conv_bwdw_kernel"); return MT_OK; }
@@ -4377,8 +4334,7 @@ extern "C" int mt_conv3d_bwd_weight_io_supported(const mt_conv3d_t* p, const mt_
   const int xdt = conv_src_dtype(p);
   if (xdt < 0 || !mt_dtype_ok(ysrc->dtype)) return 0;
   if (xdt == MT_F32 && ysrc->dtype == MT_F32) return 1;
-  static int use_fast_q = -1;
-  if (use_fast_q < 0) { const char* e = getenv("MT_BWDW_FAST"); use_fast_q = e ? atoi(e) : 1; }
+  constexpr int use_fast_q = 1;
   if (!use_fast_q) return 0;
   const int ydt = ysrc->dtype;
   if (bwdw_is_stem(p, ysrc)) return (xdt == MT_F32 && ydt != MT_F16) ? 1 : 0;       // fp32 network input, fp32 | bf16 gradient
@@ -4408,8 +4364,7 @@ extern "C" int mt_conv3d_bwd_weight(const mt_conv3d_t* p, const mt_src_t* ysrc, 
   P.c = *p;
   if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
   P.y = *ysrc;
-  static int use_fast = -1;
-  if (use_fast < 0) { const char* e = getenv("MT_BWDW_FAST"); use_fast = e ? atoi(e) : 1; }
+  constexpr int use_fast = 1;
   if (use_fast && bwdw_is_stem(p, ysrc)) {
     P.TD = 2; P.TH = 4; P.TW = 32;
     P.tilesD = mt_cdiv(p->Do, 2); P.tilesH = mt_cdiv(p->Ho, 4); P.tilesW = mt_cdiv(p->Wo, 32);

@@ -345,11 +345,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long ts_last = __builtin_amdgcn_s_memtime();
 #endif
-  // Co-resident workgroups that start together stay in phase (same code, same step time): both stage, both multiply, both store at the
-  // same moments and the phases ADD.  The second resident of a CU (launch order: eight XCDs round-robin, 32 CUs each) starts late by
-  // P.stagger x 8k cycles — a fraction of a tile period — and keeps that offset for the whole (persistent) kernel.
-  if (P.stagger > 0 && ((blockIdx.x >> 3) >> 5) & 1)
-    for (int k = 0; k < P.stagger; ++k) __builtin_amdgcn_s_sleep(127);
   X16Geo cur, nxt;
   decode(it0, cur);
   nxt = cur;

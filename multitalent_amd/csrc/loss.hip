@@ -335,8 +335,7 @@ extern "C" int mt_multitalent_loss_fwd(const float* logits, int cs, const float*
   int nblk;
   if (cs == C) {            // contiguous logits (what the engine produces): flat coalesced kernel
     nblk = lf_blocks(V, C);
-    static int sparse = -1;
-    if (sparse < 0) { const char* e = getenv("MT_LOSS_SPARSE"); sparse = e ? atoi(e) : 1; }
+    constexpr int sparse = 1;
     if (sparse) hipLaunchKernelGGL(mt_loss_fwd_sparse_kernel, dim3(nblk, B), dim3(256), 0, st, logits, target, V, C, valid, lut, nblk, lf_vpb(lf_A(C) / C), (float*)ws);
     else hipLaunchKernelGGL(mt_loss_fwd_flat_kernel, dim3(nblk, B), dim3(256), 0, st, logits, target, V, C, valid, lut, nblk, lf_A(C), (float*)ws);
   } else {
@@ -387,8 +386,7 @@ extern "C" int mt_multitalent_loss_bwd(const float* logits, int cs, const float*
                                        const uint64_t* valid, const uint64_t* lut, const float* gstats,
                                        float* dlogits, int dcs, mt_stream_t stream) {
   MT_REQUIRE(logits && target && valid && lut && gstats && dlogits && B > 0 && V > 0 && C > 0 && C <= 64, "multitalent_loss_bwd: bad args");
-  static int wide = -1;
-  if (wide < 0) { const char* e = getenv("MT_LOSS_SPARSE"); wide = e ? atoi(e) : 1; }
+  constexpr int wide = 1;
   const long vpb = lf_vpb(lf_A(C) / C);
   // C >= 2: the quad's channel index is unwrapped by ONE conditional subtraction (c + 3 < 2C), wrong for a single channel
   if (cs == C && dcs == C && wide && C >= 2 && ((V * C) & 3) == 0 && ((vpb * C) & 3) == 0 && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0)

@@ -514,8 +514,7 @@ extern "C" int mt_inorm_lrelu_bwd(float* g, int gcs, const float* y, int ycs, co
   // contiguous tensors take the vectorised lane-constant-channel path
   const int vec = (gcs == C && ycs == C && ag_fast(ydtype, gdtype)) ? dense_vec(C, V * C, gdtype, {g, y}) : 0;
   const bool contig = vec > 0 && (C / vec <= 256);
-  static int small_on = -1;
-  if (small_on < 0) { const char* e = getenv("MT_INORM_SMALL"); small_on = e ? atoi(e) : 1; }
+  constexpr int small_on = 1;
   const int svec = gdtype == MT_F32 ? 4 : 8;
   if (small_on && contig && part == nullptr && vec == svec && (long)N * V <= INORM_SMALL_MAX) {
     InBwdSmall S;

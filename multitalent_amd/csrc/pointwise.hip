@@ -957,7 +957,7 @@ static bool pw_head_ok(const mt_pointwise_t* p, const PwKParams& P) {
          !p->accumulate && p->stats_part == nullptr && (P.Vb % 32) == 0 && p->Di == p->Db && p->Hi == p->Hb && p->Wi == p->Wb &&
          ((((uintptr_t)p->out) & 15) == 0) && ((P.Vb * p->Cout) % 4 == 0);
 }
-static int pw_use_head_env() { static int v = -1; if (v < 0) { const char* e = getenv("MT_PW_HEAD"); v = e ? atoi(e) : 1; } return v; }
+static constexpr int pw_use_head_env() { return 1; }
 // the part of the launch plan the kernel choice depends on (shared by mt_pointwise_fwd and mt_pointwise_pack_layout)
 static void pw_plan(const mt_pointwise_t* p, PwKParams& P, bool& narrow, bool& head) {
   P.c = *p;
@@ -986,8 +986,7 @@ extern "C" int mt_pointwise_io_supported(const mt_pointwise_t* p) {
 }
 // 16-bit products (mt_pointwise_t.mma == 1): fp16 source; pw_head_kernel (fp32 logits) or pw_fast_kernel writing fp16 (transposed convs)
 static bool pw_m16(const mt_pointwise_t* p, const PwKParams& P, bool narrow, bool head) {
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_PW_M16"); use = e ? atoi(e) : 1; }
+  constexpr int use = 1;
   if (!use || p->mma != 1 || p->src.dtype != MT_F16 || narrow || p->scatter) return false;
   if ((p->src.cs & 1) || (((uintptr_t)p->src.ptr) & 3)) return false;
   return head ? true : (p->odtype == MT_F16 && P.ntaps >= 2);
@@ -1021,8 +1020,7 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   MT_REQUIRE(P.ntaps == 1 || P.ntaps == 2 || P.ntaps == 4 || P.ntaps == 8, "pointwise: unsupported tap count %d", P.ntaps);
   MT_REQUIRE(P.nchunks * PW_CK <= PW_MAXC, "pointwise: Cin = %d exceeds %d", p->Cin, PW_MAXC);
   {
-    static int use_wide = -1;
-    if (use_wide < 0) { const char* e = getenv("MT_PW_WIDE"); use_wide = e ? atoi(e) : 1; }
+    constexpr int use_wide = 1;
     const bool shape_ok = use_wide && P.ntaps >= 4 && p->soW == 2 && p->soH == 2 && (p->Wb % 32) == 0 && p->Cout <= 32 && (p->Cout % 2) == 0 &&
                           !p->accumulate && p->stats_part == nullptr && p->siD == 1 && p->siH == 1 && p->siW == 1;
     P.wide = 0;
@@ -1032,15 +1030,13 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
   const mt_src_t& S = p->src;
   // 16-byte loads whatever the alignment: a raw buffer_load_dwordx4 only needs dword alignment and range-checks per dword
   // (tools/ubench/oob128.hip); the 47-channel gradient of the heads (188-byte rows) went through eight scalar loads per chunk before
-  static int force_vec = -1;
-  if (force_vec < 0) { const char* e = getenv("MT_PW_VEC"); force_vec = e ? atoi(e) : 0; }
+  constexpr int force_vec = 0;
   int vec = 4;
   if (!any16 && (force_vec == 1 || force_vec == 2 || force_vec == 4)) vec = force_vec;
   if (vec == 2 && !((S.cs % 2) == 0 && (((uintptr_t)S.ptr) & 7) == 0)) vec = 1;
   hipStream_t st = (hipStream_t)stream;
   {
-    static int use_head = -1;
-    if (use_head < 0) { const char* e = getenv("MT_PW_HEAD"); use_head = e ? atoi(e) : 1; }
+    constexpr int use_head = 1;
     if (use_head && os == MT_F32 && pw_narrow_ok(p, P)) {
       long blocks = (P.Vb + 255) / 256; if (blocks > 4096) blocks = 4096;
       const dim3 g2((unsigned)blocks, (unsigned)p->N);
@@ -1081,8 +1077,7 @@ extern "C" int mt_pointwise_fwd(const mt_pointwise_t* p, mt_stream_t stream) {
     case 2: PW_LAUNCH(2); break;
     case 4: PW_LAUNCH(4); break;
     default: {
-      static int split8 = -1;
-      if (split8 < 0) { const char* e = getenv("MT_PW_SPLIT8"); split8 = e ? atoi(e) : 1; }
+      constexpr int split8 = 1;
       if (split8 && p->stats_part == nullptr) { grid.z = 2; PW_LAUNCH(4); }      // two workgroups of four taps (see pw_fast_kernel)
       else PW_LAUNCH(8);
       break;
@@ -1554,8 +1549,7 @@ __global__ __launch_bounds__(64) void head_narrow_reduce_kernel(const float* par
   else if (dbias != nullptr) dbias[co] = accumulate ? dbias[co] + (float)s : (float)s;
 }
 static bool head_bwd_narrow_ok(const mt_src_t* x, int dycs, int dxcs, int Cin, int Cout, long V, int N, const float* dx) {
-  static int use = -1;
-  if (use < 0) { const char* e = getenv("MT_PW_HEAD"); use = e ? atoi(e) : 1; }
+  constexpr int use = 1;
   return use && Cout <= 4 && (Cin == 30 || Cin == 32) && x->cs == Cin && dxcs == Cin && N <= HN_BLOCKS &&
          (x->scale == nullptr || (x->slope >= 0.f && x->slope <= 1.f)) && (double)V * Cin * 4.0 < 2147483648.0;
 }
@@ -1570,8 +1564,7 @@ static inline int head_bwd_waves(int N, long V) {
 // Cin <= 32 only: the two-input-tile instantiation (Cin <= 64) needs 182 VGPRs (one wave per SIMD) and measured 0.70 ms on the
 // 24x96x96 level — slower than the generic kernels there; it stays compiled for the tests of the accumulation logic (MT_HEAD_BWD_WIDE=1)
 extern "C" int mt_head_bwd_supported(int Cin, int Cout) {
-  static int wide = -1;
-  if (wide < 0) { const char* e = getenv("MT_HEAD_BWD_WIDE"); wide = e ? atoi(e) : 0; }
+  constexpr int wide = 0;
   return Cin >= 1 && Cin <= (wide ? 64 : 32) && Cout >= 1 && Cout <= 64;
 }
 extern "C" size_t mt_head_bwd_workspace(int N, long V, int Cin, int Cout) {
@@ -1623,8 +1616,7 @@ extern "C" int mt_head_bwd(const mt_src_t* x, const float* dy, int dycs, int N, 
   P.nwaves = head_bwd_waves(N, V); P.ntiles = (long)N * ((V + 31) / 32);
   const int nci = (Cin + 31) / 32;
   hipStream_t st = (hipStream_t)stream;
-  static int staged = -1;                   // MT_HEAD_BWD_STAGED=0: operands straight from global memory also for dense tensors
-  if (staged < 0) { const char* e = getenv("MT_HEAD_BWD_STAGED"); staged = e ? atoi(e) : 1; }
+  constexpr int staged = 1;
   const bool dense = staged && x->cs == Cin && dxcs == Cin && dycs == Cout && (mt_is16(xs) ? (Cin % 2) == 0 : true);
 #define HB(NCI_, ST_) do { if (xs == MT_F16) hipLaunchKernelGGL((head_bwd_kernel<NCI_, MT_F16, MT_BF16, ST_>), dim3(P.nwaves / 4), dim3(256), 0, st, P);          \
                       else if (xs == MT_BF16) hipLaunchKernelGGL((head_bwd_kernel<NCI_, MT_BF16, MT_BF16, ST_>), dim3(P.nwaves / 4), dim3(256), 0, st, P);   \

@@ -413,7 +413,7 @@ class TConvOp(_Op):
         dx = ConvNormOp._grad_like(eng, self.src)
 
         def build(ins, outs):
-            p = ops.fill_conv(ins, self._geom(), self.tu.in_channels, out0=outs[0])
+            p = ops.fill_conv(ins, self._geom(), self.tu.in_channels, out0=outs[0], mma=eng.mma)
             p.csplit = self.tu.in_channels
             return p
         return eng.io(self.name + '.bwdd', [Act(g)], [Act(dx)], build, ops.conv_io_supported, grad_ins=True)
@@ -425,7 +425,7 @@ class TConvOp(_Op):
         # backward-weight: X = dOut (channels = Cout_t), Y = tconv input (lazy act, channels = Cin_t)
         with eng.weight_stream() as side:
             iow = eng.io(self.name + '.bwdw', [Act(g), self.src.act], [],
-                         lambda ins, outs: (ops.fill_conv(ins[:1], self._geom(), self.tu.in_channels), ins[1]),
+                         lambda ins, outs: (ops.fill_conv(ins[:1], self._geom(), self.tu.in_channels, mma=eng.mma), ins[1]),
                          lambda py: ops.conv_bwd_weight_io_supported(py[0], py[1]), grad_ins=[True, False])
             pw, yact = iow.build()
             iow.pre()
@@ -859,7 +859,6 @@ class Engine:
         # _plan() or set_precision() clear it — parameter VALUES changing (every optimizer step) just re-runs it
         key = need_grad
         prog = self._pack_programs.get(key)
-        ops.set_mma(self.mma)
         if key not in self._pack_programs:   # record the ops' packing calls once; afterwards every step is one batched launch
             def record(bwd):
                 rec, owner = [], []
@@ -938,7 +937,6 @@ class Engine:
         if not x.is_cuda:
             raise RuntimeError("multitalent_amd: the network runs on a HIP device only (got a CPU tensor); there is no CPU fallback")
         self.attach(x.device)
-        ops.set_mma(self.mma)
         self._iter += 1
         N, Cin = x.shape[0], x.shape[1]
         spatial = tuple(x.shape[2:])
@@ -967,7 +965,6 @@ class Engine:
     def backward(self, dlogits):
         """dlogits: list (module output order) of NDHWC gradient tensors or None.  Fills flat_grad."""
         self.flat_grad.zero_()
-        ops.set_mma(self.mma)
         nside = self.bwdw_streams if self.flat_grad.is_cuda else 0
         if len(self.wstreams) != nside:
             self.wstreams = [self._side_stream() for _ in range(nside)]

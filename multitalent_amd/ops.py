@@ -5,6 +5,7 @@ libmtseg_hip.so.  Activations are NDHWC tensors [N, D, H, W, C] (possibly channe
 storage of the mixed-precision mode — float16 (activations) / bfloat16 (gradients) (mt_src_t.dtype / odtype).  There is NO CPU fallback: tensors must live on a HIP device.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -114,8 +115,70 @@ _MMA = 0
 
 
 def set_mma(mode):
+    """DEFAULT matrix input type of fill_conv / fill_pointwise when their caller passes none (kernel-level tests and tools; the engine
+    passes its own): 0 = fp32 (exact), 1 = bf16 inputs with fp32 accumulation.  Host-side convenience — the C ABI takes mt_conv3d_t.mma."""
     global _MMA
     _MMA = int(mode)
+
+
+# ---- kernel selection (mt_conv3d_t.select / max_workgroups, ABI 4) ------------------------------------------------------------------
+# The library keeps no process-wide switches: which kernel family serves a problem is a field of the problem.  What lives HERE is the
+# default this process writes into the structs it builds — 0 (the library's policy) unless a test, an A/B tool (MT_SELECT) or
+# set_option changes it.  The legacy option names of rounds 1-5 map onto the fields.
+_SEL_SHIFT = {'conv_wino': 0, 'conv_bf16': 2, 'conv_x16': 4, 'conv_tapsplit': 6, 'bwdw_wino': 8, 'bwdw_tr16': 10, 'bwdw_cw': 12}
+_SEL_ALIASES = {'wino': 'conv_wino', 'm16': 'conv_bf16', 'x16': 'conv_x16', 'tapsplit': 'conv_tapsplit'}
+_select = 0
+_caps = {}
+
+
+def _sel_set(name, code):
+    global _select
+    sh = _SEL_SHIFT[name]
+    _select = (_select & ~(3 << sh)) | ((code & 3) << sh)
+
+
+def set_option(name, value):
+    """Default kernel selection of the problems this process builds (tests, A/B tools).  Legacy names and values:
+    conv_wino | conv_bf16 | conv_tapsplit: 0 never, 1 the library's policy, 2 wherever eligible; bwdw_wino: 0 | 1;
+    conv_x16 | bwdw_tr16: 0 | 1 | n > 1 = wherever eligible with at most n workgroups (4096: no cap); wino_persist: n > 1 = at most n workers
+    per output-channel tile; bwdw_cw: 4 (policy) | 2 | 1 | 104 (four tiles also on small problems)."""
+    name = _SEL_ALIASES.get(name, name)
+    value = int(value)
+    if name == 'wino_persist':
+        _caps.pop(name, None) if value <= 1 else _caps.__setitem__(name, value)
+    elif name in ('conv_x16', 'bwdw_tr16'):
+        _sel_set(name, 1 if value == 0 else 0 if value == 1 else (2 if name == 'conv_x16' else 0))
+        _caps.pop(name, None) if value <= 1 or value >= 4096 else _caps.__setitem__(name, value)
+    elif name == 'bwdw_cw':
+        _sel_set(name, {4: 0, 1: 1, 2: 2, 104: 3}[value])
+    elif name in _SEL_SHIFT:
+        _sel_set(name, {0: 1, 1: 0, 2: 2}[value])
+    else:
+        raise ValueError("set_option: unknown option %r" % (name,))
+
+
+def apply_selection(p):
+    """Write the process default selection into an mt_conv3d_t that was built earlier (tests that keep ONE struct while they switch
+    between kernel families)."""
+    p.select = _select
+    p.max_workgroups = min(_caps.values()) if _caps else 0
+    return p
+
+
+def options_are_default():
+    return _select == _select_env and not _caps and _MMA == 0
+
+
+def _parse_select_env():
+    """MT_SELECT="x16=off,wino=force,tapsplit=off": the default selection of a whole process (A/B runs of bench.py: tools/ab_env.sh)."""
+    for item in os.environ.get('MT_SELECT', '').replace(' ', '').split(','):
+        if item:
+            k, v = item.split('=')
+            k = _SEL_ALIASES.get(k, k)
+            if k == 'bwdw_cw':
+                set_option(k, int(v))
+            else:
+                _sel_set(k, {'default': 0, 'off': 1, 'force': 2}[v])
 
 
 def fill_conv(srcs, geom, Cout, wpack=None, bias=None, out0=None, out1=None, csplit=None, accumulate=False,
@@ -124,6 +187,8 @@ def fill_conv(srcs, geom, Cout, wpack=None, bias=None, out0=None, out1=None, csp
     place = (stored_spatial, out_stride, out_offset): logical output o is written at o*stride + offset."""
     p = mt_conv3d_t()
     p.mma = _MMA if mma is None else int(mma)
+    p.select = _select
+    p.max_workgroups = min(_caps.values()) if _caps else 0
     p.nsrc = len(srcs)
     for i, a in enumerate(srcs):
         p.src[i] = a.src()
@@ -189,10 +254,6 @@ def conv_ck(p):
     if ck <= 0:
         raise RuntimeError("conv3d: no kernel configuration for this shape")
     return ck
-
-
-def set_option(name, value):
-    _lib.check(_lib.load().mt_set_option(name.encode(), int(value)), 'set_option')
 
 
 def conv_pack_layout(p):
@@ -597,3 +658,7 @@ def downsample_seg_nearest(seg, out_spatial, remove_minus_one=False, out=None):
     _lib.check(_lib.load().mt_downsample_seg_nearest(_ptr(seg), B * Cn, D, H, W, _ptr(out), *[int(i) for i in out_spatial],
                                                     int(remove_minus_one), _stream()), 'downsample_seg_nearest')
     return out
+
+
+_parse_select_env()
+_select_env = _select

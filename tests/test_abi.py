@@ -19,7 +19,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), "missing export: " + s
     assert set(_lib.SIGNATURES) == set(syms), (set(_lib.SIGNATURES) ^ set(syms))
-    assert lib.mt_abi_version() == _lib.MT_ABI_VERSION == 3
+    assert lib.mt_abi_version() == _lib.MT_ABI_VERSION == 4
 
 
 def test_struct_sizes_match_c_layout():

@@ -284,6 +284,12 @@ def test_grad_allreducer_side_stream_on_rccl_world1(dev):
     assert p.exitcode == 0 and ret[0] is True
 
 
+def _launcher_free_env():
+    """os.environ without the rendezvous variables other tests of this process set for their single-rank process groups (test_drivers_gpu,
+    test_trainer_gpu: RANK / WORLD_SIZE): bench.py --gpus N must start its own ranks."""
+    return {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'MT_FORCE_REDUCER')}
+
+
 @pytest.mark.parametrize("extra", [['--batch', '1'], ['--workload', 'infer', '--mirror', '0', '--volume', '96', '256', '256']])
 def test_bench_two_ranks_self_validation_on_one_gpu(extra):
     """The N > 1 code path of bench.py with both ranks on cuda:0 and gloo as the transport (MT_BENCH_ONE_GPU=1; a box with one GPU
@@ -294,7 +300,7 @@ def test_bench_two_ranks_self_validation_on_one_gpu(extra):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-also', '--no-roofline'] + extra,
-                         capture_output=True, text=True, timeout=1200, env=dict(os.environ, MT_BENCH_ONE_GPU='1'))
+                         capture_output=True, text=True, timeout=1200, env=dict(_launcher_free_env(), MT_BENCH_ONE_GPU='1'))
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['value'] > 0 and 'comm' in line, line
@@ -317,7 +323,7 @@ def test_bench_eight_ranks_on_one_gpu(extra):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--no-also', '--no-roofline'] + extra,
-                         capture_output=True, text=True, timeout=1800, env=dict(os.environ, MT_BENCH_ONE_GPU='1'))
+                         capture_output=True, text=True, timeout=1800, env=dict(_launcher_free_env(), MT_BENCH_ONE_GPU='1'))
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 8 and line['value'] > 0 and 'comm' in line, line
@@ -338,7 +344,7 @@ def test_bench_headline_survives_a_failing_also_leg():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-roofline'],
                          capture_output=True, text=True, timeout=1200,
-                         env=dict(os.environ, MT_BENCH_ONE_GPU='1', MT_BENCH_INJECT_ALSO_FAILURE='all'))
+                         env=dict(_launcher_free_env(), MT_BENCH_ONE_GPU='1', MT_BENCH_INJECT_ALSO_FAILURE='all'))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 2, out.stdout[-2000:]

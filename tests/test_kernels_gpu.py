@@ -141,7 +141,7 @@ def test_conv_tapsplit_strided(dev, N, cins, Cout, shape, stride, lazy):
     try:
         for mode, kernel in ((1, 'conv_tapsplit_kernel<2, false, 0, 0, 1, %d, 2, 2>' % stride[0]), (0, 'conv_fast_strided_kernel')):
             ops.set_option('conv_tapsplit', mode)
-            assert ops.conv_kernel_name(probe).startswith(kernel), ops.conv_kernel_name(probe)
+            assert ops.conv_kernel_name(ops.apply_selection(probe)).startswith(kernel), ops.conv_kernel_name(probe)
             out, part = run_conv(dev, xs, w, b, stride, (1, 1, 1), lazy=lz, stats=True)
             got = to_ncdhw(out.cpu())
             assert relerr(got, ref) < 1e-5, mode
@@ -258,6 +258,7 @@ def test_conv_bwd_data_strided_one_launch(dev, Cin, Cout, shape, stride, acc, mm
     try:
         for ts in (1, 0):
             ops.set_option('conv_tapsplit', ts)
+            ops.apply_selection(p)
             names.add(ops.conv_bwd_data_strided_kernel_name(p).split('<')[0])
             dx.copy_(base.to(dev))
             ops.conv3d_bwd_data_strided(p)
@@ -338,6 +339,7 @@ def test_conv_bwd_weight(dev, Cin, Cout, shape, k, stride):
     if k == (3, 3, 3) and stride == (1, 1, 1) and Cin > 1 and shape[2] > 16 and shape[0] >= 3:
         # these shapes take the Winograd kernel by default: the direct marching kernel must agree too
         ops.set_option('bwdw_wino', 0)
+        ops.apply_selection(p)
         try:
             dw2 = torch.full(w.shape, float('nan'), device=dev)
             ws2 = torch.empty(max(ops.conv3d_bwd_weight_workspace(p) // 4, 1), device=dev)
@@ -382,6 +384,7 @@ def test_conv_bwd_weight_winograd_1x3x3(dev, cins, Cout, shape, lazy):
     try:
         for mode in (1, 0):
             ops.set_option('bwdw_wino', mode)
+            ops.apply_selection(p)
             ws = torch.full((max(ops.conv3d_bwd_weight_workspace(p) // 4, 1),), float('nan'), device=dev)
             dw = torch.full(w.shape, float('nan'), device=dev)
             ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)
@@ -391,7 +394,7 @@ def test_conv_bwd_weight_winograd_1x3x3(dev, cins, Cout, shape, lazy):
             assert relerr(res[mode], 2 * w.grad) < 2e-5, mode
     finally:
         ops.set_option('bwdw_wino', 1)
-    assert ops.conv_bwd_weight_kernel_name(p, ya) == 'conv_bwdw_wino_kernel<2, KD = 1>'
+    assert ops.conv_bwd_weight_kernel_name(ops.apply_selection(p), ya) == 'conv_bwdw_wino_kernel<2, KD = 1>'
     assert relerr(res[1], res[0]) < 2e-5
 
 
@@ -434,6 +437,7 @@ def test_conv_bwd_weight_cout_tiles_per_workgroup(dev, Cin, Cout, shape, k, stri
     try:
         for cw in (4, 1):
             ops.set_option('bwdw_cw', 100 + cw if cw > 1 else 1)     # (+ 100: also on volumes this small)
+            ops.apply_selection(p)
             ws = torch.full((max(ops.conv3d_bwd_weight_workspace(p) // 4, 1),), float('nan'), device=dev)
             dw = torch.full(w.shape, float('nan'), device=dev)
             ops.conv3d_bwd_weight(p, ya, dw, ops.conv_weight_strides(dw), False, ws)

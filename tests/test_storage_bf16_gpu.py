@@ -421,6 +421,14 @@ def test_strided_stage_conv_bf16_storage_bitexact(dev, Cin, Cout, shape, stride,
     """forward strided 3x3x3 (bf16 source; bf16 or fp32 destination) and its one-launch backward-data (dY bf16 or fp32, dX bf16)."""
     ops = _ops()
     ops.set_option('conv_tapsplit', 0)           # this test is about conv_fast_strided_kernel (grids this small take the tap-split form by default)
+    try:
+        _strided_stage_conv_bf16_storage_bitexact(dev, Cin, Cout, shape, stride, out_bf16)
+    finally:
+        ops.set_option('conv_tapsplit', 1)
+
+
+def _strided_stage_conv_bf16_storage_bitexact(dev, Cin, Cout, shape, stride, out_bf16):
+    ops = _ops()
     g = torch.Generator().manual_seed(6)
     N = 2
     geom = ops.ConvGeom(shape, (3, 3, 3), stride, (1, 1, 1))
@@ -536,6 +544,7 @@ def test_bwdw_tr16_vs_host(dev, cins, Cout, shape, k, lazy, cap, xdt):
     y = ops.Act(dy.to(dev).to(torch.bfloat16))
     p = ops.fill_conv(srcs, geom, Cout, mma=1)
     ops.set_option('bwdw_tr16', cap)
+    ops.apply_selection(p)
     try:
         assert ops.conv_bwd_weight_io_supported(p, y)
         name = ops.conv_bwd_weight_kernel_name(p, y)
@@ -869,7 +878,16 @@ def test_tiled_backward_weight_bf16_products(dev, kind):
     same operand rounding (activated operands rounded to bf16, exact products); ragged tiles, both tile shapes, accumulate"""
     import torch.nn.functional as F
     ops = _ops()
-    ops.set_option('bwdw_cw', 104)          # several cout tiles per workgroup also on volumes this small (conftest resets the option)
+    ops.set_option('bwdw_cw', 104)          # several cout tiles per workgroup also on volumes this small
+    try:
+        _tiled_backward_weight_bf16_products(dev, kind)
+    finally:
+        ops.set_option('bwdw_cw', 4)
+
+
+def _tiled_backward_weight_bf16_products(dev, kind):
+    import torch.nn.functional as F
+    ops = _ops()
     g = torch.Generator().manual_seed(46)
     N = 2
     f16, b16, f32 = torch.float16, torch.bfloat16, torch.float32
@@ -932,10 +950,11 @@ def test_tiled_backward_weight_bf16_products(dev, kind):
         ops.set_option('bwdw_cw', 1)
         try:
             dw1 = torch.full((Cout, Cin) + k, float('nan'), device=dev)
-            ops.conv3d_bwd_weight(p, ya, dw1, ops.conv_weight_strides(dw1), False, ws)
+            ops.conv3d_bwd_weight(ops.apply_selection(p), ya, dw1, ops.conv_weight_strides(dw1), False, ws)
             torch.cuda.synchronize()
         finally:
             ops.set_option('bwdw_cw', 104)
+            ops.apply_selection(p)
         assert float((dw1 - dw).abs().max()) <= 1e-5 * float(dw.abs().max())
     # MT_BWDW_FAST16 decides between kernels of the same result up to the product type: the fp32-product kernel is within bf16 operand rounding
     p0 = ops.fill_conv(acts, geom, Cout, mma=0)
