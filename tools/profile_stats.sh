@@ -1,10 +1,10 @@
-# rocprofv3 kernel statistics of bench.py for every workload (fp32 + bf16): gpurun_out/prof_r5/<tag>_kernel_stats.csv + the bench lines
-# usage: bash tools/profile_r5.sh [tags...]   (default: all)
+# rocprofv3 kernel statistics of bench.py for every workload (fp32 + bf16): gpurun_out/prof_${ROUND:-r6}/<tag>_kernel_stats.csv + the bench lines
+# usage: bash ROUND=r6 tools/profile_stats.sh [tags...]   (default: all)
 # The statistics are taken with the weight-gradient stream serialised (MT_BWDW_STREAMS=0: every kernel runs alone, its duration is
 # the kernel's — what bench.py's `roofline` pass measures); the tag *_overlap keeps the default overlap (durations then include
 # the time two streams' kernels share the CUs).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r5
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_${ROUND:-r6}
 mkdir -p $O
 run() {  # tag, bench args...
   tag=$1; shift
