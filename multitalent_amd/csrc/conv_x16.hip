@@ -18,15 +18,22 @@
 #include "bwdw_common.h"
 #include "conv16_common.h"
 
-typedef unsigned x16_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned x16_u32x3 __attribute__((ext_vector_type(3)));
-typedef unsigned x16_u32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef X16_SLOT
+#define X16_SLOT 0
+#endif
+#ifndef X16_DESYNC
+#define X16_DESYNC 0
+#endif
+#ifndef X16_PRIO
+#define X16_PRIO 0
+#endif
 #ifndef X16_ABL
 #define X16_ABL 0    // compile-time timing ablations: 1 no patch / weight loads, 2 no conversion + LDS writes, 4 no epilogue, 8 no MFMAs, 16 no wait for the weight DMA, 32 no global stores
 #endif
 
-struct X16Geo { int nb, ntile, od0, oh0, ow0, sb; };
+#include "conv_x16_epi.inc"
+
 #ifndef X16_TS
 #define X16_TS 0     // 1: per-phase s_memtime totals of every wave -> (long long*)c.out1 [workgroup][wave][8] (tools/bench_fwd16.py --ts)
 #endif
@@ -220,130 +227,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
 
-  // ---- epilogue of a tile.  A lane of the 32x32 accumulator owns ONE output channel (li) of 16 voxels, four at a time consecutive
-  // (rows 4jj .. 4jj+3 <-> voxels 8jj + 4 lhalf ..+3): bias (+ the old value of an accumulated destination), ONE rounding, and the four
-  // voxels go as one 8-byte granule into a [channel][voxel] image of the wave (64 bytes per channel, granule index XOR s(channel),
-  // s(r) = ((r >> 1) ^ (r >> 3)) & 7: conflict-free for the stores and for the reads below).  ds_read_b64_tr_b16 then hands every lane
-  // four consecutive CHANNELS of one voxel — lane p = 4j + q of a 16-lane group addresses an 8-byte granule, lane i receives element
-  // i & 3 of the granules addressed by lanes 4j + (i >> 2) — here: quad q = channel octet q, its four lanes = the four voxels of a
-  // granule, so two reads give the lane the 16-byte piece (voxel, octet) and a store instruction writes 16 voxels x 64 contiguous
-  // bytes.  No cross-lane exchange, no selects; statistics of the values as stored with v_dot2c (the lane's own channel).
-  // One destination (the dispatcher keeps two-destination problems on conv_bf16_kernel).
-  typedef short x16_s4 __attribute__((ext_vector_type(4)));
-  typedef _Float16 x16_h2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 x16_b2 __attribute__((ext_vector_type(2)));
-  auto dot2 = [&](unsigned a, unsigned b, float acc0) __attribute__((always_inline)) {
-    if constexpr (ST == MT_F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(x16_h2, a), __builtin_bit_cast(x16_h2, b), acc0, false);
-    else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(x16_b2, a), __builtin_bit_cast(x16_b2, b), acc0, false);
-  };
-  auto swz = [](int r) { return ((r >> 1) ^ (r >> 3)) & 7; };
-  auto tr_read = [&](int byteoff) __attribute__((always_inline)) {
-    return __builtin_bit_cast(x16_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((x16_s4 __attribute__((address_space(3)))*)(stg + byteoff)));
-  };
-  auto epilogue = [&](const X16Geo& g) __attribute__((always_inline)) {
-    const int co = g.ntile * 32 + li;
-    const int ncv = min(32, c.Cout - g.ntile * 32);            // valid output channels of the tile (even)
-    const float bv = tabb[co];
-    const int nvox = min(32, c.Wo - g.ow0);
-    const bool stats = c.stats_part != nullptr;
-    const size_t out_sample = (size_t)c.Do * c.Ho * c.Wo;
-    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)g.nb * out_sample * c.ocs0 * 2), 0,
-                                                                   (int)(out_sample * c.ocs0 * 2), 0x00020000);
-    const int tailb = (ncv * 2) & 15;
-    // the lane's two pieces of a tile row: octet O = quad of the 16-lane group, voxels V0 and V0 + 16, V0 = 8 (lane >> 5) + 4 ((lane >> 4) & 1) + (lane & 3)
-    const int O = (lane >> 2) & 3, hw = lane >> 5, g1 = (lane >> 4) & 1;
-    const int V0 = 8 * hw + 4 * g1 + (lane & 3);
-    const bool full = 8 * O + 8 <= ncv, tail = 8 * O < ncv && !full;
-    const int pbase = (V0 * c.ocs0 + g.ntile * 32 + 8 * O) * 2, pstep = 16 * c.ocs0 * 2;
-    // as address supplier of the transposed reads: lane p = 4 j + q of its group addresses channel row 8 q + 4 hq + j, granule 4 pi + 2 hw + g1
-    const int row0 = 8 * (lane & 3) + ((lane & 15) >> 2);
-    const int rbase = row0 * 64 + (((2 * hw + g1) ^ swz(row0)) * 8);       // (pi, hq) = (0, 0); hq: + 256, granule ^ 2; pi: granule ^ 4
-    const int wsw = swz(li);
-    unsigned char* const wrow = stg + li * 64;
-    float s1 = 0.f, s2 = 0.f;
-    const unsigned ones = ST == MT_F16 ? 0x3c003c00u : 0x3f803f80u;
-    x16_u32x4 old[2][2];
-    auto load_old = [&](int m, x16_u32x4 (&o)[2]) __attribute__((always_inline)) {
-      const int od = g.od0 + wave, oh = g.oh0 + m;
-      const int rowoff = ((od * c.Ho + oh) * c.Wo + g.ow0) * c.ocs0 * 2;
-      const bool rv = od < c.Do && oh < c.Ho;
-#pragma unroll
-      for (int pi = 0; pi < 2; ++pi) {
-        const int off = (rv && V0 + 16 * pi < nvox && (full || tail)) ? pbase + pi * pstep : (int)0x80000000;
-        o[pi] = __builtin_bit_cast(x16_u32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, off, rv ? rowoff : 0, 0));
-      }
-    };
-    if constexpr (ACC) load_old(0, old[0]);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int od = g.od0 + wave, oh = g.oh0 + m;
-      if constexpr (ACC) { if (m + 1 < 4) load_old(m + 1, old[(m + 1) & 1]); }       // (the old values of the next row are in flight while this one is finished)
-      if (od < c.Do && oh < c.Ho) {
-        if constexpr (ACC) {
-          // accumulate: the old values travel the other way — pieces into a [voxel][channel] image, transposed reads give the lane its channel
-#pragma unroll
-          for (int pi = 0; pi < 2; ++pi) {
-            const x16_u32x4 o = old[m & 1][pi];
-            const int Vp = V0 + 16 * pi;
-            x16_u32x2 lo, hi; lo[0] = o[0]; lo[1] = o[1]; hi[0] = o[2]; hi[1] = o[3];
-            *(x16_u32x2*)(stg + Vp * 64 + (((2 * O) ^ swz(Vp)) * 8)) = lo;
-            *(x16_u32x2*)(stg + Vp * 64 + (((2 * O + 1) ^ swz(Vp)) * 8)) = hi;
-          }
-        }
-        x16_u32x2 pk[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          float x0 = acc[0][m][4 * jj] + bv, x1 = acc[0][m][4 * jj + 1] + bv, x2 = acc[0][m][4 * jj + 2] + bv, x3 = acc[0][m][4 * jj + 3] + bv;
-          if constexpr (ACC) {
-            const int vox = 8 * jj + 4 * lhalf + ((lane & 15) >> 2);
-            const x16_u32x2 u = tr_read(vox * 64 + (((4 * (li >> 4) + (lane & 3)) ^ swz(vox)) * 8));
-            x0 += mt_lo16<ST>(u[0]); x1 += mt_hi16<ST>(u[0]); x2 += mt_lo16<ST>(u[1]); x3 += mt_hi16<ST>(u[1]);
-          }
-          if (nvox < 32) {
-            const int v0 = 8 * jj + 4 * lhalf;
-            x0 = v0 < nvox ? x0 : 0.f; x1 = v0 + 1 < nvox ? x1 : 0.f; x2 = v0 + 2 < nvox ? x2 : 0.f; x3 = v0 + 3 < nvox ? x3 : 0.f;
-          }
-          pk[jj][0] = mt_pk16<ST>(x0, x1);
-          pk[jj][1] = mt_pk16<ST>(x2, x3);
-          if (stats) {
-            s1 = dot2(pk[jj][0], ones, s1); s1 = dot2(pk[jj][1], ones, s1);
-            s2 = dot2(pk[jj][0], pk[jj][0], s2); s2 = dot2(pk[jj][1], pk[jj][1], s2);
-          }
-        }
-        // (ACC: every lane's transposed reads of the old image are done — same wave, LDS in order — before the new image overwrites it)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) *(x16_u32x2*)(wrow + (((2 * jj + lhalf) ^ wsw) * 8)) = pk[jj];
-        const int rowoff = ((od * c.Ho + oh) * c.Wo + g.ow0) * c.ocs0 * 2;
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-          const int ra0 = rbase ^ (32 * pi);
-          const x16_u32x2 u0 = tr_read(ra0), u1 = tr_read((ra0 ^ 16) + 256);
-          x16_u32x4 piece; piece[0] = u0[0]; piece[1] = u0[1]; piece[2] = u1[0]; piece[3] = u1[1];
-          const bool vok = V0 + 16 * pi < nvox;
-          const int poff = (vok && full) ? pbase + pi * pstep : (int)0x80000000;
-          if (X16_ABL & 32) { if (piece[0] == 0x12345u) __builtin_amdgcn_raw_buffer_store_b128(piece, ro, poff, rowoff, 0); continue; }
-          __builtin_amdgcn_raw_buffer_store_b128(piece, ro, poff, rowoff, 0);
-          if (tailb) {
-            const int pofft = (vok && tail) ? pbase + pi * pstep : (int)0x80000000;
-            if (tailb == 4) __builtin_amdgcn_raw_buffer_store_b32(piece[0], ro, pofft, rowoff, 0);
-            else if (tailb == 8) __builtin_amdgcn_raw_buffer_store_b64(u0, ro, pofft, rowoff, 0);
-            else { x16_u32x3 t; t[0] = piece[0]; t[1] = piece[1]; t[2] = piece[2]; __builtin_amdgcn_raw_buffer_store_b96(t, ro, pofft, rowoff, 0); }
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (stats) {
-      if (co >= c.Cout) { s1 = 0.f; s2 = 0.f; }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (lhalf == 0) { ((float*)stg)[li * 2] = s1; ((float*)stg)[li * 2 + 1] = s2; }
-    }
-  };
-
 #if X16_TS
   unsigned long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long ts_last = __builtin_amdgcn_s_memtime();
+#endif
+#if X16_DESYNC || X16_PRIO
+  {
+#if X16_SLOT == 1
+    const int slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 1;      // HW_ID.wave_id: this wave's slot on its SIMD
+#elif X16_SLOT == 2
+    const int slot = ((int)blockIdx.x >> 3) & 1;
+#else
+    const int slot = (int)blockIdx.x >= ((int)gridDim.x >> 1);          // (experiment) the second co-resident workgroup of a CU
+#endif
+    if (X16_PRIO && slot == (X16_PRIO > 0 ? 1 : 0)) __builtin_amdgcn_s_setprio(X16_PRIO > 0 ? X16_PRIO : -X16_PRIO);
+    if (slot) for (int i = 0; i < X16_DESYNC; ++i) __builtin_amdgcn_s_sleep(100);
+  }
 #endif
   X16Geo cur, nxt;
   decode(it0, cur);
@@ -403,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         front(std::integral_constant<int, 1>(), ch1, true);
       }
       if (last) {
-        if (!(X16_ABL & 4)) epilogue(cur);
+        if (!(X16_ABL & 4)) x16_epilogue<ST, ACC>(c, acc, stg, tabb, cur, wave, lane);
         else if (acc[0][0][0] == 12345.678f) ((float*)c.out0)[0] = acc[0][3][3];
         zero_acc();
       }

@@ -49,7 +49,8 @@ for li, (cins, cout, shape, k) in enumerate(LAYERS):
         byts = 2.0 * N * shape[0] * shape[1] * shape[2] * (C + cout)
         res = {}
         for mode in a.modes:
-            ops.set_option('conv_x16', 4096 if mode else 0)        # 4096: conv_x16_kernel wherever eligible (1 = the dispatcher's rule)
+            ops.set_option('conv_x16', 4096 if mode == 1 else 0)   # 4096: conv_x16_kernel wherever eligible (1 = the dispatcher's rule)
+            ops.set_option('conv_x16s', 4096 if mode == 2 else 1)  # mode 2: conv_x16s_kernel (the pipelined form)
             out = torch.zeros((N,) + tuple(geom.out) + (cout,), device=dev, dtype=H)
             p = ops.fill_conv(srcs, geom, cout, out0=ops.Act(out), bias=b, mma=1, accumulate=bool(a.acc and dtn == 'bf16'))
             name = ops.conv_kernel_name(p)
@@ -82,8 +83,9 @@ for li, (cins, cout, shape, k) in enumerate(LAYERS):
             res[mode] = (out.float(), part.sum(1))
             print("%-34s %s %s->%d %s k%s: %7.1f us  %6.0f TFLOP/s (%.2f of 2500)  %.2f TB/s algorithmic" % (
                 name[:34], dtn, '+'.join(map(str, cins)), cout, 'x'.join(map(str, shape)), ''.join(map(str, k)), ms * 1e3, flops / ms / 1e9, flops / ms / 1e9 / 2500, byts / ms / 1e9))
-        if len(res) == 2:
-            d = (res[0][0] - res[1][0]).abs().max().item() / res[0][0].abs().max().item()
-            ds = ((res[0][1] - res[1][1]).abs().max() / res[0][1].abs().max()).item()
+        for m_ in [m for m in res if m != 0 and 0 in res]:
+            d = (res[0][0] - res[m_][0]).abs().max().item() / res[0][0].abs().max().item()
+            ds = ((res[0][1] - res[m_][1]).abs().max() / res[0][1].abs().max()).item()
             print("   max |x16 - conv_bf16| / max|y| = %.2e, statistics %.2e" % (d, ds))
 ops.set_option('conv_x16', 1)
+ops.set_option('conv_x16s', 1)
