@@ -44,7 +44,3 @@ struct X16Params {
 };
 int mt_conv_x16_workgroups(int nitems);
 int mt_launch_conv_x16(const X16Params& P, int KD, int dt, hipStream_t st);
-// conv_x16s.hip: the same problems as ONE software pipeline per wave (one workgroup per CU, LDS double buffers); aff = a source carries a lazy activation
-bool mt_conv_x16s_fits(int KD, int nchunks, int ncot);
-int mt_conv_x16s_workgroups(int nitems);
-int mt_launch_conv_x16s(const X16Params& P, int KD, int dt, bool aff, hipStream_t st);

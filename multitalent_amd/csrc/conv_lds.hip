@@ -2451,15 +2451,7 @@ static bool conv_x16_geometry_ok(const mt_conv3d_t* p, int cfg) {
   if ((long)p->N * mt_cdiv(p->Do, 4) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 32) * mt_cdiv(p->Cout, 32) >= 2147483647L) return false;
   return true;
 }
-// conv_x16s_kernel: the problems conv_x16_kernel takes (any cout tile count), where its LDS double buffers fit
-static bool conv_x16s_ok(const mt_conv3d_t* p, int cfg) {
-  const int sel = mt_sel3(p, MT_SEL_X16S);
-  if (sel != 2) return false;                                   // (policy: off — measured per layer in tools/bench_fwd16.py)
-  if (!conv_x16_geometry_ok(p, cfg)) return false;
-  const int nch = mt_cdiv(p->src[0].C, FCK) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, FCK) : 0);
-  return mt_conv_x16s_fits(p->KD, nch, mt_cdiv(p->Cout, 32));
-}
-static int launch_x16(const mt_conv3d_t* p, hipStream_t st, bool pipelined = false) {
+static int launch_x16(const mt_conv3d_t* p, hipStream_t st) {
   X16Params P;
   P.c = *p;
   if (P.c.nsrc == 1) { P.c.src[1] = P.c.src[0]; P.c.src[1].C = 0; }
@@ -2475,9 +2467,8 @@ static int launch_x16(const mt_conv3d_t* p, hipStream_t st, bool pipelined = fal
     P.pair[P.npairs][0] = (short)i; P.pair[P.npairs][1] = (short)(two ? i + 1 : -1);
     i += two ? 2 : 1;
   }
-  P.nwg = pipelined ? mt_conv_x16s_workgroups(P.nitems) : mt_conv_x16_workgroups(P.nitems);
+  P.nwg = mt_conv_x16_workgroups(P.nitems);
   if (p->max_workgroups > 0 && P.nwg > p->max_workgroups) P.nwg = p->max_workgroups;
-  if (pipelined) return mt_launch_conv_x16s(P, p->KD, conv_src_dtype(p), p->src[0].scale != nullptr || (p->nsrc == 2 && p->src[1].scale != nullptr), st);
   return mt_launch_conv_x16(P, p->KD, conv_src_dtype(p), st);
 }
 
@@ -2672,7 +2663,6 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
   const ConvPlan pl = conv_plan(p);
   const int i = pl.cfg;
   if (i < 0) return MT_EINVAL;
-  if (pl.kind == CONV_BF16 && conv_x16s_ok(p, i)) { snprintf(buf, n, "conv_x16s_kernel<%d, %d>", p->KD, conv_src_dtype(p)); return MT_OK; }
   if (pl.kind == CONV_BF16 && conv_x16_ok(p, i)) { snprintf(buf, n, "conv_x16_kernel<%d, %d>", p->KD, conv_src_dtype(p)); return MT_OK; }
   if (pl.kind == CONV_BF16) {
     // the instance launch_bf16 picks, as the profiler prints it: <MW, RH, TD, VEC, NT, NW, KD, XS, OS, MTY>
@@ -2755,7 +2745,6 @@ extern "C" int mt_conv3d_fwd(const mt_conv3d_t* p, mt_stream_t stream) {
              "(ask mt_conv3d_io_supported, convert with mt_cast)", p->src[0].dtype, p->nsrc == 2 ? p->src[1].dtype : -1, p->odtype);
   MT_REQUIRE(p->bstats.y == nullptr || pl.kind == CONV_WINO, "conv3d: bstats set on a problem whose kernel does not compute them "
              "(ask mt_conv3d_bwd_stats_supported)");
-  if (pl.kind == CONV_BF16 && conv_x16s_ok(p, i)) return launch_x16(p, (hipStream_t)stream, true);
   if (pl.kind == CONV_BF16 && conv_x16_ok(p, i)) return launch_x16(p, (hipStream_t)stream);
   if (pl.kind == CONV_BF16) return launch_bf16(p, i, (hipStream_t)stream);
   const ConvCfg& g = kCfgs[i];

@@ -19,17 +19,8 @@
 #include "conv16_common.h"
 
 
-#ifndef X16_SLOT
-#define X16_SLOT 0
-#endif
-#ifndef X16_DESYNC
-#define X16_DESYNC 0
-#endif
-#ifndef X16_PRIO
-#define X16_PRIO 0
-#endif
 #ifndef X16_ABL
-#define X16_ABL 0    // compile-time timing ablations: 1 no patch / weight loads, 2 no conversion + LDS writes, 4 no epilogue, 8 no MFMAs, 16 no wait for the weight DMA, 32 no global stores
+#define X16_ABL 0    // compile-time timing ablations: 1 no patch / weight loads, 2 no conversion + LDS writes, 4 no epilogue, 8 no MFMAs, 16 no wait for the weight DMA, 32 no global stores, 64 epilogue without transposed reads + stores, 128 epilogue computes the values only
 #endif
 
 #include "conv_x16_epi.inc"
@@ -230,19 +221,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #if X16_TS
   unsigned long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long ts_last = __builtin_amdgcn_s_memtime();
-#endif
-#if X16_DESYNC || X16_PRIO
-  {
-#if X16_SLOT == 1
-    const int slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 1;      // HW_ID.wave_id: this wave's slot on its SIMD
-#elif X16_SLOT == 2
-    const int slot = ((int)blockIdx.x >> 3) & 1;
-#else
-    const int slot = (int)blockIdx.x >= ((int)gridDim.x >> 1);          // (experiment) the second co-resident workgroup of a CU
-#endif
-    if (X16_PRIO && slot == (X16_PRIO > 0 ? 1 : 0)) __builtin_amdgcn_s_setprio(X16_PRIO > 0 ? X16_PRIO : -X16_PRIO);
-    if (slot) for (int i = 0; i < X16_DESYNC; ++i) __builtin_amdgcn_s_sleep(100);
-  }
 #endif
   X16Geo cur, nxt;
   decode(it0, cur);

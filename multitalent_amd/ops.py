@@ -125,8 +125,8 @@ def set_mma(mode):
 # The library keeps no process-wide switches: which kernel family serves a problem is a field of the problem.  What lives HERE is the
 # default this process writes into the structs it builds — 0 (the library's policy) unless a test, an A/B tool (MT_SELECT) or
 # set_option changes it.  The legacy option names of rounds 1-5 map onto the fields.
-_SEL_SHIFT = {'conv_wino': 0, 'conv_bf16': 2, 'conv_x16': 4, 'conv_tapsplit': 6, 'bwdw_wino': 8, 'bwdw_tr16': 10, 'bwdw_cw': 12, 'conv_x16s': 14}
-_SEL_ALIASES = {'wino': 'conv_wino', 'm16': 'conv_bf16', 'x16': 'conv_x16', 'x16s': 'conv_x16s', 'tapsplit': 'conv_tapsplit'}
+_SEL_SHIFT = {'conv_wino': 0, 'conv_bf16': 2, 'conv_x16': 4, 'conv_tapsplit': 6, 'bwdw_wino': 8, 'bwdw_tr16': 10, 'bwdw_cw': 12}
+_SEL_ALIASES = {'wino': 'conv_wino', 'm16': 'conv_bf16', 'x16': 'conv_x16', 'tapsplit': 'conv_tapsplit'}
 _select = 0
 _caps = {}
 
@@ -146,8 +146,8 @@ def set_option(name, value):
     value = int(value)
     if name == 'wino_persist':
         _caps.pop(name, None) if value <= 1 else _caps.__setitem__(name, value)
-    elif name in ('conv_x16', 'bwdw_tr16', 'conv_x16s'):
-        _sel_set(name, 1 if value == 0 else 0 if value == 1 else (2 if name in ('conv_x16', 'conv_x16s') else 0))
+    elif name in ('conv_x16', 'bwdw_tr16'):
+        _sel_set(name, 1 if value == 0 else 0 if value == 1 else (2 if name == 'conv_x16' else 0))
         _caps.pop(name, None) if value <= 1 or value >= 4096 else _caps.__setitem__(name, value)
     elif name == 'bwdw_cw':
         _sel_set(name, {4: 0, 1: 1, 2: 2, 104: 3}[value])

@@ -50,7 +50,6 @@ for li, (cins, cout, shape, k) in enumerate(LAYERS):
         res = {}
         for mode in a.modes:
             ops.set_option('conv_x16', 4096 if mode == 1 else 0)   # 4096: conv_x16_kernel wherever eligible (1 = the dispatcher's rule)
-            ops.set_option('conv_x16s', 4096 if mode == 2 else 1)  # mode 2: conv_x16s_kernel (the pipelined form)
             out = torch.zeros((N,) + tuple(geom.out) + (cout,), device=dev, dtype=H)
             p = ops.fill_conv(srcs, geom, cout, out0=ops.Act(out), bias=b, mma=1, accumulate=bool(a.acc and dtn == 'bf16'))
             name = ops.conv_kernel_name(p)
@@ -88,4 +87,3 @@ for li, (cins, cout, shape, k) in enumerate(LAYERS):
             ds = ((res[0][1] - res[m_][1]).abs().max() / res[0][1].abs().max()).item()
             print("   max |x16 - conv_bf16| / max|y| = %.2e, statistics %.2e" % (d, ds))
 ops.set_option('conv_x16', 1)
-ops.set_option('conv_x16s', 1)
