@@ -921,6 +921,12 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
 // waves are 2 M tiles (one output plane each) x 2 N tiles, so every staged voxel feeds 64 output channels.
 // BF = true (mixed precision, mt_conv3d_t.mma == 1): bf16 LDS image and v_mfma_f32_32x32x16_bf16 through mt_stage_bf16 / bf16_chunk.
 // XS / OS (BF only): storage types of the source / destination (mt_src_t.dtype, mt_conv3d_t.odtype); MTY: matrix type (mt_stage_bf16).
+#ifndef FS_STAG
+#define FS_STAG 0
+#endif
+#ifndef FS_ABL
+#define FS_ABL 0   // compile-time timing ablations of conv_fast_strided_kernel (fp32): 1 no staging, 4 no epilogue, 8 no MFMAs
+#endif
 template <int SD, int SH, int SW, int VEC, bool BF = false, int XS = MT_F32, int OS = MT_F32, int MTY = MT_BF16>
 __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParams P) {
   static_assert(BF || (XS == MT_F32 && OS == MT_F32), "16-bit storage is served by the 16-bit matrix path");
@@ -943,6 +949,9 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
 
+#if FS_STAG
+  { const int lin = blockIdx.x + blockIdx.y * gridDim.x; if (lin >= 256 && lin < 512) for (int i = 0; i < FS_STAG; ++i) __builtin_amdgcn_s_sleep(100); }
+#endif
   int abase[1];
   abase[0] = ((dm * SD * LH + (li >> 3) * SH) * LWP + (li & 7) * SW) * PITCH + lhalf * (BF ? 4 : 8);
   f32x16 accb[1][1];
@@ -961,11 +970,12 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
       bf16_chunk<1, 1, LH, LWP, 3, MTY>((const unsigned*)lds, abase3, wlane, 0, accb);
     } else {
       const float* wlane = c.wpack + (size_t)(ntile * P.nchunks + ch) * (27 * 512) + lane * 4;
-      mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
+      if (!(FS_ABL & 1)) mt_stage_fast2<LD, LH, LW, VEC>(lds, c, cc, nb, od0 * SD - 1, oh0 * SH - 1, ow0 * SW - 1, lane, wave);
       __syncthreads();
-      fast_chunk<1, LH, LWP>(lds, abase, wlane, acc);
+      if (!(FS_ABL & 8)) fast_chunk<1, LH, LWP>(lds, abase, wlane, acc);
     }
   }
+  if ((FS_ABL & 4) && acc[0][0] != 12345.f) return;
 
   const int co = ntile_raw * 32 + li;
   const bool covalid = nt_ok && co < c.Cout;
@@ -1031,6 +1041,8 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
     }
   }
 }
+
+#include "conv_strided_pp.inc"
 
 // ================================================================================================
 // 3x3x3 stride-1 convolution for the LOW-RESOLUTION stages (<= 6x24x24 voxels, 256-320 channels): the standard tiling yields
@@ -2229,6 +2241,10 @@ static bool conv_fast_strided_ok(const mt_conv3d_t* p) {
   if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return false;
   return true;
 }
+// conv_fast_strided_pp_kernel: fp32 storage and arithmetic, channel strides that take 8-byte loads
+static bool strided_pp_ok(const mt_conv3d_t* p) {
+  return mt_sel3(p, MT_SEL_STRIDED_PP) != 0 && !strided_use_bf16(p) && conv_fast_vec(p) == 2 && conv_slopes_ok(p);
+}
 template <int SD>
 static int launch_fast_strided_t(const mt_conv3d_t* p, hipStream_t st) {
   constexpr int TD = 2, TH = 4, TW = 8, LD = (TD - 1) * SD + 3, LH = (TH - 1) * 2 + 3, LW = (TW - 1) * 2 + 3;
@@ -2252,6 +2268,14 @@ static int launch_fast_strided_t(const mt_conv3d_t* p, hipStream_t st) {
     else if (sd == MT_BF16) MT_FS_LAUNCH(MT_BF16, MT_F32, MT_BF16, 4);
     else MT_FS_LAUNCH(MT_F32, MT_F32, MT_BF16, 2);
 #undef MT_FS_LAUNCH
+  } else if (strided_pp_ok(p)) {
+    // persistent, software-pipelined form (conv_strided_pp.inc): one workgroup per CU, contiguous item ranges
+    const int ny = mt_cdiv(p->Cout, 64), nitems = P.nsb * p->N * ny;
+    const int cap = p->max_workgroups > 0 ? p->max_workgroups : mt_device_cus(mt_current_device());
+    auto kfn = conv_fast_strided_pp_kernel<SD>;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsp_lds_bytes<SD>());
+    if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", fsp_lds_bytes<SD>(), hipGetErrorString(e)); return MT_EHIP; }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(nitems < cap ? nitems : cap)), dim3(256), fsp_lds_bytes<SD>(), st, P, nitems, ny);
   } else if (conv_fast_vec(p) == 2) {
     hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 2>()), st, P);
   } else {
@@ -2692,6 +2716,8 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
     const int sd = conv_src_dtype(p);
     if (strided_use_bf16(p) && sd > 0)
       snprintf(buf, n, "conv_fast_strided_kernel<%d, %d, %d, 4, true, %d, %d, %d>", p->SD, p->SH, p->SW, sd, p->odtype == sd ? sd : 0, sd == MT_F16 ? MT_F16 : MT_BF16);
+    else if (strided_pp_ok(p))
+      snprintf(buf, n, "conv_fast_strided_pp_kernel<%d>", p->SD);
     else
       snprintf(buf, n, strided_use_bf16(p) ? "conv_fast_strided_kernel<%d, %d, %d, %d, true, 0, 0, 1>" : "conv_fast_strided_kernel<%d, %d, %d, %d, false, 0, 0, 1>",
                p->SD, p->SH, p->SW, conv_fast_vec(p));

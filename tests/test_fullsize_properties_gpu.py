@@ -72,7 +72,7 @@ def conv_bwd_weight(ops, x, g, w_shape, geom):
     (30, 30, (48, 192, 192), (1, 1, 1), 'conv_fast_kernel'),         # the dominant layer of the benchmark
     (60, 30, (48, 192, 192), (1, 1, 1), 'conv_fast_kernel'),         # decoder stage 0, two chunks per source
     (1, 30, (48, 192, 192), (1, 1, 1), 'conv_stem_kernel'),          # stem
-    (30, 60, (48, 192, 192), (2, 2, 2), 'conv_fast_strided_kernel'), # first strided stage
+    (30, 60, (48, 192, 192), (2, 2, 2), 'conv_fast_strided'), # first strided stage
     (240, 320, (6, 24, 24), (2, 2, 2), 'conv_tapsplit_kernel'),      # 120 workgroups in the strided tiling: taps split over the waves
     (320, 320, (3, 12, 12), (1, 1, 1), 'conv_tapsplit_kernel'),      # low-resolution stage
     (320, 320, (3, 12, 12), (1, 2, 2), 'conv_tapsplit_kernel'),      # bottleneck
