@@ -134,7 +134,6 @@ typedef struct {
 #define MT_SEL_BWDW_TR16 10  /* conv_bwdw_tr16_kernel (16-bit X, bf16 dY) */
 #define MT_SEL_BWDW_CW 12    /* cout tiles per workgroup of the tiled backward-weight kernels: 0 = up to 4 where a workgroup walks enough tiles,
                                 1 = one, 2 = at most two, 3 = up to 4 also on small problems */
-#define MT_SEL_STRIDED_PP 14  /* conv_fast_strided_pp_kernel (persistent, pipelined) for the fp32 strided 3x3x3 stage convolutions; OFF: conv_fast_strided_kernel */
 #define MT_SEL_GET(sel, shift) (((sel) >> (shift)) & 3u)
 
 const char* mt_last_error(void);

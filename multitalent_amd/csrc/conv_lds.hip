@@ -921,9 +921,6 @@ __global__ __launch_bounds__(256) void conv_fast_kernel(const ConvKParams P) {
 // waves are 2 M tiles (one output plane each) x 2 N tiles, so every staged voxel feeds 64 output channels.
 // BF = true (mixed precision, mt_conv3d_t.mma == 1): bf16 LDS image and v_mfma_f32_32x32x16_bf16 through mt_stage_bf16 / bf16_chunk.
 // XS / OS (BF only): storage types of the source / destination (mt_src_t.dtype, mt_conv3d_t.odtype); MTY: matrix type (mt_stage_bf16).
-#ifndef FS_STAG
-#define FS_STAG 0
-#endif
 #ifndef FS_ABL
 #define FS_ABL 0   // compile-time timing ablations of conv_fast_strided_kernel (fp32): 1 no staging, 4 no epilogue, 8 no MFMAs
 #endif
@@ -949,9 +946,6 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
   const int sb = (td * P.tilesH + th) * P.tilesW + tw;
   const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
 
-#if FS_STAG
-  { const int lin = blockIdx.x + blockIdx.y * gridDim.x; if (lin >= 256 && lin < 512) for (int i = 0; i < FS_STAG; ++i) __builtin_amdgcn_s_sleep(100); }
-#endif
   int abase[1];
   abase[0] = ((dm * SD * LH + (li >> 3) * SH) * LWP + (li & 7) * SW) * PITCH + lhalf * (BF ? 4 : 8);
   f32x16 accb[1][1];
@@ -1041,8 +1035,6 @@ __global__ __launch_bounds__(256) void conv_fast_strided_kernel(const ConvKParam
     }
   }
 }
-
-#include "conv_strided_pp.inc"
 
 // ================================================================================================
 // 3x3x3 stride-1 convolution for the LOW-RESOLUTION stages (<= 6x24x24 voxels, 256-320 channels): the standard tiling yields
@@ -2241,10 +2233,6 @@ static bool conv_fast_strided_ok(const mt_conv3d_t* p) {
   if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return false;
   return true;
 }
-// conv_fast_strided_pp_kernel: fp32 storage and arithmetic, channel strides that take 8-byte loads
-static bool strided_pp_ok(const mt_conv3d_t* p) {
-  return mt_sel3(p, MT_SEL_STRIDED_PP) != 0 && !strided_use_bf16(p) && conv_fast_vec(p) == 2 && conv_slopes_ok(p);
-}
 template <int SD>
 static int launch_fast_strided_t(const mt_conv3d_t* p, hipStream_t st) {
   constexpr int TD = 2, TH = 4, TW = 8, LD = (TD - 1) * SD + 3, LH = (TH - 1) * 2 + 3, LW = (TW - 1) * 2 + 3;
@@ -2268,14 +2256,6 @@ static int launch_fast_strided_t(const mt_conv3d_t* p, hipStream_t st) {
     else if (sd == MT_BF16) MT_FS_LAUNCH(MT_BF16, MT_F32, MT_BF16, 4);
     else MT_FS_LAUNCH(MT_F32, MT_F32, MT_BF16, 2);
 #undef MT_FS_LAUNCH
-  } else if (strided_pp_ok(p)) {
-    // persistent, software-pipelined form (conv_strided_pp.inc): one workgroup per CU, contiguous item ranges
-    const int ny = mt_cdiv(p->Cout, 64), nitems = P.nsb * p->N * ny;
-    const int cap = p->max_workgroups > 0 ? p->max_workgroups : mt_device_cus(mt_current_device());
-    auto kfn = conv_fast_strided_pp_kernel<SD>;
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsp_lds_bytes<SD>());
-    if (e != hipSuccess) { mt_set_error("conv3d: cannot raise dynamic LDS to %zu: %s", fsp_lds_bytes<SD>(), hipGetErrorString(e)); return MT_EHIP; }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(nitems < cap ? nitems : cap)), dim3(256), fsp_lds_bytes<SD>(), st, P, nitems, ny);
   } else if (conv_fast_vec(p) == 2) {
     hipLaunchKernelGGL((conv_fast_strided_kernel<SD, 2, 2, 2>), grid, dim3(256), (stage_lds_bytes<LD, LH, LW, 2>()), st, P);
   } else {
@@ -2716,8 +2696,6 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
     const int sd = conv_src_dtype(p);
     if (strided_use_bf16(p) && sd > 0)
       snprintf(buf, n, "conv_fast_strided_kernel<%d, %d, %d, 4, true, %d, %d, %d>", p->SD, p->SH, p->SW, sd, p->odtype == sd ? sd : 0, sd == MT_F16 ? MT_F16 : MT_BF16);
-    else if (strided_pp_ok(p))
-      snprintf(buf, n, "conv_fast_strided_pp_kernel<%d>", p->SD);
     else
       snprintf(buf, n, strided_use_bf16(p) ? "conv_fast_strided_kernel<%d, %d, %d, %d, true, 0, 0, 1>" : "conv_fast_strided_kernel<%d, %d, %d, %d, false, 0, 0, 1>",
                p->SD, p->SH, p->SW, conv_fast_vec(p));

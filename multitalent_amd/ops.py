@@ -125,7 +125,7 @@ def set_mma(mode):
 # The library keeps no process-wide switches: which kernel family serves a problem is a field of the problem.  What lives HERE is the
 # default this process writes into the structs it builds — 0 (the library's policy) unless a test, an A/B tool (MT_SELECT) or
 # set_option changes it.  The legacy option names of rounds 1-5 map onto the fields.
-_SEL_SHIFT = {'conv_wino': 0, 'conv_bf16': 2, 'conv_x16': 4, 'conv_tapsplit': 6, 'bwdw_wino': 8, 'bwdw_tr16': 10, 'bwdw_cw': 12, 'strided_pp': 14}
+_SEL_SHIFT = {'conv_wino': 0, 'conv_bf16': 2, 'conv_x16': 4, 'conv_tapsplit': 6, 'bwdw_wino': 8, 'bwdw_tr16': 10, 'bwdw_cw': 12}
 _SEL_ALIASES = {'wino': 'conv_wino', 'm16': 'conv_bf16', 'x16': 'conv_x16', 'tapsplit': 'conv_tapsplit'}
 _select = 0
 _caps = {}
@@ -141,12 +141,11 @@ def set_option(name, value):
     """Default kernel selection of the problems this process builds (tests, A/B tools).  Legacy names and values:
     conv_wino | conv_bf16 | conv_tapsplit: 0 never, 1 the library's policy, 2 wherever eligible; bwdw_wino: 0 | 1;
     conv_x16 | bwdw_tr16: 0 | 1 | n > 1 = wherever eligible with at most n workgroups (4096: no cap); wino_persist: n > 1 = at most n workers
-    per output-channel tile; bwdw_cw: 4 (policy) | 2 | 1 | 104 (four tiles also on small problems); strided_pp: 0 | 1;
-    strided_pp_workgroups: n > 0 = at most n workgroups for conv_fast_strided_pp_kernel."""
+    per output-channel tile; bwdw_cw: 4 (policy) | 2 | 1 | 104 (four tiles also on small problems)."""
     name = _SEL_ALIASES.get(name, name)
     value = int(value)
-    if name in ('wino_persist', 'strided_pp_workgroups'):     # caps only (mt_conv3d_t.max_workgroups)
-        _caps.pop(name, None) if value <= (1 if name == 'wino_persist' else 0) else _caps.__setitem__(name, value)
+    if name == 'wino_persist':
+        _caps.pop(name, None) if value <= 1 else _caps.__setitem__(name, value)
     elif name in ('conv_x16', 'bwdw_tr16'):
         _sel_set(name, 1 if value == 0 else 0 if value == 1 else (2 if name == 'conv_x16' else 0))
         _caps.pop(name, None) if value <= 1 or value >= 4096 else _caps.__setitem__(name, value)

@@ -116,48 +116,6 @@ def test_conv_fwd(dev, N, Cin, Cout, shape, k, stride):
     assert np.allclose(s[..., 1].numpy(), (ref.double() ** 2).sum((2, 3, 4)).numpy(), rtol=1e-4)
 
 
-@pytest.mark.parametrize("N,cins,Cout,shape,stride,lazy,cap", [
-    (2, (30,), 60, (12, 40, 48), (2, 2, 2), True, 0),        # several items per workgroup, two chunks
-    (2, (30,), 60, (12, 40, 48), (2, 2, 2), True, 7),        # seven workgroups: every one walks many items, ranges cross samples
-    (1, (30,), 60, (6, 12, 34), (2, 2, 2), False, 3),        # ragged tiles in every direction
-    (2, (24, 16), 70, (5, 9, 11), (2, 2, 2), True, 5),       # odd extents, two sources, three cout tiles with a tail (an idle wave pair)
-    (1, (40,), 34, (3, 7, 9), (1, 2, 2), False, 2),          # stride (1,2,2), one chunk triple
-    (3, (16,), 64, (4, 8, 16), (2, 2, 2), True, 1),          # ONE workgroup walks everything (single chunk per item)
-])
-def test_conv_fast_strided_pp(dev, N, cins, Cout, shape, stride, lazy, cap):
-    """conv_fast_strided_pp_kernel (persistent, software-pipelined, each wave one k half of every chunk; the default of the fp32 strided
-    stage convs): against F.conv3d, against the one-shot conv_fast_strided_kernel it replaces (same products, the k halves summed in a
-    different but fixed order -> fp32 rounding apart), and bit-identical for any number of workgroups (mt_conv3d_t.max_workgroups),
-    per-block statistics included."""
-    ops = _ops()
-    g = torch.Generator().manual_seed(77)
-    xs = [torch.randn((N, ci) + shape, generator=g) for ci in cins]
-    lz = [(torch.rand((N, ci), generator=g) + 0.5, torch.randn((N, ci), generator=g) * 0.3, 0.01) for ci in cins] if lazy else None
-    Cin = sum(cins)
-    w = torch.randn((Cout, Cin, 3, 3, 3), generator=g) / np.sqrt(Cin * 27)
-    b = torch.randn(Cout, generator=g)
-    ref = F.conv3d(ref_inputs(xs, lz), w, b, stride=stride, padding=1)
-    geom = ops.ConvGeom(shape, (3, 3, 3), stride, (1, 1, 1))
-    probe = ops.fill_conv([ops.Act(torch.empty((N,) + shape + (ci,), device=dev)) for ci in cins], geom, Cout,
-                          out0=ops.Act(torch.empty((N,) + tuple(geom.out) + (Cout,), device=dev)))
-    res = {}
-    try:
-        ops.set_option('conv_tapsplit', 0)
-        for mode, pp, wg, kernel in (('pp', 1, 0, 'conv_fast_strided_pp_kernel<%d>' % stride[0]), ('capped', 1, cap or 2, 'conv_fast_strided_pp_kernel'),
-                                     ('one-shot', 0, 0, 'conv_fast_strided_kernel<%d, 2, 2, 2, false' % stride[0])):
-            ops.set_option('strided_pp', pp)
-            ops.set_option('strided_pp_workgroups', wg)
-            assert ops.conv_kernel_name(ops.apply_selection(probe)).startswith(kernel), ops.conv_kernel_name(probe)
-            out, part = run_conv(dev, xs, w, b, stride, (1, 1, 1), lazy=lz, stats=True)
-            res[mode] = (out.cpu(), part.cpu())
-    finally:
-        ops.set_option('conv_tapsplit', 1); ops.set_option('strided_pp', 1); ops.set_option('strided_pp_workgroups', 0)
-    assert relerr(to_ncdhw(res['pp'][0]), ref) < 1e-5
-    assert torch.equal(res['pp'][0], res['capped'][0]) and torch.equal(res['pp'][1], res['capped'][1])
-    assert relerr(res['pp'][0], res['one-shot'][0]) < 2e-6
-    assert torch.allclose(res['pp'][1].double().sum(1), res['one-shot'][1].double().sum(1), rtol=1e-5, atol=1e-4)
-
-
 @pytest.mark.parametrize("N,cins,Cout,shape,stride,lazy", [
     (2, (240,), 320, (6, 24, 24), (2, 2, 2), True),       # the 120-workgroup stage conv of the benchmark networks
     (2, (320,), 320, (3, 12, 12), (1, 2, 2), True),       # bottleneck, 40 workgroups in the standard tiling
