@@ -9,8 +9,8 @@ struct ConvKParams {
   mt_conv3d_t c;
   int tilesD, tilesH, tilesW, nsb;
   int nchunks, ntaps;
-  int dbg;       // timing ablations (MT_CONV_DBG): 1 skip staging, 2 skip weight loads, 4 skip epilogue, 8 skip MFMA
-  int stagger;   // one-time start delay (units of ~6.4k cycles) per residency slot of the first block wave
+  int dbg;       // 0 (timing ablations of conv_fwd_kernel when set by hand: 1 skip staging, 2 skip weight loads, 4 skip epilogue, 8 skip MFMA, 16 stamps)
+  int stagger;   // 0 (one-time start delay per residency slot of the first block wave: measured without effect, rounds 3 and 6)
   ConvChunk chunk[MT_MAX_CHUNKS];
 };
 

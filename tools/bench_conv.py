@@ -49,24 +49,6 @@ if a.mode == 'fwd':
         print('  %-15s %10.0f | %10.0f' % ('total', t[:, 0:4, :10].sum(2)[used[:, 0:4]].mean(), t[:, 4:8, :10].sum(2)[used[:, 4:8]].mean()))
         print('  stagers: wait for the patch in flight at the top of phase 1: %.0f ; store_patch: %.0f ; (phase1 work row = issue_patch)' % (t[:, 4:8, 9][used[:, 4:8]].mean(), t[:, 4:8, 10][used[:, 4:8]].mean()))
         print('  stagers, slot 11 (DMA kernel: activation in place; slot 9 = fragment issue + wait, slot 10 = scale/shift + request): %.0f' % t[:, 4:8, 11][used[:, 4:8]].mean())
-    if int(os.environ.get('MT_CONV_DBG', '0')) & 16:
-        nblk = N * ops.conv_stats_blocks(p)
-        ts = torch.zeros((nblk, 4, 16), dtype=torch.int64, device=dev)
-        p.out1 = ts.data_ptr()
-        run(); torch.cuda.synchronize()
-        tsc = ts.cpu().numpy()
-        import numpy as np
-        t0 = tsc[:, :, 0].min()
-        names = ['start', 'bar0', 'staged0', 'sync0', 'comp0', 'bar1', 'staged1', 'sync1', 'comp1', 'epi_done', 'end']
-        d = np.diff(tsc[:, :, :11], axis=2).astype(float)
-        print('phase durations (cycles), median over waves/blocks:')
-        for i in range(10):
-            print('  %-9s -> %-9s %9.0f  (p10 %8.0f p90 %8.0f)' % (names[i], names[i + 1], np.median(d[:, :, i]), np.percentile(d[:, :, i], 10), np.percentile(d[:, :, i], 90)))
-        life = (tsc[:, :, 10] - tsc[:, :, 0]).astype(float)
-        print('  block wave lifetime median %.0f; kernel span %.0f cycles' % (np.median(life), tsc[:, :, 10].max() - t0))
-        # concurrency: how many blocks start within the first 1000 cycles
-        st = np.sort(tsc[:, 0, 0] - t0)
-        print('  blocks started in first 5k cycles: %d ; start times of blocks 500..520: %s' % ((st < 5000).sum(), st[500:520:4]))
 elif a.mode == 'bwdd':          # backward-data of the strided conv in one launch (mt_conv3d_bwd_data_strided): dY [Cout] -> dX [Cin]
     dy = torch.randn_like(out)
     dx = torch.zeros((N,) + tuple(a.shape) + (Cin,), device=dev)
