@@ -956,7 +956,7 @@ def _tiled_backward_weight_bf16_products(dev, kind):
             ops.set_option('bwdw_cw', 104)
             ops.apply_selection(p)
         assert float((dw1 - dw).abs().max()) <= 1e-5 * float(dw.abs().max())
-    # MT_BWDW_FAST16 decides between kernels of the same result up to the product type: the fp32-product kernel is within bf16 operand rounding
+    # mma decides between kernels of the same result up to the product type: the fp32-product kernel is within bf16 operand rounding
     p0 = ops.fill_conv(acts, geom, Cout, mma=0)
     assert ops.conv_bwd_weight_kernel_name(p0, ya).startswith('conv_bwdw_fast_kernel')
 

@@ -4,9 +4,9 @@ run() { python tools/bench_conv.py "$@" --reps 20 2>&1 | grep -v amdgpu.ids | ta
 for sh in "12 48 48 120 120" "12 48 48 240 120" "6 24 24 240 240" "6 24 24 480 240" "6 24 24 320 320" "3 12 12 320 320"; do
   set -- $sh
   for mode in fwd bwdw; do
-    for w in 1 0; do
-      echo -n "MT_CONV_WINO=$w MT_BWDW_WINO=$w : "
-      MT_CONV_WINO=$w MT_BWDW_WINO=$w run --mode $mode --cin $4 --cout $5 --shape $1 $2 $3
+    for w in default off; do          # kernel selection of the problems this process builds (multitalent_amd/ops.py: MT_SELECT)
+      echo -n "MT_SELECT=wino=$w,bwdw_wino=$w : "
+      MT_SELECT="wino=$w,bwdw_wino=$w" run --mode $mode --cin $4 --cout $5 --shape $1 $2 $3
     done
   done
 done

@@ -1,5 +1,5 @@
 """InstanceNorm + LeakyReLU backward of the low-resolution tensors, one launch (inorm_bwd_small_kernel) against three
-(MT_INORM_SMALL=0: inorm_bwd_fast_kernel x 2 + inorm_bwd_finalize_kernel): python tools/bench_norm_small.py [--mixed 1]"""
+(inorm_bwd_fast_kernel x 2 + inorm_bwd_finalize_kernel, the form large tensors take): python tools/bench_norm_small.py [--mixed 1]"""
 import argparse, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
