@@ -2490,7 +2490,7 @@ static bool conv_wino_ok(const mt_conv3d_t* p) {
   if (mt_cdiv(p->src[0].C, WCK) + (p->nsrc == 2 ? mt_cdiv(p->src[1].C, WCK) : 0) > MT_MAX_CHUNKS) return false;
   if ((double)p->Do * p->Ho * p->Wo * p->ocs0 * 4.0 >= 2147483648.0) return false;
   const long wgs = (long)p->N * mt_cdiv(p->Do, 4) * mt_cdiv(p->Ho, 4) * mt_cdiv(p->Wo, 16) * mt_cdiv(p->Cout, 32);
-  return wgs >= 256 || use == 2;          // MT_CONV_WINO=2 forces it (tests on small shapes)
+  return wgs >= 256 || use == 2;          // MT_SEL_FORCE in the MT_SEL_WINO field forces it (tests on small shapes)
 }
 // mt_bwd_stats_t is implemented in the epilogue of the persistent register-staged Winograd kernel (conv_wino8p_kernel)
 static bool wino_serves_bwd_stats(const mt_conv3d_t* p) {
@@ -4067,7 +4067,7 @@ static void bwdw_tr16_plan(const mt_conv3d_t* p, BwdWParams* P) {
   P->nunits = 0; P->nseg = 1; P->dseg = p->Do;
 }
 // conv_bwdw_fast_kernel (fp32 storage on both sides) / conv_bwdw_fast16_kernel with several cout tiles per workgroup (channel-pair
-// staging; the geometries launch_bwdw_fast / launch_bwdw_fast16 instantiate them for): 4 when the cout tiles divide by 4, else 2, else 1.  MT_BWDW_CW=1 switches it off.
+// staging; the geometries launch_bwdw_fast / launch_bwdw_fast16 instantiate them for): 4 when the cout tiles divide by 4, else 2, else 1.  The MT_SEL_BWDW_CW field of mt_conv3d_t.select limits it.
 static int bwdw_fast_cw(const mt_conv3d_t* p, int ntiles_total, int nchunks) {
   const int g_bwdw_cw = mt_bwdw_cw(p);
   const int cap = g_bwdw_cw % 100;

@@ -1562,7 +1562,7 @@ static inline int head_bwd_waves(int N, long V) {
   return (int)((w + 3) / 4 * 4);
 }
 // Cin <= 32 only: the two-input-tile instantiation (Cin <= 64) needs 182 VGPRs (one wave per SIMD) and measured 0.70 ms on the
-// 24x96x96 level — slower than the generic kernels there; it stays compiled for the tests of the accumulation logic (MT_HEAD_BWD_WIDE=1)
+// 24x96x96 level — slower than the generic kernels there; the instantiation is not dispatched (constexpr wide = 0)
 extern "C" int mt_head_bwd_supported(int Cin, int Cout) {
   constexpr int wide = 0;
   return Cin >= 1 && Cin <= (wide ? 64 : 32) && Cout >= 1 && Cout <= 64;
