@@ -1329,8 +1329,11 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvKParams P) {
 // BF (mixed precision, bf16 source without a lazy activation = a gradient): the lane's 16-byte load IS the A fragment of
 // v_mfma_f32_32x32x16_bf16 (8 channels of its voxel), the weights are pack layout 3 — one MFMA per (chunk, tap) instead of eight fp32
 // ones.  (In fp32 this kernel is AT the fp32 matrix rate: 29 padded GFLOP in 185 us for the 60 -> 30 transposed conv of Task009.)
-template <int VEC, int XS = MT_F32, int OS = MT_F32, bool BF = false>
+// NT (fp32 only): cout tiles per wave.  The A fragments are a GATHER (32 bytes of every second 120 / 240-byte voxel per lane and tap): with one
+// tile per wave every cout tile re-requests them, and the L2 -> L1 line rate of that gather, not the matrix pipe, paces the kernel.
+template <int VEC, int XS = MT_F32, int OS = MT_F32, bool BF = false, int NT = 1>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
+  static_assert(NT == 1 || (!BF && XS == MT_F32 && OS == MT_F32), "several cout tiles per wave: the fp32 form");
   constexpr int XE = mt_ebytes<XS>(), OE = mt_ebytes<OS>();
   const mt_conv3d_t& c = P.c;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1383,9 +1386,13 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
     }
   };
 
-  f32x16 acc;
+  f32x16 accn[NT];
+  f32x16& acc = accn[0];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) accn[nt][j] = 0.f;
+  const int ntiles = (c.Cout + 31) >> 5;
   if constexpr (BF) {
     static_assert(XS == MT_BF16, "the bf16 matrix path reads a bf16 source");
     const unsigned* wq = (const unsigned*)c.wpack + (size_t)ntile * P.nchunks * ntaps * 256 + lane * 4;
@@ -1438,24 +1445,50 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
       const float t = fmaf(xa[e], sc[e], sh[e]);
       xa[e] = vok ? mt_lrelu(t, slope) : 0.f;
     }
-    const float* wq = c.wpack + ((size_t)(ntile * P.nchunks + ch) * ntaps + tap) * 512 + lane * 4;
-    const f32x4 b0 = *(const f32x4*)(wq);
-    const f32x4 b1 = *(const f32x4*)(wq + 256);
+    f32x4 b0[NT], b1[NT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], b0[e], acc, 0, 0, 0);
+    for (int nt = 0; nt < NT; ++nt) {      // (a cout tile behind the last one: tile 0's weights, its outputs are never stored)
+      const int tl = ntile * NT + nt < ntiles ? ntile * NT + nt : 0;
+      const float* wq = c.wpack + ((size_t)(tl * P.nchunks + ch) * ntaps + tap) * 512 + lane * 4;
+      b0[nt] = *(const f32x4*)(wq);
+      b1[nt] = *(const f32x4*)(wq + 256);
+    }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[4 + e], b1[e], acc, 0, 0, 0);
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) accn[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[e], b0[nt][e], accn[nt], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) accn[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[4 + e], b1[nt][e], accn[nt], 0, 0, 0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) xa[e] = xn[e];
     if (++tap == ntaps) { tap = 0; ++ch; }
   }
   }
 
+  const size_t out_sample = (size_t)V * c.ocs0;
+  __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)nb * out_sample * OE), 0, (int)(out_sample * OE), 0x00020000);
+  if constexpr (NT > 1) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = (ntile * NT + nt) * 32 + li;
+      const bool covalid = co < c.Cout;
+      const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const long v = m0 + (j & 3) + 8 * (j >> 2) + 4 * lhalf;
+        const int off = (covalid && v < V) ? (int)((v * c.ocs0 + co) * 4) : (int)0x80000000;
+        float val = accn[nt][j] + bv;
+        if (c.accumulate) val += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro, off, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), ro, off, 0, 0);
+      }
+    }
+    return;
+  }
   const int co = ntile * 32 + li;
   const bool covalid = co < c.Cout;
   const float bv = (c.bias != nullptr && covalid) ? c.bias[co] : 0.f;
-  const size_t out_sample = (size_t)V * c.ocs0;
-  __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)nb * out_sample * OE), 0, (int)(out_sample * OE), 0x00020000);
   if constexpr (OS != MT_F32) {          // channel-pair dwords (mt_pair_exchange)
     const bool odd = li & 1;
     const int coe = co & ~1;
@@ -2549,6 +2582,17 @@ static bool gather_use_bf16(const mt_conv3d_t* p) {          // mixed precision:
   constexpr int use = 1;
   return use && p->mma == 1 && p->src[0].dtype == MT_BF16 && p->src[0].scale == nullptr && !(p->src[0].cs & 1) && !(((uintptr_t)p->src[0].ptr) & 3);
 }
+// two cout tiles per wave: fp32 on both sides, at least two tiles, and a grid that still fills the chip four times over (measured, tools/bench_gather.py:
+// 30 -> 60 @ 2x24x96x96 outputs 280 -> 231 us, 60 -> 120 @ 12x48x48 97 -> 99, 120 -> 240 @ 6x24x24 70 -> 83 - the smaller levels need the workgroups more
+// than the halved gather).  GATHER_NT2 0: the one-tile form everywhere.
+#ifndef GATHER_NT2
+#define GATHER_NT2 1
+#endif
+static bool gather_nt2(const mt_conv3d_t* p) {
+  if (!(GATHER_NT2 && !gather_use_bf16(p) && p->src[0].dtype == MT_F32 && p->odtype == MT_F32 && p->Cout > 32)) return false;
+  const long wgs = (((long)p->Do * p->Ho * p->Wo + 127) / 128) * p->N * mt_cdiv(mt_cdiv(p->Cout, 32), 2);
+  return wgs >= 4L * mt_device_cus(mt_current_device());
+}
 static int launch_gather(const mt_conv3d_t* p, hipStream_t st) {
   ConvKParams P;
   P.c = *p;
@@ -2572,6 +2616,10 @@ static int launch_gather(const mt_conv3d_t* p, hipStream_t st) {
   else if (S.dtype == MT_BF16 && p->odtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_BF16, MT_BF16>), grid, dim3(256), 0, st, P);
   else if (S.dtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_BF16, MT_F32>), grid, dim3(256), 0, st, P);
   else if (p->odtype == MT_BF16) hipLaunchKernelGGL((conv_gather_kernel<4, MT_F32, MT_BF16>), grid, dim3(256), 0, st, P);
+  else if (vec == 4 && gather_nt2(p)) {
+    grid.y = (unsigned)mt_cdiv(mt_cdiv(p->Cout, 32), 2);
+    hipLaunchKernelGGL((conv_gather_kernel<4, MT_F32, MT_F32, false, 2>), grid, dim3(256), 0, st, P);
+  }
   else if (vec == 4) hipLaunchKernelGGL(conv_gather_kernel<4>, grid, dim3(256), 0, st, P);
   else if (vec == 2) hipLaunchKernelGGL(conv_gather_kernel<2>, grid, dim3(256), 0, st, P);
   else hipLaunchKernelGGL(conv_gather_kernel<1>, grid, dim3(256), 0, st, P);
@@ -2701,7 +2749,7 @@ extern "C" int mt_conv3d_kernel_name(const mt_conv3d_t* p, char* buf, size_t n) 
                p->SD, p->SH, p->SW, conv_fast_vec(p));
   }
   else if (pl.kind == CONV_RT && conv_gather_ok(p))
-    snprintf(buf, n, gather_use_bf16(p) ? "conv_gather_kernel<4, %d, %d, true>" : "conv_gather_kernel<4, %d, %d>", p->src[0].dtype, p->odtype);
+    snprintf(buf, n, gather_use_bf16(p) ? "conv_gather_kernel<4, %d, %d, true>" : gather_nt2(p) ? "conv_gather_kernel<4, %d, %d, false, 2>" : "conv_gather_kernel<4, %d, %d>", p->src[0].dtype, p->odtype);
   else if (pl.kind == CONV_RT)
     snprintf(buf, n, "conv_rt_kernel<%d, %d, %d, %d>", g.MW, g.RH, g.TD, conv_fast_vec(p));
   else

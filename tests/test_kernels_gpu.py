@@ -824,9 +824,12 @@ def test_conv_bf16_mixed_precision(dev, N, Cin, Cout, shape, two_src):
     (1, 64, 33, (5, 9, 21), (2, 2, 2)),          # odd sizes: the last input plane/row/column is unused
     (2, 60, 30, (4, 8, 16), (1, 2, 2)),
     (1, 17, 40, (4, 6, 10), (2, 2, 2)),          # odd channel stride: scalar loads
+    (2, 30, 70, (32, 64, 128), (2, 2, 2)),       # a grid that fills the chip: two cout tiles per wave, three tiles (the last wave's second one is idle)
+    (2, 30, 60, (64, 64, 130), (2, 2, 2)),       # ... two tiles, a ragged last voxel block
 ])
 def test_conv_kernel_equals_stride_gather(dev, N, Cin, Cout, shape, k):
-    """kernel == stride, pad 0 (the backward-data form of ConvTranspose3d(k = s)): conv_gather_kernel, lazy input, accumulate."""
+    """kernel == stride, pad 0 (the backward-data form of ConvTranspose3d(k = s)): conv_gather_kernel (one cout tile per wave, or two
+    on well-filled fp32 grids), lazy input, accumulate."""
     ops = _ops()
     g = torch.Generator().manual_seed(31)
     x = torch.randn((N, Cin) + shape, generator=g)
@@ -841,6 +844,10 @@ def test_conv_kernel_equals_stride_gather(dev, N, Cin, Cout, shape, k):
     out = base.to(dev)
     p = ops.fill_conv([act], geom, Cout, out0=ops.Act(out), accumulate=True)
     assert ops.conv_kernel_name(p).startswith('conv_gather_kernel')
+    wgs2 = -(-int(np.prod(geom.out)) // 128) * N * -(-(-(-Cout // 32)) // 2)          # workgroups of the two-tile form
+    assert ops.conv_kernel_name(p).endswith('false, 2>') == (Cout > 32 and wgs2 >= 4 * torch.cuda.get_device_properties(dev).multi_processor_count), \
+        ops.conv_kernel_name(p)
+    assert ops.conv_kernel_name(p).endswith('false, 2>') == (int(np.prod(shape)) >= 32 * 64 * 128)               # (the two large cases take it)
     wd = w.to(dev).contiguous()
     wp = ops.pack_conv_weights(wd, Cin, 0, Cout, k, ops.conv_weight_strides(wd), False, ops.conv_ck(p), layout=ops.conv_pack_layout(p))
     p.wpack = wp.data_ptr()
