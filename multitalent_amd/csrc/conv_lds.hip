@@ -1427,6 +1427,78 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
       }
     }
   } else {
+  if constexpr (NT > 1) {
+    // Chunk PAIRS: the two 16-channel chunks of a voxel's 32 channels (128 bytes) are requested back to back, tap-major inside the pair - the second
+    // request finds the line the first one brought in (one L2 -> L1 fill per voxel and tap instead of two).
+    const int npairs = (P.nchunks + 1) >> 1, totalp = npairs * ntaps;
+    int p_pr = 0, p_kd = 0, p_kh = 0, p_kw = 0;
+    auto load_pair = [&](float (&x)[2][8]) __attribute__((always_inline)) {
+      const int so = __builtin_amdgcn_readfirstlane((((p_kd * c.Hi + p_kh) * c.Wi + p_kw) * S.cs + 2 * p_pr * FCK) * 4);
+      const bool two = 2 * p_pr + 1 < P.nchunks;
+      if (++p_kw == c.KW) { p_kw = 0; if (++p_kh == c.KH) { p_kh = 0; if (++p_kd == c.KD) { p_kd = 0; ++p_pr; } } }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 0 || two) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, abase + g * 16, so + h * FCK * 4, 0));
+            x[h][4 * g] = t[0]; x[h][4 * g + 1] = t[1]; x[h][4 * g + 2] = t[2]; x[h][4 * g + 3] = t[3];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[h][e] = 0.f;
+        }
+      }
+    };
+    float xa[2][8], xn[2][8], sc[2][8], sh[2][8];
+    load_pair(xa);
+    for (int it = 0, pr = 0, tap = 0; it < totalp; ++it) {
+      if (it + 1 < totalp) load_pair(xn);
+      const bool two = 2 * pr + 1 < P.nchunks;
+      if (tap == 0) {                                    // per-chunk lazy-activation constants (0 for channels beyond Cin)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int cb = (2 * pr + h) * FCK + 8 * lhalf;
+            const bool cv = cb + e < c.Cin;
+            sc[h][e] = aff ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, cv ? (cb + e) * 4 : (int)0x80000000, 0, 0)) : (cv ? 1.f : 0.f);
+            sh[h][e] = aff ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, cv ? (cb + e) * 4 : (int)0x80000000, 0, 0)) : 0.f;
+          }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 0 || two) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = fmaf(xa[h][e], sc[h][e], sh[h][e]);
+            xa[h][e] = vok ? mt_lrelu(t, slope) : 0.f;
+          }
+          f32x4 b0[NT], b1[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {  // (a cout tile behind the last one: tile 0's weights, its outputs are never stored)
+            const int tl = ntile * NT + nt < ntiles ? ntile * NT + nt : 0;
+            const float* wq = c.wpack + ((size_t)(tl * P.nchunks + 2 * pr + h) * ntaps + tap) * 512 + lane * 4;
+            b0[nt] = *(const f32x4*)(wq);
+            b1[nt] = *(const f32x4*)(wq + 256);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) accn[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[h][e], b0[nt][e], accn[nt], 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) accn[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[h][4 + e], b1[nt][e], accn[nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xa[h][e] = xn[h][e];
+      if (++tap == ntaps) { tap = 0; ++pr; }
+    }
+  } else {
   float xa[8], xn[8], sc[8], sh[8];
   load_a(xa);
   for (int it = 0, ch = 0, tap = 0; it < total; ++it) {
@@ -1466,10 +1538,37 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvKParams P) {
     if (++tap == ntaps) { tap = 0; ++ch; }
   }
   }
+  }
 
   const size_t out_sample = (size_t)V * c.ocs0;
   __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)c.out0 + (size_t)nb * out_sample * OE), 0, (int)(out_sample * OE), 0x00020000);
   if constexpr (NT > 1) {
+    static_assert(NT == 2, "the wide epilogue stages 32 voxels x 64 channels per wave");
+    // Wide epilogue: the accumulator layout gives a lane ONE channel of 16 voxels (32 dword stores per lane and wave tile, each 2 x 128 bytes);
+    // through a wave-private LDS image [32 voxels][64 channels] a lane leaves with 4 channels of a voxel per 16-byte store - 8 stores of 1 KB.
+    if ((c.ocs0 & 3) == 0 && (c.Cout & 3) == 0 && ((((uintptr_t)c.out0) & 15) == 0)) {
+      __shared__ __attribute__((aligned(16))) float stg[4][32 * 64];
+      float* const sw = stg[wave];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = (ntile * NT + nt) * 32 + li;
+        const float bv = (c.bias != nullptr && co < c.Cout) ? c.bias[co] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sw[((j & 3) + 8 * (j >> 2) + 4 * lhalf) * 64 + nt * 32 + li] = accn[nt][j] + bv;
+      }
+      const int c4 = (lane & 15) * 4, vq = lane >> 4;               // this lane's 4 channels of the 64 | its voxel of each group of four
+      const int cg = ntile * 64 + c4;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int vl = k * 4 + vq;
+        f32x4 val = *(const f32x4*)(sw + vl * 64 + c4);              // (same wave: LDS operations retire in order)
+        const long v = m0 + vl;
+        const int off = (cg < c.Cout && v < V) ? (int)((v * c.ocs0 + cg) * 4) : (int)0x80000000;
+        if (c.accumulate) val += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, val), ro, off, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int co = (ntile * NT + nt) * 32 + li;
