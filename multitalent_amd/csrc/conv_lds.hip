@@ -2682,8 +2682,8 @@ static bool gather_use_bf16(const mt_conv3d_t* p) {          // mixed precision:
   return use && p->mma == 1 && p->src[0].dtype == MT_BF16 && p->src[0].scale == nullptr && !(p->src[0].cs & 1) && !(((uintptr_t)p->src[0].ptr) & 3);
 }
 // two cout tiles per wave: fp32 on both sides, at least two tiles, and a grid that still fills the chip four times over (measured, tools/bench_gather.py:
-// 30 -> 60 @ 2x24x96x96 outputs 280 -> 231 us, 60 -> 120 @ 12x48x48 97 -> 99, 120 -> 240 @ 6x24x24 70 -> 83 - the smaller levels need the workgroups more
-// than the halved gather).  GATHER_NT2 0: the one-tile form everywhere.
+// 30 -> 60 @ 2x24x96x96 outputs 280 -> 231 us (218 with the chunk pairs and the wide epilogue), 60 -> 120 @ 12x48x48 97 -> 99, 120 -> 240 @ 6x24x24 70 -> 83 -
+// the smaller levels need the workgroups more than the halved gather).  GATHER_NT2 0: the one-tile form everywhere.
 #ifndef GATHER_NT2
 #define GATHER_NT2 1
 #endif
