@@ -47,3 +47,52 @@ def test_cpu_call_fails_loudly():
                        lambda x: x, None, [[2, 2, 2]], [[3, 3, 3]] * 2, False, True, True)
     with pytest.raises(RuntimeError, match="HIP device"):
         net(torch.zeros(1, 1, 4, 8, 8))
+
+
+def test_selection_word_matches_the_header():
+    """Host logic of ABI 4's kernel selection (no GPU): the field shifts of multitalent_amd.ops are include/mtseg.h's MT_SEL_* shifts, the
+    legacy option values map onto MT_SEL_DEFAULT / OFF / FORCE, offsets of `select` / `max_workgroups` equal the C compiler's, MT_SELECT
+    is parsed into the same word, and set-then-reset leaves the process default untouched."""
+    import ctypes as C
+    import subprocess
+    import sys
+    import tempfile
+    from multitalent_amd import ops
+    from multitalent_amd._lib import mt_conv3d_t
+    txt = open(os.path.join(ROOT, 'include', 'mtseg.h')).read()
+    shifts = {m.group(1): int(m.group(2)) for m in re.finditer(r'#define MT_SEL_([A-Z0-9_]+)\s+(\d+)u?\b', txt)}
+    assert (shifts.pop('DEFAULT'), shifts.pop('OFF'), shifts.pop('FORCE')) == (0, 1, 2)
+    names = {'WINO': 'conv_wino', 'M16': 'conv_bf16', 'X16': 'conv_x16', 'TAPSPLIT': 'conv_tapsplit', 'BWDW_WINO': 'bwdw_wino',
+             'BWDW_TR16': 'bwdw_tr16', 'BWDW_CW': 'bwdw_cw'}
+    assert {names[k]: v for k, v in shifts.items()} == ops._SEL_SHIFT
+    assert len(set(shifts.values())) == len(shifts) and all(v % 2 == 0 and v + 2 <= 32 for v in shifts.values())
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "mtseg.h"\nint main(){printf("%zu %zu\\n", offsetof(mt_conv3d_t, select), '
+           'offsetof(mt_conv3d_t, max_workgroups));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, 't.c'), 'w').write(src)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 't.c'), '-o', os.path.join(d, 't')])
+        offs = [int(x) for x in subprocess.check_output([os.path.join(d, 't')]).decode().split()]
+    assert offs == [mt_conv3d_t.select.offset, mt_conv3d_t.max_workgroups.offset]
+    assert ops.options_are_default()
+    base = ops._select
+    try:
+        ops.set_option('conv_wino', 0)
+        assert (ops._select >> shifts['WINO']) & 3 == 1                  # never -> MT_SEL_OFF
+        ops.set_option('conv_wino', 2)
+        assert (ops._select >> shifts['WINO']) & 3 == 2                  # wherever eligible -> MT_SEL_FORCE
+        ops.set_option('conv_x16', 4096)
+        assert (ops._select >> shifts['X16']) & 3 == 2 and not ops._caps
+        ops.set_option('conv_x16', 7)
+        p = ops.apply_selection(mt_conv3d_t())
+        assert p.max_workgroups == 7 and p.select == ops._select
+        ops.set_option('bwdw_cw', 2)
+        assert (ops._select >> shifts['BWDW_CW']) & 3 == 2
+        assert not ops.options_are_default()
+    finally:
+        ops.set_option('conv_wino', 1); ops.set_option('conv_x16', 1); ops.set_option('bwdw_cw', 4)
+    assert ops._select == base and ops.options_are_default()
+    code = ("import multitalent_amd.ops as o; print(o._select, o.options_are_default())")
+    env = dict(os.environ, MT_SELECT='x16=off, wino=force,tapsplit=off')
+    out = subprocess.check_output([sys.executable, '-c', code], env=env, cwd=ROOT).decode().split()
+    want = (1 << shifts['X16']) | (2 << shifts['WINO']) | (1 << shifts['TAPSPLIT'])
+    assert int(out[0]) == want and out[1] == 'True'                     # (the environment's word IS that process's default)
