@@ -7,8 +7,8 @@
  * device pointers owned by the caller (torch), a hipStream_t and plain sizes.  No torch types,
  * no allocation, no synchronisation inside (mt_probe_device excepted, see there); every function returns 0
  * on success or a negative MT_E* code (text via mt_last_error(), thread-local).  Threading: launches are
- * re-entrant per stream and per device; the only mutable state are the process-wide kernel-selection knobs
- * of mt_set_option (atomics) and per-device one-time kernel attributes.
+ * re-entrant per stream and per device; since ABI 4 there is no mutable process-wide state (kernel selection is a field of the
+ * problem struct, see "State" below) - only per-device caches of immutable properties and one-time kernel attributes.
  *
  * Layout: activations are NDHWC ("channels last"), fp32 or — in the mixed-precision mode, for the tensors the caller chooses —
  * bf16 (`dtype` = MT_BF16: the pointer then addresses 2-byte elements although it is typed `float*`), possibly a channel slice of a
